@@ -1,0 +1,37 @@
+# -*- coding: utf-8 -*-
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "speech-recognition_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def has_gpu():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return False
+    n = ctypes.c_int(0)
+    return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
