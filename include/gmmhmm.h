@@ -1,0 +1,154 @@
+/*
+ * gmmhmm.h -- C ABI of the MI355X-native GMM-HMM core (libgmmhmm.so).
+ *
+ * Drop-in boundary for the hot path of tjysdsg/speech-recognition's
+ * `sr/recognition` package.  The reference has no FFI layer of its own (it is
+ * pure Python/numpy), so each entry point below names the reference function
+ * whose inner loop it replaces (paths relative to the reference repo); the
+ * Python mirror in speech-recognition_amd/sr/recognition binds them with
+ * ctypes and keeps the reference's names, arguments and error behaviour
+ * (INTEGRATION.md shows the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no C++/torch types.
+ *   - every call returns 0 (GH_OK) or a negative gh_status; the message of the
+ *     last failure on the calling thread is `gh_last_error()`.
+ *   - host pointers are caller-owned and only read/written during the call;
+ *     `*_dev` arguments are device pointers on the context's GPU.
+ *   - handles are created/destroyed by the library; one gh_ctx per GPU; a
+ *     handle is not thread-safe, distinct handles are.
+ *   - all costs are NEGATIVE LOG likelihoods ("cost" in the reference), arcs
+ *     are `cost[to, from]`, +inf = no arc (decode.py:12-13).
+ *   - dtype: GH_F32 or GH_F64 selects the arithmetic of the likelihood kernel
+ *     and the type of the resident feature / likelihood matrices; the dynamic
+ *     programs always accumulate in fp64 (reference arithmetic is float64).
+ */
+#ifndef GMMHMM_H
+#define GMMHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GH_OK = 0,
+    GH_ERR_INVALID = -1,     /* bad argument (shape, NULL, range)                       */
+    GH_ERR_HIP = -2,         /* a HIP runtime call failed                               */
+    GH_ERR_NOMEM = -3,       /* device or host allocation failed                        */
+    GH_ERR_NODEVICE = -4,    /* no usable GPU                                           */
+    GH_ERR_SELF_POINTER = -5,/* a DP cell chose itself as origin: decode.py:120-121     */
+    GH_ERR_UNSUPPORTED = -6  /* shape outside what the kernels are built for            */
+} gh_status;
+
+typedef enum { GH_F32 = 0, GH_F64 = 1 } gh_dtype;
+
+typedef struct gh_ctx gh_ctx;            /* one GPU: device id, stream, scratch arena      */
+typedef struct gh_gmm gh_gmm;            /* S diagonal-covariance mixtures, packed SoA      */
+typedef struct gh_batch gh_batch;        /* ragged batch of utterances resident in HBM      */
+typedef struct gh_lattices gh_lattices;  /* one or more DP graphs (rows, arcs, starts, ends)*/
+
+const char* gh_last_error(void);
+int gh_version(void);
+
+/* ------------------------------------------------------------------ context */
+int gh_ctx_create(int device, gh_ctx** out);
+void gh_ctx_destroy(gh_ctx* ctx);
+int gh_ctx_sync(gh_ctx* ctx);
+/* raw hipStream_t of the context (for hipEvent timing / torch interop) */
+void* gh_ctx_stream(gh_ctx* ctx);
+
+/* ----------------------------------------------------------- emission model
+ * Packs S states x M components x D dims.  Replaces the per-state object graph
+ * GMM -> [MultivariateNormal] (hmm_state.py:5-45,100-120).  `weight` is used as
+ * given (NOT renormalised: hmm_state.py:115 multiplies whatever `w` holds).
+ * var <= 0 is rejected (the reference raises LinAlgError from np.linalg.inv,
+ * hmm_state.py:17,30). */
+int gh_gmm_create(gh_ctx* ctx, int S, int M, int D,
+                  const double* mean /*[S,M,D]*/, const double* var /*[S,M,D]*/,
+                  const double* weight /*[S,M]*/, gh_gmm** out);
+void gh_gmm_destroy(gh_gmm* g);
+
+/* ---------------------------------------------------------------- utterances
+ * feats: row-major [N, D] (N = utt_offsets[U]); utterance u owns frames
+ * [utt_offsets[u], utt_offsets[u+1]).  Replaces the Python list of per-utterance
+ * np.ndarray[T_u, D] every reference entry point takes (hmm.py:57, decode.py:80). */
+int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
+                    const void* feats_host, const int64_t* utt_offsets, gh_batch** out);
+/* same, features already in HBM (e.g. a torch tensor's data_ptr); not copied, not freed */
+int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
+                  void* feats_dev, const int64_t* utt_offsets, gh_batch** out);
+void gh_batch_destroy(gh_batch* b);
+
+/* ------------------------------------------------ A3: batched GMM.evaluate
+ * nll[n, s] = -log sum_m w[s,m] N(x_n; mean[s,m], diag var[s,m])  for every
+ * frame of the batch and every state (hmm_state.py:114-120, log-domain).
+ * The [N, S] matrix stays resident in the batch (dtype of the batch) for the
+ * dynamic programs; `out_host` (may be NULL) receives a copy.
+ * gh_loglik_dev_ptr returns the resident matrix (device pointer, [N,S]). */
+int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host /*[N,S] or NULL*/);
+void* gh_loglik_dev_ptr(gh_batch* b);
+/* weighted component densities in the log domain, log(w_m pdf_m(x)) for one
+ * state over arbitrary frames (hmm_state.py:114-116 with
+ * return_neg_log_likelihood=False, in logs): out[n, m], fp64. */
+int gh_component_loglik(gh_ctx* ctx, const gh_gmm* g, int state, int64_t N,
+                        const double* x_host /*[N,D]*/, double* out_host /*[N,M]*/);
+/* A2: diagonal-Gaussian negative log-likelihood / Euclidean distance matrix
+ * dist[i, n] between frames x[n] and templates y[i] (hmm_state.py:48-58;
+ * default dist_fun of kmeans.py:111,167).  var may be NULL (Euclidean),
+ * [1,D] (shared, kmeans.py:183 uses cov[0]) or [K,D] (dtw with variance[i],
+ * decode.py:38,59). */
+int gh_distance_matrix(gh_ctx* ctx, int64_t N, int K, int D, const double* x_host /*[N,D]*/,
+                       const double* y_host /*[K,D]*/, const double* var_host, int var_rows,
+                       double* out_host /*[K,N]*/);
+
+/* ------------------------------------------------------------ DP graphs
+ * L graphs, concatenated.  Graph l owns rows [row_off[l], row_off[l+1]) etc;
+ * arc endpoints and start/end rows are LOCAL row indices of their graph.
+ *   row_state[r]  >= 0 : emitting row scored by that state of the gh_gmm
+ *                 == -1: non-emitting row (NES, hmm_state.py:81-97; evaluate -> 0)
+ *   arcs          : finite entries of the reference's dense transitions[to, from]
+ *   start rows    : cells (r, 0) initialised with their emission only; the
+ *                   reference has exactly one, row 0 (decode.py:99-101); stacking
+ *                   W isolated word models into one graph gives W of them
+ *   end rows      : candidate final rows in the LAST column, in the caller's
+ *                   order (decode.py:126-134: the last of equal minima wins)
+ * Replaces the dense R x R matrix built by build_state_sequences
+ * (continuous_speech.py:13-53) / HMM.transitions (hmm.py:24). */
+int gh_lattices_create(gh_ctx* ctx, int L,
+                       const int64_t* row_off /*[L+1]*/, const int32_t* row_state,
+                       const int64_t* arc_off /*[L+1]*/, const int32_t* arc_to,
+                       const int32_t* arc_from, const double* arc_cost,
+                       const int64_t* start_off /*[L+1]*/, const int32_t* start_rows,
+                       const int64_t* end_off /*[L+1]*/, const int32_t* end_rows,
+                       gh_lattices** out);
+void gh_lattices_destroy(gh_lattices* l);
+
+/* --------------------------------------------------- A6: decode_hmm_states
+ * Viterbi over graph utt_lattice[u] (NULL: graph 0) for every utterance of the
+ * batch, using the resident likelihood matrix (gh_loglik must have run).
+ * Reproduces decode.py:80-146 including same-column hops through non-emitting
+ * rows, first-minimum tie-break among origins, last-minimum among end points,
+ * and the path convention (end -> start, end cell excluded, stops on reaching
+ * column 0).
+ *   out_end_cost  [sum_u n_end(u)]  cost of every end row at the last column
+ *   out_best_end  [U]               index (into the graph's end list) chosen
+ *   out_path      [path_off[U], 2]  (row, col) pairs, utterance u at path_off[u];
+ *                                   path_off[u+1]-path_off[u] >= gh_viterbi_path_cap
+ *   out_path_len  [U]
+ *   out_costs     full cost matrices, utterance u at costs_off[u], row-major
+ *                 [R_u, T_u] like the reference's `costs` (tests / single-utterance API)
+ * Any output pointer may be NULL. */
+int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
+               const int32_t* utt_lattice /*[U] or NULL*/,
+               double* out_end_cost, int32_t* out_best_end,
+               int32_t* out_path, const int64_t* path_off /*[U+1]*/, int32_t* out_path_len,
+               double* out_costs, const int64_t* costs_off /*[U+1]*/);
+/* upper bound on the number of path cells of an utterance of T frames on graph l */
+int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMMHMM_H */

@@ -172,6 +172,10 @@ def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
     while j != 0:
         i, j = bp[i, j]
         path.append([i, j])
+        if len(path) > R * T:
+            # unreachable cells can point at each other inside one column; the reference
+            # would loop forever here -- the oracle (test infrastructure) refuses instead
+            raise RuntimeError("back-trace does not terminate")
     path = np.array(path)
     if return_bp:
         return costs, path, end, bp

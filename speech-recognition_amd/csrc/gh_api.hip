@@ -1,0 +1,518 @@
+// Host side of the C ABI: handles, packing, launch orchestration.
+#include "gh_internal.h"
+#include "gh_viterbi.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+void gh_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* gh_last_error(void) { return g_err.c_str(); }
+extern "C" int gh_version(void) { return 1; }
+
+// ------------------------------------------------------------------ context
+extern "C" int gh_ctx_create(int device, gh_ctx** out) {
+    GH_REQUIRE(out, "gh_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        gh_set_error("gh_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+        return GH_ERR_NODEVICE;
+    }
+    GH_REQUIRE(device >= 0 && device < n, "gh_ctx_create: device %d out of range [0,%d)", device, n);
+    GH_HIP(hipSetDevice(device));
+    gh_ctx* c = new gh_ctx();
+    c->device = device;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    hipDeviceProp_t prop;
+    GH_HIP(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    GH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    GH_HIP(hipMalloc((void**)&c->d_flag, sizeof(int)));
+    GH_HIP(hipMemset(c->d_flag, 0, sizeof(int)));
+    *out = c;
+    return GH_OK;
+}
+
+extern "C" void gh_ctx_destroy(gh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->scratch) hipFree(c->scratch);
+    hipFree(c->d_flag);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int gh_ctx_sync(gh_ctx* c) {
+    GH_REQUIRE(c, "gh_ctx_sync: ctx is NULL");
+    GH_HIP(hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+extern "C" void* gh_ctx_stream(gh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->scratch_bytes) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) GH_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 8 + (1u << 20);
+        GH_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return GH_OK;
+}
+
+namespace {
+
+// carve 256-byte aligned pieces out of the context scratch
+struct Carver {
+    size_t total = 0;
+    std::vector<std::pair<void**, size_t>> items;  // (destination pointer, offset)
+    template <typename T> void add(T** dst, size_t count) {
+        items.push_back({reinterpret_cast<void**>(dst), total});
+        total += (count * sizeof(T) + 255) & ~size_t(255);
+    }
+    int commit(gh_ctx* ctx) {
+        void* base = nullptr;
+        int rc = gh_scratch(ctx, total ? total : 256, &base);
+        if (rc) return rc;
+        for (auto& it : items) *it.first = static_cast<char*>(base) + it.second;
+        return GH_OK;
+    }
+};
+
+template <typename T> int upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    if (src.empty()) return GH_OK;
+    GH_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    GH_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GH_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------- model
+extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mean, const double* var,
+                             const double* weight, gh_gmm** out) {
+    GH_REQUIRE(ctx && out && mean && var && weight, "gh_gmm_create: NULL argument");
+    GH_REQUIRE(S > 0 && M > 0 && D > 0, "gh_gmm_create: S=%d M=%d D=%d must be positive", S, M, D);
+    *out = nullptr;
+    GH_HIP(hipSetDevice(ctx->device));
+    const int G = S * M;
+    const int KP = (D + 3) & ~3;
+    gh_gmm* g = new gh_gmm();
+    g->ctx = ctx;
+    g->S = S; g->M = M; g->D = D; g->KP = KP;
+    g->hA.assign((size_t)G * KP, 0.0);
+    g->hB.assign((size_t)G * KP, 0.0);
+    g->hC.assign(G, 0.0);
+    std::vector<double> ivar((size_t)G * D), logc(G);
+    const double log2pi = std::log(2.0 * M_PI);
+    for (int i = 0; i < G; ++i) {
+        double sum_logv = 0, sum_m2 = 0;
+        for (int d = 0; d < D; ++d) {
+            const double v = var[(size_t)i * D + d], mu = mean[(size_t)i * D + d];
+            if (!(v > 0)) {  // np.linalg.inv(diag(var)) raises LinAlgError on a zero pivot (hmm_state.py:17)
+                delete g;
+                gh_set_error("gh_gmm_create: var[%d,%d,%d]=%g is not positive (singular covariance)",
+                             i / M, i % M, d, v);
+                return GH_ERR_INVALID;
+            }
+            const double iv = 1.0 / v;
+            ivar[(size_t)i * D + d] = iv;
+            g->hA[(size_t)i * KP + d] = -0.5 * iv;
+            g->hB[(size_t)i * KP + d] = mu * iv;
+            sum_logv += std::log(v);
+            sum_m2 += mu * mu * iv;
+        }
+        logc[i] = std::log(weight[i]) - 0.5 * (D * log2pi + sum_logv);  // log(0) = -inf: component off
+        g->hC[i] = logc[i] - 0.5 * sum_m2;
+    }
+    std::vector<float> fA(g->hA.begin(), g->hA.end()), fB(g->hB.begin(), g->hB.end()),
+        fC(g->hC.begin(), g->hC.end());
+    std::vector<double> vmean(mean, mean + (size_t)G * D);
+    int rc = GH_OK;
+    if ((rc = upload(&g->dA64, g->hA)) || (rc = upload(&g->dB64, g->hB)) || (rc = upload(&g->dC64, g->hC)) ||
+        (rc = upload(&g->dA32, fA)) || (rc = upload(&g->dB32, fB)) || (rc = upload(&g->dC32, fC)) ||
+        (rc = upload(&g->dMean, vmean)) || (rc = upload(&g->dIvar, ivar)) || (rc = upload(&g->dLogc, logc))) {
+        gh_gmm_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return GH_OK;
+}
+
+extern "C" void gh_gmm_destroy(gh_gmm* g) {
+    if (!g) return;
+    hipSetDevice(g->ctx->device);
+    hipFree(g->dA64); hipFree(g->dB64); hipFree(g->dC64);
+    hipFree(g->dA32); hipFree(g->dB32); hipFree(g->dC32);
+    hipFree(g->dMean); hipFree(g->dIvar); hipFree(g->dLogc);
+    delete g;
+}
+
+// -------------------------------------------------------------------- batch
+static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U, const int64_t* off,
+                        gh_batch** out) {
+    GH_REQUIRE(ctx && out && off, "gh_batch: NULL argument");
+    GH_REQUIRE(dtype == GH_F32 || dtype == GH_F64, "gh_batch: bad dtype %d", (int)dtype);
+    GH_REQUIRE(D > 0 && N >= 0 && U >= 0, "gh_batch: D=%d N=%lld U=%lld", D, (long long)N, (long long)U);
+    GH_REQUIRE(off[0] == 0 && off[U] == N, "gh_batch: utt_offsets must run from 0 to N");
+    for (int64_t u = 0; u < U; ++u)
+        GH_REQUIRE(off[u + 1] >= off[u], "gh_batch: utt_offsets not monotone at %lld", (long long)u);
+    GH_HIP(hipSetDevice(ctx->device));
+    gh_batch* b = new gh_batch();
+    b->ctx = ctx; b->dtype = dtype; b->D = D; b->N = N; b->U = U;
+    b->feats = nullptr; b->owns_feats = false; b->nll = nullptr; b->nll_S = 0; b->d_offsets = nullptr;
+    b->offsets.assign(off, off + U + 1);
+    b->max_T = 0;
+    for (int64_t u = 0; u < U; ++u) b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
+    int rc = upload(&b->d_offsets, b->offsets);
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return GH_OK;
+}
+
+extern "C" int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U, const void* feats,
+                               const int64_t* off, gh_batch** out) {
+    GH_REQUIRE(feats || N == 0, "gh_batch_create: feats is NULL");
+    int rc = batch_common(ctx, dtype, D, N, U, off, out);
+    if (rc) return rc;
+    gh_batch* b = *out;
+    const size_t bytes = (size_t)N * D * (dtype == GH_F64 ? 8 : 4);
+    b->owns_feats = true;
+    if (bytes) {
+        hipError_t e = hipMalloc(&b->feats, bytes);
+        if (e == hipSuccess) e = hipMemcpy(b->feats, feats, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            gh_set_error("gh_batch_create: %s", hipGetErrorString(e));
+            gh_batch_destroy(b);
+            *out = nullptr;
+            return e == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+        }
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U, void* feats_dev,
+                             const int64_t* off, gh_batch** out) {
+    GH_REQUIRE(feats_dev || N == 0, "gh_batch_wrap: feats_dev is NULL");
+    int rc = batch_common(ctx, dtype, D, N, U, off, out);
+    if (rc) return rc;
+    (*out)->feats = feats_dev;
+    return GH_OK;
+}
+
+extern "C" void gh_batch_destroy(gh_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->owns_feats && b->feats) hipFree(b->feats);
+    if (b->nll) hipFree(b->nll);
+    if (b->d_offsets) hipFree(b->d_offsets);
+    delete b;
+}
+
+// ------------------------------------------------------------------- loglik
+extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host) {
+    GH_REQUIRE(ctx && g && b, "gh_loglik: NULL argument");
+    GH_REQUIRE(g->D == b->D, "gh_loglik: feature dim %d != model dim %d (hmm_state.py:45)", b->D, g->D);
+    GH_HIP(hipSetDevice(ctx->device));
+    const size_t esz = b->dtype == GH_F64 ? 8 : 4;
+    if (b->nll && b->nll_S != g->S) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        GH_HIP(hipFree(b->nll));
+        b->nll = nullptr;
+    }
+    if (!b->nll && b->N > 0) {
+        GH_HIP(hipMalloc(&b->nll, (size_t)b->N * g->S * esz));
+        b->nll_S = g->S;
+    }
+    int rc = gh_launch_loglik(ctx, g, b);
+    if (rc) return rc;
+    if (out_host && b->N > 0) {
+        GH_HIP(hipMemcpyAsync(out_host, b->nll, (size_t)b->N * g->S * esz, hipMemcpyDeviceToHost, ctx->stream));
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GH_OK;
+}
+
+extern "C" void* gh_loglik_dev_ptr(gh_batch* b) { return b ? b->nll : nullptr; }
+
+// ----------------------------------------------------------------- lattices
+extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, const int32_t* row_state,
+                                  const int64_t* arc_off, const int32_t* arc_to, const int32_t* arc_from,
+                                  const double* arc_cost, const int64_t* start_off, const int32_t* start_rows,
+                                  const int64_t* end_off, const int32_t* end_rows, gh_lattices** out) {
+    GH_REQUIRE(ctx && out && row_off && row_state && arc_off && start_off && end_off && end_rows,
+               "gh_lattices_create: NULL argument");
+    GH_REQUIRE(L > 0, "gh_lattices_create: L=%d", L);
+    *out = nullptr;
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t Rtot = row_off[L], Atot = arc_off[L], Etot = end_off[L];
+    GH_REQUIRE(row_off[0] == 0 && arc_off[0] == 0 && start_off[0] == 0 && end_off[0] == 0,
+               "gh_lattices_create: offsets must start at 0");
+    std::vector<int32_t> h_state(row_state, row_state + Rtot), h_ptr, h_order(Rtot), h_lev, h_end;
+    std::vector<uint8_t> h_start(Rtot, 0);
+    std::vector<uint32_t> h_prow(Atot);
+    std::vector<double> h_pcost(Atot);
+    gh_lattices* lt = new gh_lattices();
+    lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0;
+    lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
+    lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr;
+    lt->d_desc = nullptr;
+    h_end.assign(end_rows, end_rows + Etot);
+    for (int l = 0; l < L; ++l) {
+        const int64_t r0 = row_off[l], a0 = arc_off[l];
+        const int R = (int)(row_off[l + 1] - r0), A = (int)(arc_off[l + 1] - a0);
+        const int ns = (int)(start_off[l + 1] - start_off[l]), ne = (int)(end_off[l + 1] - end_off[l]);
+#define GH_LFAIL(...) do { gh_set_error(__VA_ARGS__); delete lt; return GH_ERR_INVALID; } while (0)
+        if (R <= 0 || R > 0x7FFE) GH_LFAIL("gh_lattices_create: graph %d has %d rows (1..32766 supported)", l, R);
+        if (ne <= 0) GH_LFAIL("gh_lattices_create: graph %d has no end row", l);
+        for (int k = 0; k < ns; ++k) {
+            const int r = start_rows[start_off[l] + k];
+            if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: start row %d out of range", r);
+            h_start[r0 + r] = 1;
+        }
+        for (int k = 0; k < ne; ++k) {
+            const int r = end_rows[end_off[l] + k];
+            if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: end row %d out of range", r);
+        }
+        // CSR by destination, ascending origin (tie-break contract, decode.py:105-118)
+        std::vector<int> idx(A);
+        std::iota(idx.begin(), idx.end(), 0);
+        for (int k = 0; k < A; ++k) {
+            const int to = arc_to[a0 + k], fr = arc_from[a0 + k];
+            if (to < 0 || to >= R || fr < 0 || fr >= R) GH_LFAIL("gh_lattices_create: arc %d out of range", k);
+            if (std::isinf(arc_cost[a0 + k]) || std::isnan(arc_cost[a0 + k]))
+                GH_LFAIL("gh_lattices_create: arc %d has a non-finite cost (omit absent arcs)", k);
+        }
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+            const int tx = arc_to[a0 + x], ty = arc_to[a0 + y];
+            if (tx != ty) return tx < ty;
+            return arc_from[a0 + x] < arc_from[a0 + y];
+        });
+        const size_t ptr_base = h_ptr.size();
+        h_ptr.resize(ptr_base + R + 1, 0);
+        int32_t* ptr = h_ptr.data() + ptr_base;
+        std::vector<int> level(R, 0);
+        for (int k = 0; k < A; ++k) ptr[arc_to[a0 + idx[k]] + 1]++;
+        for (int r = 0; r < R; ++r) ptr[r + 1] += ptr[r];
+        for (int k = 0; k < A; ++k) {
+            const int to = arc_to[a0 + idx[k]], fr = arc_from[a0 + idx[k]];
+            uint32_t w = (uint32_t)fr;
+            const bool same = h_state[r0 + to] < 0 || h_state[r0 + fr] < 0;  // decode.py:109
+            if (same) {
+                w |= GH_ARC_SAME;
+                if (fr >= to) w |= GH_ARC_DEAD;  // not yet computed in this column: still +inf
+            }
+            h_prow[a0 + k] = w;
+            h_pcost[a0 + k] = arc_cost[a0 + idx[k]];
+        }
+        // levels: rows ascending, so every live same-column origin (< row) is already levelled
+        int nlev = 1;
+        for (int r = 0; r < R; ++r) {
+            int lv = 0;
+            for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                const uint32_t w = h_prow[a0 + p];
+                if ((w & GH_ARC_SAME) && !(w & GH_ARC_DEAD)) lv = std::max(lv, level[w & GH_ARC_ROW] + 1);
+            }
+            level[r] = lv;
+            nlev = std::max(nlev, lv + 1);
+        }
+        const size_t lev_base = h_lev.size();
+        h_lev.resize(lev_base + nlev + 1, 0);
+        int32_t* lp = h_lev.data() + lev_base;
+        for (int r = 0; r < R; ++r) lp[level[r] + 1]++;
+        int max_level_rows = 0;
+        for (int k = 0; k < nlev; ++k) { max_level_rows = std::max(max_level_rows, lp[k + 1]); lp[k + 1] += lp[k]; }
+        {
+            std::vector<int> fill(lp, lp + nlev);
+            for (int r = 0; r < R; ++r) h_order[r0 + fill[level[r]]++] = r;
+        }
+        int max_state = -1;
+        for (int r = 0; r < R; ++r) max_state = std::max(max_state, h_state[r0 + r]);
+        gh_lattice_host lh;
+        lh.R = R; lh.A = A; lh.nlev = nlev; lh.n_start = ns; lh.n_end = ne;
+        lh.row_base = r0; lh.arc_base = a0; lh.end_base = end_off[l]; lh.max_state = max_state;
+        lt->lat.push_back(lh);
+        gh_lattices::desc d;
+        d.R = R; d.nlev = nlev; d.n_end = ne; d.pad = max_level_rows;
+        d.row_base = r0; d.ptr_base = (int64_t)ptr_base; d.arc_base = a0; d.lev_base = (int64_t)lev_base;
+        d.end_base = end_off[l];
+        lt->h_desc.push_back(d);
+        lt->max_R = std::max(lt->max_R, R);
+        lt->max_nlev = std::max(lt->max_nlev, nlev);
+#undef GH_LFAIL
+    }
+    int rc = GH_OK;
+    if ((rc = upload(&lt->d_row_state, h_state)) || (rc = upload(&lt->d_row_start, h_start)) ||
+        (rc = upload(&lt->d_pred_ptr, h_ptr)) || (rc = upload(&lt->d_pred_row, h_prow)) ||
+        (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
+        (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_end_rows, h_end)) ||
+        (rc = upload(&lt->d_desc, lt->h_desc))) {
+        gh_lattices_destroy(lt);
+        return rc;
+    }
+    *out = lt;
+    return GH_OK;
+}
+
+extern "C" void gh_lattices_destroy(gh_lattices* l) {
+    if (!l) return;
+    hipSetDevice(l->ctx->device);
+    hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
+    hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
+    hipFree(l->d_desc);
+    delete l;
+}
+
+extern "C" int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T) {
+    if (!lat || l < 0 || l >= lat->L) return -1;
+    return T * lat->lat[l].nlev;  // at most one cell per (column, level)
+}
+
+// ------------------------------------------------------------------ viterbi
+extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                          double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
+                          const int64_t* path_off, int32_t* out_path_len, double* out_costs,
+                          const int64_t* costs_off) {
+    GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
+    GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
+    GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
+    GH_REQUIRE(!out_costs || costs_off, "gh_viterbi: out_costs needs costs_off");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U;
+    if (U == 0) return GH_OK;
+    const int S = b->nll_S;
+    const bool want_path = out_path != nullptr;
+    for (int l = 0; l < lat->L; ++l)
+        GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
+                   lat->lat[l].max_state, S);
+    // per-utterance bookkeeping (host)
+    std::vector<int64_t> end_off(U + 1, 0), perm(U);
+    for (int64_t u = 0; u < U; ++u) {
+        const int l = utt_lattice ? utt_lattice[u] : 0;
+        GH_REQUIRE(l >= 0 && l < lat->L, "gh_viterbi: utt_lattice[%lld]=%d out of range", (long long)u, l);
+        end_off[u + 1] = end_off[u] + lat->lat[l].n_end;
+        if (want_path) {
+            const int64_t T = b->offsets[u + 1] - b->offsets[u];
+            GH_REQUIRE(path_off[u + 1] - path_off[u] >= (T > 1 ? T * lat->lat[l].nlev : 0),
+                       "gh_viterbi: path capacity of utterance %lld too small", (long long)u);
+        }
+    }
+    std::iota(perm.begin(), perm.end(), (int64_t)0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) {
+        return b->offsets[x + 1] - b->offsets[x] > b->offsets[y + 1] - b->offsets[y];
+    });
+    // back-pointer scratch is chunked (<= 4 GiB per launch)
+    const size_t BP_BUDGET = (size_t)4 << 30;
+    std::vector<int64_t> bp_off(U, 0);
+    std::vector<int64_t> chunk_begin{0};
+    size_t bp_max = 0;
+    if (want_path) {
+        size_t acc = 0;
+        for (int64_t k = 0; k < U; ++k) {
+            const int64_t u = perm[k];
+            const int l = utt_lattice ? utt_lattice[u] : 0;
+            const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+            if (acc && (acc + need) * 2 > BP_BUDGET) {
+                chunk_begin.push_back(k);
+                bp_max = std::max(bp_max, acc);
+                acc = 0;
+            }
+            bp_off[k] = (int64_t)acc;
+            acc += need;
+        }
+        bp_max = std::max(bp_max, acc);
+    }
+    chunk_begin.push_back(U);
+    const int64_t n_path = want_path ? path_off[U] : 0;
+    const int64_t n_costs = out_costs ? costs_off[U] : 0;
+
+    gh_vit_args a;
+    memset(&a, 0, sizeof a);
+    int64_t *d_perm, *d_bpoff, *d_endoff, *d_pathoff = nullptr, *d_costsoff = nullptr;
+    int32_t *d_uttlat = nullptr, *d_bestend, *d_path = nullptr, *d_pathlen = nullptr;
+    double *d_endcost, *d_costs = nullptr;
+    uint16_t* d_bp = nullptr;
+    Carver cv;
+    cv.add(&d_perm, U); cv.add(&d_bpoff, U); cv.add(&d_endoff, U + 1);
+    cv.add(&d_bestend, U); cv.add(&d_endcost, end_off[U]);
+    if (utt_lattice) cv.add(&d_uttlat, U);
+    if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); cv.add(&d_bp, bp_max); }
+    if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+    GH_HIP(hipMemcpyAsync(d_perm, perm.data(), U * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
+    if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (out_costs) GH_HIP(hipMemcpyAsync(d_costsoff, costs_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+
+    a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_start = lat->d_row_start;
+    a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
+    a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
+    a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
+    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = d_perm;
+    a.bp = d_bp; a.bp_off = d_bpoff; a.end_cost = d_endcost; a.end_off = d_endoff; a.best_end = d_bestend;
+    a.path = d_path; a.path_off = d_pathoff; a.path_len = d_pathlen; a.costs = d_costs; a.costs_off = d_costsoff;
+    a.flag = ctx->d_flag;
+
+    int max_level_rows = 1;
+    for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
+    const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
+    const size_t lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
+    if (lds > 160 * 1024) {
+        gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
+        return GH_ERR_UNSUPPORTED;
+    }
+    for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
+        a.u_begin = chunk_begin[c];
+        rc = gh_launch_viterbi(ctx, a, chunk_begin[c + 1] - chunk_begin[c], block, lds, b->dtype == GH_F64, want_path);
+        if (rc) return rc;
+    }
+    int flag = 0;
+    GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (out_end_cost) GH_HIP(hipMemcpyAsync(out_end_cost, d_endcost, end_off[U] * 8, hipMemcpyDeviceToHost, st));
+    if (out_best_end) GH_HIP(hipMemcpyAsync(out_best_end, d_bestend, U * 4, hipMemcpyDeviceToHost, st));
+    if (want_path) {
+        GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
+        GH_HIP(hipMemcpyAsync(out_path_len, d_pathlen, U * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, n_costs * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    if (flag & 1) {
+        gh_set_error("gh_viterbi: a DP cell chose itself as its origin (decode.py:120-121)");
+        return GH_ERR_SELF_POINTER;
+    }
+    if (flag & 4) {
+        gh_set_error("gh_viterbi: back-trace does not terminate (cycle of same-column arcs between unreachable cells)");
+        return GH_ERR_INVALID;
+    }
+    if (flag & 2) {
+        gh_set_error("gh_viterbi: back-trace reached a cell without predecessor");
+        return GH_ERR_INVALID;
+    }
+    return GH_OK;
+}

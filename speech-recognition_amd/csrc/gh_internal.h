@@ -1,0 +1,105 @@
+// Internal structures of libgmmhmm (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/gmmhmm.h"
+
+void gh_set_error(const char* fmt, ...);
+
+#define GH_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            gh_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return (e_ == hipErrorOutOfMemory) ? GH_ERR_NOMEM : GH_ERR_HIP;              \
+        }                                                                                \
+    } while (0)
+
+#define GH_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            gh_set_error(__VA_ARGS__);        \
+            return GH_ERR_INVALID;            \
+        }                                     \
+    } while (0)
+
+struct gh_ctx {
+    int device;
+    hipStream_t stream;
+    int n_cu;
+    // growable device scratch (back-pointers, partial statistics, ...)
+    void* scratch;
+    size_t scratch_bytes;
+    int* d_flag;  // device error flag (self-pointing DP cell etc.)
+};
+
+int gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
+
+// Parameter layout shared by the likelihood kernels (GEMM form):
+//   ll[g] = C[g] + sum_d ( A[g,d] * x_d^2 + B[g,d] * x_d )
+//   A = -0.5/var, B = mean/var, C = log w - 0.5*(D log 2pi + sum log var + sum mean^2/var)
+// g = s*M + m.  KP = D rounded up to a multiple of 4 (zero padded).
+struct gh_gmm {
+    gh_ctx* ctx;
+    int S, M, D, KP;
+    std::vector<double> hA, hB, hC;  // host fp64 master copies [G,KP], [G,KP], [G]
+    double *dA64, *dB64, *dC64;      // device fp64
+    float *dA32, *dB32, *dC32;       // device fp32
+    // plain parameters (fp64) for the training kernels: mean, inv_var [G,D], logc [G]
+    double *dMean, *dIvar, *dLogc;
+};
+
+struct gh_batch {
+    gh_ctx* ctx;
+    gh_dtype dtype;
+    int D;
+    int64_t N, U;
+    void* feats;  // device [N,D]
+    bool owns_feats;
+    std::vector<int64_t> offsets;  // host [U+1]
+    int64_t* d_offsets;            // device [U+1]
+    int64_t max_T;
+    void* nll;  // device [N,S] (dtype) after gh_loglik
+    int nll_S;
+};
+
+// arc flag bits stored in pred_row
+#define GH_ARC_SAME 0x80000000u  // reads the SAME column (touches a non-emitting row)
+#define GH_ARC_DEAD 0x40000000u  // same-column origin >= destination: reads +inf
+#define GH_ARC_ROW 0x3fffffffu
+
+struct gh_lattice_host {
+    int R, A, nlev, n_start, n_end;
+    int64_t row_base, arc_base, end_base;  // offsets into the concatenated device arrays
+    int max_state;
+};
+
+struct gh_lattices {
+    gh_ctx* ctx;
+    int L;
+    std::vector<gh_lattice_host> lat;
+    // concatenated device arrays
+    int32_t* d_row_state;  // [Rtot] state or -1
+    uint8_t* d_row_start;  // [Rtot] 1 = start row
+    int32_t* d_pred_ptr;   // [Rtot + L] CSR per graph (R_l + 1 entries each, local to arc_base)
+    uint32_t* d_pred_row;  // [Atot] origin row | flags, ascending origin per destination
+    double* d_pred_cost;   // [Atot]
+    int32_t* d_order;      // [Rtot] rows sorted by (level, row)
+    int32_t* d_level_ptr;  // per graph: nlev+1 entries at lev_base
+    int32_t* d_end_rows;   // [Etot]
+    // per-graph descriptor table on device
+    struct desc {
+        int32_t R, nlev, n_end, pad;
+        int64_t row_base, ptr_base, arc_base, lev_base, end_base;
+    };
+    desc* d_desc;
+    std::vector<desc> h_desc;
+    int max_R, max_nlev;
+};
+
+// kernels (gh_loglik.hip / gh_viterbi.hip)
+int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);

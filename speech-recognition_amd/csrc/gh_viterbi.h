@@ -1,0 +1,36 @@
+#pragma once
+#include "gh_internal.h"
+
+// Kernel argument block of the lattice Viterbi (all pointers are device pointers).
+struct gh_vit_args {
+    const gh_lattices::desc* descs;
+    const int32_t* row_state;
+    const uint8_t* row_start;
+    const int32_t* pred_ptr;
+    const uint32_t* pred_row;
+    const double* pred_cost;
+    const int32_t* order;
+    const int32_t* level_ptr;
+    const int32_t* end_rows;
+    const void* nll;  // [N,S] float or double
+    int S;
+    int r_pad;                // LDS column stride (>= max R, even)
+    const int64_t* utt_off;   // [U+1] frame offsets
+    const int32_t* utt_lat;   // [U] graph of each utterance, or null (graph 0)
+    const int64_t* perm;      // launch slot -> utterance (longest first), or null
+    int64_t u_begin;          // first launch slot of this chunk
+    uint16_t* bp;             // back-pointer scratch of this chunk
+    const int64_t* bp_off;    // [slots] offset of each launch slot's [T,R] block
+    double* end_cost;         // [sum n_end]
+    const int64_t* end_off;   // [U]
+    int32_t* best_end;        // [U]
+    int32_t* path;            // [.., 2]
+    const int64_t* path_off;  // [U+1]
+    int32_t* path_len;        // [U]
+    double* costs;            // optional full matrices
+    const int64_t* costs_off; // [U+1]
+    int* flag;
+};
+
+int gh_launch_viterbi(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int block, size_t lds_bytes,
+                      bool f64, bool want_path);

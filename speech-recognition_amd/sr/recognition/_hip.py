@@ -1,0 +1,319 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libgmmhmm.so (the C ABI declared in include/gmmhmm.h).
+
+This is the only door from the Python mirror of `sr.recognition` to the GPU.
+There is NO CPU fallback: if the library is missing or no MI355X is visible,
+every entry point raises `BackendError`.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("GMMHMM_LIB") or os.path.normpath(
+    os.path.join(_HERE, "..", "..", "lib", "libgmmhmm.so"))
+
+GH_F32, GH_F64 = 0, 1
+GH_ERR_SELF_POINTER = -5
+
+_c_i32p = C.POINTER(C.c_int32)
+_c_i64p = C.POINTER(C.c_int64)
+_c_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/gmmhmm.h one to one
+SIGNATURES = {
+    "gh_last_error": (C.c_char_p, []),
+    "gh_version": (C.c_int, []),
+    "gh_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_ctx_destroy": (None, [C.c_void_p]),
+    "gh_ctx_sync": (C.c_int, [C.c_void_p]),
+    "gh_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "gh_gmm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p,
+                                C.POINTER(C.c_void_p)]),
+    "gh_gmm_destroy": (None, [C.c_void_p]),
+    "gh_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
+                                  C.POINTER(C.c_void_p)]),
+    "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
+                                C.POINTER(C.c_void_p)]),
+    "gh_batch_destroy": (None, [C.c_void_p]),
+    "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
+    "gh_component_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _c_f64p, _c_f64p]),
+    "gh_distance_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p,
+                                     C.c_int, _c_f64p]),
+    "gh_lattices_create": (C.c_int, [C.c_void_p, C.c_int, _c_i64p, _c_i32p, _c_i64p, _c_i32p, _c_i32p,
+                                     _c_f64p, _c_i64p, _c_i32p, _c_i64p, _c_i32p, C.POINTER(C.c_void_p)]),
+    "gh_lattices_destroy": (None, [C.c_void_p]),
+    "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
+                             _c_i32p, _c_f64p, _c_i64p]),
+    "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
+}
+
+
+class BackendError(RuntimeError):
+    """The HIP backend is unavailable or a library call failed."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(path=None):
+    """dlopen libgmmhmm.so and declare every prototype.  Needs no GPU."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise BackendError(
+                "libgmmhmm.so not found at %s -- build it with `python speech-recognition_amd/build.py` "
+                "(there is no CPU fallback)" % p)
+        try:
+            lib = C.CDLL(p)
+        except OSError as e:
+            raise BackendError("cannot load %s: %s" % (p, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        msg = lib.gh_last_error().decode("utf-8", "replace")
+        if rc == GH_ERR_SELF_POINTER:
+            raise NameError("FUCKED")  # the reference's own exception (decode.py:120-121)
+        raise BackendError("libgmmhmm error %d: %s" % (rc, msg))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Context:
+    """One GPU (gh_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.gh_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def sync(self):
+        _check(self.lib, self.lib.gh_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.gh_ctx_stream(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("GMMHMM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx
+
+
+class PackedGMM:
+    """S mixtures x M components x D dims on the GPU (gh_gmm)."""
+
+    def __init__(self, ctx, mean, var, weight):
+        mean, var, weight = _f64(mean), _f64(var), _f64(weight)
+        S, M, D = mean.shape
+        assert var.shape == (S, M, D) and weight.shape == (S, M)
+        self.ctx, self.S, self.M, self.D = ctx, S, M, D
+        h = C.c_void_p()
+        rc = ctx.lib.gh_gmm_create(ctx.h, S, M, D, _ptr(mean, _c_f64p), _ptr(var, _c_f64p),
+                                   _ptr(weight, _c_f64p), C.byref(h))
+        if rc == -1 and b"singular" in ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")  # hmm_state.py:17,30
+        _check(ctx.lib, rc)
+        self.h = h
+
+    def component_loglik(self, state, x):
+        x = _f64(x)
+        out = np.empty((x.shape[0], self.M))
+        _check(self.ctx.lib, self.ctx.lib.gh_component_loglik(self.ctx.h, self.h, int(state), x.shape[0],
+                                                              _ptr(x, _c_f64p), _ptr(out, _c_f64p)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gh_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Ragged batch of utterances resident in HBM (gh_batch)."""
+
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None):
+        self.ctx = ctx
+        self.np_dtype = np.dtype(dtype)
+        assert self.np_dtype in (np.dtype(np.float32), np.dtype(np.float64))
+        if utterances is not None:
+            lens = [len(u) for u in utterances]
+            offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=offsets[1:])
+            D = np.asarray(utterances[0]).shape[1] if lens else 1
+            feats = (np.concatenate([np.asarray(u, dtype=self.np_dtype).reshape(-1, D) for u in utterances])
+                     if lens else np.zeros((0, D), dtype=self.np_dtype))
+        feats = np.ascontiguousarray(feats, dtype=self.np_dtype)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.N, self.D = feats.shape
+        self.U = len(self.offsets) - 1
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.gh_batch_create(ctx.h, GH_F64 if self.np_dtype == np.float64 else GH_F32, self.D,
+                                                self.N, self.U, feats.ctypes.data_as(C.c_void_p),
+                                                _ptr(self.offsets, _c_i64p), C.byref(h)))
+        self.h = h
+        self.S = None
+
+    @property
+    def lengths(self):
+        return np.diff(self.offsets)
+
+    def loglik(self, gmm, fetch=True):
+        """A3 for every frame x state; the [N,S] matrix stays resident for the DPs."""
+        out = np.empty((self.N, gmm.S), dtype=self.np_dtype) if fetch else None
+        _check(self.ctx.lib, self.ctx.lib.gh_loglik(self.ctx.h, gmm.h, self.h,
+                                                    None if out is None else out.ctypes.data_as(C.c_void_p)))
+        self.S = gmm.S
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gh_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Lattices:
+    """One or more DP graphs on the GPU (gh_lattices).
+
+    `graphs` is a list of dicts with keys
+        row_state [R] int (-1 = non-emitting), arc_to, arc_from [A] int, arc_cost [A] float,
+        start_rows, end_rows (lists of local row indices)
+    """
+
+    def __init__(self, ctx, graphs):
+        self.ctx = ctx
+        L = len(graphs)
+        cat = lambda key, dt: np.ascontiguousarray(
+            np.concatenate([np.asarray(g[key], dtype=dt).ravel() for g in graphs]) if L else np.zeros(0, dt), dtype=dt)
+        off = lambda key: np.ascontiguousarray(
+            np.concatenate([[0], np.cumsum([len(g[key]) for g in graphs])]), dtype=np.int64)
+        self.row_off, self.arc_off = off("row_state"), off("arc_to")
+        self.start_off, self.end_off = off("start_rows"), off("end_rows")
+        self.n_end = [len(g["end_rows"]) for g in graphs]
+        self.R = [len(g["row_state"]) for g in graphs]
+        row_state = cat("row_state", np.int32)
+        arc_to, arc_from = cat("arc_to", np.int32), cat("arc_from", np.int32)
+        arc_cost = cat("arc_cost", np.float64)
+        start_rows, end_rows = cat("start_rows", np.int32), cat("end_rows", np.int32)
+        self.end_rows = [np.asarray(g["end_rows"], dtype=np.int64) for g in graphs]
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.gh_lattices_create(
+            ctx.h, L, _ptr(self.row_off, _c_i64p), _ptr(row_state, _c_i32p), _ptr(self.arc_off, _c_i64p),
+            _ptr(arc_to, _c_i32p), _ptr(arc_from, _c_i32p), _ptr(arc_cost, _c_f64p),
+            _ptr(self.start_off, _c_i64p), _ptr(start_rows, _c_i32p), _ptr(self.end_off, _c_i64p),
+            _ptr(end_rows, _c_i32p), C.byref(h)))
+        self.h = h
+        self.L = L
+
+    def path_cap(self, l, T):
+        return int(self.ctx.lib.gh_viterbi_path_cap(self.h, int(l), int(T)))
+
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False):
+        """A6 for every utterance.  Returns dict(end_cost [list per utt], best_end [U],
+        paths [list of int64 [K,2]], costs [list of [R,T]])."""
+        lib, U = self.ctx.lib, batch.U
+        lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
+        lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
+        T = batch.lengths
+        n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
+        end_off = np.concatenate([[0], np.cumsum(n_end)])
+        end_cost = np.empty(int(end_off[-1]), dtype=np.float64)
+        best_end = np.empty(U, dtype=np.int32)
+        path = path_off = path_len = costs = costs_off = None
+        if want_path:
+            cap = np.array([self.path_cap(lidx[u], T[u]) if T[u] > 1 else 0 for u in range(U)], dtype=np.int64)
+            path_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.int64)
+            path = np.empty((int(path_off[-1]), 2), dtype=np.int32)
+            path_len = np.empty(U, dtype=np.int32)
+        if want_costs:
+            Rs = np.asarray(self.R, dtype=np.int64)[lidx]
+            costs_off = np.concatenate([[0], np.cumsum(Rs * T)]).astype(np.int64)
+            costs = np.empty(int(costs_off[-1]), dtype=np.float64)
+        _check(lib, lib.gh_viterbi(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(end_cost, _c_f64p),
+                                   _ptr(best_end, _c_i32p), _ptr(path, _c_i32p), _ptr(path_off, _c_i64p),
+                                   _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p), _ptr(costs_off, _c_i64p)))
+        out = dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost,
+                   end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if U <= 100000 else None)
+        if want_path:
+            out["paths"] = [path[path_off[u]:path_off[u] + path_len[u]].astype(np.int64) for u in range(U)]
+        if want_costs:
+            out["costs"] = [costs[costs_off[u]:costs_off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u]))
+                            for u in range(U)]
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gh_lattices_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def distance_matrix(ctx, x, y, var=None):
+    """dist[i, n] between frames x[n] and templates y[i]; var None -> Euclid,
+    [D] -> shared variance, [K,D] -> per-template variance (mahalanobis)."""
+    x, y = _f64(x), _f64(y)
+    K, D = y.shape
+    out = np.empty((K, x.shape[0]))
+    v = None if var is None else _f64(var).reshape(-1, D)
+    _check(ctx.lib, ctx.lib.gh_distance_matrix(ctx.h, x.shape[0], K, D, _ptr(x, _c_f64p), _ptr(y, _c_f64p),
+                                               _ptr(v, _c_f64p), 0 if v is None else v.shape[0],
+                                               _ptr(out, _c_f64p)))
+    return out

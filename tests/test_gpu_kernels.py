@@ -1,0 +1,243 @@
+# -*- coding: utf-8 -*-
+"""GPU parity tests of the HIP kernels, called through the C ABI (ctypes),
+against the CPU oracle and the golden vectors captured from the reference.
+
+Tolerances: likelihoods fp64 1e-10 rel (north star: 1e-5), fp32 1e-3 rel (north
+star: 1e-3); DP costs fp64 1e-10 rel; paths / end choices / decodes bit-exact.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sr.recognition import _hip
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    return hip.default_context()
+
+
+def arcs_of(trans):
+    to, frm = np.nonzero(~np.isinf(trans))
+    return to, frm, trans[to, frm]
+
+
+def graph(row_state, trans, start_rows, end_rows):
+    to, frm, cost = arcs_of(trans)
+    return dict(row_state=row_state, arc_to=to, arc_from=frm, arc_cost=cost, start_rows=start_rows,
+                end_rows=end_rows)
+
+
+# ---------------------------------------------------------------------------- A3
+@pytest.mark.parametrize("tag", ["m1d13", "m8d39"])
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-10), (np.float32, 1e-3)])
+def test_loglik_golden(hip, ctx, tag, dtype, rtol):
+    g = load_golden("G1_gmm_evaluate_" + tag)
+    gmm = hip.PackedGMM(ctx, g["means"], g["vars"], g["w"])
+    b = hip.Batch(ctx, feats=g["X"], offsets=[0, len(g["X"])], dtype=dtype)
+    nll = b.loglik(gmm)
+    np.testing.assert_allclose(nll, g["nll"], rtol=rtol)
+    if dtype == np.float64:
+        comp = gmm.component_loglik(7, g["X"])
+        np.testing.assert_allclose(np.exp(comp), g["comp"][:, 7], rtol=1e-9)
+
+
+@pytest.mark.parametrize("S,M,D,N", [(3, 1, 6, 130), (50, 8, 39, 1000), (7, 5, 13, 257), (4, 3, 50, 64), (2, 9, 24, 63)])
+def test_loglik_vs_oracle_shapes(hip, ctx, S, M, D, N):
+    rng = np.random.default_rng(S * 100 + M)
+    means = rng.normal(size=(S, M, D))
+    vars_ = rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    X = rng.normal(size=(N, D)) * 1.3
+    ref = O.gmm_neg_loglik_batch(X, means, vars_, w)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    for dtype, rtol in ((np.float64, 1e-11), (np.float32, 1e-3)):
+        b = hip.Batch(ctx, feats=X, offsets=[0, 10, 10, N], dtype=dtype)
+        np.testing.assert_allclose(b.loglik(gmm), ref, rtol=rtol)
+
+
+def test_loglik_zero_weight_and_singular(hip, ctx):
+    rng = np.random.default_rng(5)
+    means, vars_ = rng.normal(size=(2, 3, 4)), rng.uniform(0.5, 1.5, size=(2, 3, 4))
+    w = np.array([[0.5, 0.0, 0.5], [1.0, 0.0, 0.0]])
+    X = rng.normal(size=(9, 4))
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, feats=X, offsets=[0, 9])
+    with np.errstate(divide="ignore"):
+        ref = O.gmm_neg_loglik_batch(X, means, vars_, w)
+    np.testing.assert_allclose(b.loglik(gmm), ref, rtol=1e-11)
+    vars_[1, 2, 3] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        hip.PackedGMM(ctx, means, vars_, w)
+
+
+# ---------------------------------------------------------------------------- A6
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_viterbi_isolated_golden(hip, ctx, tag):
+    """G3: each word model on its own (one graph per word, reference semantics:
+    single start row 0, end row R-1) AND all words stacked into one graph."""
+    g = load_golden("G3_isolated_decode_" + tag)
+    means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]
+    W, n, M, D = means.shape
+    U = len(g["words"])
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    xs = [g["x%d" % u] for u in range(U)]
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    graphs = [graph(np.arange(n) + i * n, trans, [0], [n - 1]) for i in range(W)]
+    lat = hip.Lattices(ctx, graphs)
+    for i in range(W):
+        r = lat.viterbi(b, utt_lattice=np.full(U, i), want_costs=True)
+        for u in range(U):
+            ref = g["costs_%d_%d" % (u, i)]
+            fin = ~np.isinf(ref)
+            np.testing.assert_array_equal(np.isinf(r["costs"][u]), ~fin)
+            np.testing.assert_allclose(r["costs"][u][fin], ref[fin], rtol=1e-10)
+            np.testing.assert_array_equal(r["paths"][u], g["path_%d_%d" % (u, i)])
+    # stacked: W independent chains in one graph, one start and one end row per word
+    big = np.full((W * n, W * n), np.inf)
+    for i in range(W):
+        big[i * n:(i + 1) * n, i * n:(i + 1) * n] = trans
+    st = hip.Lattices(ctx, [graph(np.arange(W * n), big, [i * n for i in range(W)], [i * n + n - 1 for i in range(W)])])
+    r = st.viterbi(b, want_path=False)
+    for u in range(U):
+        np.testing.assert_allclose(r["end_cost"][u], g["evaluate_%d" % u], rtol=1e-10)
+        assert int(np.argmin(r["end_cost"][u])) == int(g["words"][u])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_viterbi_lattice_golden(hip, ctx, dtype):
+    """G4: K-layer word lattices (same-column hops through non-emitting rows)."""
+    g = load_golden("G4_lattice_decode")
+    means, vars_, w, wt = g["means"], g["vars"], g["w"], g["word_trans"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    graphs, xs, Ks = [], [], (1, 2, 3, 7)
+    for K in Ks:
+        p = "K%d_" % K
+        rw, rs = g[p + "row_word"], g[p + "row_state"]
+        graphs.append(dict(row_state=np.where(rw < 0, -1, rw * n + rs), arc_to=g[p + "arc_to"],
+                           arc_from=g[p + "arc_from"], arc_cost=g[p + "arc_cost"], start_rows=[0],
+                           end_rows=g[p + "ends"]))
+        xs.append(g[p + "x"])
+    lat = hip.Lattices(ctx, graphs)
+    b = hip.Batch(ctx, xs, dtype=dtype)
+    b.loglik(gmm, fetch=False)
+    r = lat.viterbi(b, utt_lattice=np.arange(len(Ks)), want_costs=True)
+    for u, K in enumerate(Ks):
+        p = "K%d_" % K
+        ref = g[p + "costs"]
+        fin = ~np.isinf(ref)
+        np.testing.assert_array_equal(np.isinf(r["costs"][u]), ~fin)
+        np.testing.assert_allclose(r["costs"][u][fin], ref[fin], rtol=1e-10 if dtype == np.float64 else 1e-5)
+        np.testing.assert_array_equal(r["paths"][u], g[p + "path"])
+        rw = g[p + "row_word"]
+        assert O.path_to_words(r["paths"][u], rw < 0, rw) == list(g[p + "digits"])
+
+
+def test_viterbi_edges_golden(hip, ctx):
+    g = load_golden("G6_decode_edges")
+    means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, [g["t1_x"], g["t2_x"], g["tie_x"], np.zeros((0, means.shape[2]))])
+    b.loglik(gmm, fetch=False)
+    lat = hip.Lattices(ctx, [
+        graph(np.arange(5), trans, [0], [4]),
+        graph([0, 1, 2, 3, 3], g["tie_trans"], [0], [3, 4]),
+        graph([0, 1, 2, 3, 3], g["tie_trans"], [0], [4, 3]),
+        graph([0, 1, 1], g["ptie_trans"], [0], [2]),
+    ])
+    r = lat.viterbi(b, utt_lattice=[0, 0, 1, 0], want_costs=True)
+    # T = 1: every arc reads column 0 itself; empty path
+    np.testing.assert_allclose(r["costs"][0], g["t1_costs"], rtol=1e-10)
+    assert r["paths"][0].shape[0] == 0
+    # T = 2: unreachable end, back-pointers of all-inf cells still followed
+    ref = g["t2_costs"]
+    np.testing.assert_array_equal(np.isinf(r["costs"][1]), np.isinf(ref))
+    np.testing.assert_array_equal(r["paths"][1], g["t2_path"])
+    assert np.isinf(r["end_cost"][1][0])
+    # equal end costs: the last listed end wins
+    np.testing.assert_array_equal(r["paths"][2], g["tie_path"])
+    assert r["best_end"][2] == 1 and r["end_cost"][2][0] == r["end_cost"][2][1]
+    assert r["paths"][3].shape[0] == 0 and r["best_end"][3] == -1  # empty utterance
+    r2 = lat.viterbi(b, utt_lattice=[0, 0, 2, 3])
+    np.testing.assert_array_equal(r2["paths"][2], g["tie_path_rev"])
+    r3 = lat.viterbi(b, utt_lattice=[3, 3, 3, 3], want_costs=True)
+    np.testing.assert_allclose(r3["costs"][2], g["ptie_costs"], rtol=1e-10)
+    np.testing.assert_array_equal(r3["paths"][2], g["ptie_path"])
+
+
+def test_viterbi_random_graphs_vs_oracle(hip, ctx):
+    """Random sparse graphs with non-emitting rows at random positions (multi-level
+    same-column chains, dead same-column back arcs) against the oracle."""
+    rng = np.random.default_rng(77)
+    S, M, D = 6, 2, 5
+    means, vars_ = rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    graphs, xs, refs = [], [], []
+    while len(graphs) < 24:
+        R = int(rng.integers(3, 40))
+        row_state = rng.integers(0, S, size=R)
+        row_state[rng.random(R) < 0.3] = -1
+        trans = np.full((R, R), np.inf)
+        for r in range(R):
+            for o in rng.integers(0, R, size=rng.integers(1, 4)):
+                trans[r, o] = rng.uniform(0.1, 3.0)
+        ends = list(rng.integers(0, R, size=rng.integers(1, 4)))
+        T = int(rng.integers(2, 30))
+        x = rng.normal(size=(T, D))
+        nes = row_state < 0
+        states = [None if nes[r] else (means[row_state[r]], vars_[row_state[r]], w[row_state[r]]) for r in range(R)]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = O.decode_states(O.emission_matrix(x, states), nes, trans, end_points=[[e, -1] for e in ends])
+        except (IndexError, NameError, RuntimeError):
+            continue  # graphs on which the reference itself raises / never returns
+        graphs.append(graph(row_state, trans, [0], ends))
+        xs.append(x)
+        refs.append(ref)
+    lat = hip.Lattices(ctx, graphs)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    r = lat.viterbi(b, utt_lattice=np.arange(len(xs)), want_costs=True)
+    for u, (costs, path) in enumerate(refs):
+        fin = ~np.isinf(costs)
+        np.testing.assert_array_equal(np.isinf(r["costs"][u]), ~fin)
+        np.testing.assert_allclose(r["costs"][u][fin], costs[fin], rtol=1e-10)
+        np.testing.assert_array_equal(r["paths"][u], path.reshape(-1, 2))
+
+
+def test_viterbi_self_pointer_is_nameerror(hip, ctx):
+    gmm = hip.PackedGMM(ctx, np.zeros((1, 1, 2)), np.ones((1, 1, 2)), np.ones((1, 1)))
+    b = hip.Batch(ctx, [np.zeros((3, 2))])
+    b.loglik(gmm, fetch=False)
+    trans = np.full((2, 2), np.inf)
+    trans[1, 1] = 0.0  # non-emitting self loop: first (only) candidate is the cell itself
+    lat = hip.Lattices(ctx, [graph([0, -1], trans, [0], [1])])
+    with pytest.raises(NameError):
+        lat.viterbi(b)
+
+
+# ---------------------------------------------------------------------------- A2
+def test_distance_matrix(hip, ctx):
+    g = load_golden("G2_mahalanobis")
+    v1, v2, var = g["v1"], g["v2"], g["var"]
+    out = hip.distance_matrix(ctx, v1, v2[:1], var[:1])
+    ref = np.array([O.mahalanobis(a, v2[0], var[0]) for a in v1])
+    np.testing.assert_allclose(out[0], ref, rtol=1e-13)
+    out = hip.distance_matrix(ctx, v1, v2, var)
+    np.testing.assert_allclose(np.diag(out), g["out"], rtol=1e-13)
+    out = hip.distance_matrix(ctx, v1, v2)
+    np.testing.assert_allclose(out[3, 5], np.linalg.norm(v1[5] - v2[3]), rtol=1e-14)
