@@ -102,11 +102,13 @@ def gmm_neg_loglik_batch(X, means, vars_, w):
     return out
 
 
-def emission_matrix(x, states):
+def emission_matrix(x, states, dense=False):
     """E[R,T] for a reference-style state list.  `states[r]` is None for a
     non-emitting row (NES.evaluate -> 0, hmm_state.py:90-91) or a
     (means[M,D], vars[M,D], w[M]) tuple (A3).  Distinct tuples are evaluated
-    once and shared between rows (the reference recomputes per cell)."""
+    once and shared between rows (the reference recomputes per cell).
+    `dense=True` evaluates through dense inv(diag(var)) matrices like the
+    reference does (hmm_state.py:17,42) -- used when timing the CPU baseline."""
     T = len(x)
     E = np.zeros((len(states), T))
     cache = {}
@@ -115,7 +117,8 @@ def emission_matrix(x, states):
             continue
         key = id(st)
         if key not in cache:
-            cache[key] = np.array([gmm_evaluate(x[t], *st) for t in range(T)])
+            dinv = np.array([np.linalg.inv(np.diag(v)) for v in st[1]]) if dense else None
+            cache[key] = np.array([gmm_evaluate(x[t], *st, dense_inv=dinv) for t in range(T)])
         E[r] = cache[key]
     return E
 
