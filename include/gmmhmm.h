@@ -148,6 +148,43 @@ int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
 /* upper bound on the number of path cells of an utterance of T frames on graph l */
 int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T);
 
+/* ------------------------------------------------------------------ A5: dtw
+ * Template DP of every utterance of an fp64 batch against the n template rows y
+ * (decode.py:7-77): every origin of the previous column is a candidate (+inf arcs
+ * included), first minimum wins, optional beam with the reference's "-1 mark"
+ * semantics, path from (n-1, T-1) back to (0, 0), end cell excluded.
+ *   var        NULL: Euclidean norm (default dist_fun); [n,D]: mahalanobis(x, y[i], var[i])
+ *   trans      dense [n,n], +inf = no arc
+ *   beam       <= 0: no pruning
+ *   dist_host  optional caller-supplied distances (an arbitrary Python dist_fun evaluated
+ *              by the caller), utterance u = [n, T_u] block at n*utt_offsets[u]; then y/var unused
+ *   out_costs  same layout as dist_host (marked cells: -1 in the last column, +inf elsewhere)
+ *   out_path   [N, 2] (row, col) pairs, utterance u at utt_offsets[u]; out_path_len [U]
+ * n <= 64. */
+int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, const double* var,
+           const double* trans, int beam, const double* dist_host,
+           double* out_costs, int32_t* out_path, int32_t* out_path_len);
+
+/* ---------------------------------------------- A14: k-means assignment step
+ * clusters[i] = argmin_c dist(centroid_c, x_i) over frames [first, first+count) of an
+ * fp64 batch (the N x k loop of kmeans.py:180-186).  var NULL: Euclidean; var [D]: the
+ * shared variance cov[0] of kmeans.py:183 (mahalanobis).  First minimum wins. */
+int gh_kmeans_assign(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t count, int k,
+                     const double* centroids /*[k,D]*/, const double* var /*[D] or NULL*/,
+                     int32_t* out_clusters /*[count]*/);
+
+/* ------------------------------------------- A7: mixture-EM E-step statistics
+ * For frames [first, first+count) of an fp64 batch and the FIRST k components given:
+ * r_ic = w_c pdf_c(x_i) / sum_{c<k} w_c pdf_c(x_i)   (hmm_state.py:127-133), accumulated as
+ *   out_stats[c, 0] = sum_i r_ic,  [c, 1+d] = sum_i r_ic (x_id - mean_cd),
+ *   [c, 1+D+d] = sum_i r_ic (x_id - mean_cd)^2      (centred on the CURRENT mean given here)
+ * i.e. the sufficient statistics of hmm_state.py:134-143,148:
+ *   new mean = mean + S1/S0,  new var = S2/S0 - (S1/S0)^2,  new weight = S0/count.
+ * This is the buffer the multi-GPU trainer all-reduces.  out_loglik (may be NULL) = sum_i log sum_{c<k} w_c pdf_c. */
+int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t count, int k,
+                     const double* mean /*[k,D]*/, const double* var /*[k,D]*/, const double* weight /*[k]*/,
+                     double* out_stats /*[k, 1+2D]*/, double* out_loglik);
+
 #ifdef __cplusplus
 }
 #endif

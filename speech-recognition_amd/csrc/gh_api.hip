@@ -1,6 +1,7 @@
 // Host side of the C ABI: handles, packing, launch orchestration.
 #include "gh_internal.h"
 #include "gh_viterbi.h"
+#include "gh_dtw.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -129,9 +130,10 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
         double sum_logv = 0, sum_m2 = 0;
         for (int d = 0; d < D; ++d) {
             const double v = var[(size_t)i * D + d], mu = mean[(size_t)i * D + d];
-            if (!(v > 0)) {  // np.linalg.inv(diag(var)) raises LinAlgError on a zero pivot (hmm_state.py:17)
+            if (v == 0) {  // np.linalg.inv(diag(var)) raises LinAlgError on a zero pivot (hmm_state.py:17);
+                           // NaN / negative variances pass and poison the likelihood, as in the reference
                 delete g;
-                gh_set_error("gh_gmm_create: var[%d,%d,%d]=%g is not positive (singular covariance)",
+                gh_set_error("gh_gmm_create: var[%d,%d,%d]=%g (singular covariance)",
                              i / M, i % M, d, v);
                 return GH_ERR_INVALID;
             }
@@ -301,8 +303,8 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int k = 0; k < A; ++k) {
             const int to = arc_to[a0 + k], fr = arc_from[a0 + k];
             if (to < 0 || to >= R || fr < 0 || fr >= R) GH_LFAIL("gh_lattices_create: arc %d out of range", k);
-            if (std::isinf(arc_cost[a0 + k]) || std::isnan(arc_cost[a0 + k]))
-                GH_LFAIL("gh_lattices_create: arc %d has a non-finite cost (omit absent arcs)", k);
+            if (std::isinf(arc_cost[a0 + k]))  // NaN is kept: the reference treats it as an arc (isinf(nan) is False)
+                GH_LFAIL("gh_lattices_create: arc %d has an infinite cost (omit absent arcs, decode.py:106)", k);
         }
         std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
             const int tx = arc_to[a0 + x], ty = arc_to[a0 + y];
@@ -512,6 +514,81 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     }
     if (flag & 2) {
         gh_set_error("gh_viterbi: back-trace reached a cell without predecessor");
+        return GH_ERR_INVALID;
+    }
+    return GH_OK;
+}
+
+// ---------------------------------------------------------------------- dtw
+extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, const double* var,
+                      const double* trans, int beam, const double* dist_host, double* out_costs,
+                      int32_t* out_path, int32_t* out_path_len) {
+    GH_REQUIRE(ctx && b && trans, "gh_dtw: NULL argument");
+    GH_REQUIRE(dist_host || y, "gh_dtw: need template rows or a distance matrix");
+    GH_REQUIRE(n > 1 && n <= 64, "gh_dtw: n=%d (2..64 supported; decode.py:22 asserts n > 1)", n);
+    GH_REQUIRE(b->dtype == GH_F64 || dist_host, "gh_dtw: built-in distances need an fp64 batch");
+    GH_REQUIRE(!out_path || out_path_len, "gh_dtw: out_path needs out_path_len");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U, N = b->N;
+    const int D = b->D;
+    if (U == 0) return GH_OK;
+    for (int64_t u = 0; u < U; ++u)
+        GH_REQUIRE(b->offsets[u + 1] - b->offsets[u] > 1, "gh_dtw: utterance %lld has fewer than 2 frames (decode.py:22)",
+                   (long long)u);
+    std::vector<double> logdet(n, 0.0);
+    if (var && !dist_host)
+        for (int i = 0; i < n; ++i) {
+            double prod = 1.0;
+            for (int d = 0; d < D; ++d) prod *= var[(size_t)i * D + d];
+            logdet[i] = 0.5 * std::log(std::pow(2.0 * M_PI, D) * prod);  // hmm_state.py:58
+        }
+    std::vector<int64_t> moff(U + 1);  // n * frame offset: [n,T] blocks
+    for (int64_t u = 0; u <= U; ++u) moff[u] = (int64_t)n * b->offsets[u];
+    double *d_y = nullptr, *d_var = nullptr, *d_ld = nullptr, *d_tr, *d_E = nullptr, *d_costs = nullptr;
+    int64_t* d_moff;
+    uint8_t* d_bp;
+    int32_t *d_path = nullptr, *d_plen = nullptr;
+    Carver cv;
+    cv.add(&d_tr, (size_t)n * n); cv.add(&d_moff, U + 1); cv.add(&d_bp, (size_t)n * N);
+    if (!dist_host) { cv.add(&d_y, (size_t)n * D); if (var) { cv.add(&d_var, (size_t)n * D); cv.add(&d_ld, n); } }
+    if (dist_host) cv.add(&d_E, (size_t)n * N);
+    if (out_costs) cv.add(&d_costs, (size_t)n * N);
+    if (out_path) { cv.add(&d_path, 2 * (size_t)N); cv.add(&d_plen, U); }
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+    GH_HIP(hipMemcpyAsync(d_tr, trans, (size_t)n * n * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_moff, moff.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (d_y) GH_HIP(hipMemcpyAsync(d_y, y, (size_t)n * D * 8, hipMemcpyHostToDevice, st));
+    if (d_var) {
+        GH_HIP(hipMemcpyAsync(d_var, var, (size_t)n * D * 8, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemcpyAsync(d_ld, logdet.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+    if (d_E) GH_HIP(hipMemcpyAsync(d_E, dist_host, (size_t)n * N * 8, hipMemcpyHostToDevice, st));
+    gh_dtw_args a;
+    memset(&a, 0, sizeof a);
+    a.x = dist_host ? nullptr : (const double*)b->feats;
+    a.E = d_E; a.e_off = d_moff; a.utt_off = b->d_offsets; a.n = n; a.D = D; a.beam = beam;
+    a.y = d_y; a.var = d_var; a.logdet = d_ld; a.trans = d_tr; a.bp = d_bp; a.bp_off = d_moff;
+    a.costs = d_costs; a.costs_off = d_moff; a.path = d_path; a.path_off = b->d_offsets; a.path_len = d_plen;
+    a.flag = ctx->d_flag;
+    rc = gh_launch_dtw(ctx, a, U);
+    if (rc) return rc;
+    int flag = 0;
+    GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, (size_t)n * N * 8, hipMemcpyDeviceToHost, st));
+    if (out_path) {
+        GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        GH_HIP(hipMemcpyAsync(out_path_len, d_plen, U * 4, hipMemcpyDeviceToHost, st));
+    }
+    GH_HIP(hipStreamSynchronize(st));
+    if (flag & 8) {
+        gh_set_error("gh_dtw: the beam pruned every origin of a column (np.argmin of an empty list)");
+        return GH_ERR_INVALID;
+    }
+    if (flag & 2) {
+        gh_set_error("gh_dtw: back-trace left the matrix: cell (0,0) is not reachable from the end cell");
         return GH_ERR_INVALID;
     }
     return GH_OK;

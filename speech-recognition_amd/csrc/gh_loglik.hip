@@ -25,14 +25,23 @@ template <> __device__ __forceinline__ double gh_log<double>(double x) { return 
 
 template <typename T>
 __device__ __forceinline__ void lse_push(T ll, T& mx, T& sm) {
-    // running (max, sum of exp(. - max)); -inf components (w == 0) contribute nothing
+    // running (max, sum of exp(. - max)).  A NaN component (NaN parameters) poisons the state,
+    // like the reference's linear-domain sum does; a -inf component (w == 0) adds nothing.
+    if (ll != ll) { sm = T(NAN); return; }
+    if (ll == -INFINITY) return;
     T d = ll - mx;
     if (d > T(0)) {
         sm = sm * gh_exp<T>(-d) + T(1);
         mx = ll;
-    } else if (d == d) {  // not NaN (-inf - -inf)
+    } else {
         sm += gh_exp<T>(d);
     }
+}
+
+template <typename T>
+__device__ __forceinline__ T lse_finish(T mx, T sm) {
+    if (sm != sm) return T(NAN);
+    return (sm > T(0)) ? -(mx + gh_log<T>(sm)) : T(INFINITY);
 }
 
 // KP = padded feature length (multiple of 4), compile-time so x/x^2 stay in registers.
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(64) void loglik_kernel(const T* __restrict__ X, int
             }
             lse_push(acc0, mx, sm);
         }
-        T nll = (sm > T(0)) ? -(mx + gh_log<T>(sm)) : T(INFINITY);
+        T nll = lse_finish<T>(mx, sm);
         if (lane < nrows) out[n * S + s] = nll;
     }
 }
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X,
             }
             lse_push(acc, mx, sm);
         }
-        T nll = (sm > T(0)) ? -(mx + gh_log<T>(sm)) : T(INFINITY);
+        T nll = lse_finish<T>(mx, sm);
         if (lane < nrows) out[n * S + s] = nll;
     }
 }

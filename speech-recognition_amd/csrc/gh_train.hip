@@ -1,0 +1,254 @@
+// Training-side kernels (fp64):
+//   * k-means assignment  (reference: inner N x k loop of kmeans, kmeans.py:180-186)
+//   * mixture-EM E-step sufficient statistics (reference: GMM.em, hmm_state.py:127-143)
+#include "gh_internal.h"
+#include <cmath>
+
+namespace {
+
+// ---------------------------------------------------------------- k-means assign
+// One frame per lane; centroids (and the shared variance) are staged in LDS and read
+// by broadcast.  dist = 0.5*log((2pi)^D prod var) + 0.5*sum (c-x)/var*(c-x)
+// (mahalanobis(centroid, x, cov[0]), kmeans.py:183) or ||c-x|| (default dist_fun);
+// np.argmin => first minimum.
+__global__ void kmeans_assign_kernel(const double* __restrict__ X, int64_t N, int D, int k,
+                                     const double* __restrict__ cent, const double* __restrict__ var,
+                                     double logdet, int32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* sc = sm;           // [k,D]
+    double* sv = sm + k * D;   // [D]
+    for (int i = threadIdx.x; i < k * D; i += blockDim.x) sc[i] = cent[i];
+    if (var) for (int i = threadIdx.x; i < D; i += blockDim.x) sv[i] = var[i];
+    __syncthreads();
+    const int64_t nidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nidx >= N) return;
+    const double* x = X + nidx * D;
+    double best = 0;
+    int bi = 0;
+    for (int c = 0; c < k; ++c) {
+        double q = 0, dist;
+        if (var) {
+            for (int d = 0; d < D; ++d) { const double t = sc[c * D + d] - x[d]; q += t / sv[d] * t; }
+            dist = logdet + 0.5 * q;
+        } else {
+            for (int d = 0; d < D; ++d) { const double t = sc[c * D + d] - x[d]; q = fma(t, t, q); }
+            dist = sqrt(q);
+        }
+        if (c == 0 || dist < best || (dist != dist && best == best)) { best = dist; bi = c; }  // np.argmin
+    }
+    out[nidx] = bi;
+}
+
+// ------------------------------------------------------------------ EM statistics
+// Tile of F frames per iteration.  Phase 1 (lane = frame): weighted component log
+// densities of the first k components, responsibilities r = softmax over those k
+// (hmm_state.py:128-133) into LDS.  Phase 2 (lane = (component, dim) pair):
+// S0[c] += r, S1[c,d] += r (x_d - mean_cd), S2[c,d] += r (x_d - mean_cd)^2 from the LDS tile
+// -- no shuffles, no atomics.  Centring on the component's current mean keeps the
+// single-pass variance S2/S0 - (S1/S0)^2 free of cancellation (the reference makes a
+// second pass over the data around the new mean, hmm_state.py:141-143).  Each workgroup writes one partial [k, 1+2D]; the host adds the partials in
+// a fixed order (deterministic).
+constexpr int EM_MAXP = 8;  // pairs per lane: k*(D+1) <= 8*256
+
+__global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict__ X, int64_t N, int D, int k,
+                                                       const double* __restrict__ mean,
+                                                       const double* __restrict__ ivar,
+                                                       const double* __restrict__ logc, int F,
+                                                       double* __restrict__ partial, double* __restrict__ ll_partial) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* xt = sm;               // [F,D]
+    double* rt = sm + F * D;       // [k,F]
+    double* pm = rt + k * F;       // [k,D] mean
+    double* pv = pm + k * D;       // [k,D] inverse variance
+    double* pc = pv + k * D;       // [k]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < k * D; i += 256) { pm[i] = mean[i]; pv[i] = ivar[i]; }
+    for (int i = tid; i < k; i += 256) pc[i] = logc[i];
+    const int P = k * (D + 1);
+    double s1[EM_MAXP], s2[EM_MAXP];
+#pragma unroll
+    for (int q = 0; q < EM_MAXP; ++q) { s1[q] = 0; s2[q] = 0; }
+    double ll_sum = 0;
+    const int64_t ntiles = (N + F - 1) / F;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * F;
+        const int nf = (int)((N - n0 < F) ? (N - n0) : F);
+        __syncthreads();
+        for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
+        __syncthreads();
+        for (int f = tid; f < F; f += 256) {
+            if (f < nf) {
+                const double* x = xt + f * D;
+                double mx = -INFINITY;
+                bool bad = false;  // a NaN density makes the whole row NaN (p /= NaN row sum, hmm_state.py:130-133)
+                for (int c = 0; c < k; ++c) {
+                    double q = 0;
+                    for (int d = 0; d < D; ++d) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
+                    const double ll = pc[c] - 0.5 * q;
+                    rt[c * F + f] = ll;
+                    bad |= (ll != ll);
+                    mx = fmax(mx, ll);
+                }
+                double sum = 0;
+                for (int c = 0; c < k; ++c) {
+                    const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * F + f] - mx);
+                    rt[c * F + f] = e;
+                    sum += e;
+                }
+                const double inv = bad ? NAN : (sum > 0 ? 1.0 / sum : 0.0);
+                for (int c = 0; c < k; ++c) rt[c * F + f] = bad ? NAN : rt[c * F + f] * inv;
+                if (bad) ll_sum = NAN;
+                else if (sum > 0) ll_sum += mx + log(sum);
+            } else {
+                for (int c = 0; c < k; ++c) rt[c * F + f] = 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EM_MAXP; ++q) {
+            const int p = tid + q * 256;
+            if (p < P) {
+                const int c = p / (D + 1), d = p % (D + 1);
+                const double* r = rt + c * F;
+                double a1 = 0, a2 = 0;
+                if (d == D) {
+                    for (int f = 0; f < nf; ++f) a1 += r[f];
+                } else {
+                    for (int f = 0; f < nf; ++f) {
+                        const double xv = xt[f * D + d] - pm[c * D + d];  // centred on the current mean
+                        const double rx = r[f] * xv;
+                        a1 += rx;
+                        a2 = fma(rx, xv, a2);
+                    }
+                }
+                s1[q] += a1;
+                s2[q] += a2;
+            }
+        }
+    }
+    double* out = partial + (int64_t)blockIdx.x * k * (1 + 2 * D);
+#pragma unroll
+    for (int q = 0; q < EM_MAXP; ++q) {
+        const int p = tid + q * 256;
+        if (p < P) {
+            const int c = p / (D + 1), d = p % (D + 1);
+            double* o = out + c * (1 + 2 * D);
+            if (d == D) o[0] = s1[q];
+            else { o[1 + d] = s1[q]; o[1 + D + d] = s2[q]; }
+        }
+    }
+    // per-block sum of frame log-likelihoods (over the first k components)
+    __shared__ double red[256];
+    red[tid] = ll_sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) ll_partial[blockIdx.x] = red[0];
+}
+
+}  // namespace
+
+static int frames_f64(const gh_batch* b, int64_t first, int64_t count, const char* who) {
+    GH_REQUIRE(b->dtype == GH_F64, "%s: needs an fp64 batch", who);
+    GH_REQUIRE(first >= 0 && count >= 0 && first + count <= b->N, "%s: frame range [%lld,+%lld) outside the batch",
+               who, (long long)first, (long long)count);
+    return GH_OK;
+}
+
+extern "C" int gh_kmeans_assign(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t count, int k,
+                                const double* centroids, const double* var, int32_t* out_clusters) {
+    GH_REQUIRE(ctx && b && centroids && out_clusters, "gh_kmeans_assign: NULL argument");
+    GH_REQUIRE(k > 0, "gh_kmeans_assign: k=%d", k);
+    int rc = frames_f64(b, first, count, "gh_kmeans_assign");
+    if (rc) return rc;
+    if (count == 0) return GH_OK;
+    GH_HIP(hipSetDevice(ctx->device));
+    const int D = b->D;
+    double logdet = 0;
+    if (var) {
+        double prod = 1.0;
+        for (int d = 0; d < D; ++d) prod *= var[d];
+        logdet = 0.5 * std::log(std::pow(2.0 * M_PI, D) * prod);  // hmm_state.py:58
+    }
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t bc = al((size_t)k * D * 8), bv = al((size_t)D * 8);
+    void* base;
+    rc = gh_scratch(ctx, bc + bv + (size_t)count * 4, &base);
+    if (rc) return rc;
+    double* dc = (double*)base;
+    double* dv = (double*)((char*)base + bc);
+    int32_t* dout = (int32_t*)((char*)base + bc + bv);
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemcpyAsync(dc, centroids, (size_t)k * D * 8, hipMemcpyHostToDevice, st));
+    if (var) GH_HIP(hipMemcpyAsync(dv, var, (size_t)D * 8, hipMemcpyHostToDevice, st));
+    const size_t lds = ((size_t)k * D + D) * 8;
+    GH_REQUIRE(lds <= 64 * 1024, "gh_kmeans_assign: k*D too large for LDS staging");
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), lds, st,
+                       (const double*)b->feats + first * D, count, D, k, dc, var ? dv : nullptr, logdet, dout);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipMemcpyAsync(out_clusters, dout, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}
+
+extern "C" int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t count, int k,
+                                const double* mean, const double* var, const double* weight,
+                                double* out_stats, double* out_loglik) {
+    GH_REQUIRE(ctx && b && mean && var && weight && out_stats, "gh_em_accumulate: NULL argument");
+    int rc = frames_f64(b, first, count, "gh_em_accumulate");
+    if (rc) return rc;
+    const int D = b->D;
+    GH_REQUIRE(k > 0 && k * (D + 1) <= EM_MAXP * 256, "gh_em_accumulate: k=%d x D=%d unsupported", k, D);
+    const int W = 1 + 2 * D;
+    for (int i = 0; i < k * W; ++i) out_stats[i] = 0.0;
+    if (out_loglik) *out_loglik = 0.0;
+    if (count == 0) return GH_OK;
+    GH_HIP(hipSetDevice(ctx->device));
+    std::vector<double> ivar((size_t)k * D), logc(k);
+    const double log2pi = std::log(2.0 * M_PI);
+    for (int c = 0; c < k; ++c) {
+        double sl = 0;
+        for (int d = 0; d < D; ++d) {
+            const double v = var[(size_t)c * D + d];
+            GH_REQUIRE(v != 0, "gh_em_accumulate: var[%d,%d]=%g (singular covariance)", c, d, v);
+            ivar[(size_t)c * D + d] = 1.0 / v;
+            sl += std::log(v);
+        }
+        logc[c] = std::log(weight[c]) - 0.5 * (D * log2pi + sl);
+    }
+    int F = 256;
+    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)k * f + 2 * (size_t)k * D + k) * 8; };
+    while (F > 32 && lds_need(F) > 96 * 1024) F >>= 1;
+    GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_em_accumulate: D=%d k=%d does not fit LDS", D, k);
+    const int64_t ntiles = (count + F - 1) / F;
+    const int grid = (int)std::min<int64_t>(ntiles, 2 * (int64_t)ctx->n_cu);
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t bm = al((size_t)k * D * 8), bl = al((size_t)k * 8), bp = al((size_t)grid * k * W * 8),
+                 bll = al((size_t)grid * 8);
+    void* base;
+    rc = gh_scratch(ctx, 2 * bm + bl + bp + bll, &base);
+    if (rc) return rc;
+    char* p = (char*)base;
+    double *dm = (double*)p, *div = (double*)(p + bm), *dl = (double*)(p + 2 * bm), *dpart = (double*)(p + 2 * bm + bl),
+           *dll = (double*)(p + 2 * bm + bl + bp);
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemcpyAsync(dm, mean, (size_t)k * D * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(div, ivar.data(), (size_t)k * D * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(dl, logc.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(em_stats_kernel, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats + first * D,
+                       count, D, k, dm, div, dl, F, dpart, dll);
+    GH_HIP(hipGetLastError());
+    std::vector<double> part((size_t)grid * k * W), llp(grid);
+    GH_HIP(hipMemcpyAsync(part.data(), dpart, part.size() * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(llp.data(), dll, llp.size() * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    double ll = 0;
+    for (int g = 0; g < grid; ++g) {
+        for (int i = 0; i < k * W; ++i) out_stats[i] += part[(size_t)g * k * W + i];
+        ll += llp[g];
+    }
+    if (out_loglik) *out_loglik = ll;
+    return GH_OK;
+}

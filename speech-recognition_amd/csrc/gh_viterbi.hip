@@ -79,9 +79,10 @@ __global__ void viterbi_kernel(gh_vit_args a) {
                         double best = 0;
                         for (int p = p0; p < p1; ++p) {
                             const double v = pred_cost[p] + cur[pred_row[p] & GH_ARC_ROW];
-                            if (p == p0 || v < best) best = v;
+                            if (p == p0 || v < best || (v != v && best == best)) best = v;
                         }
                         c = best + e;
+                        if (c != c) c = INF;
                     }
                 }
                 cur[r] = c;
@@ -115,9 +116,11 @@ __global__ void viterbi_kernel(gh_vit_args a) {
                                 double v;
                                 if (w & GH_ARC_DEAD) v = INF;
                                 else v = pred_cost[p] + ((w & GH_ARC_SAME) ? cur[o] : prev[o]);
-                                if (p == p0 || v < best) { best = v; bw = w; }
+                                // np.argmin: the first NaN wins over everything, else the first minimum
+                                if (p == p0 || v < best || (v != v && best == best)) { best = v; bw = w; }
                             }
                             c = best + e;
+                            if (c != c) c = INF;  // min(inf, nan) keeps inf (decode.py:124)
                             const int o = (int)(bw & GH_ARC_ROW);
                             if ((bw & GH_ARC_SAME) && o == r) atomicOr(a.flag, 1);  // decode.py:120-121
                             b = (uint16_t)(o | ((bw & GH_ARC_SAME) ? 0x8000u : 0u));

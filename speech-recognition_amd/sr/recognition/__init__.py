@@ -1,2 +1,16 @@
 # -*- coding: utf-8 -*-
-from . import _hip  # noqa: F401
+"""`sr.recognition` -- GMM-HMM training / decoding core, MI355X-native.
+
+Same importable names as the reference package (sr/recognition/__init__.py:1-5):
+dtw, decode_hmm_states, HMM, kmeans, skmeans, align_gmm_states, calc_transition_costs,
+get_segments_from_path, segment_data, combine_templates, calc_variance, cluster_centroids,
+build_state_sequences, continuous_train, GMM, NES, HMMState, MultivariateNormal, mahalanobis.
+All likelihood and dynamic-programming arithmetic runs in HIP kernels through
+libgmmhmm.so (see `_hip.py`); there is no CPU fallback.  Batched entry points that
+the one-utterance-at-a-time reference API cannot express live in `sr.recognition.batch`.
+"""
+from .decode import *  # noqa: F401,F403
+from .hmm import *  # noqa: F401,F403
+from .kmeans import *  # noqa: F401,F403
+from .continuous_speech import *  # noqa: F401,F403
+from .hmm_state import *  # noqa: F401,F403

@@ -49,6 +49,12 @@ SIGNATURES = {
     "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
                              _c_i32p, _c_f64p, _c_i64p]),
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
+    "gh_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f64p,
+                         _c_f64p, _c_i32p, _c_i32p]),
+    "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
+                                   _c_i32p]),
+    "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
+                                   _c_f64p, _c_f64p, _c_f64p]),
 }
 
 
@@ -212,6 +218,57 @@ class Batch:
                                                     None if out is None else out.ctypes.data_as(C.c_void_p)))
         self.S = gmm.S
         return out
+
+    def dtw(self, trans, y=None, var=None, beam=0, dist=None, want_costs=True):
+        """A5 for every utterance against the n template rows `y` (built-in Euclidean /
+        mahalanobis distance) or caller-supplied distance matrices `dist` (list of [n,T_u]).
+        Returns (costs list of [n,T_u] or None, paths list of int64 [K,2])."""
+        lib = self.ctx.lib
+        trans = _f64(trans)
+        n = trans.shape[0]
+        y = None if y is None else _f64(y)
+        var = None if var is None else _f64(var)
+        dflat = None
+        if dist is not None:
+            dflat = np.ascontiguousarray(np.concatenate([_f64(d).ravel() for d in dist]))
+        costs = np.empty(n * self.N) if want_costs else None
+        path = np.empty((self.N, 2), dtype=np.int32)
+        plen = np.empty(self.U, dtype=np.int32)
+        _check(lib, lib.gh_dtw(self.ctx.h, self.h, n, _ptr(y, _c_f64p), _ptr(var, _c_f64p), _ptr(trans, _c_f64p),
+                               int(beam), _ptr(dflat, _c_f64p), _ptr(costs, _c_f64p), _ptr(path, _c_i32p),
+                               _ptr(plen, _c_i32p)))
+        off = self.offsets
+        cl = None
+        if want_costs:
+            cl = [costs[n * off[u]:n * off[u + 1]].reshape(n, -1) for u in range(self.U)]
+        return cl, [path[off[u]:off[u] + plen[u]].astype(np.int64) for u in range(self.U)]
+
+    def kmeans_assign(self, centroids, var=None, first=0, count=None):
+        """A14 assignment step over frames [first, first+count): index of the closest centroid."""
+        centroids = _f64(centroids)
+        count = self.N - first if count is None else count
+        out = np.empty(count, dtype=np.int32)
+        v = None if var is None else _f64(var)
+        _check(self.ctx.lib, self.ctx.lib.gh_kmeans_assign(self.ctx.h, self.h, int(first), int(count),
+                                                           centroids.shape[0], _ptr(centroids, _c_f64p),
+                                                           _ptr(v, _c_f64p), _ptr(out, _c_i32p)))
+        return out.astype(np.int64)
+
+    def em_accumulate(self, mean, var, weight, first=0, count=None):
+        """A7 E-step statistics of the given k components over frames [first, first+count).
+        Returns (stats [k, 1+2D], total log-likelihood)."""
+        mean, var, weight = _f64(mean), _f64(var), _f64(weight)
+        k = mean.shape[0]
+        count = self.N - first if count is None else count
+        stats = np.empty((k, 1 + 2 * self.D))
+        ll = C.c_double(0.0)
+        rc = self.ctx.lib.gh_em_accumulate(self.ctx.h, self.h, int(first), int(count), k, _ptr(mean, _c_f64p),
+                                           _ptr(var, _c_f64p), _ptr(weight, _c_f64p), _ptr(stats, _c_f64p),
+                                           C.cast(C.byref(ll), _c_f64p))
+        if rc == -1 and b"singular" in self.ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(self.ctx.lib, rc)
+        return stats, ll.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -1,0 +1,108 @@
+# -*- coding: utf-8 -*-
+"""Batched drivers on top of the HIP kernels -- the call patterns of the reference's
+`sr/core.py:test` (isolated-word arg-min over models, core.py:63-94) and `main.py`
+(continuous-digit decode through a K-layer lattice + path post-processing,
+main.py:35,59-67), over whole utterance batches resident in HBM.
+
+These are what the benchmark and a serving caller use; the per-utterance functions
+in `decode.py` give the same numbers one utterance at a time.
+"""
+import numpy as np
+
+from . import _hip
+from . import _pack
+from .continuous_speech import packed_lattice
+
+__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "path_to_words"]
+
+
+def _stack_models(ctx, models):
+    n = len(models[0].gmm_states)
+    for m in models:
+        assert len(m.gmm_states) == n
+    return n, _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
+
+
+class IsolatedWordRecognizer:
+    """Scores every utterance against every word model and returns the arg-min word
+    (core.py:82-87: `costs = [m.evaluate(x) for m in models]; argmin`).
+
+    The W word chains are stacked into one graph (W start rows, W end rows), so one
+    gh_loglik + one gh_viterbi launch replaces U x W calls of HMM.evaluate."""
+
+    def __init__(self, models, device=None, dtype=np.float64):
+        self.ctx = _hip.default_context(device)
+        self.dtype = dtype
+        self.W = len(models)
+        self.n, self.gmm = _stack_models(self.ctx, models)
+        n, W = self.n, self.W
+        to, frm, cost = [], [], []
+        for i, m in enumerate(models):
+            t = np.asarray(m.transitions, dtype=np.float64)
+            a, b = np.nonzero(~np.isinf(t))
+            to.append(a + i * n)
+            frm.append(b + i * n)
+            cost.append(t[a, b])
+        graph = dict(row_state=np.arange(W * n, dtype=np.int32), arc_to=np.concatenate(to),
+                     arc_from=np.concatenate(frm), arc_cost=np.concatenate(cost),
+                     start_rows=np.arange(W) * n, end_rows=np.arange(W) * n + n - 1)
+        self.lat = _hip.Lattices(self.ctx, [graph])
+
+    def costs(self, batch):
+        """[U, W] matrix of HMM.evaluate values for a resident `_hip.Batch`."""
+        batch.loglik(self.gmm, fetch=False)
+        r = self.lat.viterbi(batch, want_path=False)
+        return r["end_cost_flat"].reshape(batch.U, self.W)
+
+    def recognize(self, xs):
+        """xs: list of [T_u, D] arrays -> (words [U], costs [U, W])."""
+        batch = _hip.Batch(self.ctx, xs, dtype=self.dtype)
+        try:
+            c = self.costs(batch)
+        finally:
+            batch.close()
+        return np.argmin(c, axis=1), c
+
+
+def path_to_words(path, row_state, n_per_word):
+    """main.py:59-67: reversed path rows -> drop consecutive duplicates -> first emitting
+    row of every run between non-emitting rows -> word index of that row."""
+    if len(path) == 0:
+        return []
+    rows = np.asarray(path)[:, 0][::-1]
+    rows = rows[np.insert(np.diff(rows) != 0, 0, True)]
+    st = np.asarray(row_state)[rows]
+    emitting = st >= 0
+    # first emitting row of each maximal emitting run
+    first = emitting & np.insert(~emitting[:-1], 0, True)
+    return [int(s) // n_per_word for s in st[first]]
+
+
+class ContinuousDecoder:
+    """Continuous-word decode through a K-layer lattice over all `models`
+    (main.py:35: build_state_sequences(models, [[0..W-1]] * K)), end points = last
+    layer's final states in the last column (main.py:60), then `path_to_words`."""
+
+    def __init__(self, models, n_layers=7, device=None, dtype=np.float64):
+        self.ctx = _hip.default_context(device)
+        self.dtype = dtype
+        self.n, self.gmm = _stack_models(self.ctx, models)
+        W = len(models)
+        graph, self.nes_rows = packed_lattice([m.transitions for m in models], self.n,
+                                              [list(range(W))] * n_layers)
+        self.row_state = graph["row_state"]
+        self.lat = _hip.Lattices(self.ctx, [graph])
+
+    def decode_batch(self, batch):
+        batch.loglik(self.gmm, fetch=False)
+        r = self.lat.viterbi(batch, want_path=True)
+        words = [path_to_words(p, self.row_state, self.n) for p in r["paths"]]
+        return words, r
+
+    def decode(self, xs):
+        """xs: list of [T_u, D] arrays -> list of word-index lists."""
+        batch = _hip.Batch(self.ctx, xs, dtype=self.dtype)
+        try:
+            return self.decode_batch(batch)[0]
+        finally:
+            batch.close()

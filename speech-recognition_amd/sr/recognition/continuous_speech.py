@@ -1,0 +1,218 @@
+# -*- coding: utf-8 -*-
+"""Word lattices and embedded (Viterbi) training on the MI355X.
+
+Mirror of the reference's `sr/recognition/continuous_speech.py`:
+`build_state_sequences` (:13-53) and `continuous_train` (:56-179) with the same
+signatures, side effects (one pickle per model and iteration) and convergence
+rule.  The alignment of ALL utterances of an outer iteration is one batched
+gh_loglik + gh_viterbi launch over features that stay resident in HBM for the
+whole training run (one graph per distinct label sequence); the per-state refit
+uses the HIP k-means / EM kernels through `kmeans` and `GMM.em`.
+"""
+import copy
+import os
+import pickle
+import warnings
+from typing import List, AnyStr
+
+import numpy as np
+
+from . import _hip
+from . import _pack
+from .kmeans import kmeans
+from .hmm_state import GMM, NES, mahalanobis
+from .hmm import HMM
+
+__all__ = ["build_state_sequences", "continuous_train"]
+
+
+def _layout(n_per_word, label_matrix):
+    """Row bookkeeping shared by the object-level and the packed lattice builders.
+    Returns (R, [(layer, label, first_row)], nes_rows)."""
+    blocks, nes_rows, r = [], [0], 1
+    for k, labels in enumerate(label_matrix):
+        for l in labels:
+            blocks.append((k, l, r))
+            r += n_per_word
+        nes_rows.append(r)
+        r += 1
+    return r, blocks, nes_rows
+
+
+def build_state_sequences(hmms: List[HMM], label_matrix: List[List[int]]):
+    """K-layer word lattice (continuous_speech.py:13-53).
+
+    Row 0 is a non-emitting state; layer k lists the states of every word in
+    `label_matrix[k]` (the state OBJECTS are shared between layers) and is closed by one
+    more non-emitting state.  Zero-cost arcs lead from the non-emitting state in front of a
+    layer to the first state of each of its words, and from each word's last state to the
+    non-emitting state behind the layer.  All words must have the same number of states.
+
+    :return: (states [R], dense transition costs [R,R] with +inf holes,
+              rows of the last layer's final emitting states)"""
+    n = len(hmms[0].gmm_states)
+    R, blocks, nes_rows = _layout(n, label_matrix)
+    trans = np.full((R, R), np.inf)
+    seq = [None] * R
+    for r in nes_rows:
+        seq[r] = NES()
+    last_layer = len(label_matrix) - 1
+    ends = []
+    for k, l, r0 in blocks:
+        word = hmms[l]
+        assert n == len(word.gmm_states)
+        seq[r0:r0 + n] = word.gmm_states
+        trans[r0:r0 + n, r0:r0 + n] = word.transitions
+        trans[r0, nes_rows[k]] = 0
+        trans[nes_rows[k + 1], r0 + n - 1] = 0
+        if k == last_layer:
+            ends.append(r0 + n - 1)
+    return seq, trans, ends
+
+
+def packed_lattice(word_transitions, n_per_word, label_matrix, state_base=None):
+    """The same lattice as a graph dict for `_hip.Lattices`, without building R x R
+    matrices or state objects: row_state = word * n + state (or state_base[word] + state)."""
+    R, blocks, nes_rows = _layout(n_per_word, label_matrix)
+    row_state = np.full(R, -1, dtype=np.int32)
+    to, frm, cost, ends = [], [], [], []
+    last_layer = len(label_matrix) - 1
+    for k, l, r0 in blocks:
+        base = l * n_per_word if state_base is None else state_base[l]
+        row_state[r0:r0 + n_per_word] = base + np.arange(n_per_word)
+        wt = np.asarray(word_transitions[l])
+        i, j = np.nonzero(~np.isinf(wt))
+        to += list(i + r0) + [r0, nes_rows[k + 1]]
+        frm += list(j + r0) + [nes_rows[k], r0 + n_per_word - 1]
+        cost += list(wt[i, j]) + [0.0, 0.0]
+        if k == last_layer:
+            ends.append(r0 + n_per_word - 1)
+    return dict(row_state=row_state, arc_to=np.asarray(to, dtype=np.int32), arc_from=np.asarray(frm, dtype=np.int32),
+                arc_cost=np.asarray(cost, dtype=np.float64), start_rows=np.array([0], dtype=np.int32),
+                end_rows=np.asarray(ends, dtype=np.int32)), nes_rows
+
+
+def forced_alignments(frames, models, label_seqs):
+    """Viterbi alignment of every utterance through its own one-word-per-layer lattice
+    (continuous_speech.py:80-89), all utterances in one launch.
+    Returns (paths, row_state per utterance) with row_state[r] = -1 on non-emitting rows,
+    else word * n + state."""
+    ctx = frames.ctx
+    n = len(models[0].gmm_states)
+    gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
+    frames.loglik(gmm, fetch=False)
+    keys, graphs, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
+    wt = [m.transitions for m in models]
+    for u, labels in enumerate(label_seqs):
+        key = tuple(labels)
+        if key not in keys:
+            keys[key] = len(graphs)
+            graphs.append(packed_lattice(wt, n, [[l] for l in labels])[0])
+        utt_graph[u] = keys[key]
+    lat = _hip.Lattices(ctx, graphs)
+    try:
+        res = lat.viterbi(frames, utt_lattice=utt_graph, want_path=True)
+    finally:
+        lat.close()
+    return res["paths"], [graphs[g]["row_state"] for g in utt_graph]
+
+
+def cut_segments(path, row_state):
+    """Frame ranges per visited state from one alignment (continuous_speech.py:90-106).
+
+    Walking the path from start to end: a run opens at the first cell of an emitting row
+    seen while no run is open; a cell of a different row closes the open run as
+    [start, c) -- c being that cell's column -- provided start < c, and does not itself
+    open a run.  Consequences kept from the reference: the frame on which a state is
+    entered inside a word is dropped, the frame on a word boundary belongs to the next
+    word only, and the final state's last run is never closed.
+    Yields (row_state value, start, stop)."""
+    open_row, open_at = None, None
+    for r, c in path[::-1]:
+        if open_at is None and row_state[r] >= 0:
+            open_row, open_at = r, c
+        if r != open_row and open_at is not None and open_at < c:
+            yield int(row_state[open_row]), int(open_at), int(c)
+            open_row, open_at = None, None
+
+
+def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List[List[int]], output_path: AnyStr,
+                     n_gaussians: int = 4,
+                     n_segments: int = 5,
+                     max_iteration: int = 1000):
+    """Embedded Viterbi training (continuous_speech.py:56-179).
+
+    Per outer iteration: forced alignment of every utterance, frames regrouped per visited
+    state, every visited state refit (binary-split k-means + EM, in first-visit order --
+    numpy's global RNG is consumed in that order), transition costs re-estimated from the
+    segment counts, every model pickled to `output_path/<index>.pkl`; stops when all models
+    compare equal (mixtures allclose) to the previous iteration's."""
+    old_models = models
+    new_models = copy.deepcopy(models)
+    n_models = len(new_models)
+    # The reference keeps the state objects of this first copy in a dict for the whole run
+    # (:64-71).  Later iterations train fresh deep copies with the same uuid hash, so its
+    # `gmm_data.get(state)` (:149) falls through to GMM.__eq__(current, first copy): a state
+    # whose mixture moved since iteration 0 is reported as "No MFCC data" and keeps its
+    # transition costs.  `first_copy` reproduces that lookup.
+    first_copy = [list(m.gmm_states) for m in new_models]
+    n = len(new_models[0].gmm_states)
+
+    frames = _hip.Batch(_hip.default_context(), data)
+    try:
+        for it in range(max_iteration):
+            print('=' * 25)
+            print('Continuous training iteration:', it)
+            print('Building state sequences')
+            print('Rearranging data, this may take a while...')
+            paths, row_states = forced_alignments(frames, new_models, label_seqs)
+            gmm_data = {}
+            for x, path, rs in zip(data, paths, row_states):
+                for sid, a, b in cut_segments(path, rs):
+                    gmm_data.setdefault(sid, []).append(x[a:b])
+            print('Complete data rearrangement')
+            print("=" * 25)
+
+            print('Doing HMM training...')
+            for sid, segs in gmm_data.items():
+                state: GMM = new_models[sid // n].gmm_states[sid % n]
+                seg = np.vstack(segs)
+                n_splits = int(np.log(n_gaussians))
+                assert n_splits > 0
+                centroids = np.mean(seg, axis=0).reshape((1, -1))
+                weights = np.full(n_gaussians, 1 / n_segments)
+                for i in range(n_splits):
+                    k = 2 ** (i + 1)
+                    centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=0)
+                    clusters, centroids, variance = kmeans(seg, k, centroids, dist_fun=mahalanobis)
+                    ids, counts = np.unique(clusters, return_counts=True)
+                    for c in ids:
+                        weights[c] = counts[c] / n_segments  # (:135-137)
+                    state.update_models(centroids, variance, weights[:k])
+                    state.em(seg, k)
+
+            print('Updating other model parameters...')
+            for mi in range(n_models):
+                for si in range(n):
+                    segs = gmm_data.get(mi * n + si)
+                    current = new_models[mi].gmm_states[si]
+                    if segs is not None and current is not first_copy[mi][si] and not (current == first_copy[mi][si]):
+                        segs = None
+                    if segs is None:
+                        warnings.warn("No MFCC data for state", UserWarning)
+                        continue
+                    p_jump = len(segs) / sum(s.shape[0] for s in segs)
+                    if si < n - 1:
+                        new_models[mi].transitions[si + 1, si] = -np.log(p_jump)
+                    new_models[mi].transitions[si, si] = -np.log(1 - p_jump)
+
+            for i, m in enumerate(new_models):
+                with open(os.path.join(output_path, str(i) + '.pkl'), 'wb') as f:
+                    pickle.dump(m, f)
+            if all(new_m == old_m for new_m, old_m in zip(new_models, old_models)):
+                print('Continuous training converged')
+                break
+            old_models = new_models
+            new_models = copy.deepcopy(old_models)
+    finally:
+        frames.close()

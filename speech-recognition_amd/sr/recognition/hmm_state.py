@@ -1,0 +1,217 @@
+# -*- coding: utf-8 -*-
+"""Emission models of the GMM-HMM core, evaluated on the MI355X.
+
+Mirror of the reference's `sr/recognition/hmm_state.py` (same class / function
+names, signatures, attribute names -- so pickled models keep their layout -- and
+exceptions).  Every density evaluation runs in HIP through libgmmhmm
+(`_hip.py`); this file only holds parameters and the O(M) / O(k*D) host glue
+(exp/sum of M component values, the M-step division, convergence tests).
+"""
+import uuid
+
+import numpy as np
+
+from . import _hip
+from . import _pack
+
+__all__ = ["MultivariateNormal", "mahalanobis", "HMMState", "NES", "GMM"]
+
+
+def _ctx():
+    return _hip.default_context()
+
+
+class MultivariateNormal:
+    """Diagonal-covariance Gaussian (reference: hmm_state.py:5-45).
+
+    Attributes `mean`, `_cov`, `inv_cov` as in the reference; assigning `cov`
+    refreshes `inv_cov` and raises numpy.linalg.LinAlgError for a singular
+    covariance, like the reference's np.linalg.inv does (hmm_state.py:17,30).
+    """
+
+    def __init__(self, mean, cov):
+        self.mean = mean
+        self.cov = cov
+
+    @property
+    def cov(self):
+        return self._cov
+
+    @cov.setter
+    def cov(self, val):
+        self._cov = val
+        c = np.asarray(val)
+        if c.ndim == 1:
+            if np.any(c == 0):
+                raise np.linalg.LinAlgError("Singular matrix")
+            self.inv_cov = np.diag(1.0 / c)
+        else:
+            self.inv_cov = np.linalg.inv(c)
+
+    @cov.deleter
+    def cov(self):
+        del self._cov
+
+    def _diag(self):
+        c = np.asarray(self._cov, dtype=np.float64)
+        return c if c.ndim == 1 else np.diag(c)
+
+    def pdf(self, x):
+        """Density at one frame, linear domain (hmm_state.py:36-45)."""
+        x = np.asarray(x, dtype=np.float64)
+        mean = np.asarray(self.mean, dtype=np.float64)
+        if x.shape[0] != mean.shape[0]:
+            raise NameError("The dimensions of the input don't match")
+        model = _hip.PackedGMM(_ctx(), mean[None, None, :], self._diag()[None, None, :], np.ones((1, 1)))
+        return np.exp(model.component_loglik(0, x[None, :])[0, 0])
+
+
+def mahalanobis(v1, v2, variance):
+    """Diagonal-Gaussian negative log-likelihood of v1 under N(v2, diag(variance))
+    (hmm_state.py:48-58).  Passing this function as `dist_fun` to dtw / kmeans /
+    skmeans selects the fused HIP distance kernels."""
+    v1 = np.asarray(v1, dtype=np.float64)
+    v2 = np.asarray(v2, dtype=np.float64)
+    var = np.asarray(variance, dtype=np.float64)
+    return _hip.distance_matrix(_ctx(), v1[None, :], v2[None, :], var[None, :])[0, 0]
+
+
+def euclidean(*args):
+    """||args[0] - args[1]||: the default `dist_fun` of dtw / kmeans / skmeans in the
+    reference (an anonymous lambda there, kmeans.py:111,167).  Recognised by identity and
+    run in HIP inside the batched callers."""
+    a = np.asarray(args[0], dtype=np.float64)
+    b = np.asarray(args[1], dtype=np.float64)
+    return _hip.distance_matrix(_ctx(), a[None, :], b[None, :])[0, 0]
+
+
+class HMMState:
+    """Base class of all HMM states (hmm_state.py:61-78)."""
+
+    def __init__(self):
+        self.id = uuid.uuid4().int
+        self.parent = None
+
+    def evaluate(self, x):
+        raise NotImplemented()
+
+    def __eq__(self, other):
+        raise NotImplemented()
+
+    def __hash__(self):
+        return hash(self.id)
+
+
+class NES(HMMState):
+    """Non-emitting state: costs nothing, consumes no frame (hmm_state.py:81-97)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def evaluate(self, x):
+        return 0
+
+    def __eq__(self, other):
+        return self.id == other.id
+
+    def __hash__(self):
+        return hash(self.id)
+
+
+class GMM(HMMState):
+    """Gaussian mixture state (hmm_state.py:100-179).
+
+    `n_gaussians` components start as copies of N(mu, diag(sigma)) with weight
+    1/n; `update_models` / `em` overwrite the first k of them.  Weights are used
+    as they are, never renormalised (hmm_state.py:115).
+    """
+
+    def __init__(self, mu, sigma, n_gaussians):
+        super().__init__()
+        self.n_gaussians = n_gaussians
+        self.w = np.full(n_gaussians, 1 / n_gaussians)
+        self.dists = [MultivariateNormal(mean=mu, cov=sigma) for _ in range(n_gaussians)]
+        self.mu_old = np.tile(mu, (n_gaussians, 1))
+        self.sigma_old = np.tile(sigma, (n_gaussians, 1))
+        self.w_old = np.full(n_gaussians, 1 / n_gaussians)
+
+    # ---- device side -------------------------------------------------------
+    def _device(self):
+        return _pack.device_gmm(_ctx(), [self])
+
+    def component_log_density(self, X):
+        """log(w_m * pdf_m(x_n)) for every frame and component: [N, n_gaussians] (HIP)."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] != np.asarray(self.dists[0].mean).shape[0]:
+            raise NameError("The dimensions of the input don't match")
+        return self._device().component_loglik(0, X)
+
+    def evaluate(self, x, return_neg_log_likelihood=True):
+        """-log sum_m w_m pdf_m(x), or the vector of weighted densities (hmm_state.py:114-120).
+        The linear-domain sum is kept so that a frame whose every component underflows
+        costs +inf exactly like the reference."""
+        res = np.exp(self.component_log_density(np.asarray(x, dtype=np.float64)[None, :])[0])
+        if return_neg_log_likelihood:
+            with np.errstate(divide="ignore"):
+                return -np.log(res.sum())
+        return res
+
+    def evaluate_batch(self, X):
+        """Negative log-likelihood of every row of X[N,D] (batched form of `evaluate`)."""
+        with np.errstate(divide="ignore"):
+            return -np.log(np.exp(self.component_log_density(X)).sum(axis=1))
+
+    # ---- training ----------------------------------------------------------
+    def em(self, data, n_gaussians, max_iteration=10000):
+        """EM on the first `n_gaussians` components over frames hard-assigned to this
+        state (hmm_state.py:122-159).  E-step statistics come from the HIP kernel
+        (`gh_em_accumulate`: N_c and the first / second moments around the current means, one pass
+        over the resident frames);
+        the M-step, `update_models` and the allclose convergence test stay on the host."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        k = n_gaussians
+        n, dim = data.shape
+        frames = _hip.Batch(_ctx(), feats=data, offsets=[0, n])
+        try:
+            for it in range(max_iteration):
+                means, vars_, w = _pack.gmm_arrays(self)
+                stats, _ = frames.em_accumulate(means[:k], vars_[:k], w[:k])
+                occ = stats[:, 0].copy()
+                weights = occ / n                      # p.mean(axis=0)            (:148)
+                occ[occ == 0] = 10 ** (-5)             # avoid divide by 0        (:134-136)
+                # statistics are centred on the current means m0:  S1 = sum r (x - m0), S2 = sum r (x - m0)^2
+                mu = (means[:k] * stats[:, 0][:, None] + stats[:, 1:1 + dim]) / occ[:, None]   # sum r x / N
+                # sum r (x - mu)^2 / N around the NEW mean (:141-143), from the centred sums
+                delta = mu - means[:k]
+                sigma = (stats[:, 1 + dim:] - delta * (2.0 * stats[:, 1:1 + dim] - delta * stats[:, 0][:, None])) \
+                    / occ[:, None]
+                self.update_models(mu, sigma, weights)
+                if np.allclose(mu, self.mu_old[:k, :]) and np.allclose(sigma, self.sigma_old[:k, :]) \
+                        and np.allclose(weights, self.w_old[:k]):
+                    print("EM converged at iteration:", it)
+                    break
+                print("EM iteration:", str(it), end="\r", flush=True)
+                self.mu_old[:k, :] = mu
+                self.sigma_old[:k, :] = sigma
+                self.w_old[:k] = weights
+        finally:
+            frames.close()
+
+    def update_models(self, mus, sigmas, weights):
+        k = mus.shape[0]
+        self.w[:k] = weights
+        for m in range(k):
+            self.dists[m].mean = mus[m, :]
+            self.dists[m].cov = sigmas[m, :]
+
+    def __eq__(self, other):
+        if self.n_gaussians != other.n_gaussians or not np.allclose(self.w, other.w):
+            return False
+        return all(np.allclose(a.mean, b.mean) and np.allclose(a.cov, b.cov)
+                   for a, b in zip(self.dists, other.dists))
+
+    def __len__(self):
+        return self.n_gaussians
+
+    def __hash__(self):
+        return hash(self.id)
