@@ -35,3 +35,13 @@ def has_gpu():
         return False
     n = ctypes.c_int(0)
     return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    """libgmmhmm.so, cross-compiled for gfx950 if it is not there yet (no GPU needed)."""
+    lib = os.path.join(PKG, "lib", "libgmmhmm.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+    return lib

@@ -1,0 +1,105 @@
+# -*- coding: utf-8 -*-
+"""The multi-GPU path on CPU: world_size-2 `gloo` processes shard the utterances, each
+accumulates the centred EM statistics of its shard (oracle arithmetic standing in for the
+HIP E-step), ONE all-reduce of the packed buffer combines them, and the M-step result
+equals the single-process one (tolerance, not bit-exactness,
+because the summation order differs).  Decode needs no collective: shards are disjoint
+and cover the batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _accumulate(utts, labels, means, vars_, w, k):
+    """Centred statistics [S,k,1+2D] + frame counts [S] of `utts` (state label per frame)."""
+    S, _, D = means.shape
+    stats = np.zeros((S, k, 1 + 2 * D))
+    counts = np.zeros(S)
+    for x, lab in zip(utts, labels):
+        for s in range(S):
+            xs = x[lab == s]
+            if len(xs) == 0:
+                continue
+            p = np.array([O.gmm_evaluate(f, means[s], vars_[s], w[s], neg_log=False)[:k] for f in xs])
+            r = p / p.sum(axis=1, keepdims=True)
+            for c in range(k):
+                d = xs - means[s, c]
+                stats[s, c, 0] += r[:, c].sum()
+                stats[s, c, 1:1 + D] += (r[:, [c]] * d).sum(axis=0)
+                stats[s, c, 1 + D:] += (r[:, [c]] * d * d).sum(axis=0)
+            counts[s] += len(xs)
+    return stats, counts
+
+
+def _problem():
+    rng = np.random.default_rng(3)
+    S, M, D, k = 3, 2, 4, 2
+    means = rng.normal(size=(S, M, D)) * 2
+    vars_ = rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    utts, labels = [], []
+    for u in range(9):
+        T = int(rng.integers(8, 20))
+        lab = np.minimum(np.arange(T) * S // T, S - 1)
+        utts.append(means[lab, rng.integers(0, M, T)] + rng.normal(size=(T, D)))
+        labels.append(lab)
+    return utts, labels, means, vars_, w, k
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "speech-recognition_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from sr.recognition.parallel import shard_utterances, StatsAllReducer, distributed_em_iteration
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        utts, labels, means, vars_, w, k = _problem()
+        mine = shard_utterances([len(u) for u in utts], world)[rank]
+        acc = lambda m, v, ww: _accumulate([utts[i] for i in mine], [labels[i] for i in mine], m, v, ww, k)
+        mu, sigma, wn = distributed_em_iteration(acc, means[:, :k], vars_, w, reducer=StatsAllReducer())
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mu=mu, sigma=sigma, w=wn, mine=mine)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stats_allreduce_world2_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from sr.recognition.parallel import distributed_em_iteration, shard_utterances
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    utts, labels, means, vars_, w, k = _problem()
+    acc = lambda m, v, ww: _accumulate(utts, labels, m, v, ww, k)
+    mu, sigma, wn = distributed_em_iteration(acc, means[:, :k], vars_, w, reducer=None)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for r in (r0, r1):  # every rank ends the iteration with the same, correct model
+        np.testing.assert_allclose(r["mu"], mu, rtol=1e-12)
+        np.testing.assert_allclose(r["sigma"], sigma, rtol=1e-10)
+        np.testing.assert_allclose(r["w"], wn, rtol=1e-12)
+    assert sorted(np.concatenate([r0["mine"], r1["mine"]]).tolist()) == list(range(len(utts)))
+    # and the M-step equals the reference's EM iteration per state (oracle)
+    for s in range(means.shape[0]):
+        data = np.concatenate([x[lab == s] for x, lab in zip(utts, labels)])
+        st = dict(means=means[s].copy(), vars=vars_[s].copy(), w=w[s].copy())
+        O.gmm_em(data, st["means"], st["vars"], st["w"], k, max_iteration=1,
+                 old=(st["means"].copy() * 0, st["vars"].copy() * 0, st["w"].copy() * 0))
+        np.testing.assert_allclose(mu[s], st["means"][:k], rtol=1e-10)
+        np.testing.assert_allclose(sigma[s], st["vars"][:k], rtol=1e-9)
+        np.testing.assert_allclose(wn[s], st["w"][:k], rtol=1e-10)

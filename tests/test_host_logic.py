@@ -1,0 +1,204 @@
+# -*- coding: utf-8 -*-
+"""Host-side logic of the `sr.recognition` mirror that needs no GPU: segment
+bookkeeping, lattice construction (object-level and packed), alignment cutting,
+decode post-processing, state packing, sharding and the M-step -- checked against
+the reference goldens and the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+
+
+@pytest.fixture(scope="module")
+def R(built_library):
+    import sr.recognition as R
+    return R
+
+
+def make_hmm(R, means, vars_, w, trans):
+    h = R.HMM(means.shape[0])
+    h.gmm_states = []
+    for s in range(means.shape[0]):
+        g = R.GMM(means[s, 0].copy(), vars_[s, 0].copy(), means.shape[1])
+        g.update_models(means[s].copy(), vars_[s].copy(), w[s].copy())
+        h.gmm_states.append(g)
+    h.transitions = trans.copy()
+    return h
+
+
+def test_exported_names(R):
+    import sr
+    for name in ("dtw", "decode_hmm_states", "HMM", "GMM", "NES", "HMMState", "MultivariateNormal", "mahalanobis",
+                 "kmeans", "skmeans", "align_gmm_states", "calc_transition_costs", "get_segments_from_path",
+                 "segment_data", "combine_templates", "calc_variance", "cluster_centroids", "build_state_sequences",
+                 "continuous_train"):
+        assert hasattr(R, name), name
+    for name in ("HMMState", "HMM", "decode_hmm_states", "GMM", "build_state_sequences", "NES"):
+        assert hasattr(sr, name), name  # reference sr/__init__.py:2
+
+
+def test_segment_helpers_match_golden_and_oracle(R):
+    g = load_golden("G9_hmm_fit_single")
+    np.testing.assert_array_equal(R.get_segments_from_path(g["gsp_path"], 5), g["gsp_out"])
+    np.testing.assert_allclose(R.calc_transition_costs(2, g["ctc_lens"]), g["ctc_out"], rtol=0)
+    s5 = load_golden("G5_dtw")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_array_equal(R.calc_transition_costs(2, s5["seg_lens_skip"]), s5["trans_skip"])
+    ys = [g["y%d" % i] for i in range(int(g["n"]))]
+    starts = np.array([[0, 5, 11, 18, 25]] * len(ys))
+    ref = O.segment_data(ys, 5, starts)
+    got = R.segment_data(ys, len(ys), 5, starts)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    mu, var = R.combine_templates(ys, len(ys), 5, starts)
+    rmu, rvar = O.combine_templates(ys, 5, starts)
+    np.testing.assert_array_equal(mu, rmu)
+    np.testing.assert_array_equal(var, rvar)
+    np.testing.assert_array_equal(R.calc_variance(ys[0].T), np.cov(ys[0].T).diagonal())
+    np.testing.assert_allclose(R.calc_variance(ys[0].T), np.var(ys[0], axis=0, ddof=1), rtol=1e-12)
+    cl = np.array([0, 1, 1, 0, 2, 2, 2])
+    np.testing.assert_array_equal(R.cluster_centroids(ys[0][:7], cl, 3), O.cluster_centroids(ys[0][:7], cl, 3))
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 7])
+def test_build_state_sequences_matches_reference(R, K):
+    g = load_golden("G4_lattice_decode")
+    W, n = g["means"].shape[:2]
+    hmms = [make_hmm(R, g["means"][i], g["vars"][i], g["w"][i], g["word_trans"]) for i in range(W)]
+    p = "K%d_" % K
+    seq, trans, ends = R.build_state_sequences(hmms, [list(range(W))] * K)
+    assert len(seq) == int(g[p + "R"]) == 1 + K * (W * n + 1)
+    assert list(ends) == list(g[p + "ends"])
+    ref = np.full_like(trans, np.inf)
+    ref[g[p + "arc_to"], g[p + "arc_from"]] = g[p + "arc_cost"]
+    np.testing.assert_array_equal(trans, ref)
+    for r, s in enumerate(seq):
+        w, st = g[p + "row_word"][r], g[p + "row_state"][r]
+        assert (type(s) is R.NES) == (w < 0)
+        if w >= 0:
+            assert s is hmms[w].gmm_states[st]  # shared objects, not copies
+    # the packed builder describes the same graph
+    from sr.recognition.continuous_speech import packed_lattice
+    from sr.recognition import _pack
+    pk, nes_rows = packed_lattice([h.transitions for h in hmms], n, [list(range(W))] * K)
+    dense = np.full_like(trans, np.inf)
+    dense[pk["arc_to"], pk["arc_from"]] = pk["arc_cost"]
+    np.testing.assert_array_equal(dense, ref)
+    np.testing.assert_array_equal(pk["end_rows"], g[p + "ends"])
+    np.testing.assert_array_equal(pk["row_state"], np.where(g[p + "row_word"] < 0, -1,
+                                                            g[p + "row_word"] * n + g[p + "row_state"]))
+    row_state, uniq = _pack.pack_states(seq)
+    assert len(uniq) == W * n
+    np.testing.assert_array_equal(row_state, pk["row_state"])
+    g2 = _pack.graph_from_dense(row_state, trans, [0], ends)
+    assert sorted(zip(g2["arc_to"], g2["arc_from"])) == sorted(zip(pk["arc_to"], pk["arc_from"]))
+
+
+def test_path_postprocessing_matches_reference_main(R):
+    from sr.recognition.batch import path_to_words
+    g = load_golden("G4_lattice_decode")
+    n = g["means"].shape[1]
+    for K in (1, 2, 3, 7):
+        p = "K%d_" % K
+        rw, rs = g[p + "row_word"], g[p + "row_state"]
+        row_state = np.where(rw < 0, -1, rw * n + rs)
+        assert path_to_words(g[p + "path"], row_state, n) == list(g[p + "digits"])
+    assert path_to_words(np.array([]), [0], n) == []
+
+
+def test_cut_segments_matches_reference_rule(R):
+    """The frame ranges cut from the reference's own alignment path, against the oracle's
+    restatement of continuous_speech.py:90-106."""
+    from sr.recognition.continuous_speech import cut_segments, packed_lattice
+    g = load_golden("G4_lattice_decode")
+    W, n = g["means"].shape[:2]
+    labels = list(g["forced_labels"])
+    pk, _ = packed_lattice([g["word_trans"]] * W, n, [[l] for l in labels])
+    got = list(cut_segments(g["forced_path"], pk["row_state"]))
+    # reference rule, straight from the oracle's loop
+    rw, rs, nes, _, _ = O.build_state_sequences(n, [g["word_trans"]] * W, [[l] for l in labels])
+    exp, start, cur = [], None, None
+    for r, c in reversed(g["forced_path"].tolist()):
+        if start is None and not nes[r]:
+            start, cur = c, r
+        if r != cur and start is not None and start < c:
+            exp.append((int(rw[cur]) * n + int(rs[cur]), start, c))
+            start, cur = None, None
+    assert got == exp and len(got) >= 2 * n
+    # consequences the docstring promises: entering frame dropped inside a word, final run open
+    assert all(b > a for _, a, b in got)
+    assert got[-1][0] != labels[-1] * n + n - 1 or got[-1][2] < len(g["forced_x"])
+
+
+def test_pack_states_pads_mixed_mixture_sizes(R):
+    from sr.recognition import _pack
+    a = R.GMM(np.zeros(3), np.ones(3), 2)
+    b = R.GMM(np.ones(3), np.full(3, 2.0), 4)
+    row_state, uniq = _pack.pack_states([R.NES(), a, b, a, R.NES()])
+    np.testing.assert_array_equal(row_state, [-1, 0, 1, 0, -1])
+    means, vars_, w = _pack.stack_gmms(uniq)
+    assert means.shape == (2, 4, 3)
+    np.testing.assert_array_equal(w[0], [0.5, 0.5, 0, 0])
+    np.testing.assert_array_equal(vars_[0, 2:], np.ones((2, 3)))
+    c = R.GMM(np.zeros(5), np.ones(5), 2)
+    with pytest.raises(NameError):
+        _pack.stack_gmms([a, c])
+
+
+def test_gmm_object_semantics_without_gpu(R):
+    g = R.GMM(np.arange(3.0), np.ones(3), 4)
+    assert len(g) == 4 and g.w.tolist() == [0.25] * 4 and g.mu_old.shape == (4, 3)
+    assert sorted(g.__dict__) == ["dists", "id", "mu_old", "n_gaussians", "parent", "sigma_old", "w", "w_old"]
+    assert sorted(g.dists[0].__dict__) == ["_cov", "inv_cov", "mean"]
+    g.update_models(np.ones((2, 3)), np.full((2, 3), 2.0), np.array([0.7, 0.1]))
+    assert g.w.tolist() == [0.7, 0.1, 0.25, 0.25]  # not renormalised
+    np.testing.assert_array_equal(g.dists[1].inv_cov, np.diag([0.5] * 3))
+    with pytest.raises(np.linalg.LinAlgError):
+        g.update_models(np.ones((1, 3)), np.zeros((1, 3)), np.array([1.0]))
+    import copy
+    h = copy.deepcopy(g)
+    assert h.id == g.id and hash(h) == hash(g)
+    a = R.HMM(5)
+    with pytest.raises(AssertionError):
+        a.use_gmm = False
+        a[0]
+
+
+def test_shard_utterances_balances_frames(R):
+    from sr.recognition.parallel import shard_utterances
+    rng = np.random.default_rng(0)
+    lens = rng.integers(50, 151, size=1000)
+    shards = shard_utterances(lens, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(1000))
+    loads = np.array([lens[s].sum() for s in shards])
+    assert loads.max() - loads.min() <= lens.max()
+    assert [len(s) for s in shard_utterances([5, 4], 4)] == [1, 1, 0, 0]
+
+
+def test_m_step_from_centred_statistics_matches_reference_em(R):
+    """One reference EM iteration (oracle) == m_step on centred sufficient statistics."""
+    from sr.recognition.parallel import m_step
+    g = load_golden("G7_gmm_em")
+    data, k = g["data"], 3
+    means, vars_, w = g["init_means"].copy(), g["init_vars"].copy(), g["init_w"].copy()
+    p = np.array([O.gmm_evaluate(x, means, vars_, w, neg_log=False)[:k] for x in data])
+    r = p / p.sum(axis=1, keepdims=True)
+    D = data.shape[1]
+    stats = np.zeros((1, k, 1 + 2 * D))
+    for c in range(k):
+        d = data - means[c]
+        stats[0, c, 0] = r[:, c].sum()
+        stats[0, c, 1:1 + D] = (r[:, [c]] * d).sum(axis=0)
+        stats[0, c, 1 + D:] = (r[:, [c]] * d * d).sum(axis=0)
+    mu, sigma, wn = m_step(stats, [len(data)], means[None, :k])
+    st = O.new_gmm_state(g["mu0"], g["var0"], len(w))
+    st["means"][:], st["vars"][:], st["w"][:] = means, vars_, w
+    O.gmm_em(data, st["means"], st["vars"], st["w"], k, max_iteration=1,
+             old=(st["mu_old"], st["sigma_old"], st["w_old"]))
+    np.testing.assert_allclose(mu[0], st["means"][:k], rtol=1e-12)
+    np.testing.assert_allclose(sigma[0], st["vars"][:k], rtol=1e-11)
+    np.testing.assert_allclose(wn[0], st["w"][:k], rtol=1e-12)
