@@ -149,11 +149,40 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     }
     std::vector<float> fA(g->hA.begin(), g->hA.end()), fB(g->hB.begin(), g->hB.end()),
         fC(g->hC.begin(), g->hC.end());
+    // ---- MFMA operand packing (see gh_loglik_mfma.hip) ----
+    int M_pad = 1;
+    if (M <= 16) { while (M_pad < M) M_pad <<= 1; } else { M_pad = (M + 15) & ~15; }
+    const int n_tiles = (S * M_pad + 15) / 16, KS = KP / 2;
+    g->M_pad = M_pad;
+    g->n_tiles = n_tiles;
+    g->dApk64 = nullptr; g->dCpk64 = nullptr; g->dApk32 = nullptr; g->dCpk32 = nullptr;
+    std::vector<double> apk64((size_t)n_tiles * KS * 64, 0.0), cpk64((size_t)n_tiles * 16, -INFINITY);
+    std::vector<float> apk32(apk64.size(), 0.f), cpk32(cpk64.size(), -INFINITY);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int j = 0; j < 16; ++j) {  // j = natural position inside the tile
+            const int gp = t * 16 + j, s = gp / M_pad, m = gp % M_pad;
+            if (s >= S || m >= M) continue;  // padding component: weight 0 (C = -inf, P = 0)
+            const int go = s * M + m;
+            cpk64[gp] = g->hC[go];
+            cpk32[gp] = (float)g->hC[go];
+            // accumulator row that makes lane group q = j/4 hold this component in register j%4:
+            // f64 16x16x4: row = (lane>>4) + 4*reg  ->  row = j/4 + 4*(j%4); f32: row = 4*(lane>>4) + reg = j
+            const int row64 = (j >> 2) + 4 * (j & 3), row32 = j;
+            for (int ks = 0; ks < KS; ++ks)
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int kk = 4 * ks + kq;
+                    const double v = kk < KP ? g->hA[(size_t)go * KP + kk] : g->hB[(size_t)go * KP + kk - KP];
+                    apk64[((size_t)t * KS + ks) * 64 + kq * 16 + row64] = v;
+                    apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)v;
+                }
+        }
     std::vector<double> vmean(mean, mean + (size_t)G * D);
     int rc = GH_OK;
     if ((rc = upload(&g->dA64, g->hA)) || (rc = upload(&g->dB64, g->hB)) || (rc = upload(&g->dC64, g->hC)) ||
         (rc = upload(&g->dA32, fA)) || (rc = upload(&g->dB32, fB)) || (rc = upload(&g->dC32, fC)) ||
-        (rc = upload(&g->dMean, vmean)) || (rc = upload(&g->dIvar, ivar)) || (rc = upload(&g->dLogc, logc))) {
+        (rc = upload(&g->dMean, vmean)) || (rc = upload(&g->dIvar, ivar)) || (rc = upload(&g->dLogc, logc)) ||
+        (rc = upload(&g->dApk64, apk64)) || (rc = upload(&g->dCpk64, cpk64)) ||
+        (rc = upload(&g->dApk32, apk32)) || (rc = upload(&g->dCpk32, cpk32))) {
         gh_gmm_destroy(g);
         return rc;
     }
@@ -167,6 +196,7 @@ extern "C" void gh_gmm_destroy(gh_gmm* g) {
     hipFree(g->dA64); hipFree(g->dB64); hipFree(g->dC64);
     hipFree(g->dA32); hipFree(g->dB32); hipFree(g->dC32);
     hipFree(g->dMean); hipFree(g->dIvar); hipFree(g->dLogc);
+    hipFree(g->dApk64); hipFree(g->dCpk64); hipFree(g->dApk32); hipFree(g->dCpk32);
     delete g;
 }
 
@@ -247,7 +277,10 @@ extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_ho
         GH_HIP(hipMalloc(&b->nll, (size_t)b->N * g->S * esz));
         b->nll_S = g->S;
     }
-    int rc = gh_launch_loglik(ctx, g, b);
+    // matrix-core kernel when the shape is covered, vector kernel otherwise (GMMHMM_LOGLIK=valu forces it)
+    static const bool force_valu = [] { const char* e = getenv("GMMHMM_LOGLIK"); return e && !strcmp(e, "valu"); }();
+    int rc = force_valu ? 1 : gh_launch_loglik_mfma(ctx, g, b);
+    if (rc == 1) rc = gh_launch_loglik(ctx, g, b);
     if (rc) return rc;
     if (out_host && b->N > 0) {
         GH_HIP(hipMemcpyAsync(out_host, b->nll, (size_t)b->N * g->S * esz, hipMemcpyDeviceToHost, ctx->stream));

@@ -51,6 +51,11 @@ struct gh_gmm {
     float *dA32, *dB32, *dC32;       // device fp32
     // plain parameters (fp64) for the training kernels: mean, inv_var [G,D], logc [G]
     double *dMean, *dIvar, *dLogc;
+    // MFMA operand packing (gh_loglik_mfma.hip): mixtures padded to M_pad components,
+    // Gaussians to n_tiles*16 rows; Apk[tile][kstep][lane] fragments, Cpk[tile*16 + j]
+    int M_pad, n_tiles;
+    double *dApk64, *dCpk64;
+    float *dApk32, *dCpk32;
 };
 
 struct gh_batch {
@@ -103,3 +108,4 @@ struct gh_lattices {
 
 // kernels (gh_loglik.hip / gh_viterbi.hip)
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
+int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);  // 1 = shape not covered
