@@ -156,7 +156,8 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     g->M_pad = M_pad;
     g->n_tiles = n_tiles;
     g->dApk64 = nullptr; g->dCpk64 = nullptr; g->dApk32 = nullptr; g->dCpk32 = nullptr;
-    std::vector<double> apk64((size_t)n_tiles * KS * 64, 0.0), cpk64((size_t)n_tiles * 16, -INFINITY);
+    // (+2 all-zero tiles: the kernel's run-ahead operand loads stay in bounds)
+    std::vector<double> apk64((size_t)(n_tiles + 2) * KS * 64, 0.0), cpk64((size_t)(n_tiles + 2) * 16, -INFINITY);
     std::vector<float> apk32(apk64.size(), 0.f), cpk32(cpk64.size(), -INFINITY);
     for (int t = 0; t < n_tiles; ++t)
         for (int j = 0; j < 16; ++j) {  // j = natural position inside the tile
@@ -216,7 +217,14 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;
     for (int64_t u = 0; u < U; ++u) b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
+    b->perm.resize(U);
+    std::iota(b->perm.begin(), b->perm.end(), (int64_t)0);
+    std::stable_sort(b->perm.begin(), b->perm.end(), [&](int64_t x, int64_t y) {
+        return off[x + 1] - off[x] > off[y + 1] - off[y];
+    });
+    b->d_perm = nullptr;
     int rc = upload(&b->d_offsets, b->offsets);
+    if (!rc) rc = upload(&b->d_perm, b->perm);
     if (rc) { delete b; return rc; }
     *out = b;
     return GH_OK;
@@ -259,6 +267,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
     if (b->owns_feats && b->feats) hipFree(b->feats);
     if (b->nll) hipFree(b->nll);
     if (b->d_offsets) hipFree(b->d_offsets);
+    if (b->d_perm) hipFree(b->d_perm);
     delete b;
 }
 
@@ -441,22 +450,29 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     for (int l = 0; l < lat->L; ++l)
         GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
                    lat->lat[l].max_state, S);
-    // per-utterance bookkeeping (host)
-    std::vector<int64_t> end_off(U + 1, 0), perm(U);
-    for (int64_t u = 0; u < U; ++u) {
-        const int l = utt_lattice ? utt_lattice[u] : 0;
-        GH_REQUIRE(l >= 0 && l < lat->L, "gh_viterbi: utt_lattice[%lld]=%d out of range", (long long)u, l);
-        end_off[u + 1] = end_off[u] + lat->lat[l].n_end;
-        if (want_path) {
+    // per-utterance bookkeeping (host); with one graph for all utterances everything is implicit
+    const bool uniform = utt_lattice == nullptr;
+    const std::vector<int64_t>& perm = b->perm;
+    std::vector<int64_t> end_off;
+    int64_t n_end_total = 0;
+    if (uniform) {
+        n_end_total = U * lat->lat[0].n_end;
+    } else {
+        end_off.assign(U + 1, 0);
+        for (int64_t u = 0; u < U; ++u) {
+            const int l = utt_lattice[u];
+            GH_REQUIRE(l >= 0 && l < lat->L, "gh_viterbi: utt_lattice[%lld]=%d out of range", (long long)u, l);
+            end_off[u + 1] = end_off[u] + lat->lat[l].n_end;
+        }
+        n_end_total = end_off[U];
+    }
+    if (want_path)
+        for (int64_t u = 0; u < U; ++u) {
+            const int l = uniform ? 0 : utt_lattice[u];
             const int64_t T = b->offsets[u + 1] - b->offsets[u];
             GH_REQUIRE(path_off[u + 1] - path_off[u] >= (T > 1 ? T * lat->lat[l].nlev : 0),
                        "gh_viterbi: path capacity of utterance %lld too small", (long long)u);
         }
-    }
-    std::iota(perm.begin(), perm.end(), (int64_t)0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) {
-        return b->offsets[x + 1] - b->offsets[x] > b->offsets[y + 1] - b->offsets[y];
-    });
     // back-pointer scratch is chunked (<= 4 GiB per launch)
     const size_t BP_BUDGET = (size_t)4 << 30;
     std::vector<int64_t> bp_off(U, 0);
@@ -484,13 +500,14 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
 
     gh_vit_args a;
     memset(&a, 0, sizeof a);
-    int64_t *d_perm, *d_bpoff, *d_endoff, *d_pathoff = nullptr, *d_costsoff = nullptr;
+    int64_t *d_bpoff = nullptr, *d_endoff = nullptr, *d_pathoff = nullptr, *d_costsoff = nullptr;
     int32_t *d_uttlat = nullptr, *d_bestend, *d_path = nullptr, *d_pathlen = nullptr;
     double *d_endcost, *d_costs = nullptr;
     uint16_t* d_bp = nullptr;
     Carver cv;
-    cv.add(&d_perm, U); cv.add(&d_bpoff, U); cv.add(&d_endoff, U + 1);
-    cv.add(&d_bestend, U); cv.add(&d_endcost, end_off[U]);
+    if (want_path) cv.add(&d_bpoff, U);
+    if (!uniform) cv.add(&d_endoff, U + 1);
+    cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
     if (utt_lattice) cv.add(&d_uttlat, U);
     if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); cv.add(&d_bp, bp_max); }
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
@@ -498,9 +515,8 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
-    GH_HIP(hipMemcpyAsync(d_perm, perm.data(), U * 8, hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (want_path) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
+    if (!uniform) GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
     if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (out_costs) GH_HIP(hipMemcpyAsync(d_costsoff, costs_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
@@ -509,7 +525,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
     a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
     a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
-    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = d_perm;
+    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
     a.bp = d_bp; a.bp_off = d_bpoff; a.end_cost = d_endcost; a.end_off = d_endoff; a.best_end = d_bestend;
     a.path = d_path; a.path_off = d_pathoff; a.path_len = d_pathlen; a.costs = d_costs; a.costs_off = d_costsoff;
     a.flag = ctx->d_flag;
@@ -529,7 +545,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     }
     int flag = 0;
     GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (out_end_cost) GH_HIP(hipMemcpyAsync(out_end_cost, d_endcost, end_off[U] * 8, hipMemcpyDeviceToHost, st));
+    if (out_end_cost) GH_HIP(hipMemcpyAsync(out_end_cost, d_endcost, n_end_total * 8, hipMemcpyDeviceToHost, st));
     if (out_best_end) GH_HIP(hipMemcpyAsync(out_best_end, d_bestend, U * 4, hipMemcpyDeviceToHost, st));
     if (want_path) {
         GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));

@@ -70,6 +70,9 @@ struct gh_batch {
     int64_t max_T;
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
+    // launch order of the DP kernels: utterances sorted longest first (computed once)
+    std::vector<int64_t> perm;
+    int64_t* d_perm;
 };
 
 // arc flag bits stored in pred_row

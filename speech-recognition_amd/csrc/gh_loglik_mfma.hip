@@ -44,9 +44,34 @@ template <> struct Acc<float> {
     }
 };
 
+// exp(x) for x <= 0 (what a log-sum-exp needs), branch-free, ~1 ulp: n = rint(x log2 e),
+// r = x - n ln2 (two-step, fma), Taylor degree 13 on |r| <= ln2/2, scale by 2^n (v_ldexp_f64:
+// underflows to 0 / subnormals by itself).  NaN stays NaN, -inf gives 0.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = (x < -1000.0) ? -1000.0 : x;  // keeps NaN (comparison false)
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;            // 1/13!
+    p = fma(p, r, 2.0876756987868098979e-09);        // 1/12!
+    p = fma(p, r, 2.5052108385441718775e-08);        // 1/11!
+    p = fma(p, r, 2.7557319223985890653e-07);        // 1/10!
+    p = fma(p, r, 2.7557319223985892511e-06);        // 1/9!
+    p = fma(p, r, 2.4801587301587301566e-05);        // 1/8!
+    p = fma(p, r, 1.9841269841269841253e-04);        // 1/7!
+    p = fma(p, r, 1.3888888888888889419e-03);        // 1/6!
+    p = fma(p, r, 8.3333333333333332177e-03);        // 1/5!
+    p = fma(p, r, 4.1666666666666664354e-02);        // 1/4!
+    p = fma(p, r, 1.6666666666666665741e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 template <typename T> __device__ __forceinline__ T t_exp(T x);
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp_nonpos(x); }
 template <typename T> __device__ __forceinline__ T t_log(T x);
 template <> __device__ __forceinline__ float t_log<float>(float x) { return __logf(x); }
 template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
@@ -55,11 +80,8 @@ template <typename T> __device__ __forceinline__ T xor_lane(T v, int mask);
 template <> __device__ __forceinline__ float xor_lane<float>(float v, int mask) { return __shfl_xor(v, mask, 64); }
 template <> __device__ __forceinline__ double xor_lane<double>(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
-template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm) {
-    // -(mx + log sm); NaN parameters poison the state, an all-(-inf) state costs +inf
-    if (sm != sm) return T(NAN);
-    return (sm > T(0)) ? -(mx + t_log<T>(sm)) : T(INFINITY);
-}
+// -(mx + log sm), branch-free: sm == 0 (every component off) gives +inf, NaN stays NaN
+template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm) { return -(mx + t_log<T>(sm)); }
 
 // max and sum-of-exp over the 4 registers of one lane, then over `width` lane groups (1, 2 or 4)
 template <typename T, typename V>
@@ -75,13 +97,67 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm) {
     sm = e;
 }
 
-// KS = number of k-steps (K = 4*KS = 2*KP).
-template <typename T, int KS>
+// One tile's epilogue: log-sum-exp over the mixture components held in the accumulators of
+// both column tiles, written into the LDS output tile.  MP = padded mixture size (compile
+// time); MP == 32 stands for "several tiles per state" (M_pad = 16 * tiles_per_state, run
+// time), merged through (run_mx, run_sm).  Straight-line code: lanes with nothing to store
+// write to a per-lane dummy slot behind the tile, so the whole epilogue can be scheduled
+// under the next tile's MFMAs.
+template <typename T, typename V, int MP>
+__device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int t, int f, int q, int S, int RS,
+                                              int chunk_s0, int tiles_per_state, T* lds, T* dummy,
+                                              T (&run_mx)[2], T (&run_sm)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const V& acc = c ? acc1 : acc0;
+        T* orow = lds + (16 * c + f) * RS - chunk_s0;
+        if (MP == 1) {
+            const int s = 16 * t + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *((s + r < S) ? orow + s + r : dummy) = -acc[r];
+        } else if (MP == 2) {
+            const int s = 8 * t + 2 * q;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
+                const T m = fmax(x0, x1);
+                const T ms = (m == -INFINITY) ? T(0) : m;
+                const T e = t_exp<T>(x0 - ms) + t_exp<T>(x1 - ms);
+                *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e);
+            }
+        } else if (MP <= 16) {
+            constexpr int width = MP / 4;  // lane groups per state: 1, 2 or 4
+            T mx, sm;
+            tile_lse<T, V>(acc, width, mx, sm);
+            const int s = (16 / MP) * t + q / width;
+            *(((q & (width - 1)) == 0 && s < S) ? orow + s : dummy) = nll_of<T>(mx, sm);
+        } else {
+            T mx, sm;
+            tile_lse<T, V>(acc, 4, mx, sm);
+            const T m = fmax(run_mx[c], mx);
+            const T ms = (m == -INFINITY) ? T(0) : m;
+            run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms) + sm * t_exp<T>(mx - ms);
+            run_mx[c] = m;
+            const bool last = (t + 1) % tiles_per_state == 0;
+            const int s = t / tiles_per_state;
+            *((last && q == 0 && s < S) ? orow + s : dummy) = nll_of<T>(run_mx[c], run_sm[c]);
+            run_mx[c] = last ? T(-INFINITY) : run_mx[c];
+            run_sm[c] = last ? T(0) : run_sm[c];
+        }
+    }
+}
+
+// KS = number of k-steps (K = 4*KS = 2*KP).  A fragments travel through a ring of R = KS/2
+// registers: slot j serves k-step j, is refilled with k-step j+R of the same tile, serves it,
+// and is refilled with k-step j of the NEXT tile -- every load has half a tile of MFMAs
+// (R*2 instructions, >= 1280 cycles in fp64) to return from L2.
+template <typename T, int KS, int MP>
 __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
                                                          T* __restrict__ out) {
     typedef typename Acc<T>::type V;
+    constexpr int R = KS / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
     const int lane = threadIdx.x;
@@ -111,96 +187,74 @@ __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X
     }
     __syncthreads();
 
-    // ---- stream the Gaussian tiles -----------------------------------------------------
-    T a_cur[KS], a_nxt[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_cur[ks] = Apk[(int64_t)ks * 64 + lane];
-
-    const int states_per_tile = (M_pad <= 16) ? 16 / M_pad : 0;
-    const int tiles_per_state = (M_pad <= 16) ? 1 : M_pad / 16;
-    T run_mx[2] = {-INFINITY, -INFINITY}, run_sm[2] = {T(0), T(0)};  // M_pad > 16: across tiles
-    int chunk_s0 = 0;  // first state held in the LDS output tile
-    const int SC = (M_pad <= 16) ? chunk_tiles * states_per_tile : chunk_tiles / tiles_per_state;
+    const int tiles_per_state = (MP <= 16) ? 1 : M_pad / 16;
+    const int SC = (MP <= 16) ? chunk_tiles * (16 / (MP <= 16 ? MP : 16)) : chunk_tiles / tiles_per_state;
     const int RS = (S <= SC) ? S : SC;  // LDS row stride: whole matrix rows when they fit one chunk
+    T* dummy = lds + 32 * RS + lane;    // per-lane slot behind the output tile
+    T run_mx[2] = {-INFINITY, -INFINITY}, run_sm[2] = {T(0), T(0)};
+    int chunk_s0 = 0;  // first state held in the LDS output tile
 
-    for (int t = 0; t < n_tiles; ++t) {
-        if (t + 1 < n_tiles) {
-            const T* nx = Apk + (int64_t)(t + 1) * KS * 64 + lane;
+    // ---- stream the Gaussian tiles; the epilogue of tile t-1 runs under the MFMAs of tile t ----
+    // (the host pads Apk / Cpk with one all-zero tile, so the run-ahead loads stay in bounds)
+    T ring[R];
+    const T* ap = Apk + lane;  // next fragment to fetch
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a_nxt[ks] = nx[ks * 64];
-        }
-        V acc0, acc1;
-        {
-            const T* cp = Cpk + t * 16 + 4 * q;
+    for (int j = 0; j < R; ++j) ring[j] = ap[j * 64];
+    ap += R * 64;
+    V c_nxt, p0, p1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { acc0[r] = cp[r]; acc1[r] = cp[r]; }
-        }
+    for (int r = 0; r < 4; ++r) c_nxt[r] = Cpk[4 * q + r];
+
+    // one tile of MFMAs: accumulators start at C (prefetched), ring refilled as it is consumed
+    auto mfma_tile = [&](int t, V& acc0, V& acc1) {
+        acc0 = c_nxt;
+        acc1 = c_nxt;
+        const T* cp = Cpk + (t + 1) * 16 + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c_nxt[r] = cp[r];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            acc0 = Acc<T>::mfma(a_cur[ks], b[0][ks], acc0);
-            acc1 = Acc<T>::mfma(a_cur[ks], b[1][ks], acc1);
+            const T a = ring[ks % R];
+            acc0 = Acc<T>::mfma(a, b[0][ks], acc0);
+            acc1 = Acc<T>::mfma(a, b[1][ks], acc1);
+            ring[ks % R] = ap[ks * 64];
         }
-        // ---- epilogue: log-sum-exp over the mixture, into the LDS output tile ----------
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const V& acc = c ? acc1 : acc0;
-            T* orow = lds + (16 * c + f) * RS;
-            if (M_pad == 1) {
-                const int s = 16 * t + 4 * q - chunk_s0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (s + r + chunk_s0 < S) orow[s + r] = -acc[r];
-            } else if (M_pad == 2) {
-                const int s = 8 * t + 2 * q - chunk_s0;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
-                    const T m = fmax(x0, x1);
-                    const T ms = (m == -INFINITY) ? T(0) : m;
-                    const T e = t_exp<T>(x0 - ms) + t_exp<T>(x1 - ms);
-                    if (s + h + chunk_s0 < S) orow[s + h] = nll_of<T>(m, e);
-                }
-            } else if (M_pad <= 16) {
-                const int width = M_pad / 4;  // lane groups per state: 1, 2 or 4
-                T mx, sm;
-                tile_lse<T, V>(acc, width, mx, sm);
-                const int s = states_per_tile * t + q / width;
-                if ((q & (width - 1)) == 0 && s < S) orow[s - chunk_s0] = nll_of<T>(mx, sm);
-            } else {
-                T mx, sm;
-                tile_lse<T, V>(acc, 4, mx, sm);
-                // merge this tile into the running (max, sum) of the state
-                const T m = fmax(run_mx[c], mx);
-                const T ms = (m == -INFINITY) ? T(0) : m;
-                run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms) + sm * t_exp<T>(mx - ms);
-                run_mx[c] = m;
-                if ((t + 1) % tiles_per_state == 0) {
-                    const int s = t / tiles_per_state;
-                    if (q == 0 && s < S) orow[s - chunk_s0] = nll_of<T>(run_mx[c], run_sm[c]);
-                    run_mx[c] = -INFINITY;
-                    run_sm[c] = T(0);
-                }
+        ap += KS * 64;
+    };
+    auto flush = [&]() {
+        const int cnt = ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
+        __syncthreads();
+        if (cnt == S) {  // whole rows: the [nrows, S] block is contiguous in memory
+            T* dst = out + n0 * S;
+            const int total = nrows * S;
+            for (int i = lane; i < total; i += 64) dst[i] = lds[i];
+        } else if (cnt > 0) {
+            for (int r = 0; r < nrows; ++r) {
+                T* dst = out + (n0 + r) * S + chunk_s0;
+                for (int j = lane; j < cnt; j += 64) dst[j] = lds[r * RS + j];
             }
         }
-        // ---- flush the LDS tile when its state chunk is complete -----------------------
-        if ((t + 1) % chunk_tiles == 0 || t + 1 == n_tiles) {
-            const int cnt = ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
-            __syncthreads();
-            if (cnt == S) {  // whole rows: the [nrows, S] block is contiguous in memory
-                T* dst = out + n0 * S;
-                const int total = nrows * S;
-                for (int i = lane; i < total; i += 64) dst[i] = lds[i];
-            } else if (cnt > 0) {
-                for (int r = 0; r < nrows; ++r) {
-                    T* dst = out + (n0 + r) * S + chunk_s0;
-                    for (int j = lane; j < cnt; j += 64) dst[j] = lds[r * RS + j];
-                }
-            }
-            __syncthreads();
-            chunk_s0 += SC;
-        }
+        __syncthreads();
+        chunk_s0 += SC;
+    };
+
+    mfma_tile(0, p0, p1);
+    for (int t = 1; t < n_tiles; ++t) {
+        V acc0, acc1;
+        mfma_tile(t, acc0, acc1);
+        tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, run_mx, run_sm);
+        // schedule: one MFMA, then a slice of the previous tile's epilogue VALU work
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        for (int i = 0; i < 2 * KS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, sizeof(T) == 8 ? 5 : 3, 0);  // VALU
+        }
+        if (t % chunk_tiles == 0) flush();
+        p0 = acc0;
+        p1 = acc1;
     }
+    tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, run_mx, run_sm);
+    flush();
 }
 
 template <typename T>
@@ -219,14 +273,23 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
         chunk_tiles = (S <= 64) ? n_tiles : 64 * tps;
     }
     const int SC = (M_pad <= 16) ? chunk_tiles * (16 / M_pad) : chunk_tiles / (M_pad / 16);
-    const size_t lds = (size_t)32 * std::max(std::min(SC, S), g->D) * sizeof(T);
+    const size_t lds = ((size_t)32 * std::max(std::min(SC, S), g->D) + 64) * sizeof(T);
     const unsigned grid = (unsigned)((N + 31) / 32);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
-#define GH_MF_CASE(ks)                                                                                  \
-    case ks:                                                                                            \
-        hipLaunchKernelGGL((loglik_mfma_kernel<T, ks>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                           Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, out);                              \
+#define GH_MF_LAUNCH(ks, mp)                                                                                \
+    hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
+                       Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, out)
+#define GH_MF_CASE(ks)                                   \
+    case ks:                                             \
+        switch (M_pad) {                                 \
+            case 1: GH_MF_LAUNCH(ks, 1); break;          \
+            case 2: GH_MF_LAUNCH(ks, 2); break;          \
+            case 4: GH_MF_LAUNCH(ks, 4); break;          \
+            case 8: GH_MF_LAUNCH(ks, 8); break;          \
+            case 16: GH_MF_LAUNCH(ks, 16); break;        \
+            default: GH_MF_LAUNCH(ks, 32); break;        \
+        }                                                \
         break;
     switch (KS) {
         GH_MF_CASE(2)
@@ -238,6 +301,7 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
             return 1;  // not an MFMA shape: caller falls back to the vector kernel
     }
 #undef GH_MF_CASE
+#undef GH_MF_LAUNCH
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

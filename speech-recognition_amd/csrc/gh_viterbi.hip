@@ -139,7 +139,7 @@ __global__ void viterbi_kernel(gh_vit_args a) {
     if (tid == 0) {
         double best = INF;
         int bi = -1;
-        double* ec = a.end_cost ? a.end_cost + a.end_off[u] : nullptr;
+        double* ec = a.end_cost ? a.end_cost + (a.end_off ? a.end_off[u] : u * n_end) : nullptr;
         for (int k = 0; k < n_end; ++k) {
             const double c = prev[end_rows[k]];
             if (ec) ec[k] = c;

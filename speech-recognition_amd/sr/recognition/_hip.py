@@ -343,7 +343,7 @@ class Lattices:
                                    _ptr(best_end, _c_i32p), _ptr(path, _c_i32p), _ptr(path_off, _c_i64p),
                                    _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p), _ptr(costs_off, _c_i64p)))
         out = dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost,
-                   end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if U <= 100000 else None)
+                   end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if U <= 2048 else None)
         if want_path:
             out["paths"] = [path[path_off[u]:path_off[u] + path_len[u]].astype(np.int64) for u in range(U)]
         if want_costs:
