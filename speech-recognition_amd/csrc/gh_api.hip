@@ -44,6 +44,17 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     GH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     GH_HIP(hipMalloc((void**)&c->d_flag, sizeof(int)));
     GH_HIP(hipMemset(c->d_flag, 0, sizeof(int)));
+    {   // tables of the fp64 exp/log used by the likelihood epilogue, computed in long double
+        double t[384];
+        for (int j = 0; j < 128; ++j) {
+            t[j] = (double)exp2l((long double)j / 128.0L);
+            const double inv = (double)(1.0L / (0.5L + ((long double)j + 0.5L) / 256.0L));
+            t[128 + j] = inv;
+            t[256 + j] = (double)(-logl((long double)inv));
+        }
+        GH_HIP(hipMalloc((void**)&c->d_fp64_tables, sizeof t));
+        GH_HIP(hipMemcpy(c->d_fp64_tables, t, sizeof t, hipMemcpyHostToDevice));
+    }
     *out = c;
     return GH_OK;
 }
@@ -54,6 +65,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* c) {
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
     hipFree(c->d_flag);
+    hipFree(c->d_fp64_tables);
     hipStreamDestroy(c->stream);
     delete c;
 }

@@ -35,6 +35,7 @@ struct gh_ctx {
     void* scratch;
     size_t scratch_bytes;
     int* d_flag;  // device error flag (self-pointing DP cell etc.)
+    double* d_fp64_tables;  // [384] exp2 / inv / -log tables of the fp64 log-sum-exp (gh_loglik_mfma.hip)
 };
 
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out);

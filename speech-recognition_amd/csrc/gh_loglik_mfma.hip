@@ -44,55 +44,104 @@ template <> struct Acc<float> {
     }
 };
 
-// exp(x) for x <= 0 (what a log-sum-exp needs), branch-free, ~1 ulp: n = rint(x log2 e),
-// r = x - n ln2 (two-step, fma), Taylor degree 13 on |r| <= ln2/2, scale by 2^n (v_ldexp_f64:
-// underflows to 0 / subnormals by itself).  NaN stays NaN, -inf gives 0.
-__device__ __forceinline__ double exp_nonpos(double x) {
-    x = (x < -1000.0) ? -1000.0 : x;  // keeps NaN (comparison false)
-    const double n = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;            // 1/13!
-    p = fma(p, r, 2.0876756987868098979e-09);        // 1/12!
-    p = fma(p, r, 2.5052108385441718775e-08);        // 1/11!
-    p = fma(p, r, 2.7557319223985890653e-07);        // 1/10!
-    p = fma(p, r, 2.7557319223985892511e-06);        // 1/9!
-    p = fma(p, r, 2.4801587301587301566e-05);        // 1/8!
-    p = fma(p, r, 1.9841269841269841253e-04);        // 1/7!
-    p = fma(p, r, 1.3888888888888889419e-03);        // 1/6!
-    p = fma(p, r, 8.3333333333333332177e-03);        // 1/5!
-    p = fma(p, r, 4.1666666666666664354e-02);        // 1/4!
-    p = fma(p, r, 1.6666666666666665741e-01);        // 1/3!
+// ---- fp64 exp / log for the log-sum-exp epilogue -------------------------------------
+// On gfx950 fp64 MFMA and fp64 VALU share the same FMA pipeline (measured with
+// tools/mfma_coissue.hip: their times ADD), so every fp64 VALU instruction of the epilogue
+// is paid in full next to the MFMAs.  Both functions are therefore table driven (128-entry
+// tables in LDS, filled once per workgroup) with short polynomials, branch-free:
+//   exp: x = n ln2/128 + r, |r| <= ln2/256;  2^(n/128) = 2^(n>>7) * T[n&127];
+//        exp(r) - 1 by a degree-5 polynomial (|error| < 6e-19)           ~11 fp64 ops
+//   log: s = m 2^e, m in [.5,1); m * INV[j] = 1 + rho, |rho| <= 2^-8, j = top 7 mantissa
+//        bits; log s = e ln2 + L[j] + log1p(rho), degree-6 polynomial      ~12 fp64 ops
+// Accuracy ~1e-16 absolute on exp (arguments are <= 0) and on log of sums in [1, M].
+struct Fp64Tables {
+    double exp2[128];   // 2^(j/128)
+    double inv[128];    // 1 / centre of mantissa bin j, centre = 0.5 + (j + 0.5)/256
+    double nlog[128];   // -log(inv[j])
+};
+
+__device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tab) {
+    x = (x < -745.0) ? -745.0 : x;  // keeps NaN (comparison false); exp(-745) is the last subnormal
+    const double n = __builtin_rint(x * 184.66496523378731);         // 128 / ln 2
+    double r = fma(n, -0.00541521234663378, x);                      // ln2/128, high part (32 bits)
+    r = fma(n, -1.4907929134926466e-12, r);                          // low part
+    const int ni = (int)n;
+    const double t = tab[ni & 127];
+    double p = fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);  // 1/120, 1/24
+    p = fma(p, r, 1.6666666666666665741e-01);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)n);
+    p = p * r;                                                        // exp(r) - 1
+    return __builtin_ldexp(fma(t, p, t), ni >> 7);
 }
 
-template <typename T> __device__ __forceinline__ T t_exp(T x);
-template <> __device__ __forceinline__ float t_exp<float>(float x) { return __expf(x); }
-template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp_nonpos(x); }
-template <typename T> __device__ __forceinline__ T t_log(T x);
-template <> __device__ __forceinline__ float t_log<float>(float x) { return __logf(x); }
-template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
+__device__ __forceinline__ double log_pos(double s, const double* __restrict__ inv,
+                                          const double* __restrict__ nlog) {
+    const double m = __builtin_amdgcn_frexp_mant(s);   // [0.5, 1)
+    const int e = __builtin_amdgcn_frexp_exp(s);
+    const int j = (__double2hiint(m) >> 13) & 127;
+    const double rho = fma(m, inv[j], -1.0);
+    double p = fma(rho, -1.6666666666666665741e-01, 0.2);
+    p = fma(p, rho, -0.25);
+    p = fma(p, rho, 3.3333333333333331483e-01);
+    p = fma(p, rho, -0.5);
+    p = fma(p, rho, 1.0);
+    const double r = fma((double)e, 6.93147180559945286e-01, fma(p, rho, nlog[j]));
+    return (s == 0.0) ? -INFINITY : r;  // NaN stays NaN
+}
 
-template <typename T> __device__ __forceinline__ T xor_lane(T v, int mask);
-template <> __device__ __forceinline__ float xor_lane<float>(float v, int mask) { return __shfl_xor(v, mask, 64); }
-template <> __device__ __forceinline__ double xor_lane<double>(double v, int mask) { return __shfl_xor(v, mask, 64); }
+// `tab` = Fp64Tables image in LDS (unused by the fp32 path, which has v_exp_f32 / v_log_f32)
+template <typename T> __device__ __forceinline__ T t_exp(T x, const double* tab);
+template <> __device__ __forceinline__ float t_exp<float>(float x, const double*) { return __expf(x); }
+template <> __device__ __forceinline__ double t_exp<double>(double x, const double* tab) { return exp_nonpos(x, tab); }
+template <typename T> __device__ __forceinline__ T t_log(T x, const double* tab);
+template <> __device__ __forceinline__ float t_log<float>(float x, const double*) { return __logf(x); }
+template <> __device__ __forceinline__ double t_log<double>(double x, const double* tab) {
+    return log_pos(x, tab + 128, tab + 256);
+}
+
+// Cross-lane pair exchange without LDS: gfx950's v_permlane16_swap / v_permlane32_swap swap
+// 16-lane rows (resp. 32-lane halves) between two registers; fed the same value twice they
+// leave (own row, partner row) pairs in the two results, so op(a, b) is the xor-16 (xor-32)
+// butterfly -- 1 VALU op per dword instead of a ds_bpermute round trip.
+template <int W> __device__ __forceinline__ void swap_rows(unsigned v, unsigned& a, unsigned& b) {
+    if (W == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        a = r[0]; b = r[1];
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        a = r[0]; b = r[1];
+    }
+}
+template <int W> __device__ __forceinline__ void pair_of(float v, float& a, float& b) {
+    unsigned x, y;
+    swap_rows<W>(__float_as_uint(v), x, y);
+    a = __uint_as_float(x); b = __uint_as_float(y);
+}
+template <int W> __device__ __forceinline__ void pair_of(double v, double& a, double& b) {
+    unsigned xl, yl, xh, yh;
+    swap_rows<W>((unsigned)__double2loint(v), xl, yl);
+    swap_rows<W>((unsigned)__double2hiint(v), xh, yh);
+    a = __hiloint2double((int)xh, (int)xl); b = __hiloint2double((int)yh, (int)yl);
+}
+template <typename T, int W> __device__ __forceinline__ T pair_max(T v) { T a, b; pair_of<W>(v, a, b); return fmax(a, b); }
+template <typename T, int W> __device__ __forceinline__ T pair_sum(T v) { T a, b; pair_of<W>(v, a, b); return a + b; }
 
 // -(mx + log sm), branch-free: sm == 0 (every component off) gives +inf, NaN stays NaN
-template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm) { return -(mx + t_log<T>(sm)); }
+template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm, const double* tab) {
+    return -(mx + t_log<T>(sm, tab));
+}
 
 // max and sum-of-exp over the 4 registers of one lane, then over `width` lane groups (1, 2 or 4)
 template <typename T, typename V>
-__device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm) {
+__device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, const double* tab) {
     T m = fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
-    if (width >= 2) m = fmax(m, xor_lane<T>(m, 16));
-    if (width >= 4) m = fmax(m, xor_lane<T>(m, 32));
+    if (width >= 2) m = pair_max<T, 16>(m);
+    if (width >= 4) m = pair_max<T, 32>(m);
     const T ms = (m == -INFINITY) ? T(0) : m;  // all components off: exp(-inf - 0) = 0
-    T e = t_exp<T>(a[0] - ms) + t_exp<T>(a[1] - ms) + t_exp<T>(a[2] - ms) + t_exp<T>(a[3] - ms);
-    if (width >= 2) e += xor_lane<T>(e, 16);
-    if (width >= 4) e += xor_lane<T>(e, 32);
+    T e = t_exp<T>(a[0] - ms, tab) + t_exp<T>(a[1] - ms, tab) + t_exp<T>(a[2] - ms, tab) + t_exp<T>(a[3] - ms, tab);
+    if (width >= 2) e = pair_sum<T, 16>(e);
+    if (width >= 4) e = pair_sum<T, 32>(e);
     mx = m;
     sm = e;
 }
@@ -106,7 +155,7 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm) {
 template <typename T, typename V, int MP>
 __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int t, int f, int q, int S, int RS,
                                               int chunk_s0, int tiles_per_state, T* lds, T* dummy,
-                                              T (&run_mx)[2], T (&run_sm)[2]) {
+                                              const double* tab, T (&run_mx)[2], T (&run_sm)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const V& acc = c ? acc1 : acc0;
@@ -122,25 +171,25 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
                 const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
                 const T m = fmax(x0, x1);
                 const T ms = (m == -INFINITY) ? T(0) : m;
-                const T e = t_exp<T>(x0 - ms) + t_exp<T>(x1 - ms);
-                *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e);
+                const T e = t_exp<T>(x0 - ms, tab) + t_exp<T>(x1 - ms, tab);
+                *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e, tab);
             }
         } else if (MP <= 16) {
             constexpr int width = MP / 4;  // lane groups per state: 1, 2 or 4
             T mx, sm;
-            tile_lse<T, V>(acc, width, mx, sm);
+            tile_lse<T, V>(acc, width, mx, sm, tab);
             const int s = (16 / MP) * t + q / width;
-            *(((q & (width - 1)) == 0 && s < S) ? orow + s : dummy) = nll_of<T>(mx, sm);
+            *(((q & (width - 1)) == 0 && s < S) ? orow + s : dummy) = nll_of<T>(mx, sm, tab);
         } else {
             T mx, sm;
-            tile_lse<T, V>(acc, 4, mx, sm);
+            tile_lse<T, V>(acc, 4, mx, sm, tab);
             const T m = fmax(run_mx[c], mx);
             const T ms = (m == -INFINITY) ? T(0) : m;
-            run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms) + sm * t_exp<T>(mx - ms);
+            run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms, tab) + sm * t_exp<T>(mx - ms, tab);
             run_mx[c] = m;
             const bool last = (t + 1) % tiles_per_state == 0;
             const int s = t / tiles_per_state;
-            *((last && q == 0 && s < S) ? orow + s : dummy) = nll_of<T>(run_mx[c], run_sm[c]);
+            *((last && q == 0 && s < S) ? orow + s : dummy) = nll_of<T>(run_mx[c], run_sm[c], tab);
             run_mx[c] = last ? T(-INFINITY) : run_mx[c];
             run_sm[c] = last ? T(0) : run_sm[c];
         }
@@ -155,6 +204,7 @@ template <typename T, int KS, int MP>
 __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
+                                                         const double* __restrict__ tables, int tab_off,
                                                          T* __restrict__ out) {
     typedef typename Acc<T>::type V;
     constexpr int R = KS / 2;
@@ -164,6 +214,10 @@ __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X
     const int f = lane & 15, q = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const int nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
+    double* tab = reinterpret_cast<double*>(smem_raw + tab_off);  // exp / log tables (fp64 path)
+    if (sizeof(T) == 8) {
+        for (int i = lane; i < 384; i += 64) tab[i] = tables[i];
+    }
 
     // ---- frames: global -> LDS (coalesced) -> B fragments in registers ----------------
     {
@@ -242,7 +296,7 @@ __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X
     for (int t = 1; t < n_tiles; ++t) {
         V acc0, acc1;
         mfma_tile(t, acc0, acc1);
-        tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, run_mx, run_sm);
+        tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
         // schedule: one MFMA, then a slice of the previous tile's epilogue VALU work
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) {
@@ -253,7 +307,7 @@ __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X
         p0 = acc0;
         p1 = acc1;
     }
-    tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, run_mx, run_sm);
+    tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
     flush();
 }
 
@@ -273,13 +327,17 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
         chunk_tiles = (S <= 64) ? n_tiles : 64 * tps;
     }
     const int SC = (M_pad <= 16) ? chunk_tiles * (16 / M_pad) : chunk_tiles / (M_pad / 16);
-    const size_t lds = ((size_t)32 * std::max(std::min(SC, S), g->D) + 64) * sizeof(T);
+    size_t lds = ((size_t)32 * std::max(std::min(SC, S), g->D) + 64) * sizeof(T);
+    lds = (lds + 15) & ~size_t(15);
+    const int tab_off = (int)lds;
+    if (sizeof(T) == 8) lds += 384 * sizeof(double);
+    const double* tables = ctx->d_fp64_tables;
     const unsigned grid = (unsigned)((N + 31) / 32);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
 #define GH_MF_LAUNCH(ks, mp)                                                                                \
     hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                       Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, out)
+                       Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out)
 #define GH_MF_CASE(ks)                                   \
     case ks:                                             \
         switch (M_pad) {                                 \
