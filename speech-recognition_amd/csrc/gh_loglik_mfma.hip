@@ -200,8 +200,15 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
 // registers: slot j serves k-step j, is refilled with k-step j+R of the same tile, serves it,
 // and is refilled with k-step j of the NEXT tile -- every load has half a tile of MFMAs
 // (R*2 instructions, >= 1280 cycles in fp64) to return from L2.
+// Measured on MI355X (tools/variant_bench.sh): forcing an MFMA/VALU interleave with
+// sched_group_barrier is 6-10 % SLOWER than letting the MFMAs issue back to back (fp32/fp64
+// MFMA and VALU share one pipeline: nothing overlaps, the interleave only adds bubbles), and a
+// 3-waves/SIMD register cap helps fp32 (+4 %) but costs fp64 (-4 %).
+#ifndef GH_MF_SGB
+#define GH_MF_SGB 0
+#endif
 template <typename T, int KS, int MP>
-__global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
                                                          const double* __restrict__ tables, int tab_off,
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64) void loglik_mfma_kernel(const T* __restrict__ X
         tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
         // schedule: one MFMA, then a slice of the previous tile's epilogue VALU work
 #pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {
+        for (int i = 0; i < (GH_MF_SGB ? 2 * KS : 0); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, sizeof(T) == 8 ? 5 : 3, 0);  // VALU
         }
