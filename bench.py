@@ -112,6 +112,22 @@ class HipEvents:
         return float(ms.value)
 
 
+def profiled_traffic(dtype, n_frames):
+    """HBM bytes per launch of the likelihood kernel from the committed PMC passes
+    (profiles/r01b_pmc_traffic_f64.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    runs of this same command); None when no profile matches this dtype / workload size."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_%s.json" % dtype)
+    try:
+        d = json.load(open(path))["kernels"]
+        k = next(v for name, v in d.items() if name.startswith("loglik"))
+        esz = 8 if dtype == "f64" else 4
+        if abs(k["algorithmic_bytes_per_launch"] - n_frames * esz * (39 + 50)) > 1e-3 * k["algorithmic_bytes_per_launch"]:
+            return None
+        return k["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(wl, n_utts=20):
     """The numpy oracle run the way the reference runs (per-frame GMM.evaluate through dense
     inverse covariances, per-cell Python DP), one core, on the first `n_utts` utterances."""
@@ -243,7 +259,7 @@ def main():
             "roofline": {
                 "kernel": "loglik_kernel (batched GMM.evaluate)", "bound": "mfma",
                 "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None,
+                "traffic": profiled_traffic(args.dtype, N_frames),
                 "kernel_ms": ll_avg_s * 1e3,
                 "hbm_achieved_GBps": bytes_per_frame * N_frames / ll_avg_s / 1e9,
                 "hbm_frac": bytes_per_frame * N_frames / ll_avg_s / PEAK_HBM,
