@@ -185,6 +185,21 @@ int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t coun
                      const double* mean /*[k,D]*/, const double* var /*[k,D]*/, const double* weight /*[k]*/,
                      double* out_stats /*[k, 1+2D]*/, double* out_loglik);
 
+/* ----------------------------------------------- A13: forward-backward
+ * NOT in the reference (it trains by Viterbi alignment only); the sum-product twin of
+ * gh_viterbi: same graphs, same same-column rule for arcs touching a non-emitting row,
+ * start = the start rows in column 0, end = the end rows in the last column, log domain fp64.
+ *   out_logp   [U]     log P(utterance)  (= -cost; -inf if no path)
+ *   out_alpha / out_beta / out_gamma   optional [R_u, T_u] matrices at mat_off[u]:
+ *              log alpha, log beta, and the posterior of passing through the cell
+ *   want_occ   != 0: keep occ[n, s] = sum of gamma over the rows scored by state s, for every
+ *              frame, resident in the batch (input of the Baum-Welch statistics);
+ *              out_occ (may be NULL) receives a copy [N, S]. */
+int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b,
+                        const int32_t* utt_lattice /*[U] or NULL*/, int want_occ,
+                        double* out_logp, double* out_alpha, double* out_beta, double* out_gamma,
+                        const int64_t* mat_off /*[U+1]*/, double* out_occ);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 #include "gh_internal.h"
 #include "gh_viterbi.h"
 #include "gh_dtw.h"
+#include "gh_fb.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -226,6 +227,7 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     gh_batch* b = new gh_batch();
     b->ctx = ctx; b->dtype = dtype; b->D = D; b->N = N; b->U = U;
     b->feats = nullptr; b->owns_feats = false; b->nll = nullptr; b->nll_S = 0; b->d_offsets = nullptr;
+    b->occ = nullptr;
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;
     for (int64_t u = 0; u < U; ++u) b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
@@ -278,6 +280,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
     hipStreamSynchronize(b->ctx->stream);
     if (b->owns_feats && b->feats) hipFree(b->feats);
     if (b->nll) hipFree(b->nll);
+    if (b->occ) hipFree(b->occ);
     if (b->d_offsets) hipFree(b->d_offsets);
     if (b->d_perm) hipFree(b->d_perm);
     delete b;
@@ -327,12 +330,14 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
                "gh_lattices_create: offsets must start at 0");
     std::vector<int32_t> h_state(row_state, row_state + Rtot), h_ptr, h_order(Rtot), h_lev, h_end;
     std::vector<uint8_t> h_start(Rtot, 0);
-    std::vector<uint32_t> h_prow(Atot);
-    std::vector<double> h_pcost(Atot);
+    std::vector<uint32_t> h_prow(Atot), h_srow(Atot);
+    std::vector<double> h_pcost(Atot), h_scost(Atot);
+    std::vector<int32_t> h_sptr;
     gh_lattices* lt = new gh_lattices();
     lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0;
     lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
-    lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr;
+    lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
+    lt->d_succ_cost = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr;
     lt->d_desc = nullptr;
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
@@ -345,11 +350,12 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int k = 0; k < ns; ++k) {
             const int r = start_rows[start_off[l] + k];
             if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: start row %d out of range", r);
-            h_start[r0 + r] = 1;
+            h_start[r0 + r] |= 1;
         }
         for (int k = 0; k < ne; ++k) {
             const int r = end_rows[end_off[l] + k];
             if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: end row %d out of range", r);
+            h_start[r0 + r] |= 2;  // bit1 = end row (forward-backward)
         }
         // CSR by destination, ascending origin (tie-break contract, decode.py:105-118)
         std::vector<int> idx(A);
@@ -381,6 +387,22 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             }
             h_prow[a0 + k] = w;
             h_pcost[a0 + k] = arc_cost[a0 + idx[k]];
+        }
+        // transposed CSR (by origin) for the backward pass; h_sptr shares ptr_base with h_ptr
+        {
+            h_sptr.resize(ptr_base + R + 1, 0);
+            int32_t* sp = h_sptr.data() + ptr_base;
+            for (int r = 0; r < R; ++r)
+                for (int p = ptr[r]; p < ptr[r + 1]; ++p) sp[(h_prow[a0 + p] & GH_ARC_ROW) + 1]++;
+            for (int r = 0; r < R; ++r) sp[r + 1] += sp[r];
+            std::vector<int> fill(sp, sp + R);
+            for (int r = 0; r < R; ++r)
+                for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                    const uint32_t w = h_prow[a0 + p];
+                    const int o = (int)(w & GH_ARC_ROW), k = fill[o]++;
+                    h_srow[a0 + k] = (uint32_t)r | (w & ~GH_ARC_ROW);
+                    h_scost[a0 + k] = h_pcost[a0 + p];
+                }
         }
         // levels: rows ascending, so every live same-column origin (< row) is already levelled
         int nlev = 1;
@@ -422,6 +444,8 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     if ((rc = upload(&lt->d_row_state, h_state)) || (rc = upload(&lt->d_row_start, h_start)) ||
         (rc = upload(&lt->d_pred_ptr, h_ptr)) || (rc = upload(&lt->d_pred_row, h_prow)) ||
         (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
+        (rc = upload(&lt->d_succ_ptr, h_sptr)) || (rc = upload(&lt->d_succ_row, h_srow)) ||
+        (rc = upload(&lt->d_succ_cost, h_scost)) ||
         (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_end_rows, h_end)) ||
         (rc = upload(&lt->d_desc, lt->h_desc))) {
         gh_lattices_destroy(lt);
@@ -436,6 +460,7 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipSetDevice(l->ctx->device);
     hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
     hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
+    hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
     hipFree(l->d_desc);
     delete l;
 }
@@ -652,5 +677,90 @@ extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, co
         gh_set_error("gh_dtw: back-trace left the matrix: cell (0,0) is not reachable from the end cell");
         return GH_ERR_INVALID;
     }
+    return GH_OK;
+}
+
+// --------------------------------------------------------- forward-backward
+extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b, const int32_t* utt_lattice,
+                                   int want_occ, double* out_logp, double* out_alpha, double* out_beta,
+                                   double* out_gamma, const int64_t* mat_off, double* out_occ) {
+    GH_REQUIRE(ctx && lat && b, "gh_forward_backward: NULL argument");
+    GH_REQUIRE(b->nll || b->N == 0, "gh_forward_backward: gh_loglik has not been run on this batch");
+    GH_REQUIRE(!(out_alpha || out_beta || out_gamma) || mat_off, "gh_forward_backward: matrices need mat_off");
+    GH_REQUIRE(!out_occ || want_occ, "gh_forward_backward: out_occ needs want_occ");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U;
+    if (U == 0) return GH_OK;
+    const int S = b->nll_S;
+    for (int l = 0; l < lat->L; ++l)
+        GH_REQUIRE(lat->lat[l].max_state < S, "gh_forward_backward: graph %d uses state %d but the model has %d", l,
+                   lat->lat[l].max_state, S);
+    if (utt_lattice)
+        for (int64_t u = 0; u < U; ++u)
+            GH_REQUIRE(utt_lattice[u] >= 0 && utt_lattice[u] < lat->L, "gh_forward_backward: utt_lattice[%lld] out of range",
+                       (long long)u);
+    if (want_occ && !b->occ && b->N > 0) GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
+    // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
+    const size_t BUDGET = (size_t)4 << 30;
+    std::vector<int64_t> soff(U, 0), chunk_begin{0};
+    size_t acc = 0, smax = 0;
+    for (int64_t k = 0; k < U; ++k) {
+        const int64_t u = b->perm[k];
+        const int l = utt_lattice ? utt_lattice[u] : 0;
+        const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+        if (acc && (acc + need) * 8 > BUDGET) { chunk_begin.push_back(k); smax = std::max(smax, acc); acc = 0; }
+        soff[k] = (int64_t)acc;
+        acc += need;
+    }
+    smax = std::max(smax, acc);
+    chunk_begin.push_back(U);
+    const bool mats = out_alpha || out_beta || out_gamma;
+    const int64_t n_mat = mats ? mat_off[U] : 0;
+    int64_t *d_soff, *d_matoff = nullptr;
+    int32_t* d_uttlat = nullptr;
+    double *d_scratch, *d_logp, *d_alpha = nullptr, *d_beta = nullptr, *d_gamma = nullptr;
+    Carver cv;
+    cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
+    if (utt_lattice) cv.add(&d_uttlat, U);
+    if (mats) cv.add(&d_matoff, U + 1);
+    if (out_alpha) cv.add(&d_alpha, n_mat);
+    if (out_beta) cv.add(&d_beta, n_mat);
+    if (out_gamma) cv.add(&d_gamma, n_mat);
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemcpyAsync(d_soff, soff.data(), U * 8, hipMemcpyHostToDevice, st));
+    if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
+    if (mats) GH_HIP(hipMemcpyAsync(d_matoff, mat_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    gh_fb_args a;
+    memset(&a, 0, sizeof a);
+    a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_flag = lat->d_row_start;
+    a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
+    a.succ_ptr = lat->d_succ_ptr; a.succ_row = lat->d_succ_row; a.succ_cost = lat->d_succ_cost;
+    a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
+    a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
+    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
+    a.alpha_scratch = d_scratch; a.scratch_off = d_soff; a.logp = d_logp;
+    a.out_alpha = d_alpha; a.out_beta = d_beta; a.out_gamma = d_gamma; a.mat_off = d_matoff;
+    a.occ = want_occ ? b->occ : nullptr;
+    int max_level_rows = 1;
+    for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
+    const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
+    const size_t lds = ((size_t)2 * a.r_pad + 3 * (size_t)S) * sizeof(double);
+    if (lds > 150 * 1024) {
+        gh_set_error("gh_forward_backward: %d rows + %d states need %zu B of LDS", lat->max_R, S, lds);
+        return GH_ERR_UNSUPPORTED;
+    }
+    for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
+        a.u_begin = chunk_begin[c];
+        rc = gh_launch_fb(ctx, a, chunk_begin[c + 1] - chunk_begin[c], block, lds, b->dtype == GH_F64);
+        if (rc) return rc;
+    }
+    if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_logp, U * 8, hipMemcpyDeviceToHost, st));
+    if (out_alpha) GH_HIP(hipMemcpyAsync(out_alpha, d_alpha, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_beta) GH_HIP(hipMemcpyAsync(out_beta, d_beta, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_gamma) GH_HIP(hipMemcpyAsync(out_gamma, d_gamma, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
     return GH_OK;
 }

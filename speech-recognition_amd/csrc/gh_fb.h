@@ -1,0 +1,35 @@
+#pragma once
+#include "gh_internal.h"
+
+// Kernel argument block of the forward-backward kernel (device pointers).
+struct gh_fb_args {
+    const gh_lattices::desc* descs;
+    const int32_t* row_state;
+    const uint8_t* row_flag;  // bit0 = start row, bit1 = end row
+    const int32_t* pred_ptr;
+    const uint32_t* pred_row;
+    const double* pred_cost;
+    const int32_t* succ_ptr;
+    const uint32_t* succ_row;
+    const double* succ_cost;
+    const int32_t* order;
+    const int32_t* level_ptr;
+    const int32_t* end_rows;
+    const void* nll;
+    int S;
+    int r_pad;
+    const int64_t* utt_off;
+    const int32_t* utt_lat;
+    const int64_t* perm;
+    int64_t u_begin;
+    double* alpha_scratch;       // [T,R] per launch slot
+    const int64_t* scratch_off;  // [slots]
+    double* logp;                // [U]
+    double* out_alpha;           // optional [R,T] per utterance at mat_off[u]
+    double* out_beta;
+    double* out_gamma;
+    const int64_t* mat_off;      // [U+1]
+    double* occ;                 // optional [N,S] frame x state occupancies
+};
+
+int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, size_t lds_bytes, bool f64);

@@ -71,6 +71,7 @@ struct gh_batch {
     int64_t max_T;
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
+    double* occ;  // device [N,S] fp64 frame x state occupancies after gh_forward_backward(want_occ)
     // launch order of the DP kernels: utterances sorted longest first (computed once)
     std::vector<int64_t> perm;
     int64_t* d_perm;
@@ -97,6 +98,10 @@ struct gh_lattices {
     int32_t* d_pred_ptr;   // [Rtot + L] CSR per graph (R_l + 1 entries each, local to arc_base)
     uint32_t* d_pred_row;  // [Atot] origin row | flags, ascending origin per destination
     double* d_pred_cost;   // [Atot]
+    // transposed arcs for the backward pass: CSR by ORIGIN row, same flag bits on the destination
+    int32_t* d_succ_ptr;   // [Rtot + L]
+    uint32_t* d_succ_row;  // [Atot] destination row | flags
+    double* d_succ_cost;   // [Atot]
     int32_t* d_order;      // [Rtot] rows sorted by (level, row)
     int32_t* d_level_ptr;  // per graph: nlev+1 entries at lev_base
     int32_t* d_end_rows;   // [Etot]

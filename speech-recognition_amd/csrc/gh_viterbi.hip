@@ -71,7 +71,7 @@ __global__ void viterbi_kernel(gh_vit_args a) {
                 const int st = row_state[r];
                 const double e = st >= 0 ? em[st] : 0.0;
                 double c = INF;
-                if (row_start[r]) {
+                if (row_start[r] & 1) {
                     c = e;
                 } else {
                     const int p0 = pred_ptr[r], p1 = pred_ptr[r + 1];
@@ -103,7 +103,7 @@ __global__ void viterbi_kernel(gh_vit_args a) {
                     const double e = st >= 0 ? em[st] : 0.0;
                     double c = INF;
                     uint16_t b = BP_NONE;
-                    if (t == 0 && row_start[r]) {
+                    if (t == 0 && (row_start[r] & 1)) {
                         c = e;  // decode.py:99-101
                     } else {
                         const int p0 = pred_ptr[r], p1 = pred_ptr[r + 1];

@@ -53,6 +53,8 @@ SIGNATURES = {
                          _c_f64p, _c_i32p, _c_i32p]),
     "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_i32p]),
+    "gh_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, C.c_int, _c_f64p, _c_f64p, _c_f64p,
+                                      _c_f64p, _c_i64p, _c_f64p]),
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
 }
@@ -349,6 +351,31 @@ class Lattices:
         if want_costs:
             out["costs"] = [costs[costs_off[u]:costs_off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u]))
                             for u in range(U)]
+        return out
+
+    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False):
+        """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]]."""
+        lib, U = self.ctx.lib, batch.U
+        lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
+        lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
+        T = batch.lengths
+        logp = np.empty(U)
+        al = be = ga = off = occ = None
+        if want_matrices:
+            Rs = np.asarray(self.R, dtype=np.int64)[lidx]
+            off = np.concatenate([[0], np.cumsum(Rs * T)]).astype(np.int64)
+            al, be, ga = (np.empty(int(off[-1])) for _ in range(3))
+        if want_occ:
+            occ = np.empty((batch.N, batch.S))
+        _check(lib, lib.gh_forward_backward(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), int(want_occ),
+                                            _ptr(logp, _c_f64p), _ptr(al, _c_f64p), _ptr(be, _c_f64p),
+                                            _ptr(ga, _c_f64p), _ptr(off, _c_i64p), _ptr(occ, _c_f64p)))
+        out = dict(logp=logp)
+        if want_matrices:
+            cut = lambda m: [m[off[u]:off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u])) for u in range(U)]
+            out.update(alpha=cut(al), beta=cut(be), gamma=cut(ga))
+        if want_occ:
+            out["occ"] = occ
         return out
 
     def close(self):

@@ -241,3 +241,71 @@ def test_distance_matrix(hip, ctx):
     np.testing.assert_allclose(np.diag(out), g["out"], rtol=1e-13)
     out = hip.distance_matrix(ctx, v1, v2)
     np.testing.assert_allclose(out[3, 5], np.linalg.norm(v1[5] - v2[3]), rtol=1e-14)
+
+
+# --------------------------------------------------------------------------- A13
+def test_forward_backward_vs_oracle(hip, ctx):
+    """Sum-product twin of A6 -- not in the reference; the oracle it is compared with is pinned
+    by brute-force path enumeration (tests/test_oracle_golden.py)."""
+    g = load_golden("G4_lattice_decode")
+    means, vars_, w, wt = g["means"], g["vars"], g["w"], g["word_trans"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    graphs, xs, refs = [], [], []
+    for K in (1, 2, 3):
+        p = "K%d_" % K
+        rw, rs = g[p + "row_word"], g[p + "row_state"]
+        row_state = np.where(rw < 0, -1, rw * n + rs)
+        graphs.append(dict(row_state=row_state, arc_to=g[p + "arc_to"], arc_from=g[p + "arc_from"],
+                           arc_cost=g[p + "arc_cost"], start_rows=[0], end_rows=g[p + "ends"]))
+        x = g[p + "x"]
+        xs.append(x)
+        R = len(rw)
+        trans = np.full((R, R), np.inf)
+        trans[g[p + "arc_to"], g[p + "arc_from"]] = g[p + "arc_cost"]
+        nll = O.gmm_neg_loglik_batch(x, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+        E = np.where(row_state[:, None] >= 0, nll[:, np.maximum(row_state, 0)].T, 0.0)
+        refs.append((O.forward_backward(E, rw < 0, trans, list(g[p + "ends"])), row_state, g[p + "costs"], g[p + "ends"]))
+    lat = hip.Lattices(ctx, graphs)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    r = lat.forward_backward(b, utt_lattice=np.arange(len(xs)), want_matrices=True, want_occ=True)
+    for u, ((la, lb, gamma, logp), row_state, vit_costs, ends) in enumerate(refs):
+        np.testing.assert_allclose(r["logp"][u], logp, rtol=1e-10)
+        for got, ref in ((r["alpha"][u], la), (r["beta"][u], lb)):
+            fin = ~np.isinf(ref)
+            np.testing.assert_array_equal(np.isinf(got), ~fin)
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["gamma"][u], gamma, rtol=1e-8, atol=1e-12)
+        # per-frame state occupancies = gamma summed over the rows of each state
+        occ = np.zeros((gamma.shape[1], W * n))
+        for row, s in enumerate(row_state):
+            if s >= 0:
+                occ[:, s] += gamma[row]
+        np.testing.assert_allclose(r["occ"][b.offsets[u]:b.offsets[u + 1]], occ, rtol=1e-8, atol=1e-12)
+        # Viterbi cost is an upper bound of -log P
+        assert min(vit_costs[e, -1] for e in ends) >= -logp - 1e-9
+
+
+def test_forward_backward_isolated_properties(hip, ctx):
+    """Left-to-right chains without non-emitting rows: sum_r gamma_t(r) = 1 for every frame,
+    log P from alpha equals log P from beta, fp32 likelihood input agrees to 1e-5."""
+    g = load_golden("G3_isolated_decode_c2")
+    means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    xs = [g["x0"], g["x1"]]
+    lat = hip.Lattices(ctx, [graph(np.arange(n) + i * n, trans, [0], [n - 1]) for i in range(W)])
+    out = {}
+    for dtype in (np.float64, np.float32):
+        b = hip.Batch(ctx, xs, dtype=dtype)
+        nll = b.loglik(gmm)
+        out[dtype] = (lat.forward_backward(b, utt_lattice=[0, 1], want_matrices=True), nll)
+    r, nll = out[np.float64]
+    for u in range(2):
+        np.testing.assert_allclose(r["gamma"][u].sum(axis=0), 1.0, rtol=1e-9)
+        e00 = nll[b.offsets[u], u * n]
+        np.testing.assert_allclose(r["beta"][u][0, 0] - e00, r["logp"][u], rtol=1e-10)
+        costs = g["costs_%d_%d" % (u, u)]
+        assert costs[-1, -1] >= -r["logp"][u]
+    np.testing.assert_allclose(out[np.float32][0]["logp"], r["logp"], rtol=1e-5)
