@@ -200,6 +200,18 @@ int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b,
                         double* out_logp, double* out_alpha, double* out_beta, double* out_gamma,
                         const int64_t* mat_off /*[U+1]*/, double* out_occ);
 
+/* ------------------------------------ Baum-Welch (soft) sufficient statistics
+ * After gh_forward_backward(want_occ = 1): for every frame n and state s,
+ *   r_nsm = occ[n,s] * w_sm pdf_sm(x_n) / sum_m' w_sm' pdf_sm'(x_n)
+ * accumulated over all frames of the batch as
+ *   out_stats[s, m, 0] = sum r,  [s, m, 1+d] = sum r (x_d - mean_smd),  [s, m, 1+D+d] = sum r (x_d - mean_smd)^2
+ * (the same centred layout as gh_em_accumulate; [S, M, 1+2D], 253 KB for 50 x 8 x 39).
+ * States whose occupancy is <= occ_floor on a whole 128-frame tile are skipped.  Deterministic
+ * (per-workgroup slabs + ordered reduction).  stats_dev (may be NULL): device pointer that
+ * receives the result instead of scratch, e.g. a torch tensor about to be all-reduced by RCCL. */
+int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor,
+                     double* out_stats /*[S,M,1+2D] or NULL*/, double* stats_dev /*or NULL*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,100 @@ __global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict_
     if (tid == 0) ll_partial[blockIdx.x] = red[0];
 }
 
+
+// ------------------------------------------------- Baum-Welch (soft) statistics
+// Every frame contributes to every state s with weight occ[n,s] (the forward-backward state
+// posterior): r_nsm = occ[n,s] * w_sm pdf_sm(x_n) / sum_m' w_sm' pdf_sm'(x_n).  Posteriors are
+// sparse (mass sits on the states near the alignment), so a tile of F frames first votes which
+// states are active at all and only those are evaluated.  Accumulation is deterministic: each
+// workgroup owns a private [S,M,1+2D] slab in HBM (L2 resident), a second kernel adds the slabs
+// in a fixed order -- no float atomics.  Statistics are centred on the current means.
+__global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict__ X, int64_t N, int D, int S, int M,
+                                                       const double* __restrict__ mean, const double* __restrict__ ivar,
+                                                       const double* __restrict__ logc, const double* __restrict__ occ,
+                                                       double occ_floor, int F, double* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* xt = sm;          // [F,D]
+    double* rt = sm + F * D;  // [M,F]
+    const int tid = threadIdx.x;
+    const int W = 1 + 2 * D;
+    double* slab = slabs + (int64_t)blockIdx.x * S * M * W;
+    const int64_t ntiles = (N + F - 1) / F;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * F;
+        const int nf = (int)((N - n0 < F) ? (N - n0) : F);
+        __syncthreads();
+        for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
+        for (int s = 0; s < S; ++s) {
+            double wgt = 0.0;
+            int active = 0;
+            if (tid < nf) {
+                wgt = occ[(n0 + tid) * S + s];
+                active = (wgt > occ_floor || wgt != wgt);
+            }
+            if (!__syncthreads_or(active)) continue;  // block-uniform vote (also orders xt / rt reuse)
+            const double* pm = mean + (int64_t)s * M * D;
+            const double* pv = ivar + (int64_t)s * M * D;
+            const double* pc = logc + (int64_t)s * M;
+            if (tid < F) {
+                const int f = tid;
+                if (f < nf && (wgt > occ_floor || wgt != wgt)) {
+                    const double* x = xt + f * D;
+                    double mx = -INFINITY;
+                    bool bad = false;
+                    for (int m = 0; m < M; ++m) {
+                        double q = 0;
+                        for (int d = 0; d < D; ++d) { const double t = x[d] - pm[m * D + d]; q = fma(t * pv[m * D + d], t, q); }
+                        const double ll = pc[m] - 0.5 * q;
+                        rt[m * F + f] = ll;
+                        bad |= (ll != ll);
+                        mx = fmax(mx, ll);
+                    }
+                    double sum = 0;
+                    for (int m = 0; m < M; ++m) {
+                        const double e = (mx == -INFINITY) ? 0.0 : exp(rt[m * F + f] - mx);
+                        rt[m * F + f] = e;
+                        sum += e;
+                    }
+                    const double inv = bad ? NAN : (sum > 0 ? wgt / sum : 0.0);
+                    for (int m = 0; m < M; ++m) rt[m * F + f] = bad ? NAN : rt[m * F + f] * inv;
+                } else {
+                    for (int m = 0; m < M; ++m) rt[m * F + f] = 0.0;
+                }
+            }
+            __syncthreads();
+            const int P = M * (D + 1);
+            for (int p = tid; p < P; p += 256) {
+                const int m = p / (D + 1), d = p % (D + 1);
+                const double* r = rt + m * F;
+                double a1 = 0, a2 = 0;
+                if (d == D) {
+                    for (int f = 0; f < nf; ++f) a1 += r[f];
+                } else {
+                    const double mu = pm[m * D + d];
+                    for (int f = 0; f < nf; ++f) {
+                        const double xv = xt[f * D + d] - mu;
+                        const double rx = r[f] * xv;
+                        a1 += rx;
+                        a2 = fma(rx, xv, a2);
+                    }
+                }
+                double* o = slab + ((int64_t)s * M + m) * W;
+                if (d == D) o[0] += a1;
+                else { o[1 + d] += a1; o[1 + D + d] += a2; }
+            }
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const double* __restrict__ slabs, int n_slabs, int64_t len, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double acc = 0;
+    for (int g = 0; g < n_slabs; ++g) acc += slabs[(int64_t)g * len + i];
+    out[i] = acc;
+}
+
 }  // namespace
 
 static int frames_f64(const gh_batch* b, int64_t first, int64_t count, const char* who) {
@@ -250,5 +344,40 @@ extern "C" int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, i
         ll += llp[g];
     }
     if (out_loglik) *out_loglik = ll;
+    return GH_OK;
+}
+
+extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor,
+                                double* out_stats, double* stats_dev) {
+    GH_REQUIRE(ctx && g && b && (out_stats || stats_dev), "gh_bw_accumulate: NULL argument");
+    GH_REQUIRE(b->dtype == GH_F64, "gh_bw_accumulate: needs an fp64 batch");
+    GH_REQUIRE(b->occ || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
+    GH_REQUIRE(g->D == b->D && g->S == b->nll_S, "gh_bw_accumulate: model / batch mismatch");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int S = g->S, M = g->M, D = g->D, W = 1 + 2 * D;
+    const int64_t len = (int64_t)S * M * W;
+    hipStream_t st = ctx->stream;
+    int F = 128;
+    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f) * 8; };
+    while (F > 32 && lds_need(F) > 64 * 1024) F >>= 1;
+    GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_bw_accumulate: D=%d M=%d does not fit LDS", D, M);
+    const int64_t ntiles = b->N > 0 ? (b->N + F - 1) / F : 0;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 2 * (int64_t)ctx->n_cu));
+    void* base;
+    const size_t slab_bytes = (size_t)grid * len * 8, out_bytes = ((size_t)len * 8 + 255) & ~size_t(255);
+    int rc = gh_scratch(ctx, out_bytes + slab_bytes, &base);
+    if (rc) return rc;
+    double* d_out = stats_dev ? stats_dev : (double*)base;
+    double* d_slabs = (double*)((char*)base + out_bytes);
+    GH_HIP(hipMemsetAsync(d_slabs, 0, slab_bytes, st));
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(bw_stats_kernel, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats, b->N, D, S, M,
+                           g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, d_slabs);
+        GH_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_slabs, grid, len, d_out);
+    GH_HIP(hipGetLastError());
+    if (out_stats) GH_HIP(hipMemcpyAsync(out_stats, d_out, (size_t)len * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
     return GH_OK;
 }

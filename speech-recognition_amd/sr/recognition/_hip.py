@@ -55,6 +55,7 @@ SIGNATURES = {
                                    _c_i32p]),
     "gh_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, C.c_int, _c_f64p, _c_f64p, _c_f64p,
                                       _c_f64p, _c_i64p, _c_f64p]),
+    "gh_bw_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _c_f64p, C.c_void_p]),
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
 }
@@ -255,6 +256,14 @@ class Batch:
                                                            centroids.shape[0], _ptr(centroids, _c_f64p),
                                                            _ptr(v, _c_f64p), _ptr(out, _c_i32p)))
         return out.astype(np.int64)
+
+    def bw_accumulate(self, gmm, occ_floor=0.0, stats_dev=None):
+        """Baum-Welch statistics [S, M, 1+2D] of the whole batch from the resident occupancies
+        (run Lattices.forward_backward(..., want_occ=True) first)."""
+        out = np.empty((gmm.S, gmm.M, 1 + 2 * self.D))
+        _check(self.ctx.lib, self.ctx.lib.gh_bw_accumulate(self.ctx.h, gmm.h, self.h, float(occ_floor),
+                                                           _ptr(out, _c_f64p), stats_dev))
+        return out
 
     def em_accumulate(self, mean, var, weight, first=0, count=None):
         """A7 E-step statistics of the given k components over frames [first, first+count).

@@ -309,3 +309,43 @@ def test_forward_backward_isolated_properties(hip, ctx):
         costs = g["costs_%d_%d" % (u, u)]
         assert costs[-1, -1] >= -r["logp"][u]
     np.testing.assert_allclose(out[np.float32][0]["logp"], r["logp"], rtol=1e-5)
+
+
+def test_baum_welch_statistics_vs_numpy(hip, ctx):
+    """gh_bw_accumulate: occupancy-weighted centred statistics of all states in one pass."""
+    g = load_golden("G3_isolated_decode_c2")
+    means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]
+    W, n, M, D = means.shape
+    S = W * n
+    fm, fv, fw = means.reshape(S, M, D), vars_.reshape(S, M, D), w.reshape(S, M)
+    gmm = hip.PackedGMM(ctx, fm, fv, fw)
+    xs = [g["x0"], g["x1"]]
+    words = [int(g["words"][0]), int(g["words"][1])]
+    lat = hip.Lattices(ctx, [graph(np.arange(n) + i * n, trans, [0], [n - 1]) for i in range(W)])
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    r = lat.forward_backward(b, utt_lattice=words, want_occ=True)
+    stats = b.bw_accumulate(gmm)
+    occ = r["occ"]
+    X = np.concatenate(xs)
+    np.testing.assert_allclose(occ.sum(axis=1), 1.0, rtol=1e-9)
+    ref = np.zeros((S, M, 1 + 2 * D))
+    for s in range(S):
+        if occ[:, s].max() == 0:
+            continue
+        p = np.array([O.gmm_evaluate(x, fm[s], fv[s], fw[s], neg_log=False) for x in X])
+        rr = occ[:, [s]] * p / p.sum(axis=1, keepdims=True)
+        for m in range(M):
+            d = X - fm[s, m]
+            ref[s, m, 0] = rr[:, m].sum()
+            ref[s, m, 1:1 + D] = (rr[:, [m]] * d).sum(axis=0)
+            ref[s, m, 1 + D:] = (rr[:, [m]] * d * d).sum(axis=0)
+    np.testing.assert_allclose(stats, ref, rtol=1e-8, atol=1e-12)
+    assert np.all(stats[[s for s in range(S) if s // n not in words]] == 0)  # unvisited words untouched
+    # M-step from the statistics: occupancy-weighted means move toward the data, variances stay positive
+    from sr.recognition.parallel import m_step
+    counts = occ.sum(axis=0)
+    vis = [s for s in range(S) if s // n in words]
+    mu, sigma, wn = m_step(stats[vis], counts[vis], fm[vis])
+    assert np.all(sigma[stats[vis][:, :, 0] > 1e-3] > 0)
+    np.testing.assert_allclose(wn.sum(axis=1), 1.0, rtol=1e-9)
