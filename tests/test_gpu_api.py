@@ -290,3 +290,38 @@ def test_continuous_train(R, iters, tmp_path):
         np.testing.assert_allclose(v, g[p + "vars"], rtol=1e-6)
         np.testing.assert_allclose(w, g[p + "w"], rtol=1e-6)
         np.testing.assert_allclose(h.transitions, g[p + "transitions"], rtol=1e-9)
+
+
+# ------------------------------------------------------- A13 + 8(e): soft EM loop
+def test_baum_welch_trainer_increases_likelihood(R):
+    """Forward-backward E-step + statistics + M-step: the total log-likelihood is monotone
+    (EM guarantee; transitions fixed), and the first iteration equals a numpy M-step computed
+    from the same occupancies."""
+    from sr.recognition.train import BaumWelchTrainer
+    g = load_golden("G11_continuous_train")
+    W, U = int(g["n_words"]), int(g["n_utts"])
+    data = [g["x%d" % i] for i in range(U)]
+    labels = [list(g["labels%d" % i]) for i in range(U)]
+    means = np.array([g["init%d_means" % wi] for wi in range(W)])
+    vars_ = np.array([g["init%d_vars" % wi] for wi in range(W)])
+    w = np.array([g["init%d_w" % wi] for wi in range(W)])
+    trans = [g["init%d_transitions" % wi] for wi in range(W)]
+    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, var_floor=1e-3)
+    # reference M-step for iteration 1 from the trainer's own E-step pieces
+    stats, counts, ll0 = tr.e_step()
+    from sr.recognition.parallel import m_step
+    seen = counts > 0
+    mu, sigma, wn = m_step(stats[seen], counts[seen], tr.means[seen])
+    hist = tr.fit(6)
+    assert abs(hist[0] - ll0) <= 1e-9 * abs(ll0)
+    assert all(b >= a - 1e-7 * abs(a) for a, b in zip(hist, hist[1:])), hist
+    assert hist[-1] > hist[0]
+    assert np.all(tr.vars > 0) and np.all(np.isfinite(tr.means))
+    np.testing.assert_allclose(tr.weights[seen].sum(axis=1), 1.0, rtol=1e-9)
+    tr2 = BaumWelchTrainer(means, vars_, w, trans, data, labels, var_floor=1e-3)
+    tr2.iteration()
+    ok = stats[seen][:, :, 0] > 0
+    np.testing.assert_allclose(tr2.means[seen][ok], mu[ok], rtol=1e-12)
+    np.testing.assert_allclose(tr2.vars[seen][ok], np.maximum(sigma, 1e-3)[ok], rtol=1e-12)
+    tr.close()
+    tr2.close()
