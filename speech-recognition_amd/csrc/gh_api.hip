@@ -328,16 +328,17 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     const int64_t Rtot = row_off[L], Atot = arc_off[L], Etot = end_off[L];
     GH_REQUIRE(row_off[0] == 0 && arc_off[0] == 0 && start_off[0] == 0 && end_off[0] == 0,
                "gh_lattices_create: offsets must start at 0");
-    std::vector<int32_t> h_state(row_state, row_state + Rtot), h_ptr, h_order(Rtot), h_lev, h_end;
+    std::vector<int32_t> h_state(row_state, row_state + Rtot), h_ptr, h_order(Rtot), h_lev, h_narrow, h_end;
     std::vector<uint8_t> h_start(Rtot, 0);
     std::vector<uint32_t> h_prow(Atot), h_srow(Atot);
     std::vector<double> h_pcost(Atot), h_scost(Atot);
     std::vector<int32_t> h_sptr;
     gh_lattices* lt = new gh_lattices();
-    lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0;
+    lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
+    for (int64_t k = 0; k < Atot; ++k) lt->has_nan_arc = lt->has_nan_arc || std::isnan(arc_cost[k]);
     lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
     lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
-    lt->d_succ_cost = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr;
+    lt->d_succ_cost = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr; lt->d_level_narrow = nullptr;
     lt->d_desc = nullptr;
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
@@ -382,6 +383,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             uint32_t w = (uint32_t)fr;
             const bool same = h_state[r0 + to] < 0 || h_state[r0 + fr] < 0;  // decode.py:109
             if (same) {
+                if (fr == to) lt->has_self_arc = true;
                 w |= GH_ARC_SAME;
                 if (fr >= to) w |= GH_ARC_DEAD;  // not yet computed in this column: still +inf
             }
@@ -421,9 +423,20 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int r = 0; r < R; ++r) lp[level[r] + 1]++;
         int max_level_rows = 0;
         for (int k = 0; k < nlev; ++k) { max_level_rows = std::max(max_level_rows, lp[k + 1]); lp[k + 1] += lp[k]; }
+        // inside a level: rows with <= 2 arcs first, then the wide rows (the lean kernel gives those
+        // 16 lanes each); ascending row index inside both groups
+        h_narrow.resize(lev_base + nlev + 1, 0);
+        int lean_lanes = 0;
         {
-            std::vector<int> fill(lp, lp + nlev);
-            for (int r = 0; r < R; ++r) h_order[r0 + fill[level[r]]++] = r;
+            std::vector<int> fill(lp, lp + nlev), nwide(nlev, 0);
+            for (int pass = 0; pass < 2; ++pass)
+                for (int r = 0; r < R; ++r) {
+                    const bool wide = ptr[r + 1] - ptr[r] > 2;
+                    if (wide != (pass == 1)) continue;
+                    h_order[r0 + fill[level[r]]++] = r;
+                    if (wide) nwide[level[r]]++; else h_narrow[lev_base + level[r]]++;
+                }
+            for (int k = 0; k < nlev; ++k) lean_lanes = std::max(lean_lanes, h_narrow[lev_base + k] + 16 * nwide[k]);
         }
         int max_state = -1;
         for (int r = 0; r < R; ++r) max_state = std::max(max_state, h_state[r0 + r]);
@@ -432,7 +445,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         lh.row_base = r0; lh.arc_base = a0; lh.end_base = end_off[l]; lh.max_state = max_state;
         lt->lat.push_back(lh);
         gh_lattices::desc d;
-        d.R = R; d.nlev = nlev; d.n_end = ne; d.pad = max_level_rows;
+        d.R = R; d.nlev = nlev; d.n_end = ne; d.pad = max_level_rows; d.lean_lanes = lean_lanes; d.pad2 = 0;
         d.row_base = r0; d.ptr_base = (int64_t)ptr_base; d.arc_base = a0; d.lev_base = (int64_t)lev_base;
         d.end_base = end_off[l];
         lt->h_desc.push_back(d);
@@ -446,7 +459,8 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
         (rc = upload(&lt->d_succ_ptr, h_sptr)) || (rc = upload(&lt->d_succ_row, h_srow)) ||
         (rc = upload(&lt->d_succ_cost, h_scost)) ||
-        (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_end_rows, h_end)) ||
+        (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_level_narrow, h_narrow)) ||
+        (rc = upload(&lt->d_end_rows, h_end)) ||
         (rc = upload(&lt->d_desc, lt->h_desc))) {
         gh_lattices_destroy(lt);
         return rc;
@@ -460,6 +474,7 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipSetDevice(l->ctx->device);
     hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
     hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
+    hipFree(l->d_level_narrow);
     hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
     hipFree(l->d_desc);
     delete l;
@@ -561,6 +576,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_start = lat->d_row_start;
     a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
     a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
+    a.level_narrow = lat->d_level_narrow;
     a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
     a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
     a.bp = d_bp; a.bp_off = d_bpoff; a.end_cost = d_endcost; a.end_off = d_endoff; a.best_end = d_bestend;
@@ -569,15 +585,43 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
 
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
-    const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
-    const size_t lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
+    int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
+    // lean kernel: <= 3 levels (the same number in every graph), one row per lane per level, arc lists
+    // that fit LDS, no NaN arc cost, no same-column self arc (GMMHMM_VITERBI=generic forces the generic one)
+    int lean_levels = 0, max_arcs = 0;
+    for (auto& lh : lat->lat) max_arcs = std::max(max_arcs, lh.A);
+    {
+        static const bool no_lean = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && !strcmp(e, "generic"); }();
+        int lean_lanes = 1;
+        for (auto& d : lat->h_desc) lean_lanes = std::max(lean_lanes, d.lean_lanes);
+        const int lb = std::max(64, (lean_lanes + 63) & ~63);
+        bool same_nlev = true;
+        for (auto& d : lat->h_desc) same_nlev = same_nlev && d.nlev == lat->max_nlev;
+        if (!no_lean && !(out_costs && !want_path) && !lat->has_nan_arc && !lat->has_self_arc && same_nlev && lat->max_nlev <= 3 && lb <= 1024 &&
+            S <= 8 * lb && max_arcs <= 4096) {
+            lean_levels = lat->max_nlev;
+            block = lb;
+        }
+    }
+    size_t lds;
+    if (lean_levels) {
+        a.em_chunk = std::max(1, std::min(8, 8 * block / std::max(S, 1)));
+        if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
+        a.arc_cap = (max_arcs + 1) & ~1;
+        lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+    } else {
+        a.em_chunk = 1;
+        lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
+    }
     if (lds > 160 * 1024) {
         gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
         return GH_ERR_UNSUPPORTED;
     }
     for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
         a.u_begin = chunk_begin[c];
-        rc = gh_launch_viterbi(ctx, a, chunk_begin[c + 1] - chunk_begin[c], block, lds, b->dtype == GH_F64, want_path);
+        const int64_t nu = chunk_begin[c + 1] - chunk_begin[c];
+        rc = lean_levels ? gh_launch_viterbi_lean(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path, lean_levels)
+                         : gh_launch_viterbi(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path);
         if (rc) return rc;
     }
     int flag = 0;

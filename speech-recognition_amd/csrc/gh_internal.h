@@ -104,15 +104,19 @@ struct gh_lattices {
     double* d_succ_cost;   // [Atot]
     int32_t* d_order;      // [Rtot] rows sorted by (level, row)
     int32_t* d_level_ptr;  // per graph: nlev+1 entries at lev_base
+    int32_t* d_level_narrow;  // per graph, same indexing: rows of the level with <= 2 arcs (they come first in d_order)
     int32_t* d_end_rows;   // [Etot]
     // per-graph descriptor table on device
     struct desc {
-        int32_t R, nlev, n_end, pad;
+        int32_t R, nlev, n_end, pad;  // pad = max rows of a level
+        int32_t lean_lanes, pad2;     // max over levels of (narrow rows + 16 * wide rows): lean kernel block
         int64_t row_base, ptr_base, arc_base, lev_base, end_base;
     };
     desc* d_desc;
     std::vector<desc> h_desc;
     int max_R, max_nlev;
+    bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
+    bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };
 
 // kernels (gh_loglik.hip / gh_viterbi.hip)

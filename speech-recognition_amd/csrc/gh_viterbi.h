@@ -11,10 +11,13 @@ struct gh_vit_args {
     const double* pred_cost;
     const int32_t* order;
     const int32_t* level_ptr;
+    const int32_t* level_narrow;  // rows of each level with <= 2 arcs (first in `order`)
     const int32_t* end_rows;
     const void* nll;  // [N,S] float or double
     int S;
     int r_pad;                // LDS column stride (>= max R, even)
+    int em_chunk;             // lean kernel: columns of emissions prefetched per chunk, >= 1
+    int arc_cap;              // lean kernel: LDS slots for a graph's arc list
     const int64_t* utt_off;   // [U+1] frame offsets
     const int32_t* utt_lat;   // [U] graph of each utterance, or null (graph 0)
     const int64_t* perm;      // launch slot -> utterance (longest first), or null
@@ -34,3 +37,6 @@ struct gh_vit_args {
 
 int gh_launch_viterbi(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int block, size_t lds_bytes,
                       bool f64, bool want_path);
+// lean kernel (gh_viterbi_lean.hip): <= 3 levels, one row per lane per level, no NaN / self arcs
+int gh_launch_viterbi_lean(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int block, size_t lds_bytes,
+                           bool f64, bool want_path, int levels);

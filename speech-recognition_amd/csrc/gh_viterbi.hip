@@ -19,9 +19,12 @@ namespace {
 
 constexpr uint16_t BP_NONE = 0xFFFFu;
 
+// Generic kernel: any graph (any number of levels / rows / arcs, NaN arc costs, same-column self
+// arcs).  The common graphs take the lean kernel in gh_viterbi_lean.hip instead.
 template <typename ET, bool WANT_PATH>
 __global__ void viterbi_kernel(gh_vit_args a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int s_bi;
     const int tid = threadIdx.x, bd = blockDim.x;
     const int64_t slot = a.u_begin + blockIdx.x;
     const int64_t u = a.perm ? a.perm[slot] : slot;
@@ -146,27 +149,55 @@ __global__ void viterbi_kernel(gh_vit_args a) {
             if (best >= c) { best = c; bi = k; }  // '>=': last minimum wins (decode.py:131)
         }
         if (a.best_end) a.best_end[u] = bi;
-        if (WANT_PATH) {
-            int len = 0;
-            if (T > 1 && bi >= 0) {
-                int32_t* path = a.path + 2 * a.path_off[u];
-                int i = end_rows[bi], j = T - 1;
-                const int64_t cap = a.path_off[u + 1] - a.path_off[u];
-                while (j != 0) {  // decode.py:143-145
+        s_bi = bi;
+    }
+    __syncthreads();
+    // ---- back-trace (decode.py:143-145).  Lane 0 walks the back-pointers; the (row, col) pairs are
+    // parked in LDS and flushed by the whole workgroup, so the dependent bp loads of the walk are not
+    // serialised behind path stores (vmcnt retires in order).
+    if (WANT_PATH) {
+        __shared__ int s_state[4];  // i, j, len, done
+        int32_t* pbuf = reinterpret_cast<int32_t*>(lds);  // the cost columns are dead now
+        const int PB = a.r_pad + S / 2 - 1;                // pairs per flush (cost columns + emission vector)
+        int32_t* path = a.path + 2 * a.path_off[u];
+        const int64_t cap = a.path_off[u + 1] - a.path_off[u];
+        if (tid == 0) {
+            const int bi = s_bi;
+            s_state[0] = (bi >= 0) ? end_rows[bi] : 0;
+            s_state[1] = T - 1;
+            s_state[2] = 0;
+            s_state[3] = !(T > 1 && bi >= 0);
+        }
+        __syncthreads();
+        while (!s_state[3]) {
+            int n_new = 0;
+            if (tid == 0) {
+                int i = s_state[0], j = s_state[1], len = s_state[2];
+                while (j != 0 && n_new < PB) {
                     const uint16_t b = bp[(int64_t)j * R + i];
-                    if (b == BP_NONE) { atomicOr(a.flag, 2); break; }
+                    if (b == BP_NONE) { atomicOr(a.flag, 2); j = 0; break; }
                     // all-inf cells may point along dead same-column arcs and cycle (the reference
                     // would spin forever); a live path has at most one cell per (column, level)
-                    if (len >= cap) { atomicOr(a.flag, 4); break; }
+                    if (len + n_new >= cap) { atomicOr(a.flag, 4); j = 0; break; }
                     i = b & 0x7FFF;
                     if (!(b & 0x8000u)) --j;
-                    path[2 * len] = i;
-                    path[2 * len + 1] = j;
-                    ++len;
+                    pbuf[2 * n_new] = i;
+                    pbuf[2 * n_new + 1] = j;
+                    ++n_new;
                 }
+                s_state[0] = i; s_state[1] = j;
+                s_state[3] = (j == 0);
+                pbuf[2 * PB] = n_new;
             }
-            a.path_len[u] = len;
+            __syncthreads();
+            n_new = pbuf[2 * PB];
+            const int len = s_state[2];
+            for (int k = tid; k < 2 * n_new; k += bd) path[2 * (int64_t)len + k] = pbuf[k];
+            __syncthreads();
+            if (tid == 0) s_state[2] = len + n_new;
+            __syncthreads();
         }
+        if (tid == 0) a.path_len[u] = s_state[2];
     }
 }
 

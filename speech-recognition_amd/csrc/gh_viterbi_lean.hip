@@ -1,0 +1,361 @@
+// Lean Viterbi kernel for the graphs that matter in practice (isolated word chains, K-layer word
+// lattices, forced-alignment lattices): <= 3 levels, every level fits one row per lane, S <=
+// blockDim, no NaN arc costs, no same-column self arc.  Same semantics as the generic kernel in
+// gh_viterbi.hip (reference: decode_hmm_states, sr/recognition/decode.py:80-146); everything a
+// lane needs per column is precomputed ONCE into registers so that the per-column work of a
+// row is ~20 instructions:
+//   * two register arcs per row (cost + 32-bit LDS byte addresses for even and odd columns; a
+//     missing / dead arc is padded with cost +inf -- it can never win the strict '<');
+//   * rows with more arcs (non-emitting rows collecting all word ends) get 16 lanes each: the
+//     lanes scan the LDS-resident arc list in parallel and a DPP row reduction (value, then
+//     lowest arc index: np.argmin's first minimum) replaces a serial chain of LDS round trips;
+//   * the column loop is unrolled by two so the prev/cur swap costs nothing;
+//   * emission vectors arrive in chunks of CH columns, prefetched one chunk ahead (registers ->
+//     LDS), with a zero slot for non-emitting rows;
+//   * back-pointer stores use running per-level pointers; the back-trace is buffered in LDS.
+#include "gh_internal.h"
+#include "gh_viterbi.h"
+#include <type_traits>
+
+namespace {
+
+constexpr uint16_t BP_NONE = 0xFFFFu;
+constexpr int NPRE = 8;
+
+__device__ __forceinline__ double& lds_at(char* smem, unsigned off) { return *reinterpret_cast<double*>(smem + off); }
+
+// lane i <- lane i+K of the same 16-lane row (rows do not wrap: lanes past the end keep their value)
+template <int K> __device__ __forceinline__ int row_shl(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x100 | K, 0xF, 0xF, false);
+}
+template <int K> __device__ __forceinline__ void min_step(double& best, int& idx) {
+    const int lo = row_shl<K>(__double2loint(best)), hi = row_shl<K>(__double2hiint(best));
+    const int oi = row_shl<K>(idx);
+    const double ov = __hiloint2double(hi, lo);
+    const bool take = (ov < best) || (ov == best && oi < idx);
+    best = take ? ov : best;
+    idx = take ? oi : idx;
+}
+
+template <typename ET, bool WANT_PATH, bool WANT_COSTS, int NL>
+__global__ void viterbi_lean_kernel(gh_vit_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_bi;
+    __shared__ int s_state[4];
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int64_t slot = a.u_begin + blockIdx.x;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const int l = a.utt_lat ? a.utt_lat[u] : 0;
+    const gh_lattices::desc dsc = a.descs[l];
+    const int R = dsc.R, n_end = dsc.n_end;
+    const int32_t* row_state = a.row_state + dsc.row_base;
+    const uint8_t* row_start = a.row_start + dsc.row_base;
+    const int32_t* pred_ptr = a.pred_ptr + dsc.ptr_base;
+    const uint32_t* pred_row = a.pred_row + dsc.arc_base;
+    const double* pred_cost = a.pred_cost + dsc.arc_base;
+    const int32_t* order = a.order + dsc.row_base;
+    const int32_t* level_ptr = a.level_ptr + dsc.lev_base;
+    const int32_t* level_narrow = a.level_narrow + dsc.lev_base;
+    const int32_t* end_rows = a.end_rows + dsc.end_base;
+    const int64_t f0 = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - f0);
+    const int S = a.S, S1 = S + 1;  // slot S of every emission vector is 0.0 (non-emitting rows)
+    const ET* nll = static_cast<const ET*>(a.nll) + f0 * S;
+    const double INF = INFINITY;
+    // LDS map (bytes): [colA r_pad*8][colB r_pad*8][em 2*CH*S1*8][arc cost arc_cap*8][arc row arc_cap*4]
+    const unsigned COLB = (unsigned)a.r_pad * 8u;
+    const unsigned EM0 = 2u * COLB;
+    const int CH = a.em_chunk;
+    const unsigned EMCH = (unsigned)(CH * S1) * 8u;
+    const unsigned ARC0 = EM0 + 2u * EMCH;
+    double* s_cost = reinterpret_cast<double*>(smem + ARC0);
+    uint32_t* s_w = reinterpret_cast<uint32_t*>(smem + ARC0 + (unsigned)a.arc_cap * 8u);
+    double* costs = WANT_COSTS ? a.costs + a.costs_off[u] : nullptr;  // full matrices: tests / one-utterance API
+    uint16_t* bp = WANT_PATH ? a.bp + a.bp_off[slot] : nullptr;
+
+    if (T <= 0) {
+        if (tid == 0) {
+            if (a.best_end) a.best_end[u] = -1;
+            if (a.path_len) a.path_len[u] = 0;
+        }
+        return;
+    }
+    for (int r = tid; r < R; r += bd) { lds_at(smem, r * 8u) = INF; lds_at(smem, COLB + r * 8u) = INF; }
+    {   // arc list of the graph -> LDS (for the wide rows)
+        const int n_arcs = pred_ptr[R];
+        for (int p = tid; p < n_arcs && p < a.arc_cap; p += bd) { s_cost[p] = pred_cost[p]; s_w[p] = pred_row[p]; }
+    }
+    // ---- per-lane row descriptors ------------------------------------------------------------
+    int f_r[NL], f_na[NL], f_p0[NL];
+    bool f_start[NL];
+    unsigned f_em[NL];           // byte offset of the row's emission inside an emission vector
+    unsigned f_a0[NL], f_a1[NL]; // LDS byte address of arc 0 / 1 at EVEN columns (prev = colA, cur = colB)
+    int f_d0[NL], f_d1[NL];      // what to add at odd columns
+    double f_c0[NL], f_c1[NL];
+    uint16_t f_b0[NL], f_b1[NL];
+    // wide rows (> 2 arcs): lane group g = tid / 16 owns wide row g of the level, lane j = tid % 16 its arcs j, j+16, ..
+    int w_r[NL], w_p0[NL], w_na[NL];
+    unsigned w_em[NL];
+    bool w_start[NL];
+#pragma unroll
+    for (int lev = 0; lev < NL; ++lev) {
+        const int n_narrow = level_narrow[lev];
+        const int i = level_ptr[lev] + tid;
+        f_r[lev] = -1; f_na[lev] = 0; f_p0[lev] = 0; f_start[lev] = false; f_em[lev] = (unsigned)S * 8u;
+        f_a0[lev] = 0; f_a1[lev] = 0; f_d0[lev] = 0; f_d1[lev] = 0; f_c0[lev] = INF; f_c1[lev] = INF;
+        f_b0[lev] = BP_NONE; f_b1[lev] = BP_NONE;
+        w_r[lev] = -1; w_p0[lev] = 0; w_na[lev] = 0; w_em[lev] = (unsigned)S * 8u; w_start[lev] = false;
+        {
+            const int iw = level_ptr[lev] + n_narrow + (tid >> 4);
+            if (iw < level_ptr[lev + 1]) {
+                const int r = order[iw];
+                const int st = row_state[r];
+                w_r[lev] = r;
+                w_p0[lev] = pred_ptr[r];
+                w_na[lev] = pred_ptr[r + 1] - pred_ptr[r];
+                w_em[lev] = (unsigned)(st >= 0 ? st : S) * 8u;
+                w_start[lev] = (row_start[r] & 1) != 0;
+            }
+        }
+        if (tid < n_narrow) {
+            const int r = order[i];
+            const int st = row_state[r];
+            const int p0 = pred_ptr[r], na = pred_ptr[r + 1] - p0;
+            f_r[lev] = r;
+            f_na[lev] = na;
+            f_p0[lev] = p0;
+            f_start[lev] = (row_start[r] & 1) != 0;
+            f_em[lev] = (unsigned)(st >= 0 ? st : S) * 8u;
+            if (na >= 1) {
+                const uint32_t w = pred_row[p0];
+                const unsigned o = w & GH_ARC_ROW;
+                const bool same = (w & GH_ARC_SAME) != 0;
+                f_c0[lev] = (w & GH_ARC_DEAD) ? INF : pred_cost[p0];
+                f_a0[lev] = (same ? COLB : 0u) + o * 8u;
+                f_d0[lev] = same ? -(int)COLB : (int)COLB;
+                f_b0[lev] = (uint16_t)(o | (same ? 0x8000u : 0u));
+            }
+            if (na >= 2) {
+                const uint32_t w = pred_row[p0 + 1];
+                const unsigned o = w & GH_ARC_ROW;
+                const bool same = (w & GH_ARC_SAME) != 0;
+                f_c1[lev] = (w & GH_ARC_DEAD) ? INF : pred_cost[p0 + 1];
+                f_a1[lev] = (same ? COLB : 0u) + o * 8u;
+                f_d1[lev] = same ? -(int)COLB : (int)COLB;
+                f_b1[lev] = (uint16_t)(o | (same ? 0x8000u : 0u));
+            }
+        }
+    }
+
+    if (T == 1) {
+        // decode.py:113 with c == 0: column c-1 wraps onto column 0 itself: serial ascending sweep
+        double* cur = reinterpret_cast<double*>(smem);
+        __syncthreads();
+        if (tid == 0) {
+            for (int r = 0; r < R; ++r) {
+                const int st = row_state[r];
+                const double e = st >= 0 ? (double)nll[st] : 0.0;
+                double c = INF;
+                if (row_start[r] & 1) {
+                    c = e;
+                } else {
+                    const int p0 = pred_ptr[r], p1 = pred_ptr[r + 1];
+                    if (p0 < p1) {
+                        double best = 0;
+                        for (int p = p0; p < p1; ++p) {
+                            const double v = pred_cost[p] + cur[pred_row[p] & GH_ARC_ROW];
+                            if (p == p0 || v < best) best = v;
+                        }
+                        c = best + e;
+                        if (c != c) c = INF;
+                    }
+                }
+                cur[r] = c;
+                if (WANT_COSTS) costs[r] = c;
+            }
+        }
+        __syncthreads();
+    } else {
+        // ---- emission chunks: chunk 0 straight to LDS, then one chunk ahead through registers ----
+        ET pre[NPRE];
+        const int chunk_elems = CH * S;
+        {
+            const int n0 = (T < CH ? T : CH) * S;
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int i = tid + k * bd;
+                if (i < n0) lds_at(smem, EM0 + (unsigned)((i / S) * S1 + i % S) * 8u) = (double)nll[i];
+            }
+            for (int c = tid; c < 2 * CH; c += bd) lds_at(smem, EM0 + (unsigned)(c * S1 + S) * 8u) = 0.0;
+        }
+        uint16_t* bp_p[NL];
+        double* co_p[NL];
+#pragma unroll
+        for (int lev = 0; lev < NL; ++lev) {
+            bp_p[lev] = WANT_PATH ? bp + (f_r[lev] >= 0 ? f_r[lev] : 0) : nullptr;
+            co_p[lev] = WANT_COSTS ? costs + (int64_t)(f_r[lev] >= 0 ? f_r[lev] : 0) * T : nullptr;
+        }
+        int kc = 0, ci = 0;  // chunk index, column inside the chunk
+        // one column; PAR = column parity (compile time)
+        auto column = [&](int t, auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            if (ci == 0) {
+                const int64_t base = (int64_t)(kc + 1) * chunk_elems, lim = (int64_t)T * S;
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k) {
+                    const int i = tid + k * bd;
+                    pre[k] = (i < chunk_elems && base + i < lim) ? nll[base + i] : ET(0);
+                }
+            }
+            __syncthreads();
+            const unsigned emv = EM0 + (unsigned)(kc & 1) * EMCH + (unsigned)(ci * S1) * 8u;
+#pragma unroll
+            for (int lev = 0; lev < NL; ++lev) {
+                if (f_r[lev] >= 0) {
+                    const double v0 = f_c0[lev] + lds_at(smem, f_a0[lev] + (PAR ? f_d0[lev] : 0));
+                    const double v1 = f_c1[lev] + lds_at(smem, f_a1[lev] + (PAR ? f_d1[lev] : 0));
+                    const bool pick1 = v1 < v0;
+                    double best = pick1 ? v1 : v0;
+                    uint16_t b = pick1 ? f_b1[lev] : f_b0[lev];
+                    const double e = lds_at(smem, emv + f_em[lev]);
+                    double c = best + e;
+                    c = (c != c) ? INF : c;                 // min(inf, nan) keeps inf (decode.py:124)
+                    if (f_na[lev] == 0) { c = INF; b = BP_NONE; }      // rows without arcs stay +inf (:116-117)
+                    if (t == 0 && f_start[lev]) { c = e; b = BP_NONE; }  // decode.py:99-101
+                    lds_at(smem, (PAR ? 0u : COLB) + (unsigned)f_r[lev] * 8u) = c;
+                    if (WANT_PATH) { *bp_p[lev] = b; bp_p[lev] += R; }
+                    if (WANT_COSTS) { *co_p[lev] = c; co_p[lev] += 1; }
+                }
+                if (w_r[lev] >= 0) {  // wide row: 16 lanes scan its arcs, then reduce (value, lowest arc index)
+                    const unsigned prevb = PAR ? COLB : 0u, curb = PAR ? 0u : COLB;
+                    double best = INF;
+                    int bidx = 0x7fffffff;
+                    for (int p = w_p0[lev] + (tid & 15); p < w_p0[lev] + w_na[lev]; p += 16) {
+                        const uint32_t w = s_w[p];
+                        const unsigned o = w & GH_ARC_ROW;
+                        const double v = (w & GH_ARC_DEAD) ? INF : s_cost[p] + lds_at(smem, ((w & GH_ARC_SAME) ? curb : prevb) + o * 8u);
+                        if (v < best || bidx == 0x7fffffff) { best = v; bidx = p; }
+                    }
+                    min_step<8>(best, bidx);
+                    min_step<4>(best, bidx);
+                    min_step<2>(best, bidx);
+                    min_step<1>(best, bidx);
+                    if ((tid & 15) == 0) {
+                        const uint32_t w = s_w[bidx];
+                        uint16_t b = (uint16_t)((w & GH_ARC_ROW) | ((w & GH_ARC_SAME) ? 0x8000u : 0u));
+                        const double e = lds_at(smem, emv + w_em[lev]);
+                        double c = best + e;
+                        c = (c != c) ? INF : c;
+                        if (t == 0 && w_start[lev]) { c = e; b = BP_NONE; }
+                        lds_at(smem, curb + (unsigned)w_r[lev] * 8u) = c;
+                        if (WANT_PATH) bp[(int64_t)t * R + w_r[lev]] = b;
+                        if (WANT_COSTS) costs[(int64_t)w_r[lev] * T + t] = c;
+                    }
+                }
+                if (lev + 1 < NL) __syncthreads();
+            }
+            if (ci == CH - 1) {  // park the prefetched chunk in the other buffer
+                const unsigned dst = EM0 + (unsigned)((kc + 1) & 1) * EMCH;
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k) {
+                    const int i = tid + k * bd;
+                    if (i < chunk_elems) lds_at(smem, dst + (unsigned)((i / S) * S1 + i % S) * 8u) = (double)pre[k];
+                }
+                ci = 0;
+                ++kc;
+            } else {
+                ++ci;
+            }
+        };
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            column(t, std::integral_constant<int, 0>{});
+            column(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < T) column(t, std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+    // the last column is in colB if T is odd (even-parity column written last), else colA
+    const double* last = reinterpret_cast<const double*>(smem + ((T & 1) ? (T == 1 ? 0u : COLB) : 0u));
+    if (tid == 0) {
+        double best = INF;
+        int bi = -1;
+        double* ec = a.end_cost ? a.end_cost + (a.end_off ? a.end_off[u] : u * n_end) : nullptr;
+        for (int k = 0; k < n_end; ++k) {
+            const double c = last[end_rows[k]];
+            if (ec) ec[k] = c;
+            if (best >= c) { best = c; bi = k; }  // '>=': last minimum wins (decode.py:131)
+        }
+        if (a.best_end) a.best_end[u] = bi;
+        s_bi = bi;
+    }
+    __syncthreads();
+    if (WANT_PATH) {
+        int32_t* pbuf = reinterpret_cast<int32_t*>(smem);
+        const int PB = a.r_pad + CH * S1 - 1;
+        int32_t* path = a.path + 2 * a.path_off[u];
+        const int64_t cap = a.path_off[u + 1] - a.path_off[u];
+        if (tid == 0) {
+            const int bi = s_bi;
+            s_state[0] = (bi >= 0) ? end_rows[bi] : 0;
+            s_state[1] = T - 1;
+            s_state[2] = 0;
+            s_state[3] = !(T > 1 && bi >= 0);
+        }
+        __syncthreads();
+        while (!s_state[3]) {
+            int n_new = 0;
+            if (tid == 0) {
+                int i = s_state[0], j = s_state[1];
+                const int len = s_state[2];
+                while (j != 0 && n_new < PB) {
+                    const uint16_t b = bp[(int64_t)j * R + i];
+                    if (b == BP_NONE) { atomicOr(a.flag, 2); j = 0; break; }
+                    if (len + n_new >= cap) { atomicOr(a.flag, 4); j = 0; break; }
+                    i = b & 0x7FFF;
+                    if (!(b & 0x8000u)) --j;
+                    pbuf[2 * n_new] = i;
+                    pbuf[2 * n_new + 1] = j;
+                    ++n_new;
+                }
+                s_state[0] = i; s_state[1] = j;
+                s_state[3] = (j == 0);
+                pbuf[2 * PB] = n_new;
+            }
+            __syncthreads();
+            n_new = pbuf[2 * PB];
+            const int len = s_state[2];
+            for (int k = tid; k < 2 * n_new; k += bd) path[2 * (int64_t)len + k] = pbuf[k];
+            __syncthreads();
+            if (tid == 0) s_state[2] = len + n_new;
+            __syncthreads();
+        }
+        if (tid == 0) a.path_len[u] = s_state[2];
+    }
+}
+
+}  // namespace
+
+int gh_launch_viterbi_lean(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int block, size_t lds_bytes,
+                           bool f64, bool want_path, int levels) {
+    if (n_utts <= 0) return GH_OK;
+    dim3 grid((unsigned)n_utts), blk((unsigned)block);
+    const bool wc = a.costs != nullptr;
+#define GH_VL(ET, WP, WC, NLV) hipLaunchKernelGGL((viterbi_lean_kernel<ET, WP, WC, NLV>), grid, blk, lds_bytes, ctx->stream, a)
+#define GH_VL_N(ET, WP, WC)                      \
+    switch (levels) {                            \
+        case 1: GH_VL(ET, WP, WC, 1); break;     \
+        case 2: GH_VL(ET, WP, WC, 2); break;     \
+        default: GH_VL(ET, WP, WC, 3); break;    \
+    }
+    // (full cost matrices are a test / single-utterance feature: only the path variant carries them)
+    if (f64) {
+        if (wc) { GH_VL_N(double, true, true) } else if (want_path) { GH_VL_N(double, true, false) } else { GH_VL_N(double, false, false) }
+    } else {
+        if (wc) { GH_VL_N(float, true, true) } else if (want_path) { GH_VL_N(float, true, false) } else { GH_VL_N(float, false, false) }
+    }
+#undef GH_VL_N
+#undef GH_VL
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
