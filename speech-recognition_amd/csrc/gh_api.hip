@@ -339,6 +339,9 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
     lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
     lt->d_succ_cost = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr; lt->d_level_narrow = nullptr;
+    lt->chain_ok = false; lt->chain_skip = false; lt->chain_groups = 0;
+    lt->d_ch_cost0 = lt->d_ch_cost1 = lt->d_ch_cost2 = nullptr; lt->d_ch_info = nullptr;
+    lt->d_ch_end_slot = nullptr; lt->d_ch_group_row0 = nullptr;
     lt->d_desc = nullptr;
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
@@ -453,7 +456,56 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         lt->max_nlev = std::max(lt->max_nlev, nlev);
 #undef GH_LFAIL
     }
+    // ---- chain form: one graph, one level, arcs only from r, r-1, r-2, distinct end rows ----
+    std::vector<double> ch0, ch1, ch2;
+    std::vector<uint8_t> chinfo;
+    std::vector<int32_t> chslot, chgroups;
+    if (L == 1 && lt->max_nlev == 1 && !lt->has_nan_arc) {
+        const int R = lt->lat[0].R;
+        const int32_t* ptr = h_ptr.data();
+        ch0.assign(R, INFINITY); ch1.assign(R, INFINITY); ch2.assign(R, INFINITY);
+        chinfo.assign(R, 3); chslot.assign(R, -1);
+        bool ok = true, skip = false;
+        for (int r = 0; r < R && ok; ++r) {
+            int first = 3;
+            for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                const int o = (int)(h_prow[p] & GH_ARC_ROW), dlt = r - o;
+                if (dlt < 0 || dlt > 2 || (h_prow[p] & (GH_ARC_SAME | GH_ARC_DEAD))) { ok = false; break; }
+                double& slot = dlt == 0 ? ch0[r] : (dlt == 1 ? ch1[r] : ch2[r]);
+                if (!std::isinf(slot)) { ok = false; break; }  // duplicate arc
+                slot = h_pcost[p];
+                if (dlt == 2) skip = true;
+                if (first == 3 || dlt > first) first = dlt;  // lowest origin == largest delta comes first
+            }
+            chinfo[r] = (uint8_t)(first | (h_start[r] & 1 ? 4 : 0));
+        }
+        for (int k = 0; ok && k < (int)h_end.size(); ++k) {
+            if (chslot[h_end[k]] >= 0) ok = false;  // duplicated end row: generic / lean kernels handle it
+            else chslot[h_end[k]] = k;
+        }
+        if (ok) {  // 64-lane groups made of whole chains (a chain starts where no arc arrives from r-1 / r-2)
+            chgroups.push_back(0);
+            int gs = 0, cs = 0;
+            for (int r = 1; r <= R && ok; ++r) {
+                const bool chain_start = r == R || (std::isinf(ch1[r]) && std::isinf(ch2[r]) &&
+                                                    (r + 1 >= R || std::isinf(ch2[r + 1])));
+                if (!chain_start) continue;
+                if (r - cs > 64) { ok = false; break; }     // one chain longer than a wave
+                if (r - gs > 64) { chgroups.push_back(cs); gs = cs; }
+                cs = r;
+            }
+            chgroups.push_back(R);
+        }
+        if (ok) { lt->chain_ok = true; lt->chain_skip = skip; lt->chain_groups = (int)chgroups.size() - 1; }
+    }
     int rc = GH_OK;
+    if (lt->chain_ok &&
+        ((rc = upload(&lt->d_ch_cost0, ch0)) || (rc = upload(&lt->d_ch_cost1, ch1)) || (rc = upload(&lt->d_ch_cost2, ch2)) ||
+         (rc = upload(&lt->d_ch_info, chinfo)) || (rc = upload(&lt->d_ch_end_slot, chslot)) ||
+         (rc = upload(&lt->d_ch_group_row0, chgroups)))) {
+        gh_lattices_destroy(lt);
+        return rc;
+    }
     if ((rc = upload(&lt->d_row_state, h_state)) || (rc = upload(&lt->d_row_start, h_start)) ||
         (rc = upload(&lt->d_pred_ptr, h_ptr)) || (rc = upload(&lt->d_pred_row, h_prow)) ||
         (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
@@ -475,6 +527,8 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
     hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
     hipFree(l->d_level_narrow);
+    hipFree(l->d_ch_cost0); hipFree(l->d_ch_cost1); hipFree(l->d_ch_cost2); hipFree(l->d_ch_info);
+    hipFree(l->d_ch_end_slot); hipFree(l->d_ch_group_row0);
     hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
     hipFree(l->d_desc);
     delete l;
@@ -530,7 +584,17 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     std::vector<int64_t> bp_off(U, 0);
     std::vector<int64_t> chunk_begin{0};
     size_t bp_max = 0;
-    if (want_path) {
+    // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
+    // the reference's wrap-around semantics, which only the lean / generic kernels implement)
+    bool use_chain = lat->chain_ok && uniform;
+    {
+        static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        if (no_chain) use_chain = false;
+        for (int64_t u = 0; use_chain && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
+    }
+    const bool want_bp = want_path || (use_chain && out_costs);
+    if (want_bp) {
         size_t acc = 0;
         for (int64_t k = 0; k < U; ++k) {
             const int64_t u = perm[k];
@@ -557,17 +621,18 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     double *d_endcost, *d_costs = nullptr;
     uint16_t* d_bp = nullptr;
     Carver cv;
-    if (want_path) cv.add(&d_bpoff, U);
+    if (want_bp) cv.add(&d_bpoff, U);
     if (!uniform) cv.add(&d_endoff, U + 1);
     cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
     if (utt_lattice) cv.add(&d_uttlat, U);
-    if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); cv.add(&d_bp, bp_max); }
+    if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
+    if (want_bp) cv.add(&d_bp, bp_max);
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
     int rc = cv.commit(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
-    if (want_path) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
+    if (want_bp) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
     if (!uniform) GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
     if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
@@ -583,6 +648,23 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     a.path = d_path; a.path_off = d_pathoff; a.path_len = d_pathlen; a.costs = d_costs; a.costs_off = d_costsoff;
     a.flag = ctx->d_flag;
 
+    if (use_chain) {
+        gh_chain_args c;
+        memset(&c, 0, sizeof c);
+        c.cost0 = lat->d_ch_cost0; c.cost1 = lat->d_ch_cost1; c.cost2 = lat->d_ch_cost2; c.row_info = lat->d_ch_info;
+        c.row_state = lat->d_row_state; c.end_slot = lat->d_ch_end_slot; c.end_rows = lat->d_end_rows;
+        c.group_row0 = lat->d_ch_group_row0; c.n_groups = lat->chain_groups; c.R = lat->lat[0].R; c.S = S;
+        c.n_end = lat->lat[0].n_end; c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm;
+        c.bp = reinterpret_cast<uint8_t*>(d_bp); c.bp_off = d_bpoff; c.end_cost = d_endcost; c.best_end = d_bestend;
+        c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen; c.costs = d_costs; c.costs_off = d_costsoff;
+        c.flag = ctx->d_flag;
+        for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
+            const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
+            rc = gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
+            if (!rc) rc = gh_launch_chain_backtrace(ctx, c, u0, nu);  // end selection (+ path when requested)
+            if (rc) return rc;
+        }
+    }
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
@@ -617,7 +699,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
         gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
         return GH_ERR_UNSUPPORTED;
     }
-    for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
+    for (size_t c = 0; !use_chain && c + 1 < chunk_begin.size(); ++c) {
         a.u_begin = chunk_begin[c];
         const int64_t nu = chunk_begin[c + 1] - chunk_begin[c];
         rc = lean_levels ? gh_launch_viterbi_lean(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path, lean_levels)

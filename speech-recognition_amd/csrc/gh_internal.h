@@ -115,6 +115,12 @@ struct gh_lattices {
     desc* d_desc;
     std::vector<desc> h_desc;
     int max_R, max_nlev;
+    // chain form (gh_viterbi_chain.hip), only for L == 1 graphs whose arcs all come from r, r-1, r-2
+    bool chain_ok, chain_skip;
+    int chain_groups;
+    double *d_ch_cost0, *d_ch_cost1, *d_ch_cost2;
+    uint8_t* d_ch_info;
+    int32_t *d_ch_end_slot, *d_ch_group_row0;
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };

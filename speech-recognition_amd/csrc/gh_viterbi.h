@@ -40,3 +40,34 @@ int gh_launch_viterbi(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int blo
 // lean kernel (gh_viterbi_lean.hip): <= 3 levels, one row per lane per level, no NaN / self arcs
 int gh_launch_viterbi_lean(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, int block, size_t lds_bytes,
                            bool f64, bool want_path, int levels);
+
+// Chain kernel (gh_viterbi_chain.hip): left-to-right graphs (arcs from r, r-1, r-2 only), one graph
+// for the whole batch.  All pointers are device pointers.
+struct gh_chain_args {
+    const double* cost0;      // [R] self-arc cost, +inf = absent
+    const double* cost1;      // [R] arc from r-1
+    const double* cost2;      // [R] arc from r-2
+    const uint8_t* row_info;  // [R] bits 0-1: code of the first (lowest-origin) arc, 3 = none; bit 2: start row
+    const int32_t* row_state; // [R]
+    const int32_t* end_slot;  // [R] position in the end list or -1
+    const int32_t* end_rows;  // [n_end]
+    const int32_t* group_row0;  // [n_groups+1] row ranges of the 64-lane groups (whole chains)
+    int n_groups, R, S, n_end;
+    const void* nll;
+    const int64_t* utt_off;
+    const int64_t* perm;
+    int64_t slot0;
+    uint8_t* bp;              // [T,R] bytes per launch slot
+    const int64_t* bp_off;
+    double* end_cost;         // [U, n_end]
+    int32_t* best_end;        // [U]
+    int32_t* path;
+    const int64_t* path_off;
+    int32_t* path_len;
+    double* costs;
+    const int64_t* costs_off;
+    int* flag;
+};
+int gh_launch_viterbi_chain(gh_ctx* ctx, const gh_chain_args& a, int64_t u_begin, int64_t n_utts, bool f64,
+                            bool want_bp, bool want_costs, bool skip);
+int gh_launch_chain_backtrace(gh_ctx* ctx, const gh_chain_args& a, int64_t u_begin, int64_t n_utts);

@@ -349,3 +349,72 @@ def test_baum_welch_statistics_vs_numpy(hip, ctx):
     mu, sigma, wn = m_step(stats[vis], counts[vis], fm[vis])
     assert np.all(sigma[stats[vis][:, :, 0] > 1e-3] > 0)
     np.testing.assert_allclose(wn.sum(axis=1), 1.0, rtol=1e-9)
+
+
+def test_viterbi_chain_kernel_skip_arcs_and_stacking(hip, ctx):
+    """Left-to-right graphs take the one-wave-per-chain-group kernel (DPP neighbour exchange, 1-byte
+    back-pointers): chains with skip transitions (calc_transition_costs' jump over an empty segment),
+    several chains stacked in one graph, > 64 rows in total (two lane groups), costs + paths + ends."""
+    rng = np.random.default_rng(123)
+    S, M, D = 12, 2, 4
+    means, vars_ = rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    xs = [rng.normal(size=(T, D)) for T in (9, 30, 2, 17)]
+    b = hip.Batch(ctx, xs)
+    nll = b.loglik(gmm)
+
+    def chain(n, skip):
+        t = np.full((n, n), np.inf)
+        for i in range(n):
+            t[i, i] = rng.uniform(0.05, 1.0)
+            if i + 1 < n:
+                t[i + 1, i] = rng.uniform(0.5, 3.0)
+            if skip and i + 2 < n and rng.random() < 0.5:
+                t[i + 2, i] = rng.uniform(0.5, 3.0)
+        return t
+
+    # (a) one chain with skips: costs, path, end against the oracle
+    n = 7
+    t1 = chain(n, True)
+    rows = rng.integers(0, S, size=n)
+    lat = hip.Lattices(ctx, [graph(rows, t1, [0], [n - 1])])
+    r = lat.viterbi(b, want_costs=True)
+    for u, x in enumerate(xs):
+        E = nll[b.offsets[u]:b.offsets[u + 1]][:, rows].T
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            costs, path = O.decode_states(E, np.zeros(n, dtype=bool), t1)
+        fin = ~np.isinf(costs)
+        np.testing.assert_array_equal(np.isinf(r["costs"][u]), ~fin)
+        np.testing.assert_allclose(r["costs"][u][fin], costs[fin], rtol=1e-12)
+        np.testing.assert_array_equal(r["paths"][u], path.reshape(-1, 2))
+    # (b) 15 chains of 6 rows stacked (90 rows -> two lane groups), every chain with its own start / end
+    W, n = 15, 6
+    big = np.full((W * n, W * n), np.inf)
+    chains = [chain(n, k % 2 == 0) for k in range(W)]
+    rows = rng.integers(0, S, size=W * n)
+    for k in range(W):
+        big[k * n:(k + 1) * n, k * n:(k + 1) * n] = chains[k]
+    st = hip.Lattices(ctx, [graph(rows, big, [k * n for k in range(W)], [k * n + n - 1 for k in range(W)])])
+    r = st.viterbi(b, want_path=True)
+    for u, x in enumerate(xs):
+        ref_end = []
+        for k in range(W):
+            E = nll[b.offsets[u]:b.offsets[u + 1]][:, rows[k * n:(k + 1) * n]].T
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                costs, path = O.decode_states(E, np.zeros(n, dtype=bool), chains[k])
+            ref_end.append((costs[-1, -1], path))
+        got = r["end_cost"][u]
+        ref = np.array([c for c, _ in ref_end])
+        np.testing.assert_array_equal(np.isinf(got), np.isinf(ref))
+        np.testing.assert_allclose(got[~np.isinf(ref)], ref[~np.isinf(ref)], rtol=1e-12)
+        # best end: the LAST of equal minima (all-inf for the 2-frame utterance -> last chain)
+        best = np.inf
+        for k, c in enumerate(ref):
+            if best >= c:
+                best, bk = c, k
+        assert r["best_end"][u] == bk
+        if np.isfinite(best):
+            np.testing.assert_array_equal(r["paths"][u] - [bk * n, 0], ref_end[bk][1].reshape(-1, 2))
