@@ -325,3 +325,10 @@ def test_baum_welch_trainer_increases_likelihood(R):
     np.testing.assert_allclose(tr2.vars[seen][ok], np.maximum(sigma, 1e-3)[ok], rtol=1e-12)
     tr.close()
     tr2.close()
+
+
+def test_reference_pickle_scores_identically(R):
+    """N2: a model pickled by the reference evaluates to the reference's own cost on the GPU."""
+    g = load_golden("G12_reference_pickle")
+    hmms = pickle.loads(g["pickle"].tobytes())
+    np.testing.assert_allclose([h.evaluate(g["x"]) for h in hmms], g["evaluate"], rtol=1e-10)

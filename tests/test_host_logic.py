@@ -202,3 +202,23 @@ def test_m_step_from_centred_statistics_matches_reference_em(R):
     np.testing.assert_allclose(mu[0], st["means"][:k], rtol=1e-12)
     np.testing.assert_allclose(sigma[0], st["vars"][:k], rtol=1e-11)
     np.testing.assert_allclose(wn[0], st["w"][:k], rtol=1e-12)
+
+
+def test_reference_pickles_load_into_the_mirror(R):
+    """N2: models pickled by the reference's own classes (module path sr.recognition.*, attribute
+    set of SURVEY.md section 5) unpickle as the mirror's classes with every parameter intact."""
+    import pickle
+    g = load_golden("G12_reference_pickle")
+    hmms = pickle.loads(g["pickle"].tobytes())
+    assert len(hmms) == 2 and all(type(h) is R.HMM for h in hmms)
+    for h, ids in zip(hmms, g["ids"]):
+        assert [type(s) for s in h.gmm_states] == [R.GMM] * 3
+        assert [str(s.id) for s in h.gmm_states] == list(ids)
+        assert sorted(h.__dict__) == ["gmm_states", "mu", "n_segments", "segments", "sigma", "transitions",
+                                      "use_em", "use_gmm"]
+        d = h.gmm_states[0].dists[0]
+        assert type(d) is R.MultivariateNormal and sorted(d.__dict__) == ["_cov", "inv_cov", "mean"]
+        np.testing.assert_allclose(np.diag(d.inv_cov), 1.0 / d.cov, rtol=1e-14)
+    # and they round-trip through the mirror's own pickling
+    again = pickle.loads(pickle.dumps(hmms))
+    assert again[0] == hmms[0] and again[1].gmm_states[2].id == hmms[1].gmm_states[2].id

@@ -403,6 +403,24 @@ def g11(R):
 
 ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
 
+
+def g12(R):
+    """N2: a pickle written by the REFERENCE's classes (data: parameters only) --
+    the mirror package must load it under the same module path and score identically."""
+    import pickle
+    rng = np.random.default_rng(121)
+    means, vars_, w, trans = synth_model(rng, 2, 3, 2, 4)
+    hmms = [make_hmm(R, means[i], vars_[i], w[i], trans) for i in range(2)]
+    x = synth_utt(rng, means, vars_, [1], 12, 12)
+    blob = pickle.dumps(hmms, protocol=2)
+    with quiet():
+        ev = np.array([h.evaluate(x) for h in hmms])
+    save("G12_reference_pickle", pickle=np.frombuffer(blob, dtype=np.uint8), x=x, evaluate=ev,
+         ids=np.array([[str(g.id) for g in h.gmm_states] for h in hmms]))
+
+
+ALL["G12"] = g12
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
