@@ -39,6 +39,8 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     c->device = device;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
     hipDeviceProp_t prop;
     GH_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -65,6 +67,7 @@ extern "C" void gh_ctx_destroy(gh_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
+    if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->d_flag);
     hipFree(c->d_fp64_tables);
     hipStreamDestroy(c->stream);
@@ -90,6 +93,20 @@ int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
+    return GH_OK;
+}
+
+int gh_pinned(gh_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->pinned_bytes) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) GH_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        GH_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
     return GH_OK;
 }
 
@@ -621,9 +638,11 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     double *d_endcost, *d_costs = nullptr;
     uint16_t* d_bp = nullptr;
     Carver cv;
+    int* d_flag2;  // [flag | best_end | end_cost] are carved back to back: ONE D2H copy into pinned memory
+    cv.add(&d_flag2, 64); cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
+    const size_t small_bytes = cv.total;
     if (want_bp) cv.add(&d_bpoff, U);
     if (!uniform) cv.add(&d_endoff, U + 1);
-    cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
     if (utt_lattice) cv.add(&d_uttlat, U);
     if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
     if (want_bp) cv.add(&d_bp, bp_max);
@@ -631,7 +650,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     int rc = cv.commit(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+    GH_HIP(hipMemsetAsync(d_flag2, 0, sizeof(int), st));
     if (want_bp) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
     if (!uniform) GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
@@ -646,7 +665,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
     a.bp = d_bp; a.bp_off = d_bpoff; a.end_cost = d_endcost; a.end_off = d_endoff; a.best_end = d_bestend;
     a.path = d_path; a.path_off = d_pathoff; a.path_len = d_pathlen; a.costs = d_costs; a.costs_off = d_costsoff;
-    a.flag = ctx->d_flag;
+    a.flag = d_flag2;
 
     if (use_chain) {
         gh_chain_args c;
@@ -657,7 +676,7 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
         c.n_end = lat->lat[0].n_end; c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm;
         c.bp = reinterpret_cast<uint8_t*>(d_bp); c.bp_off = d_bpoff; c.end_cost = d_endcost; c.best_end = d_bestend;
         c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen; c.costs = d_costs; c.costs_off = d_costsoff;
-        c.flag = ctx->d_flag;
+        c.flag = d_flag2;
         for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
             const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
             rc = gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
@@ -706,16 +725,19 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
                          : gh_launch_viterbi(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path);
         if (rc) return rc;
     }
-    int flag = 0;
-    GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (out_end_cost) GH_HIP(hipMemcpyAsync(out_end_cost, d_endcost, n_end_total * 8, hipMemcpyDeviceToHost, st));
-    if (out_best_end) GH_HIP(hipMemcpyAsync(out_best_end, d_bestend, U * 4, hipMemcpyDeviceToHost, st));
+    char* pin;
+    rc = gh_pinned(ctx, small_bytes, (void**)&pin);
+    if (rc) return rc;
+    GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
     if (want_path) {
         GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
         GH_HIP(hipMemcpyAsync(out_path_len, d_pathlen, U * 4, hipMemcpyDeviceToHost, st));
     }
     if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, n_costs * 8, hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
+    const int flag = *reinterpret_cast<int*>(pin);
+    if (out_best_end) memcpy(out_best_end, pin + ((char*)d_bestend - (char*)d_flag2), U * 4);
+    if (out_end_cost) memcpy(out_end_cost, pin + ((char*)d_endcost - (char*)d_flag2), n_end_total * 8);
     if (flag & 1) {
         gh_set_error("gh_viterbi: a DP cell chose itself as its origin (decode.py:120-121)");
         return GH_ERR_SELF_POINTER;

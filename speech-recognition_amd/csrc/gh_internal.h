@@ -35,10 +35,13 @@ struct gh_ctx {
     void* scratch;
     size_t scratch_bytes;
     int* d_flag;  // device error flag (self-pointing DP cell etc.)
+    void* pinned;         // growable page-locked host staging buffer (one D2H copy per call instead of several)
+    size_t pinned_bytes;
     double* d_fp64_tables;  // [384] exp2 / inv / -log tables of the fp64 log-sum-exp (gh_loglik_mfma.hip)
 };
 
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
+int gh_pinned(gh_ctx* ctx, size_t bytes, void** out);
 
 // Parameter layout shared by the likelihood kernels (GEMM form):
 //   ll[g] = C[g] + sum_d ( A[g,d] * x_d^2 + B[g,d] * x_d )

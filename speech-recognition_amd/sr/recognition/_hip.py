@@ -175,7 +175,8 @@ class PackedGMM:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.gh_gmm_destroy(self.h)
+            if getattr(self.ctx, "h", None):  # a handle must not outlive its context (interpreter shutdown order)
+                self.ctx.lib.gh_gmm_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -283,7 +284,8 @@ class Batch:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.gh_batch_destroy(self.h)
+            if getattr(self.ctx, "h", None):  # a handle must not outlive its context (interpreter shutdown order)
+                self.ctx.lib.gh_batch_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -389,7 +391,8 @@ class Lattices:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.gh_lattices_destroy(self.h)
+            if getattr(self.ctx, "h", None):  # a handle must not outlive its context (interpreter shutdown order)
+                self.ctx.lib.gh_lattices_destroy(self.h)
             self.h = None
 
     def __del__(self):
