@@ -61,7 +61,7 @@ struct Fp64Tables {
 };
 
 __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tab) {
-    x = (x < -745.0) ? -745.0 : x;  // keeps NaN (comparison false); exp(-745) is the last subnormal
+    x = fmax(x, -745.0);  // one v_max_f64; NaN inputs are caught by the caller's poison check instead
     const double n = __builtin_rint(x * 184.66496523378731);         // 128 / ln 2
     double r = fma(n, -0.00541521234663378, x);                      // ln2/128, high part (32 bits)
     r = fma(n, -1.4907929134926466e-12, r);                          // low part
@@ -138,8 +138,12 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, co
     T m = fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
     if (width >= 2) m = pair_max<T, 16>(m);
     if (width >= 4) m = pair_max<T, 32>(m);
-    const T ms = (m == -INFINITY) ? T(0) : m;  // all components off: exp(-inf - 0) = 0
+    const T ms = fmax(m, T(-1e300));  // all components off (-inf): exp(-inf + 1e300) = 0, no inf - inf
     T e = t_exp<T>(a[0] - ms, tab) + t_exp<T>(a[1] - ms, tab) + t_exp<T>(a[2] - ms, tab) + t_exp<T>(a[3] - ms, tab);
+    // NaN parameters / features must poison the state (the reference's linear-domain sum does), but
+    // fmax() drops NaNs: the plain sum of the four values is NaN exactly when one of them is
+    const T poison = (a[0] + a[1]) + (a[2] + a[3]);
+    e = (poison != poison) ? poison : e;
     if (width >= 2) e = pair_sum<T, 16>(e);
     if (width >= 4) e = pair_sum<T, 32>(e);
     mx = m;
@@ -170,8 +174,10 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
             for (int h = 0; h < 2; ++h) {
                 const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
                 const T m = fmax(x0, x1);
-                const T ms = (m == -INFINITY) ? T(0) : m;
-                const T e = t_exp<T>(x0 - ms, tab) + t_exp<T>(x1 - ms, tab);
+                const T ms = fmax(m, T(-1e300));
+                T e = t_exp<T>(x0 - ms, tab) + t_exp<T>(x1 - ms, tab);
+                const T poison = x0 + x1;  // NaN iff one of them is (fmax drops NaNs)
+                e = (poison != poison) ? poison : e;
                 *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e, tab);
             }
         } else if (MP <= 16) {
@@ -184,7 +190,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
             T mx, sm;
             tile_lse<T, V>(acc, 4, mx, sm, tab);
             const T m = fmax(run_mx[c], mx);
-            const T ms = (m == -INFINITY) ? T(0) : m;
+            const T ms = fmax(m, T(-1e300));
             run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms, tab) + sm * t_exp<T>(mx - ms, tab);
             run_mx[c] = m;
             const bool last = (t + 1) % tiles_per_state == 0;
