@@ -127,17 +127,8 @@ def emission_matrix(x, states, dense=False):
 _NOPTR = np.iinfo(np.int64).min  # what np.full(.., np.inf, dtype=int) yields (decode.py:95)
 
 
-def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
-    """decode_hmm_states (decode.py:80-146) on an emission matrix.
-
-    Columns outer / rows inner (decode.py:97-98); (0,0) is the only start cell
-    (:99-101); candidates are the finite arcs in ascending origin order
-    (:105-107); an arc touching a non-emitting row reads the SAME column, else
-    column c-1 -- which wraps to the last column at c == 0 (:109-114); first
-    minimum wins (:118); the last of several equal end points wins (:129-134);
-    the returned path excludes the end cell and stops on reaching column 0
-    (:143-145).
-    """
+def decode_fill(E, is_nes, trans):
+    """The forward sweep of decode_hmm_states (decode.py:94-124): cost matrix + back-pointers."""
     R, T = E.shape
     costs = np.full((R, T), np.inf)
     bp = np.full((R, T, 2), _NOPTR, dtype=np.int64)
@@ -160,6 +151,22 @@ def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
                 raise NameError("FUCKED")  # decode.py:120-121 (self-pointing cell)
             bp[r, c] = best_pt
             costs[r, c] = min(costs[r, c], best_v + E[r, c])
+    return costs, bp
+
+
+def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
+    """decode_hmm_states (decode.py:80-146) on an emission matrix.
+
+    Columns outer / rows inner (decode.py:97-98); (0,0) is the only start cell
+    (:99-101); candidates are the finite arcs in ascending origin order
+    (:105-107); an arc touching a non-emitting row reads the SAME column, else
+    column c-1 -- which wraps to the last column at c == 0 (:109-114); first
+    minimum wins (:118); the last of several equal end points wins (:129-134);
+    the returned path excludes the end cell and stops on reaching column 0
+    (:143-145).
+    """
+    R, T = E.shape
+    costs, bp = decode_fill(E, is_nes, trans)
     if end_points is None:
         end_points = [[R - 1, T - 1]]
     best = np.inf

@@ -305,6 +305,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         chunk_s0 += SC;
     };
 
+#ifndef GH_MF_PIPE
+#define GH_MF_PIPE 1
+#endif
+#if GH_MF_PIPE
     mfma_tile(0, p0, p1);
     for (int t = 1; t < n_tiles; ++t) {
         V acc0, acc1;
@@ -322,6 +326,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     }
     tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
     flush();
+#else
+    for (int t = 0; t < n_tiles; ++t) {
+        mfma_tile(t, p0, p1);
+        tile_epilogue<T, V, MP>(p0, p1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
+        if ((t + 1) % chunk_tiles == 0 && t + 1 < n_tiles) flush();
+    }
+    flush();
+#endif
 }
 
 template <typename T>

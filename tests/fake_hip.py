@@ -1,0 +1,217 @@
+# -*- coding: utf-8 -*-
+"""TEST DOUBLE of `sr.recognition._hip` for the GPU-less tier.
+
+Implements the binding's surface (Context, PackedGMM, Batch, Lattices, distance_matrix) on top
+of the CPU oracle so that the HOST LOGIC of the mirror package (object packing, lattice building,
+segment bookkeeping, training loops, error mapping) can run under `pytest -m "not gpu"`.  It lives
+in tests/ and is installed only by a test fixture (monkeypatching `_hip`'s attributes); the product
+never imports it, and the GPU tier runs the same API tests against the real library.
+"""
+import warnings
+
+import numpy as np
+
+from oracle import ref_numpy as O
+
+
+class Context:
+    def __init__(self, device=0):
+        self.device = device
+        self.h = object()
+
+    def sync(self):
+        pass
+
+    def close(self):
+        self.h = None
+
+
+_ctx = Context()
+
+
+def default_context(device=None):
+    return _ctx
+
+
+class PackedGMM:
+    def __init__(self, ctx, mean, var, weight):
+        self.mean, self.var, self.w = (np.array(a, dtype=np.float64) for a in (mean, var, weight))
+        self.S, self.M, self.D = self.mean.shape
+        if np.any(self.var == 0):
+            raise np.linalg.LinAlgError("Singular matrix")
+
+    def component_loglik(self, state, x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.log(np.array([O.gmm_evaluate(f, self.mean[state], self.var[state], self.w[state], neg_log=False)
+                                    for f in x]))
+
+    def close(self):
+        pass
+
+
+class Batch:
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None):
+        self.ctx = ctx
+        if utterances is not None:
+            lens = [len(u) for u in utterances]
+            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            D = np.asarray(utterances[0]).shape[1] if lens else 1
+            feats = np.concatenate([np.asarray(u, dtype=np.float64).reshape(-1, D) for u in utterances]) if lens \
+                else np.zeros((0, D))
+        self.feats = np.asarray(feats, dtype=np.float64)
+        self.offsets = np.asarray(offsets, dtype=np.int64)
+        self.N, self.D = self.feats.shape
+        self.U = len(self.offsets) - 1
+        self.S = None
+        self.nll = None
+        self.occ = None
+
+    @property
+    def lengths(self):
+        return np.diff(self.offsets)
+
+    def utt(self, u):
+        return self.feats[self.offsets[u]:self.offsets[u + 1]]
+
+    def loglik(self, gmm, fetch=True):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self.nll = np.array([[O.gmm_evaluate(x, gmm.mean[s], gmm.var[s], gmm.w[s]) for s in range(gmm.S)]
+                                 for x in self.feats]).reshape(self.N, gmm.S)
+        self.S = gmm.S
+        return self.nll.copy() if fetch else None
+
+    def dtw(self, trans, y=None, var=None, beam=0, dist=None, want_costs=True):
+        costs, paths = [], []
+        for u in range(self.U):
+            if dist is not None:
+                E = np.asarray(dist[u], dtype=np.float64)
+            else:
+                E = O.distance_matrix(self.utt(u), y, "euclid" if var is None else "mahalanobis", var)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                c, p = O.dtw(E, np.asarray(trans), beam=np.inf if beam <= 0 else beam)
+            costs.append(c)
+            paths.append(p.reshape(-1, 2).astype(np.int64))
+        return (costs if want_costs else None), paths
+
+    def kmeans_assign(self, centroids, var=None, first=0, count=None):
+        x = self.feats[first:first + (self.N - first if count is None else count)]
+        d = np.array([[O.euclid(c, f) if var is None else O.mahalanobis(c, f, var) for c in centroids] for f in x])
+        return np.argmin(d, axis=1).astype(np.int64)
+
+    def em_accumulate(self, mean, var, weight, first=0, count=None):
+        x = self.feats[first:first + (self.N - first if count is None else count)]
+        mean, var, weight = (np.asarray(a, dtype=np.float64) for a in (mean, var, weight))
+        if np.any(var == 0):
+            raise np.linalg.LinAlgError("Singular matrix")
+        k, D = mean.shape
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p = np.array([O.gmm_evaluate(f, mean, var, weight, neg_log=False) for f in x]).reshape(len(x), k)
+            rs = p.sum(axis=1, keepdims=True)
+            r = np.where(rs == 0, 0.0, p / np.where(rs == 0, 1.0, rs))
+            stats = np.zeros((k, 1 + 2 * D))
+            for c in range(k):
+                d = x - mean[c]
+                stats[c, 0] = r[:, c].sum()
+                stats[c, 1:1 + D] = (r[:, [c]] * d).sum(axis=0)
+                stats[c, 1 + D:] = (r[:, [c]] * d * d).sum(axis=0)
+            ll = float(np.log(rs[rs > 0]).sum())
+        return stats, ll
+
+    def close(self):
+        pass
+
+
+class Lattices:
+    def __init__(self, ctx, graphs):
+        self.ctx = ctx
+        self.graphs = graphs
+        self.L = len(graphs)
+        self.R = [len(g["row_state"]) for g in graphs]
+        self.n_end = [len(g["end_rows"]) for g in graphs]
+
+    def _dense(self, g):
+        R = len(g["row_state"])
+        t = np.full((R, R), np.inf)
+        t[np.asarray(g["arc_to"], dtype=int), np.asarray(g["arc_from"], dtype=int)] = g["arc_cost"]
+        return t
+
+    def _emissions(self, batch, u, g):
+        rs = np.asarray(g["row_state"], dtype=int)
+        nll = batch.nll[batch.offsets[u]:batch.offsets[u + 1]]
+        return np.where(rs[:, None] >= 0, nll[:, np.maximum(rs, 0)].T, 0.0), rs < 0
+
+    def path_cap(self, l, T):
+        return 3 * T
+
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False):
+        """Each start row is decoded as its own reference problem (the reference has ONE start cell,
+        row 0; a stacked graph is W independent chains), then merged."""
+        U = batch.U
+        lidx = np.zeros(U, dtype=int) if utt_lattice is None else np.asarray(utt_lattice, dtype=int)
+        out = dict(best_end=np.zeros(U, dtype=np.int32), end_cost=[], paths=[], costs=[])
+        for u in range(U):
+            g = self.graphs[lidx[u]]
+            E, nes = self._emissions(batch, u, g)
+            trans = self._dense(g)
+            R, T = E.shape
+            starts = [int(s) for s in g["start_rows"]]
+            ends = [int(e) for e in g["end_rows"]]
+            if T == 0:
+                out["best_end"][u] = -1
+                out["end_cost"].append(np.full(len(ends), np.inf))
+                out["paths"].append(np.zeros((0, 2), dtype=np.int64))
+                out["costs"].append(np.zeros((R, 0)))
+                continue
+            # the reference has ONE start cell, row 0; a graph with several start rows is that many
+            # independent sub-graphs [start, next start): fill each with the reference sweep
+            costs = np.full((R, T), np.inf)
+            bp = np.full((R, T, 2), O._NOPTR, dtype=np.int64)
+            ss = sorted(starts)
+            for k, s0 in enumerate(ss):
+                s1 = ss[k + 1] if k + 1 < len(ss) else R
+                lo = 0 if k == 0 else s0
+                sl = slice(lo, s1)
+                cs, bps = O.decode_fill(E[sl], nes[sl], trans[sl, sl])
+                costs[sl] = cs
+                bps = bps.copy()
+                bps[:, :, 0] = np.where(bps[:, :, 0] == O._NOPTR, O._NOPTR, bps[:, :, 0] + lo)
+                bp[sl] = bps
+            ec = np.array([costs[e, T - 1] for e in ends])
+            best, bi = np.inf, -1
+            for k, cst in enumerate(ec):
+                if best >= cst:
+                    best, bi = cst, k
+            out["best_end"][u] = bi
+            out["end_cost"].append(ec)
+            out["costs"].append(costs)
+            path = []
+            if want_path and T > 1 and bi >= 0:
+                i, j = ends[bi], T - 1
+                while j != 0:
+                    i, j = bp[i, j]
+                    path.append([i, j])
+                    if len(path) > R * T:
+                        raise RuntimeError("back-trace does not terminate")
+            out["paths"].append(np.array(path, dtype=np.int64).reshape(-1, 2))
+        out["end_cost_flat"] = np.concatenate(out["end_cost"]) if out["end_cost"] else np.zeros(0)
+        return out
+
+    def close(self):
+        pass
+
+
+def distance_matrix(ctx, x, y, var=None):
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    v = None if var is None else np.asarray(var, dtype=np.float64).reshape(-1, y.shape[1])
+    out = np.empty((len(y), len(x)))
+    for i in range(len(y)):
+        for n in range(len(x)):
+            out[i, n] = O.euclid(x[n], y[i]) if v is None else O.mahalanobis(x[n], y[i], v[0] if len(v) == 1 else v[i])
+    return out
+
+
+def install(monkeypatch, hip_module):
+    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context"):
+        monkeypatch.setattr(hip_module, name, globals()[name])
