@@ -161,26 +161,34 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=20)
+    ap.add_argument("--cpu-utts", type=int, default=80)
+    # rehearsal of the N > 1 path on a box with fewer GPUs: --backend gloo --device 0 lets every rank share GPU 0
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    dev = local_rank if args.device is None else args.device
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
     try:
         import torch
         have_torch_cuda = torch.cuda.is_available()
     except Exception:
         torch, have_torch_cuda = None, False
+    red_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
 
     from sr.recognition import _hip
-    ctx = _hip.Context(local_rank)
+    ctx = _hip.Context(dev)
     npdt = np.float64 if args.dtype == "f64" else np.float32
     wl = synth_workload(1002, args.utts, utt_seed=None if rank == 0 else 1002 + 7919 * rank)
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
@@ -225,9 +233,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = torch.tensor([float(N_frames), float(U)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(N_frames), float(U)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot)
         dt = float(tmax.item())
         all_frames, all_utts = float(tot[0].item()), float(tot[1].item())
