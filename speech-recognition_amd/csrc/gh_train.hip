@@ -161,8 +161,13 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                                                        const double* __restrict__ logc, const double* __restrict__ occ,
                                                        double occ_floor, int F, double* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* xt = sm;          // [F,D]
-    double* rt = sm + F * D;  // [M,F]
+    double* xt = sm;                 // [F,D]   frames of the tile
+    double* rt = xt + F * D;         // [M,F]   weighted responsibilities of the current state
+    double* pm = rt + M * F;         // [M,D]   mean        } of the current state,
+    double* pv = pm + M * D;         // [M,D]   1/variance  } staged once per (tile, state)
+    double* pc = pv + M * D;         // [M]     log-constant
+    int* s_list = reinterpret_cast<int*>(pc + M);  // [S] active states of the tile, compacted
+    __shared__ int s_count;
     const int tid = threadIdx.x;
     const int W = 1 + 2 * D;
     double* slab = slabs + (int64_t)blockIdx.x * S * M * W;
@@ -172,19 +177,36 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
         const int nf = (int)((N - n0 < F) ? (N - n0) : F);
         __syncthreads();
         for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
-        for (int s = 0; s < S; ++s) {
-            double wgt = 0.0;
-            int active = 0;
-            if (tid < nf) {
-                wgt = occ[(n0 + tid) * S + s];
-                active = (wgt > occ_floor || wgt != wgt);
+        // which states have any occupancy on this tile?  lane = state: coalesced sweeps down the
+        // [F,S] block of the occupancy matrix, ONE barrier instead of a vote per state
+        for (int s = tid; s < S; s += 256) {
+            bool any = false;
+            for (int f = 0; f < nf; ++f) {
+                const double w = occ[(n0 + f) * S + s];
+                any |= (w > occ_floor) || (w != w);
             }
-            if (!__syncthreads_or(active)) continue;  // block-uniform vote (also orders xt / rt reuse)
-            const double* pm = mean + (int64_t)s * M * D;
-            const double* pv = ivar + (int64_t)s * M * D;
-            const double* pc = logc + (int64_t)s * M;
+            s_list[s] = any ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int c = 0;
+            for (int s = 0; s < S; ++s)
+                if (s_list[s]) s_list[c++] = s;
+            s_count = c;
+        }
+        __syncthreads();
+        const int count = s_count;
+        for (int k = 0; k < count; ++k) {
+            const int s = s_list[k];
+            for (int i = tid; i < M * D; i += 256) {
+                pm[i] = mean[(int64_t)s * M * D + i];
+                pv[i] = ivar[(int64_t)s * M * D + i];
+            }
+            if (tid < M) pc[tid] = logc[(int64_t)s * M + tid];
+            __syncthreads();
             if (tid < F) {
                 const int f = tid;
+                const double wgt = (f < nf) ? occ[(n0 + f) * S + s] : 0.0;
                 if (f < nf && (wgt > occ_floor || wgt != wgt)) {
                     const double* x = xt + f * D;
                     double mx = -INFINITY;
@@ -230,6 +252,7 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                 if (d == D) o[0] += a1;
                 else { o[1 + d] += a1; o[1 + D + d] += a2; }
             }
+            __syncthreads();  // rt / pm are rewritten by the next state
         }
     }
 }
@@ -358,7 +381,7 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     const int64_t len = (int64_t)S * M * W;
     hipStream_t st = ctx->stream;
     int F = 128;
-    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f) * 8; };
+    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f + 2 * (size_t)M * D + M) * 8 + (size_t)S * 4 + 16; };
     while (F > 32 && lds_need(F) > 64 * 1024) F >>= 1;
     GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_bw_accumulate: D=%d M=%d does not fit LDS", D, M);
     const int64_t ntiles = b->N > 0 ? (b->N + F - 1) / F : 0;

@@ -364,8 +364,10 @@ class Lattices:
                             for u in range(U)]
         return out
 
-    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False):
-        """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]]."""
+    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True):
+        """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].
+        want_occ keeps the frame x state occupancies resident in the batch (input of bw_accumulate);
+        fetch_occ=False skips the [N,S] device-to-host copy."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
         lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
@@ -376,7 +378,7 @@ class Lattices:
             Rs = np.asarray(self.R, dtype=np.int64)[lidx]
             off = np.concatenate([[0], np.cumsum(Rs * T)]).astype(np.int64)
             al, be, ga = (np.empty(int(off[-1])) for _ in range(3))
-        if want_occ:
+        if want_occ and fetch_occ:
             occ = np.empty((batch.N, batch.S))
         _check(lib, lib.gh_forward_backward(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), int(want_occ),
                                             _ptr(logp, _c_f64p), _ptr(al, _c_f64p), _ptr(be, _c_f64p),
@@ -385,7 +387,7 @@ class Lattices:
         if want_matrices:
             cut = lambda m: [m[off[u]:off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u])) for u in range(U)]
             out.update(alpha=cut(al), beta=cut(be), gamma=cut(ga))
-        if want_occ:
+        if occ is not None:
             out["occ"] = occ
         return out
 

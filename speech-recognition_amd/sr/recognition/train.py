@@ -60,7 +60,7 @@ class BaumWelchTrainer:
             if self.batch.U == 0:
                 return np.zeros((self.S, self.M, 1 + 2 * self.D)), np.zeros(self.S), 0.0
             self.batch.loglik(gmm, fetch=False)
-            r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True)
+            r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False)
             stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor)
             counts = stats[:, :, 0].sum(axis=1)  # sum_n occ[n,s]: responsibilities of a state add up to its occupancy
             logp = r["logp"]

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time one soft-EM iteration (configs[2] shape: C2 model, isolated words, per-rank shard) on one GPU."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+import bench
+from sr.recognition.train import BaumWelchTrainer
+from sr.recognition import _hip
+
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
+wl = bench.synth_workload(1003, U)
+W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+labels = [[int(w)] for w in wl["words"]]
+rng = np.random.default_rng(0)
+means0 = wl["means"] + 0.3 * rng.normal(size=wl["means"].shape)   # perturbed start
+t0 = time.perf_counter()
+tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, var_floor=1e-3)
+print("setup s", time.perf_counter() - t0, flush=True)
+ctx = tr.ctx
+hist = []
+for it in range(4):
+    t0 = time.perf_counter()
+    ll = tr.iteration()
+    dt = time.perf_counter() - t0
+    hist.append(ll)
+    print("iteration %d: %.1f ms  loglik %.6e" % (it, dt * 1e3, ll), flush=True)
+# split of the E-step
+gmm = _hip.PackedGMM(ctx, tr.means, tr.vars, tr.weights)
+def t(fn, reps=3):
+    fn(); ctx.sync(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    ctx.sync(); return (time.perf_counter() - t0) / reps * 1e3
+print(json.dumps(dict(utts=U, frames=int(tr.batch.N),
+                      loglik_ms=t(lambda: tr.batch.loglik(gmm, fetch=False)),
+                      fwdbwd_ms=t(lambda: tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True, fetch_occ=False)),
+                      bw_stats_ms=t(lambda: tr.batch.bw_accumulate(gmm)),
+                      monotone=bool(all(b >= a - 1e-7 * abs(a) for a, b in zip(hist, hist[1:]))))))
