@@ -1,0 +1,106 @@
+// C ABI: error reporting, per-GPU context, scratch / pinned arenas.
+#include "gh_internal.h"
+#include "gh_host.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+void gh_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* gh_last_error(void) { return g_err.c_str(); }
+extern "C" int gh_version(void) { return 1; }
+
+// ------------------------------------------------------------------ context
+extern "C" int gh_ctx_create(int device, gh_ctx** out) {
+    GH_REQUIRE(out, "gh_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        gh_set_error("gh_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+        return GH_ERR_NODEVICE;
+    }
+    GH_REQUIRE(device >= 0 && device < n, "gh_ctx_create: device %d out of range [0,%d)", device, n);
+    GH_HIP(hipSetDevice(device));
+    gh_ctx* c = new gh_ctx();
+    c->device = device;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
+    hipDeviceProp_t prop;
+    GH_HIP(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    GH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    GH_HIP(hipMalloc((void**)&c->d_flag, sizeof(int)));
+    GH_HIP(hipMemset(c->d_flag, 0, sizeof(int)));
+    {   // tables of the fp64 exp/log used by the likelihood epilogue, computed in long double
+        double t[384];
+        for (int j = 0; j < 128; ++j) {
+            t[j] = (double)exp2l((long double)j / 128.0L);
+            const double inv = (double)(1.0L / (0.5L + ((long double)j + 0.5L) / 256.0L));
+            t[128 + j] = inv;
+            t[256 + j] = (double)(-logl((long double)inv));
+        }
+        GH_HIP(hipMalloc((void**)&c->d_fp64_tables, sizeof t));
+        GH_HIP(hipMemcpy(c->d_fp64_tables, t, sizeof t, hipMemcpyHostToDevice));
+    }
+    *out = c;
+    return GH_OK;
+}
+
+extern "C" void gh_ctx_destroy(gh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->pinned) hipHostFree(c->pinned);
+    hipFree(c->d_flag);
+    hipFree(c->d_fp64_tables);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int gh_ctx_sync(gh_ctx* c) {
+    GH_REQUIRE(c, "gh_ctx_sync: ctx is NULL");
+    GH_HIP(hipStreamSynchronize(c->stream));
+    return GH_OK;
+}
+
+extern "C" void* gh_ctx_stream(gh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->scratch_bytes) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) GH_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 8 + (1u << 20);
+        GH_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return GH_OK;
+}
+
+int gh_pinned(gh_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->pinned_bytes) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) GH_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        GH_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return GH_OK;
+}
+

@@ -1,0 +1,364 @@
+// C ABI: launch orchestration of the dynamic programs (gh_viterbi, gh_dtw, gh_forward_backward).
+#include "gh_internal.h"
+#include "gh_host.h"
+#include "gh_viterbi.h"
+#include "gh_dtw.h"
+#include "gh_fb.h"
+
+// ------------------------------------------------------------------ viterbi
+extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                          double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
+                          const int64_t* path_off, int32_t* out_path_len, double* out_costs,
+                          const int64_t* costs_off) {
+    GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
+    GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
+    GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
+    GH_REQUIRE(!out_costs || costs_off, "gh_viterbi: out_costs needs costs_off");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U;
+    if (U == 0) return GH_OK;
+    const int S = b->nll_S;
+    const bool want_path = out_path != nullptr;
+    for (int l = 0; l < lat->L; ++l)
+        GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
+                   lat->lat[l].max_state, S);
+    // per-utterance bookkeeping (host); with one graph for all utterances everything is implicit
+    const bool uniform = utt_lattice == nullptr;
+    const std::vector<int64_t>& perm = b->perm;
+    std::vector<int64_t> end_off;
+    int64_t n_end_total = 0;
+    if (uniform) {
+        n_end_total = U * lat->lat[0].n_end;
+    } else {
+        end_off.assign(U + 1, 0);
+        for (int64_t u = 0; u < U; ++u) {
+            const int l = utt_lattice[u];
+            GH_REQUIRE(l >= 0 && l < lat->L, "gh_viterbi: utt_lattice[%lld]=%d out of range", (long long)u, l);
+            end_off[u + 1] = end_off[u] + lat->lat[l].n_end;
+        }
+        n_end_total = end_off[U];
+    }
+    if (want_path)
+        for (int64_t u = 0; u < U; ++u) {
+            const int l = uniform ? 0 : utt_lattice[u];
+            const int64_t T = b->offsets[u + 1] - b->offsets[u];
+            GH_REQUIRE(path_off[u + 1] - path_off[u] >= (T > 1 ? T * lat->lat[l].nlev : 0),
+                       "gh_viterbi: path capacity of utterance %lld too small", (long long)u);
+        }
+    // back-pointer scratch is chunked (<= 4 GiB per launch)
+    const size_t BP_BUDGET = (size_t)4 << 30;
+    std::vector<int64_t> bp_off(U, 0);
+    std::vector<int64_t> chunk_begin{0};
+    size_t bp_max = 0;
+    // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
+    // the reference's wrap-around semantics, which only the lean / generic kernels implement)
+    bool use_chain = lat->chain_ok && uniform;
+    {
+        static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        if (no_chain) use_chain = false;
+        for (int64_t u = 0; use_chain && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
+    }
+    const bool want_bp = want_path || (use_chain && out_costs);
+    if (want_bp) {
+        size_t acc = 0;
+        for (int64_t k = 0; k < U; ++k) {
+            const int64_t u = perm[k];
+            const int l = utt_lattice ? utt_lattice[u] : 0;
+            const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+            if (acc && (acc + need) * 2 > BP_BUDGET) {
+                chunk_begin.push_back(k);
+                bp_max = std::max(bp_max, acc);
+                acc = 0;
+            }
+            bp_off[k] = (int64_t)acc;
+            acc += need;
+        }
+        bp_max = std::max(bp_max, acc);
+    }
+    chunk_begin.push_back(U);
+    const int64_t n_path = want_path ? path_off[U] : 0;
+    const int64_t n_costs = out_costs ? costs_off[U] : 0;
+
+    gh_vit_args a;
+    memset(&a, 0, sizeof a);
+    int64_t *d_bpoff = nullptr, *d_endoff = nullptr, *d_pathoff = nullptr, *d_costsoff = nullptr;
+    int32_t *d_uttlat = nullptr, *d_bestend, *d_path = nullptr, *d_pathlen = nullptr;
+    double *d_endcost, *d_costs = nullptr;
+    uint16_t* d_bp = nullptr;
+    Carver cv;
+    int* d_flag2;  // [flag | best_end | end_cost] are carved back to back: ONE D2H copy into pinned memory
+    cv.add(&d_flag2, 64); cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
+    const size_t small_bytes = cv.total;
+    if (want_bp) cv.add(&d_bpoff, U);
+    if (!uniform) cv.add(&d_endoff, U + 1);
+    if (utt_lattice) cv.add(&d_uttlat, U);
+    if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
+    if (want_bp) cv.add(&d_bp, bp_max);
+    if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemsetAsync(d_flag2, 0, sizeof(int), st));
+    if (want_bp) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
+    if (!uniform) GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
+    if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (out_costs) GH_HIP(hipMemcpyAsync(d_costsoff, costs_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+
+    a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_start = lat->d_row_start;
+    a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
+    a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
+    a.level_narrow = lat->d_level_narrow;
+    a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
+    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
+    a.bp = d_bp; a.bp_off = d_bpoff; a.end_cost = d_endcost; a.end_off = d_endoff; a.best_end = d_bestend;
+    a.path = d_path; a.path_off = d_pathoff; a.path_len = d_pathlen; a.costs = d_costs; a.costs_off = d_costsoff;
+    a.flag = d_flag2;
+
+    if (use_chain) {
+        gh_chain_args c;
+        memset(&c, 0, sizeof c);
+        c.cost0 = lat->d_ch_cost0; c.cost1 = lat->d_ch_cost1; c.cost2 = lat->d_ch_cost2; c.row_info = lat->d_ch_info;
+        c.row_state = lat->d_row_state; c.end_slot = lat->d_ch_end_slot; c.end_rows = lat->d_end_rows;
+        c.group_row0 = lat->d_ch_group_row0; c.n_groups = lat->chain_groups; c.R = lat->lat[0].R; c.S = S;
+        c.n_end = lat->lat[0].n_end; c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm;
+        c.bp = reinterpret_cast<uint8_t*>(d_bp); c.bp_off = d_bpoff; c.end_cost = d_endcost; c.best_end = d_bestend;
+        c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen; c.costs = d_costs; c.costs_off = d_costsoff;
+        c.flag = d_flag2;
+        for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
+            const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
+            rc = gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
+            if (!rc) rc = gh_launch_chain_backtrace(ctx, c, u0, nu);  // end selection (+ path when requested)
+            if (rc) return rc;
+        }
+    }
+    int max_level_rows = 1;
+    for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
+    int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
+    // lean kernel: <= 3 levels (the same number in every graph), one row per lane per level, arc lists
+    // that fit LDS, no NaN arc cost, no same-column self arc (GMMHMM_VITERBI=generic forces the generic one)
+    int lean_levels = 0, max_arcs = 0;
+    for (auto& lh : lat->lat) max_arcs = std::max(max_arcs, lh.A);
+    {
+        static const bool no_lean = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && !strcmp(e, "generic"); }();
+        int lean_lanes = 1;
+        for (auto& d : lat->h_desc) lean_lanes = std::max(lean_lanes, d.lean_lanes);
+        const int lb = std::max(64, (lean_lanes + 63) & ~63);
+        bool same_nlev = true;
+        for (auto& d : lat->h_desc) same_nlev = same_nlev && d.nlev == lat->max_nlev;
+        if (!no_lean && !(out_costs && !want_path) && !lat->has_nan_arc && !lat->has_self_arc && same_nlev && lat->max_nlev <= 3 && lb <= 1024 &&
+            S <= 8 * lb && max_arcs <= 4096) {
+            lean_levels = lat->max_nlev;
+            block = lb;
+        }
+    }
+    size_t lds;
+    if (lean_levels) {
+        a.em_chunk = std::max(1, std::min(8, 8 * block / std::max(S, 1)));
+        if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
+        a.arc_cap = (max_arcs + 1) & ~1;
+        lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+    } else {
+        a.em_chunk = 1;
+        lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
+    }
+    if (lds > 160 * 1024) {
+        gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
+        return GH_ERR_UNSUPPORTED;
+    }
+    for (size_t c = 0; !use_chain && c + 1 < chunk_begin.size(); ++c) {
+        a.u_begin = chunk_begin[c];
+        const int64_t nu = chunk_begin[c + 1] - chunk_begin[c];
+        rc = lean_levels ? gh_launch_viterbi_lean(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path, lean_levels)
+                         : gh_launch_viterbi(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path);
+        if (rc) return rc;
+    }
+    char* pin;
+    rc = gh_pinned(ctx, small_bytes, (void**)&pin);
+    if (rc) return rc;
+    GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
+    if (want_path) {
+        GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
+        GH_HIP(hipMemcpyAsync(out_path_len, d_pathlen, U * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, n_costs * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    const int flag = *reinterpret_cast<int*>(pin);
+    if (out_best_end) memcpy(out_best_end, pin + ((char*)d_bestend - (char*)d_flag2), U * 4);
+    if (out_end_cost) memcpy(out_end_cost, pin + ((char*)d_endcost - (char*)d_flag2), n_end_total * 8);
+    if (flag & 1) {
+        gh_set_error("gh_viterbi: a DP cell chose itself as its origin (decode.py:120-121)");
+        return GH_ERR_SELF_POINTER;
+    }
+    if (flag & 4) {
+        gh_set_error("gh_viterbi: back-trace does not terminate (cycle of same-column arcs between unreachable cells)");
+        return GH_ERR_INVALID;
+    }
+    if (flag & 2) {
+        gh_set_error("gh_viterbi: back-trace reached a cell without predecessor");
+        return GH_ERR_INVALID;
+    }
+    return GH_OK;
+}
+
+// ---------------------------------------------------------------------- dtw
+extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, const double* var,
+                      const double* trans, int beam, const double* dist_host, double* out_costs,
+                      int32_t* out_path, int32_t* out_path_len) {
+    GH_REQUIRE(ctx && b && trans, "gh_dtw: NULL argument");
+    GH_REQUIRE(dist_host || y, "gh_dtw: need template rows or a distance matrix");
+    GH_REQUIRE(n > 1 && n <= 64, "gh_dtw: n=%d (2..64 supported; decode.py:22 asserts n > 1)", n);
+    GH_REQUIRE(b->dtype == GH_F64 || dist_host, "gh_dtw: built-in distances need an fp64 batch");
+    GH_REQUIRE(!out_path || out_path_len, "gh_dtw: out_path needs out_path_len");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U, N = b->N;
+    const int D = b->D;
+    if (U == 0) return GH_OK;
+    for (int64_t u = 0; u < U; ++u)
+        GH_REQUIRE(b->offsets[u + 1] - b->offsets[u] > 1, "gh_dtw: utterance %lld has fewer than 2 frames (decode.py:22)",
+                   (long long)u);
+    std::vector<double> logdet(n, 0.0);
+    if (var && !dist_host)
+        for (int i = 0; i < n; ++i) {
+            double prod = 1.0;
+            for (int d = 0; d < D; ++d) prod *= var[(size_t)i * D + d];
+            logdet[i] = 0.5 * std::log(std::pow(2.0 * M_PI, D) * prod);  // hmm_state.py:58
+        }
+    std::vector<int64_t> moff(U + 1);  // n * frame offset: [n,T] blocks
+    for (int64_t u = 0; u <= U; ++u) moff[u] = (int64_t)n * b->offsets[u];
+    double *d_y = nullptr, *d_var = nullptr, *d_ld = nullptr, *d_tr, *d_E = nullptr, *d_costs = nullptr;
+    int64_t* d_moff;
+    uint8_t* d_bp;
+    int32_t *d_path = nullptr, *d_plen = nullptr;
+    Carver cv;
+    cv.add(&d_tr, (size_t)n * n); cv.add(&d_moff, U + 1); cv.add(&d_bp, (size_t)n * N);
+    if (!dist_host) { cv.add(&d_y, (size_t)n * D); if (var) { cv.add(&d_var, (size_t)n * D); cv.add(&d_ld, n); } }
+    if (dist_host) cv.add(&d_E, (size_t)n * N);
+    if (out_costs) cv.add(&d_costs, (size_t)n * N);
+    if (out_path) { cv.add(&d_path, 2 * (size_t)N); cv.add(&d_plen, U); }
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+    GH_HIP(hipMemcpyAsync(d_tr, trans, (size_t)n * n * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_moff, moff.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (d_y) GH_HIP(hipMemcpyAsync(d_y, y, (size_t)n * D * 8, hipMemcpyHostToDevice, st));
+    if (d_var) {
+        GH_HIP(hipMemcpyAsync(d_var, var, (size_t)n * D * 8, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemcpyAsync(d_ld, logdet.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+    if (d_E) GH_HIP(hipMemcpyAsync(d_E, dist_host, (size_t)n * N * 8, hipMemcpyHostToDevice, st));
+    gh_dtw_args a;
+    memset(&a, 0, sizeof a);
+    a.x = dist_host ? nullptr : (const double*)b->feats;
+    a.E = d_E; a.e_off = d_moff; a.utt_off = b->d_offsets; a.n = n; a.D = D; a.beam = beam;
+    a.y = d_y; a.var = d_var; a.logdet = d_ld; a.trans = d_tr; a.bp = d_bp; a.bp_off = d_moff;
+    a.costs = d_costs; a.costs_off = d_moff; a.path = d_path; a.path_off = b->d_offsets; a.path_len = d_plen;
+    a.flag = ctx->d_flag;
+    rc = gh_launch_dtw(ctx, a, U);
+    if (rc) return rc;
+    int flag = 0;
+    GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, (size_t)n * N * 8, hipMemcpyDeviceToHost, st));
+    if (out_path) {
+        GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        GH_HIP(hipMemcpyAsync(out_path_len, d_plen, U * 4, hipMemcpyDeviceToHost, st));
+    }
+    GH_HIP(hipStreamSynchronize(st));
+    if (flag & 8) {
+        gh_set_error("gh_dtw: the beam pruned every origin of a column (np.argmin of an empty list)");
+        return GH_ERR_INVALID;
+    }
+    if (flag & 2) {
+        gh_set_error("gh_dtw: back-trace left the matrix: cell (0,0) is not reachable from the end cell");
+        return GH_ERR_INVALID;
+    }
+    return GH_OK;
+}
+
+// --------------------------------------------------------- forward-backward
+extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b, const int32_t* utt_lattice,
+                                   int want_occ, double* out_logp, double* out_alpha, double* out_beta,
+                                   double* out_gamma, const int64_t* mat_off, double* out_occ) {
+    GH_REQUIRE(ctx && lat && b, "gh_forward_backward: NULL argument");
+    GH_REQUIRE(b->nll || b->N == 0, "gh_forward_backward: gh_loglik has not been run on this batch");
+    GH_REQUIRE(!(out_alpha || out_beta || out_gamma) || mat_off, "gh_forward_backward: matrices need mat_off");
+    GH_REQUIRE(!out_occ || want_occ, "gh_forward_backward: out_occ needs want_occ");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t U = b->U;
+    if (U == 0) return GH_OK;
+    const int S = b->nll_S;
+    for (int l = 0; l < lat->L; ++l)
+        GH_REQUIRE(lat->lat[l].max_state < S, "gh_forward_backward: graph %d uses state %d but the model has %d", l,
+                   lat->lat[l].max_state, S);
+    if (utt_lattice)
+        for (int64_t u = 0; u < U; ++u)
+            GH_REQUIRE(utt_lattice[u] >= 0 && utt_lattice[u] < lat->L, "gh_forward_backward: utt_lattice[%lld] out of range",
+                       (long long)u);
+    if (want_occ && !b->occ && b->N > 0) GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
+    // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
+    const size_t BUDGET = (size_t)4 << 30;
+    std::vector<int64_t> soff(U, 0), chunk_begin{0};
+    size_t acc = 0, smax = 0;
+    for (int64_t k = 0; k < U; ++k) {
+        const int64_t u = b->perm[k];
+        const int l = utt_lattice ? utt_lattice[u] : 0;
+        const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+        if (acc && (acc + need) * 8 > BUDGET) { chunk_begin.push_back(k); smax = std::max(smax, acc); acc = 0; }
+        soff[k] = (int64_t)acc;
+        acc += need;
+    }
+    smax = std::max(smax, acc);
+    chunk_begin.push_back(U);
+    const bool mats = out_alpha || out_beta || out_gamma;
+    const int64_t n_mat = mats ? mat_off[U] : 0;
+    int64_t *d_soff, *d_matoff = nullptr;
+    int32_t* d_uttlat = nullptr;
+    double *d_scratch, *d_logp, *d_alpha = nullptr, *d_beta = nullptr, *d_gamma = nullptr;
+    Carver cv;
+    cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
+    if (utt_lattice) cv.add(&d_uttlat, U);
+    if (mats) cv.add(&d_matoff, U + 1);
+    if (out_alpha) cv.add(&d_alpha, n_mat);
+    if (out_beta) cv.add(&d_beta, n_mat);
+    if (out_gamma) cv.add(&d_gamma, n_mat);
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemcpyAsync(d_soff, soff.data(), U * 8, hipMemcpyHostToDevice, st));
+    if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
+    if (mats) GH_HIP(hipMemcpyAsync(d_matoff, mat_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    gh_fb_args a;
+    memset(&a, 0, sizeof a);
+    a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_flag = lat->d_row_start;
+    a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
+    a.succ_ptr = lat->d_succ_ptr; a.succ_row = lat->d_succ_row; a.succ_cost = lat->d_succ_cost;
+    a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
+    a.nll = b->nll; a.S = S; a.r_pad = (lat->max_R + 1) & ~1;
+    a.utt_off = b->d_offsets; a.utt_lat = d_uttlat; a.perm = b->d_perm;
+    a.alpha_scratch = d_scratch; a.scratch_off = d_soff; a.logp = d_logp;
+    a.out_alpha = d_alpha; a.out_beta = d_beta; a.out_gamma = d_gamma; a.mat_off = d_matoff;
+    a.occ = want_occ ? b->occ : nullptr;
+    int max_level_rows = 1;
+    for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
+    const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
+    const size_t lds = ((size_t)2 * a.r_pad + 3 * (size_t)S) * sizeof(double);
+    if (lds > 150 * 1024) {
+        gh_set_error("gh_forward_backward: %d rows + %d states need %zu B of LDS", lat->max_R, S, lds);
+        return GH_ERR_UNSUPPORTED;
+    }
+    for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
+        a.u_begin = chunk_begin[c];
+        rc = gh_launch_fb(ctx, a, chunk_begin[c + 1] - chunk_begin[c], block, lds, b->dtype == GH_F64);
+        if (rc) return rc;
+    }
+    if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_logp, U * 8, hipMemcpyDeviceToHost, st));
+    if (out_alpha) GH_HIP(hipMemcpyAsync(out_alpha, d_alpha, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_beta) GH_HIP(hipMemcpyAsync(out_beta, d_beta, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_gamma) GH_HIP(hipMemcpyAsync(out_gamma, d_gamma, n_mat * 8, hipMemcpyDeviceToHost, st));
+    if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}
+

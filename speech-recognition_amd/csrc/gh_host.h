@@ -1,0 +1,37 @@
+// Host-side helpers shared by the C-ABI translation units (not used in device code).
+#pragma once
+#include "gh_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <utility>
+#include <vector>
+
+
+// carve 256-byte aligned pieces out of the context scratch
+struct Carver {
+    size_t total = 0;
+    std::vector<std::pair<void**, size_t>> items;  // (destination pointer, offset)
+    template <typename T> void add(T** dst, size_t count) {
+        items.push_back({reinterpret_cast<void**>(dst), total});
+        total += (count * sizeof(T) + 255) & ~size_t(255);
+    }
+    int commit(gh_ctx* ctx) {
+        void* base = nullptr;
+        int rc = gh_scratch(ctx, total ? total : 256, &base);
+        if (rc) return rc;
+        for (auto& it : items) *it.first = static_cast<char*>(base) + it.second;
+        return GH_OK;
+    }
+};
+
+template <typename T> inline int upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    if (src.empty()) return GH_OK;
+    GH_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    GH_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GH_OK;
+}
+
+

@@ -1,0 +1,229 @@
+// C ABI: DP graphs (gh_lattices): CSR by destination in ascending origin order, same-column /
+// dead arc flags, levels, narrow/wide row ordering, transposed CSR, chain form detection.
+#include "gh_internal.h"
+#include "gh_host.h"
+
+// ----------------------------------------------------------------- lattices
+extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, const int32_t* row_state,
+                                  const int64_t* arc_off, const int32_t* arc_to, const int32_t* arc_from,
+                                  const double* arc_cost, const int64_t* start_off, const int32_t* start_rows,
+                                  const int64_t* end_off, const int32_t* end_rows, gh_lattices** out) {
+    GH_REQUIRE(ctx && out && row_off && row_state && arc_off && start_off && end_off && end_rows,
+               "gh_lattices_create: NULL argument");
+    GH_REQUIRE(L > 0, "gh_lattices_create: L=%d", L);
+    *out = nullptr;
+    GH_HIP(hipSetDevice(ctx->device));
+    const int64_t Rtot = row_off[L], Atot = arc_off[L], Etot = end_off[L];
+    GH_REQUIRE(row_off[0] == 0 && arc_off[0] == 0 && start_off[0] == 0 && end_off[0] == 0,
+               "gh_lattices_create: offsets must start at 0");
+    std::vector<int32_t> h_state(row_state, row_state + Rtot), h_ptr, h_order(Rtot), h_lev, h_narrow, h_end;
+    std::vector<uint8_t> h_start(Rtot, 0);
+    std::vector<uint32_t> h_prow(Atot), h_srow(Atot);
+    std::vector<double> h_pcost(Atot), h_scost(Atot);
+    std::vector<int32_t> h_sptr;
+    gh_lattices* lt = new gh_lattices();
+    lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
+    for (int64_t k = 0; k < Atot; ++k) lt->has_nan_arc = lt->has_nan_arc || std::isnan(arc_cost[k]);
+    lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
+    lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
+    lt->d_succ_cost = nullptr; lt->d_level_ptr = nullptr; lt->d_end_rows = nullptr; lt->d_level_narrow = nullptr;
+    lt->chain_ok = false; lt->chain_skip = false; lt->chain_groups = 0;
+    lt->d_ch_cost0 = lt->d_ch_cost1 = lt->d_ch_cost2 = nullptr; lt->d_ch_info = nullptr;
+    lt->d_ch_end_slot = nullptr; lt->d_ch_group_row0 = nullptr;
+    lt->d_desc = nullptr;
+    h_end.assign(end_rows, end_rows + Etot);
+    for (int l = 0; l < L; ++l) {
+        const int64_t r0 = row_off[l], a0 = arc_off[l];
+        const int R = (int)(row_off[l + 1] - r0), A = (int)(arc_off[l + 1] - a0);
+        const int ns = (int)(start_off[l + 1] - start_off[l]), ne = (int)(end_off[l + 1] - end_off[l]);
+#define GH_LFAIL(...) do { gh_set_error(__VA_ARGS__); delete lt; return GH_ERR_INVALID; } while (0)
+        if (R <= 0 || R > 0x7FFE) GH_LFAIL("gh_lattices_create: graph %d has %d rows (1..32766 supported)", l, R);
+        if (ne <= 0) GH_LFAIL("gh_lattices_create: graph %d has no end row", l);
+        for (int k = 0; k < ns; ++k) {
+            const int r = start_rows[start_off[l] + k];
+            if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: start row %d out of range", r);
+            h_start[r0 + r] |= 1;
+        }
+        for (int k = 0; k < ne; ++k) {
+            const int r = end_rows[end_off[l] + k];
+            if (r < 0 || r >= R) GH_LFAIL("gh_lattices_create: end row %d out of range", r);
+            h_start[r0 + r] |= 2;  // bit1 = end row (forward-backward)
+        }
+        // CSR by destination, ascending origin (tie-break contract, decode.py:105-118)
+        std::vector<int> idx(A);
+        std::iota(idx.begin(), idx.end(), 0);
+        for (int k = 0; k < A; ++k) {
+            const int to = arc_to[a0 + k], fr = arc_from[a0 + k];
+            if (to < 0 || to >= R || fr < 0 || fr >= R) GH_LFAIL("gh_lattices_create: arc %d out of range", k);
+            if (std::isinf(arc_cost[a0 + k]))  // NaN is kept: the reference treats it as an arc (isinf(nan) is False)
+                GH_LFAIL("gh_lattices_create: arc %d has an infinite cost (omit absent arcs, decode.py:106)", k);
+        }
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+            const int tx = arc_to[a0 + x], ty = arc_to[a0 + y];
+            if (tx != ty) return tx < ty;
+            return arc_from[a0 + x] < arc_from[a0 + y];
+        });
+        const size_t ptr_base = h_ptr.size();
+        h_ptr.resize(ptr_base + R + 1, 0);
+        int32_t* ptr = h_ptr.data() + ptr_base;
+        std::vector<int> level(R, 0);
+        for (int k = 0; k < A; ++k) ptr[arc_to[a0 + idx[k]] + 1]++;
+        for (int r = 0; r < R; ++r) ptr[r + 1] += ptr[r];
+        for (int k = 0; k < A; ++k) {
+            const int to = arc_to[a0 + idx[k]], fr = arc_from[a0 + idx[k]];
+            uint32_t w = (uint32_t)fr;
+            const bool same = h_state[r0 + to] < 0 || h_state[r0 + fr] < 0;  // decode.py:109
+            if (same) {
+                if (fr == to) lt->has_self_arc = true;
+                w |= GH_ARC_SAME;
+                if (fr >= to) w |= GH_ARC_DEAD;  // not yet computed in this column: still +inf
+            }
+            h_prow[a0 + k] = w;
+            h_pcost[a0 + k] = arc_cost[a0 + idx[k]];
+        }
+        // transposed CSR (by origin) for the backward pass; h_sptr shares ptr_base with h_ptr
+        {
+            h_sptr.resize(ptr_base + R + 1, 0);
+            int32_t* sp = h_sptr.data() + ptr_base;
+            for (int r = 0; r < R; ++r)
+                for (int p = ptr[r]; p < ptr[r + 1]; ++p) sp[(h_prow[a0 + p] & GH_ARC_ROW) + 1]++;
+            for (int r = 0; r < R; ++r) sp[r + 1] += sp[r];
+            std::vector<int> fill(sp, sp + R);
+            for (int r = 0; r < R; ++r)
+                for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                    const uint32_t w = h_prow[a0 + p];
+                    const int o = (int)(w & GH_ARC_ROW), k = fill[o]++;
+                    h_srow[a0 + k] = (uint32_t)r | (w & ~GH_ARC_ROW);
+                    h_scost[a0 + k] = h_pcost[a0 + p];
+                }
+        }
+        // levels: rows ascending, so every live same-column origin (< row) is already levelled
+        int nlev = 1;
+        for (int r = 0; r < R; ++r) {
+            int lv = 0;
+            for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                const uint32_t w = h_prow[a0 + p];
+                if ((w & GH_ARC_SAME) && !(w & GH_ARC_DEAD)) lv = std::max(lv, level[w & GH_ARC_ROW] + 1);
+            }
+            level[r] = lv;
+            nlev = std::max(nlev, lv + 1);
+        }
+        const size_t lev_base = h_lev.size();
+        h_lev.resize(lev_base + nlev + 1, 0);
+        int32_t* lp = h_lev.data() + lev_base;
+        for (int r = 0; r < R; ++r) lp[level[r] + 1]++;
+        int max_level_rows = 0;
+        for (int k = 0; k < nlev; ++k) { max_level_rows = std::max(max_level_rows, lp[k + 1]); lp[k + 1] += lp[k]; }
+        // inside a level: rows with <= 2 arcs first, then the wide rows (the lean kernel gives those
+        // 16 lanes each); ascending row index inside both groups
+        h_narrow.resize(lev_base + nlev + 1, 0);
+        int lean_lanes = 0;
+        {
+            std::vector<int> fill(lp, lp + nlev), nwide(nlev, 0);
+            for (int pass = 0; pass < 2; ++pass)
+                for (int r = 0; r < R; ++r) {
+                    const bool wide = ptr[r + 1] - ptr[r] > 2;
+                    if (wide != (pass == 1)) continue;
+                    h_order[r0 + fill[level[r]]++] = r;
+                    if (wide) nwide[level[r]]++; else h_narrow[lev_base + level[r]]++;
+                }
+            for (int k = 0; k < nlev; ++k) lean_lanes = std::max(lean_lanes, h_narrow[lev_base + k] + 16 * nwide[k]);
+        }
+        int max_state = -1;
+        for (int r = 0; r < R; ++r) max_state = std::max(max_state, h_state[r0 + r]);
+        gh_lattice_host lh;
+        lh.R = R; lh.A = A; lh.nlev = nlev; lh.n_start = ns; lh.n_end = ne;
+        lh.row_base = r0; lh.arc_base = a0; lh.end_base = end_off[l]; lh.max_state = max_state;
+        lt->lat.push_back(lh);
+        gh_lattices::desc d;
+        d.R = R; d.nlev = nlev; d.n_end = ne; d.pad = max_level_rows; d.lean_lanes = lean_lanes; d.pad2 = 0;
+        d.row_base = r0; d.ptr_base = (int64_t)ptr_base; d.arc_base = a0; d.lev_base = (int64_t)lev_base;
+        d.end_base = end_off[l];
+        lt->h_desc.push_back(d);
+        lt->max_R = std::max(lt->max_R, R);
+        lt->max_nlev = std::max(lt->max_nlev, nlev);
+#undef GH_LFAIL
+    }
+    // ---- chain form: one graph, one level, arcs only from r, r-1, r-2, distinct end rows ----
+    std::vector<double> ch0, ch1, ch2;
+    std::vector<uint8_t> chinfo;
+    std::vector<int32_t> chslot, chgroups;
+    if (L == 1 && lt->max_nlev == 1 && !lt->has_nan_arc) {
+        const int R = lt->lat[0].R;
+        const int32_t* ptr = h_ptr.data();
+        ch0.assign(R, INFINITY); ch1.assign(R, INFINITY); ch2.assign(R, INFINITY);
+        chinfo.assign(R, 3); chslot.assign(R, -1);
+        bool ok = true, skip = false;
+        for (int r = 0; r < R && ok; ++r) {
+            int first = 3;
+            for (int p = ptr[r]; p < ptr[r + 1]; ++p) {
+                const int o = (int)(h_prow[p] & GH_ARC_ROW), dlt = r - o;
+                if (dlt < 0 || dlt > 2 || (h_prow[p] & (GH_ARC_SAME | GH_ARC_DEAD))) { ok = false; break; }
+                double& slot = dlt == 0 ? ch0[r] : (dlt == 1 ? ch1[r] : ch2[r]);
+                if (!std::isinf(slot)) { ok = false; break; }  // duplicate arc
+                slot = h_pcost[p];
+                if (dlt == 2) skip = true;
+                if (first == 3 || dlt > first) first = dlt;  // lowest origin == largest delta comes first
+            }
+            chinfo[r] = (uint8_t)(first | (h_start[r] & 1 ? 4 : 0));
+        }
+        for (int k = 0; ok && k < (int)h_end.size(); ++k) {
+            if (chslot[h_end[k]] >= 0) ok = false;  // duplicated end row: generic / lean kernels handle it
+            else chslot[h_end[k]] = k;
+        }
+        if (ok) {  // 64-lane groups made of whole chains (a chain starts where no arc arrives from r-1 / r-2)
+            chgroups.push_back(0);
+            int gs = 0, cs = 0;
+            for (int r = 1; r <= R && ok; ++r) {
+                const bool chain_start = r == R || (std::isinf(ch1[r]) && std::isinf(ch2[r]) &&
+                                                    (r + 1 >= R || std::isinf(ch2[r + 1])));
+                if (!chain_start) continue;
+                if (r - cs > 64) { ok = false; break; }     // one chain longer than a wave
+                if (r - gs > 64) { chgroups.push_back(cs); gs = cs; }
+                cs = r;
+            }
+            chgroups.push_back(R);
+        }
+        if (ok) { lt->chain_ok = true; lt->chain_skip = skip; lt->chain_groups = (int)chgroups.size() - 1; }
+    }
+    int rc = GH_OK;
+    if (lt->chain_ok &&
+        ((rc = upload(&lt->d_ch_cost0, ch0)) || (rc = upload(&lt->d_ch_cost1, ch1)) || (rc = upload(&lt->d_ch_cost2, ch2)) ||
+         (rc = upload(&lt->d_ch_info, chinfo)) || (rc = upload(&lt->d_ch_end_slot, chslot)) ||
+         (rc = upload(&lt->d_ch_group_row0, chgroups)))) {
+        gh_lattices_destroy(lt);
+        return rc;
+    }
+    if ((rc = upload(&lt->d_row_state, h_state)) || (rc = upload(&lt->d_row_start, h_start)) ||
+        (rc = upload(&lt->d_pred_ptr, h_ptr)) || (rc = upload(&lt->d_pred_row, h_prow)) ||
+        (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
+        (rc = upload(&lt->d_succ_ptr, h_sptr)) || (rc = upload(&lt->d_succ_row, h_srow)) ||
+        (rc = upload(&lt->d_succ_cost, h_scost)) ||
+        (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_level_narrow, h_narrow)) ||
+        (rc = upload(&lt->d_end_rows, h_end)) ||
+        (rc = upload(&lt->d_desc, lt->h_desc))) {
+        gh_lattices_destroy(lt);
+        return rc;
+    }
+    *out = lt;
+    return GH_OK;
+}
+
+extern "C" void gh_lattices_destroy(gh_lattices* l) {
+    if (!l) return;
+    hipSetDevice(l->ctx->device);
+    hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
+    hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
+    hipFree(l->d_level_narrow);
+    hipFree(l->d_ch_cost0); hipFree(l->d_ch_cost1); hipFree(l->d_ch_cost2); hipFree(l->d_ch_info);
+    hipFree(l->d_ch_end_slot); hipFree(l->d_ch_group_row0);
+    hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
+    hipFree(l->d_desc);
+    delete l;
+}
+
+extern "C" int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T) {
+    if (!lat || l < 0 || l >= lat->L) return -1;
+    return T * lat->lat[l].nlev;  // at most one cell per (column, level)
+}
+
