@@ -80,6 +80,16 @@ int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
 int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
                   void* feats_dev, const int64_t* utt_offsets, gh_batch** out);
 void gh_batch_destroy(gh_batch* b);
+/* N3 front-end: cepstra [N, C] (fp64, ragged by utt_offsets) -> [cepstra | delta | delta-delta]
+ * (delta_feature, sr/core.py:13-22) -> per-utterance (x - mean) / std (standardize,
+ * sr/feature/feature.py:85-88), i.e. the tail of load_wav_as_mfcc (sr/core.py:41-44), computed on the
+ * GPU into a resident batch of D = 3C features.  Every utterance needs >= 2 frames (the reference
+ * indexes feat[i + 1]).  gh_batch_fetch_features copies a batch's feature matrix back ([N, D], dtype).
+ * mode 0: stack + standardise (D = 3C); 1: stack only, raw [ceps|delta|ddelta] (D = 3C); 2: standardise the C
+ * input columns as they are (D = C). */
+int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
+                                 const double* ceps_host, const int64_t* utt_offsets, gh_batch** out);
+int gh_batch_fetch_features(gh_ctx* ctx, const gh_batch* b, void* out_host);
 
 /* ------------------------------------------------ A3: batched GMM.evaluate
  * nll[n, s] = -log sum_m w[s,m] N(x_n; mean[s,m], diag var[s,m])  for every

@@ -70,6 +70,34 @@ def euclid(v1, v2, *_):
     return np.linalg.norm(v1 - v2)
 
 
+# ------------------------------------------------------------------ N3 (front-end)
+def delta_feature(feat):
+    """core.py:13-22: central difference feat[i+1]-feat[i-1], one-sided at both ends
+    (so T == 1 raises IndexError like the reference's feat[i + 1])."""
+    T = len(feat)
+    if T < 2:
+        raise IndexError("index 1 is out of bounds for axis 0 with size %d" % T)
+    d = np.zeros(feat.shape)
+    d[0] = feat[1] - feat[0]
+    d[-1] = feat[-1] - feat[-2]
+    d[1:-1] = feat[2:] - feat[:-2]
+    return d
+
+
+def standardize(data):
+    """feature.py:85-88: per-column (x - mean) / std over the frames of one utterance
+    (population std, np.std's default ddof = 0)."""
+    c = data - np.mean(data, axis=0)
+    return c / np.std(c, axis=0)
+
+
+def stack_features(ceps):
+    """core.py:27-30 / :41-44: [ceps | delta | delta-delta] -> standardize."""
+    df = delta_feature(ceps)
+    ddf = delta_feature(df)
+    return standardize(np.concatenate([ceps, df, ddf], axis=1))
+
+
 # --------------------------------------------------------------------------- A3
 def gmm_evaluate(x, means, vars_, w, neg_log=True, dense_inv=None):
     """GMM.evaluate (hmm_state.py:114-120): -log(sum_m w_m pdf_m(x)) in the

@@ -38,6 +38,9 @@ SIGNATURES = {
     "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_batch_destroy": (None, [C.c_void_p]),
+    "gh_batch_create_from_cepstra": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _c_f64p, _c_i64p,
+                                               C.POINTER(C.c_void_p)]),
+    "gh_batch_fetch_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
     "gh_component_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _c_f64p, _c_f64p]),
@@ -189,10 +192,29 @@ class PackedGMM:
 class Batch:
     """Ragged batch of utterances resident in HBM (gh_batch)."""
 
-    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None):
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0):
         self.ctx = ctx
         self.np_dtype = np.dtype(dtype)
         assert self.np_dtype in (np.dtype(np.float32), np.dtype(np.float64))
+        if cepstra is not None:  # N3 front-end: [ceps | delta | delta-delta], standardised per utterance, on the GPU
+            lens = [len(u) for u in cepstra]
+            for n in lens:
+                if n < 2 and frontend_mode != 2:
+                    raise IndexError("index 1 is out of bounds for axis 0 with size %d" % n)  # core.py:16
+            self.offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=self.offsets[1:])
+            Cc = np.asarray(cepstra[0]).shape[1] if lens else 1
+            ceps = np.ascontiguousarray(np.concatenate([np.asarray(u, dtype=np.float64).reshape(-1, Cc) for u in cepstra])
+                                        if lens else np.zeros((0, Cc)))
+            self.N, self.D, self.U = ceps.shape[0], (Cc if frontend_mode == 2 else 3 * Cc), len(lens)
+            h = C.c_void_p()
+            _check(ctx.lib, ctx.lib.gh_batch_create_from_cepstra(
+                ctx.h, GH_F64 if self.np_dtype == np.float64 else GH_F32, int(frontend_mode), Cc, self.N, self.U,
+                _ptr(ceps, _c_f64p),
+                _ptr(self.offsets, _c_i64p), C.byref(h)))
+            self.h = h
+            self.S = None
+            return
         if utterances is not None:
             lens = [len(u) for u in utterances]
             offsets = np.zeros(len(lens) + 1, dtype=np.int64)
@@ -214,6 +236,12 @@ class Batch:
     @property
     def lengths(self):
         return np.diff(self.offsets)
+
+    def features(self):
+        """The resident feature matrix, copied back: list of [T_u, D] arrays."""
+        out = np.empty((self.N, self.D), dtype=self.np_dtype)
+        _check(self.ctx.lib, self.ctx.lib.gh_batch_fetch_features(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
+        return [out[self.offsets[u]:self.offsets[u + 1]] for u in range(self.U)]
 
     def loglik(self, gmm, fetch=True):
         """A3 for every frame x state; the [N,S] matrix stays resident for the DPs."""

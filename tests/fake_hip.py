@@ -51,8 +51,22 @@ class PackedGMM:
 
 
 class Batch:
-    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None):
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0):
         self.ctx = ctx
+        self.np_dtype = np.dtype(dtype)
+        if cepstra is not None:  # N3 front-end through the oracle
+            outs = []
+            for c in cepstra:
+                c = np.asarray(c, dtype=np.float64)
+                if frontend_mode == 2:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        outs.append(O.standardize(c))
+                    continue
+                df = O.delta_feature(c)
+                raw = np.concatenate([c, df, O.delta_feature(df)], axis=1)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    outs.append(raw if frontend_mode == 1 else O.standardize(raw))
+            utterances = outs
         if utterances is not None:
             lens = [len(u) for u in utterances]
             offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -73,6 +87,9 @@ class Batch:
 
     def utt(self, u):
         return self.feats[self.offsets[u]:self.offsets[u + 1]]
+
+    def features(self):
+        return [self.utt(u).astype(self.np_dtype) for u in range(self.U)]
 
     def loglik(self, gmm, fetch=True):
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -332,3 +332,31 @@ def test_reference_pickle_scores_identically(R):
     g = load_golden("G12_reference_pickle")
     hmms = pickle.loads(g["pickle"].tobytes())
     np.testing.assert_allclose([h.evaluate(g["x"]) for h in hmms], g["evaluate"], rtol=1e-10)
+
+
+# ------------------------------------------------------------------ N3: front-end
+def test_feature_stack_matches_reference(R):
+    import sr
+    from sr.core import delta_feature, stack_features, stack_features_batch
+    from sr.feature import standardize
+    g = load_golden("G13_feature_stack")
+    n = int(g["n"])
+    for i in range(n):
+        ceps = g["ceps%d" % i]
+        np.testing.assert_allclose(delta_feature(ceps), g["delta%d" % i], rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(stack_features(ceps), g["feats%d" % i], rtol=1e-11, atol=1e-12)
+    assert sr.delta_feature is delta_feature
+    # standardize subtracts the mean from the caller's array in place, like the reference
+    raw = np.concatenate([g["ceps2"], g["delta2"], g["ddelta2"]], axis=1)
+    arg = raw.copy()
+    out = standardize(arg)
+    np.testing.assert_allclose(out, g["feats2"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(arg, raw - raw.mean(axis=0), rtol=1e-13, atol=1e-13)
+    with pytest.raises(IndexError):
+        delta_feature(g["ceps0"][:1])
+    # batched, resident: front-end -> likelihood without a host round trip (fp64 and fp32 storage)
+    for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-6)):
+        b = stack_features_batch([g["ceps%d" % i] for i in range(1, n)], dtype=dt)
+        for i, f in zip(range(1, n), b.features()):
+            np.testing.assert_allclose(f, g["feats%d" % i], rtol=tol, atol=tol)
+        b.close()

@@ -323,3 +323,15 @@ def test_A13_forward_backward_bruteforce(seed):
     vit = min(costs[e, -1] for e in ends)
     close(vit, bmin, rtol=1e-12)
     assert vit >= -logp - 1e-12
+
+
+# ---------------------------------------------------------------------------- N3
+def test_G13_feature_stack():
+    g = load_golden("G13_feature_stack")
+    for i in range(int(g["n"])):
+        ceps = g["ceps%d" % i]
+        close(O.delta_feature(ceps), g["delta%d" % i], rtol=0)
+        close(O.delta_feature(g["delta%d" % i]), g["ddelta%d" % i], rtol=0)
+        close(O.stack_features(ceps), g["feats%d" % i], rtol=1e-12, atol=1e-13)
+    with pytest.raises(IndexError):
+        O.delta_feature(g["ceps0"][:1])

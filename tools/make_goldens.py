@@ -421,6 +421,31 @@ def g12(R):
 
 ALL["G12"] = g12
 
+
+def g13(R):
+    """N3: the feature stacking in front of the hot path.  sr/core.py cannot be imported (pyaudio,
+    python_speech_features), so its `delta_feature` is compiled from its AST; `standardize` comes from
+    the importable sr.feature."""
+    tree = ast.parse(open(os.path.join(REF, "sr", "core.py")).read())
+    fdef = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "delta_feature")
+    ns = dict(np=np)
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[fdef], type_ignores=[])), "core.py", "exec"), ns)
+    delta_feature = ns["delta_feature"]
+    standardize = importlib.import_module("sr.feature").standardize
+    rng = np.random.default_rng(131)
+    out = {}
+    for i, T in enumerate((2, 3, 57, 130)):
+        ceps = rng.normal(size=(T, 13)) * rng.uniform(0.5, 20.0, size=13) + rng.normal(size=13) * 5
+        df = delta_feature(ceps)
+        ddf = delta_feature(df)
+        feats = standardize(np.concatenate([ceps, df, ddf], axis=1))
+        out.update({"ceps%d" % i: ceps, "delta%d" % i: df, "ddelta%d" % i: ddf, "feats%d" % i: feats})
+    out["n"] = np.array(4)
+    save("G13_feature_stack", **out)
+
+
+ALL["G13"] = g13
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
