@@ -18,6 +18,8 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libgmmhmm.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+# per-file extras: MFMA results straight into VGPRs (no v_accvgpr_read/write around the epilogue): +1.5 % measured
+EXTRA = {"gh_loglik_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _sources():
@@ -43,7 +45,7 @@ def build_lib(force=False, verbose=True):
         o = os.path.join(OBJ, src[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

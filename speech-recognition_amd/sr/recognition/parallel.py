@@ -35,12 +35,16 @@ def shard_utterances(lengths, world_size):
 class StatsAllReducer:
     """Sum a packed fp64 statistics buffer over all ranks (one collective per call)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, gpu_index=None):
+        """device: torch device the buffer is reduced on.  Default: the GPU `gpu_index` (or torch's
+        current one) when the process group runs on RCCL ("nccl"), the host for gloo."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.device = device
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if device is None and self.enabled and dist.get_backend() == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device() if gpu_index is None else int(gpu_index))
+        self.device = device
 
     def __call__(self, stats):
         """stats: numpy fp64 array (any shape) -> summed over ranks, same shape."""

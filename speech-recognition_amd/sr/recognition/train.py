@@ -40,7 +40,7 @@ class BaumWelchTrainer:
         self.vars = np.array(vars_, dtype=np.float64).reshape(self.S, self.M, self.D)
         self.weights = np.array(weights, dtype=np.float64).reshape(self.S, self.M)
         self.var_floor, self.occ_floor = var_floor, occ_floor
-        self.reducer = reducer if reducer is not None else StatsAllReducer()
+        self.reducer = reducer if reducer is not None else StatsAllReducer(gpu_index=self.ctx.device)
         self.batch = _hip.Batch(self.ctx, data)
         keys, graphs = {}, []
         self.utt_graph = np.empty(len(label_seqs), dtype=np.int32)
