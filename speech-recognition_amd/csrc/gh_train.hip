@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict__ X, int64_t N, int D, int S, int M,
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ occ,
-                                                       double occ_floor, int F, double* __restrict__ slabs) {
+                                                       double occ_floor, int F, const int64_t* __restrict__ utt_off,
+                                                       int64_t U, double* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* xt = sm;                 // [F,D]   frames of the tile
     double* rt = xt + F * D;         // [M,F]   weighted responsibilities of the current state
@@ -171,10 +172,12 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
     const int tid = threadIdx.x;
     const int W = 1 + 2 * D;
     double* slab = slabs + (int64_t)blockIdx.x * S * M * W;
-    const int64_t ntiles = (N + F - 1) / F;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t n0 = tile * F;
-        const int nf = (int)((N - n0 < F) ? (N - n0) : F);
+    // tiles never straddle utterances: an utterance only occupies the states of its own graph, so a
+    // tile's active set stays small (5 states for an isolated word instead of the 10-15 of a 128-frame
+    // window over 2-3 utterances)
+    for (int64_t u = blockIdx.x; u < U; u += gridDim.x)
+    for (int64_t n0 = utt_off[u]; n0 < utt_off[u + 1]; n0 += F) {
+        const int nf = (int)((utt_off[u + 1] - n0 < F) ? (utt_off[u + 1] - n0) : F);
         __syncthreads();
         for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
         // which states have any occupancy on this tile?  lane = state: coalesced sweeps down the
@@ -384,8 +387,8 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f + 2 * (size_t)M * D + M) * 8 + (size_t)S * 4 + 16; };
     while (F > 32 && lds_need(F) > 64 * 1024) F >>= 1;
     GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_bw_accumulate: D=%d M=%d does not fit LDS", D, M);
-    const int64_t ntiles = b->N > 0 ? (b->N + F - 1) / F : 0;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 2 * (int64_t)ctx->n_cu));
+    const int64_t ntiles = b->U;  // one utterance (in chunks of F frames) per workgroup pass
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 3 * (int64_t)ctx->n_cu));
     void* base;
     const size_t slab_bytes = (size_t)grid * len * 8, out_bytes = ((size_t)len * 8 + 255) & ~size_t(255);
     int rc = gh_scratch(ctx, out_bytes + slab_bytes, &base);
@@ -395,7 +398,7 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     GH_HIP(hipMemsetAsync(d_slabs, 0, slab_bytes, st));
     if (ntiles > 0) {
         hipLaunchKernelGGL(bw_stats_kernel, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats, b->N, D, S, M,
-                           g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, d_slabs);
+                           g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, b->d_offsets, b->U, d_slabs);
         GH_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_slabs, grid, len, d_out);
