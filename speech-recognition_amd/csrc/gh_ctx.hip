@@ -47,7 +47,7 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
             t[j] = (double)exp2l((long double)j / 128.0L);
             const double inv = (double)(1.0L / (0.5L + ((long double)j + 0.5L) / 256.0L));
             t[128 + j] = inv;
-            t[256 + j] = (double)(-logl((long double)inv));
+            t[256 + j] = (double)(-logl((long double)inv) * (long double)GH_LSE_SCALE64);  // scaled log domain
         }
         GH_HIP(hipMalloc((void**)&c->d_fp64_tables, sizeof t));
         GH_HIP(hipMemcpy(c->d_fp64_tables, t, sizeof t, hipMemcpyHostToDevice));

@@ -27,6 +27,14 @@ void gh_set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 
+// Scaled log domain of the MFMA likelihood kernel (gh_loglik_mfma.hip): the packed operands
+// Apk / Cpk carry K * (log-density terms), K = 128/ln2 (fp64) or 1/ln2 (fp32); a component that
+// is switched off (weight 0, mixture padding) carries the finite constant OFF instead of -inf.
+#define GH_LSE_SCALE64 184.66496523378731614
+#define GH_LSE_SCALE32 1.4426950408889634074
+#define GH_LSE_OFF64 (-1e300)
+#define GH_LSE_OFF32 (-1e30f)
+
 struct gh_ctx {
     int device;
     hipStream_t stream;

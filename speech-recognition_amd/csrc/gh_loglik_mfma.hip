@@ -44,61 +44,78 @@ template <> struct Acc<float> {
     }
 };
 
-// ---- fp64 exp / log for the log-sum-exp epilogue -------------------------------------
+// ---- the log-sum-exp epilogue works in a SCALED log domain ---------------------------------
 // On gfx950 fp64 MFMA and fp64 VALU share the same FMA pipeline (measured with
-// tools/mfma_coissue.hip: their times ADD), so every fp64 VALU instruction of the epilogue
-// is paid in full next to the MFMAs.  Both functions are therefore table driven (128-entry
-// tables in LDS, filled once per workgroup) with short polynomials, branch-free:
-//   exp: x = n ln2/128 + r, |r| <= ln2/256;  2^(n/128) = 2^(n>>7) * T[n&127];
-//        exp(r) - 1 by a degree-5 polynomial (|error| < 6e-19)           ~11 fp64 ops
-//   log: s = m 2^e, m in [.5,1); m * INV[j] = 1 + rho, |rho| <= 2^-8, j = top 7 mantissa
-//        bits; log s = e ln2 + L[j] + log1p(rho), degree-6 polynomial      ~12 fp64 ops
-// Accuracy ~1e-16 absolute on exp (arguments are <= 0) and on log of sums in [1, M].
+// tools/mfma_coissue.hip: their times ADD), so every fp64 VALU instruction of the epilogue is
+// paid in full next to the MFMAs.  The host therefore packs P and C multiplied by
+//     K = 128/ln 2 (fp64)   or   K = 1/ln 2 (fp32),
+// so the accumulators hold K * log-density and
+//   * fp32: exp(a - m) is ONE v_exp_f32 (2^y), log is ONE v_log_f32;
+//   * fp64: y = a - m is already in units of 1/128 octave: n = rint(y), r = y - n EXACTLY,
+//     2^(y/128) = 2^(n>>7) * T[n&127] * 2^(r/128), the last factor by a degree-4 polynomial
+//     (|r| <= 1/2: relative error < 1.3e-15, absolute error of the result ~1e-17 of |nll|);
+//     no argument clamp is needed because weight-0 / padding components carry the FINITE
+//     constant GH_LSE_OFF (y = -1e300 -> n = y, r = 0, ldexp underflows to an exact 0) and
+//     NaNs propagate through the arithmetic by themselves;
+//   * log: s = m 2^e, m in [.5,1); m * INV[j] = 1 + rho, |rho| <= 2^-8 (j = top 7 mantissa
+//     bits); K ln s = 128 e + L[j] + K log1p(rho), degree-5 polynomial (abs. error < 2e-13 / K).
+// Tables (128 entries each, built in long double by gh_ctx_create) live in LDS.
 struct Fp64Tables {
     double exp2[128];   // 2^(j/128)
     double inv[128];    // 1 / centre of mantissa bin j, centre = 0.5 + (j + 0.5)/256
-    double nlog[128];   // -log(inv[j])
+    double nlog[128];   // -K log(inv[j])
 };
 
-__device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tab) {
-    x = fmax(x, -745.0);  // one v_max_f64; NaN inputs are caught by the caller's poison check instead
-    const double n = __builtin_rint(x * 184.66496523378731);         // 128 / ln 2
-    double r = fma(n, -0.00541521234663378, x);                      // ln2/128, high part (32 bits)
-    r = fma(n, -1.4907929134926466e-12, r);                          // low part
-    const int ni = (int)n;
-    const double t = tab[ni & 127];
-    double p = fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);  // 1/120, 1/24
-    p = fma(p, r, 1.6666666666666665741e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = p * r;                                                        // exp(r) - 1
-    return __builtin_ldexp(fma(t, p, t), ni >> 7);
+template <typename T> struct Dom;
+template <> struct Dom<double> {
+    static constexpr double inv_k = 1.0 / GH_LSE_SCALE64, off = GH_LSE_OFF64, off_test = GH_LSE_OFF64 * 0.1;
+};
+template <> struct Dom<float> {
+    static constexpr float inv_k = (float)(1.0 / GH_LSE_SCALE32), off = GH_LSE_OFF32, off_test = GH_LSE_OFF32 * 0.1f;
+};
+
+// IEEE maxNum in ONE instruction (fmax() adds a v_max x,x canonicalisation per operand that comes
+// out of an MFMA); a NaN operand loses, two NaNs give NaN
+__device__ __forceinline__ double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-__device__ __forceinline__ double log_pos(double s, const double* __restrict__ inv,
-                                          const double* __restrict__ nlog) {
-    const double m = __builtin_amdgcn_frexp_mant(s);   // [0.5, 1)
+// 2^(y/128) for finite y <= 0 (or NaN)
+__device__ __forceinline__ double exp2s(double y, const double* __restrict__ tab) {
+    const double n = __builtin_rint(y);
+    const double r = y - n;
+    const int ni = (int)n;  // v_cvt_i32_f64 saturates
+    const double t = tab[ni & 127];
+    double p = fma(r, 3.583032305400251285e-11, 2.6466421444330968834e-08);  // (ln2/128)^k / k!, k = 4, 3
+    p = fma(p, r, 1.4662262387640424337e-05);
+    p = fma(p, r, 5.4152123481245727298e-03);
+    p = p * r;  // 2^(r/128) - 1
+    return __builtin_ldexp(fma(t, p, t), ni >> 7);
+}
+__device__ __forceinline__ float exp2s(float y, const double*) { return __builtin_amdgcn_exp2f(y); }
+
+// K ln s for s in [1, M] (or NaN)
+__device__ __forceinline__ double logs(double s, const double* __restrict__ tab) {
+    const double* __restrict__ inv = tab + 128;
+    const double* __restrict__ nlog = tab + 256;
+    const double m = __builtin_amdgcn_frexp_mant(s);  // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(s);
     const int j = (__double2hiint(m) >> 13) & 127;
     const double rho = fma(m, inv[j], -1.0);
-    double p = fma(rho, -1.6666666666666665741e-01, 0.2);
-    p = fma(p, rho, -0.25);
-    p = fma(p, rho, 3.3333333333333331483e-01);
-    p = fma(p, rho, -0.5);
-    p = fma(p, rho, 1.0);
-    const double r = fma((double)e, 6.93147180559945286e-01, fma(p, rho, nlog[j]));
-    return (s == 0.0) ? -INFINITY : r;  // NaN stays NaN
+    double p = fma(rho, 36.932993046757463228, -46.166241308446829036);  // K/5, -K/4
+    p = fma(p, rho, 61.554988411262438714);                              // K/3
+    p = fma(p, rho, -92.332482616893658071);                             // -K/2
+    p = fma(p, rho, 184.66496523378731614);                              // K
+    return fma(p, rho, nlog[j]) + (double)(e << 7);
 }
-
-// `tab` = Fp64Tables image in LDS (unused by the fp32 path, which has v_exp_f32 / v_log_f32)
-template <typename T> __device__ __forceinline__ T t_exp(T x, const double* tab);
-template <> __device__ __forceinline__ float t_exp<float>(float x, const double*) { return __expf(x); }
-template <> __device__ __forceinline__ double t_exp<double>(double x, const double* tab) { return exp_nonpos(x, tab); }
-template <typename T> __device__ __forceinline__ T t_log(T x, const double* tab);
-template <> __device__ __forceinline__ float t_log<float>(float x, const double*) { return __logf(x); }
-template <> __device__ __forceinline__ double t_log<double>(double x, const double* tab) {
-    return log_pos(x, tab + 128, tab + 256);
-}
+__device__ __forceinline__ float logs(float s, const double*) { return __builtin_amdgcn_logf(s); }  // v_log_f32 = log2
 
 // Cross-lane pair exchange without LDS: gfx950's v_permlane16_swap / v_permlane32_swap swap
 // 16-lane rows (resp. 32-lane halves) between two registers; fed the same value twice they
@@ -124,26 +141,24 @@ template <int W> __device__ __forceinline__ void pair_of(double v, double& a, do
     swap_rows<W>((unsigned)__double2hiint(v), xh, yh);
     a = __hiloint2double((int)xh, (int)xl); b = __hiloint2double((int)yh, (int)yl);
 }
-template <typename T, int W> __device__ __forceinline__ T pair_max(T v) { T a, b; pair_of<W>(v, a, b); return fmax(a, b); }
+template <typename T, int W> __device__ __forceinline__ T pair_max(T v) { T a, b; pair_of<W>(v, a, b); return vmax(a, b); }
 template <typename T, int W> __device__ __forceinline__ T pair_sum(T v) { T a, b; pair_of<W>(v, a, b); return a + b; }
 
-// -(mx + log sm), branch-free: sm == 0 (every component off) gives +inf, NaN stays NaN
+// scaled (max, sum of 2^..) -> negative log-likelihood; every component off -> +inf; NaN stays NaN
 template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm, const double* tab) {
-    return -(mx + t_log<T>(sm, tab));
+    const T v = (mx + logs(sm, tab)) * -Dom<T>::inv_k;
+    return (mx < Dom<T>::off_test) ? T(INFINITY) : v;
 }
 
 // max and sum-of-exp over the 4 registers of one lane, then over `width` lane groups (1, 2 or 4)
 template <typename T, typename V>
 __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, const double* tab) {
-    T m = fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
+    T m = vmax(vmax(a[0], a[1]), vmax(a[2], a[3]));
     if (width >= 2) m = pair_max<T, 16>(m);
     if (width >= 4) m = pair_max<T, 32>(m);
-    const T ms = fmax(m, T(-1e300));  // all components off (-inf): exp(-inf + 1e300) = 0, no inf - inf
-    T e = t_exp<T>(a[0] - ms, tab) + t_exp<T>(a[1] - ms, tab) + t_exp<T>(a[2] - ms, tab) + t_exp<T>(a[3] - ms, tab);
-    // NaN parameters / features must poison the state (the reference's linear-domain sum does), but
-    // fmax() drops NaNs: the plain sum of the four values is NaN exactly when one of them is
-    const T poison = (a[0] + a[1]) + (a[2] + a[3]);
-    e = (poison != poison) ? poison : e;
+    // a NaN component makes its own term (and so the sum) NaN: the state is poisoned as in the
+    // reference's linear-domain sum, although vmax() dropped the NaN
+    T e = (exp2s(a[0] - m, tab) + exp2s(a[1] - m, tab)) + (exp2s(a[2] - m, tab) + exp2s(a[3] - m, tab));
     if (width >= 2) e = pair_sum<T, 16>(e);
     if (width >= 4) e = pair_sum<T, 32>(e);
     mx = m;
@@ -154,49 +169,80 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, co
 // both column tiles, written into the LDS output tile.  MP = padded mixture size (compile
 // time); MP == 32 stands for "several tiles per state" (M_pad = 16 * tiles_per_state, run
 // time), merged through (run_mx, run_sm).  Straight-line code: lanes with nothing to store
-// write to a per-lane dummy slot behind the tile, so the whole epilogue can be scheduled
-// under the next tile's MFMAs.
+// write to a per-lane dummy slot behind the tile.  When a state spans two or four lane groups
+// every group ends up with the same (max, sum) pair, so the even group finishes column tile 0
+// and the odd group column tile 1: ONE logarithm per lane instead of two.
 template <typename T, typename V, int MP>
 __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int t, int f, int q, int S, int RS,
                                               int chunk_s0, int tiles_per_state, T* lds, T* dummy,
                                               const double* tab, T (&run_mx)[2], T (&run_sm)[2]) {
+    T* orow0 = lds + f * RS - chunk_s0;
+    T* orow1 = orow0 + 16 * RS;
+    if (MP == 1) {
+        const int s = 16 * t + 4 * q;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const V& acc = c ? acc1 : acc0;
-        T* orow = lds + (16 * c + f) * RS - chunk_s0;
-        if (MP == 1) {
-            const int s = 16 * t + 4 * q;
+        for (int c = 0; c < 2; ++c) {
+            const V& acc = c ? acc1 : acc0;
+            T* orow = c ? orow1 : orow0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *((s + r < S) ? orow + s + r : dummy) = -acc[r];
-        } else if (MP == 2) {
-            const int s = 8 * t + 2 * q;
+            for (int r = 0; r < 4; ++r)
+                *((s + r < S) ? orow + s + r : dummy) = (acc[r] < Dom<T>::off_test) ? T(INFINITY) : acc[r] * -Dom<T>::inv_k;
+        }
+    } else if (MP == 2) {
+        const int s = 8 * t + 2 * q;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const V& acc = c ? acc1 : acc0;
+            T* orow = c ? orow1 : orow0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
-                const T m = fmax(x0, x1);
-                const T ms = fmax(m, T(-1e300));
-                T e = t_exp<T>(x0 - ms, tab) + t_exp<T>(x1 - ms, tab);
-                const T poison = x0 + x1;  // NaN iff one of them is (fmax drops NaNs)
-                e = (poison != poison) ? poison : e;
+                const T m = vmax(x0, x1);
+                const T e = exp2s(x0 - m, tab) + exp2s(x1 - m, tab);
                 *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e, tab);
             }
-        } else if (MP <= 16) {
-            constexpr int width = MP / 4;  // lane groups per state: 1, 2 or 4
+        }
+#ifdef GH_MF_NOEPI  // diagnostic build: MFMAs + loads only (tools/variant_bench.sh)
+    } else if (MP <= 16) {
+        const int s = (16 / MP) * t + q / (MP / 4);
+        *(((q & (MP / 4 - 1)) == 0 && s < S) ? orow0 + s : dummy) = -((acc0[0] + acc0[1]) + (acc0[2] + acc0[3]));
+        *(((q & (MP / 4 - 1)) == 0 && s < S) ? orow1 + s : dummy) = -((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
+#endif
+    } else if (MP == 4) {
+        T mx, sm;
+        const int s = 4 * t + q;
+        tile_lse<T, V>(acc0, 1, mx, sm, tab);
+        *((s < S) ? orow0 + s : dummy) = nll_of<T>(mx, sm, tab);
+        tile_lse<T, V>(acc1, 1, mx, sm, tab);
+        *((s < S) ? orow1 + s : dummy) = nll_of<T>(mx, sm, tab);
+    } else if (MP <= 16) {
+        constexpr int width = MP / 4;  // lane groups per state: 2 or 4
+        T mx0, sm0, mx1, sm1;
+        tile_lse<T, V>(acc0, width, mx0, sm0, tab);
+        tile_lse<T, V>(acc1, width, mx1, sm1, tab);
+        const bool odd = q & 1;
+        const int s = (16 / MP) * t + q / width;
+        const T v = nll_of<T>(odd ? mx1 : mx0, odd ? sm1 : sm0, tab);
+        *(((q & (width - 1)) < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
+    } else {
+        const bool last = (t + 1) % tiles_per_state == 0;
+        const int s = t / tiles_per_state;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
             T mx, sm;
-            tile_lse<T, V>(acc, width, mx, sm, tab);
-            const int s = (16 / MP) * t + q / width;
-            *(((q & (width - 1)) == 0 && s < S) ? orow + s : dummy) = nll_of<T>(mx, sm, tab);
-        } else {
-            T mx, sm;
-            tile_lse<T, V>(acc, 4, mx, sm, tab);
-            const T m = fmax(run_mx[c], mx);
-            const T ms = fmax(m, T(-1e300));
-            run_sm[c] = run_sm[c] * t_exp<T>(run_mx[c] - ms, tab) + sm * t_exp<T>(mx - ms, tab);
-            run_mx[c] = m;
-            const bool last = (t + 1) % tiles_per_state == 0;
-            const int s = t / tiles_per_state;
-            *((last && q == 0 && s < S) ? orow + s : dummy) = nll_of<T>(run_mx[c], run_sm[c], tab);
-            run_mx[c] = last ? T(-INFINITY) : run_mx[c];
+            tile_lse<T, V>(c ? acc1 : acc0, 4, mx, sm, tab);
+            // merge with the running pair: one of the two rescale factors is 2^0
+            const T d = run_mx[c] - mx;
+            const T e = exp2s((d > T(0)) ? -d : d, tab);
+            run_sm[c] = (d > T(0)) ? fma(sm, e, run_sm[c]) : fma(run_sm[c], e, sm);
+            run_mx[c] = (d > T(0)) ? run_mx[c] : mx;
+        }
+        const bool odd = q & 1;
+        const T v = nll_of<T>(odd ? run_mx[1] : run_mx[0], odd ? run_sm[1] : run_sm[0], tab);
+        *((last && q < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            run_mx[c] = last ? Dom<T>::off : run_mx[c];
             run_sm[c] = last ? T(0) : run_sm[c];
         }
     }
@@ -228,15 +274,32 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     const int nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
     double* tab = reinterpret_cast<double*>(smem_raw + tab_off);  // exp / log tables (fp64 path)
-    if (sizeof(T) == 8) {
-        for (int i = lane; i < 384; i += 64) tab[i] = tables[i];
-    }
-
-    // ---- frames: global -> LDS (coalesced) -> B fragments in registers ----------------
+    // Every load of the prologue is issued before the first wait (a load -> wait -> ds_write loop
+    // costs one HBM round trip per 64 elements: 20 in a row for a 32 x 39 tile).
     {
-        const int64_t nelem = (int64_t)nrows * D;
+        double tr[6];
+        if (sizeof(T) == 8) {
+#pragma unroll
+            for (int it = 0; it < 6; ++it) tr[it] = tables[lane + 64 * it];
+        }
+        // ---- frames: global -> LDS (coalesced) -> B fragments in registers ----------------
+        const int nelem = nrows * D;  // <= 32 * KP = 64 * KS
         const T* src = X + n0 * D;
-        for (int i = lane; i < nelem; i += 64) lds[i] = src[i];
+        T xr[KS];
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int i = lane + 64 * it;
+            xr[it] = (i < nelem) ? src[i] : T(0);
+        }
+        if (sizeof(T) == 8) {
+#pragma unroll
+            for (int it = 0; it < 6; ++it) tab[lane + 64 * it] = tr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int i = lane + 64 * it;
+            if (i < nelem) lds[i] = xr[it];
+        }
         __syncthreads();
     }
     constexpr int KQ = KS / 2;  // k-steps of the x^2 half == of the x half (KP = 4*KQ)
@@ -258,7 +321,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     const int SC = (MP <= 16) ? chunk_tiles * (16 / (MP <= 16 ? MP : 16)) : chunk_tiles / tiles_per_state;
     const int RS = (S <= SC) ? S : SC;  // LDS row stride: whole matrix rows when they fit one chunk
     T* dummy = lds + 32 * RS + lane;    // per-lane slot behind the output tile
-    T run_mx[2] = {-INFINITY, -INFINITY}, run_sm[2] = {T(0), T(0)};
+    T run_mx[2] = {Dom<T>::off, Dom<T>::off}, run_sm[2] = {T(0), T(0)};
     int chunk_s0 = 0;  // first state held in the LDS output tile
 
     // ---- stream the Gaussian tiles; the epilogue of tile t-1 runs under the MFMAs of tile t ----
@@ -291,10 +354,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     auto flush = [&]() {
         const int cnt = ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
         __syncthreads();
-        if (cnt == S) {  // whole rows: the [nrows, S] block is contiguous in memory
-            T* dst = out + n0 * S;
+        if (cnt == S) {  // whole rows: the [nrows, S] block is contiguous in memory (16 bytes per lane)
+            typedef T V16 __attribute__((ext_vector_type(16 / sizeof(T))));
+            constexpr int VE = 16 / sizeof(T);
+            T* dst = out + n0 * S;  // 32 * S * sizeof(T) bytes per block: always 16-byte aligned
             const int total = nrows * S;
-            for (int i = lane; i < total; i += 64) dst[i] = lds[i];
+            const int nvec = total / VE;
+#pragma unroll 4
+            for (int i = lane; i < nvec; i += 64)
+                reinterpret_cast<V16*>(dst)[i] = reinterpret_cast<const V16*>(lds)[i];
+            for (int i = nvec * VE + lane; i < total; i += 64) dst[i] = lds[i];
         } else if (cnt > 0) {
             for (int r = 0; r < nrows; ++r) {
                 T* dst = out + (n0 + r) * S + chunk_s0;

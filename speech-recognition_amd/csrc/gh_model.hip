@@ -50,15 +50,17 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     g->n_tiles = n_tiles;
     g->dApk64 = nullptr; g->dCpk64 = nullptr; g->dApk32 = nullptr; g->dCpk32 = nullptr;
     // (+2 all-zero tiles: the kernel's run-ahead operand loads stay in bounds)
-    std::vector<double> apk64((size_t)(n_tiles + 2) * KS * 64, 0.0), cpk64((size_t)(n_tiles + 2) * 16, -INFINITY);
-    std::vector<float> apk32(apk64.size(), 0.f), cpk32(cpk64.size(), -INFINITY);
+    std::vector<double> apk64((size_t)(n_tiles + 2) * KS * 64, 0.0), cpk64((size_t)(n_tiles + 2) * 16, GH_LSE_OFF64);
+    std::vector<float> apk32(apk64.size(), 0.f), cpk32(cpk64.size(), GH_LSE_OFF32);
     for (int t = 0; t < n_tiles; ++t)
         for (int j = 0; j < 16; ++j) {  // j = natural position inside the tile
             const int gp = t * 16 + j, s = gp / M_pad, m = gp % M_pad;
-            if (s >= S || m >= M) continue;  // padding component: weight 0 (C = -inf, P = 0)
+            if (s >= S || m >= M) continue;  // padding component: switched off (C = OFF, P = 0)
             const int go = s * M + m;
-            cpk64[gp] = g->hC[go];
-            cpk32[gp] = (float)g->hC[go];
+            // scaled log domain; a weight-0 component (C = -inf) gets the finite OFF constant, NaN stays NaN
+            const double c = g->hC[go];
+            cpk64[gp] = (c == -INFINITY) ? GH_LSE_OFF64 : std::max(c * GH_LSE_SCALE64, GH_LSE_OFF64);
+            cpk32[gp] = (c == -INFINITY) ? GH_LSE_OFF32 : (float)std::max(c * GH_LSE_SCALE32, (double)GH_LSE_OFF32);
             // accumulator row that makes lane group q = j/4 hold this component in register j%4:
             // f64 16x16x4: row = (lane>>4) + 4*reg  ->  row = j/4 + 4*(j%4); f32: row = 4*(lane>>4) + reg = j
             const int row64 = (j >> 2) + 4 * (j & 3), row32 = j;
@@ -66,8 +68,8 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
                 for (int kq = 0; kq < 4; ++kq) {
                     const int kk = 4 * ks + kq;
                     const double v = kk < KP ? g->hA[(size_t)go * KP + kk] : g->hB[(size_t)go * KP + kk - KP];
-                    apk64[((size_t)t * KS + ks) * 64 + kq * 16 + row64] = v;
-                    apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)v;
+                    apk64[((size_t)t * KS + ks) * 64 + kq * 16 + row64] = v * GH_LSE_SCALE64;
+                    apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)(v * GH_LSE_SCALE32);
                 }
         }
     std::vector<double> vmean(mean, mean + (size_t)G * D);
