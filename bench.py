@@ -95,6 +95,7 @@ class HipEvents:
         self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
 
     def new(self):
@@ -104,6 +105,10 @@ class HipEvents:
 
     def record(self, e, stream):
         assert self.hip.hipEventRecord(e, C.c_void_p(stream)) == 0
+
+    def wait(self, stream, e):
+        """Work submitted to `stream` after this call starts only when `e` has completed."""
+        assert self.hip.hipStreamWaitEvent(C.c_void_p(stream), e, 0) == 0
 
     def elapsed_ms(self, a, b):
         assert self.hip.hipEventSynchronize(b) == 0
@@ -156,8 +161,15 @@ def cpu_baseline(wl, n_utts=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight per GPU (one HIP stream + one host thread each): the host side of a step "
+                         "overlaps the other batch's kernels")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed pre-warmup: keep the GPU busy with the same step this long so that its clock governor "
+                         "reaches the sustained frequency (a cold MI355X runs ~1.9 GHz for the first few hundred ms, "
+                         "2.4 GHz afterwards: tools/wave_timeline.py); not part of --warmup / --steps")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -188,50 +200,105 @@ def main():
     red_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
 
     from sr.recognition import _hip
-    ctx = _hip.Context(dev)
     npdt = np.float64 if args.dtype == "f64" else np.float32
     wl = synth_workload(1002, args.utts, utt_seed=None if rank == 0 else 1002 + 7919 * rank)
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
     S = W * n
-    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
-    batch = _hip.Batch(ctx, feats=wl["X"], offsets=wl["off"], dtype=npdt)
-    lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
-    N_frames, U = batch.N, batch.U
-
     ev = HipEvents()
-    stream = ctx.stream
-    ll_ms = []
 
-    def step(timed):
-        if timed:
-            a, b = ev.new(), ev.new()
-            ev.record(a, stream)
-        batch.loglik(gmm, fetch=False)
-        if timed:
-            ev.record(b, stream)
-            ll_ms.append((a, b))
-        r = lat.viterbi(batch, want_path=False)
-        ec = r["end_cost_flat"].reshape(U, W)
-        return np.argmin(ec, axis=1)
+    class Lane:
+        """One in-flight batch: its own context (HIP stream, scratch, pinned buffers) and resident copies of the
+        model, the batch and the decoding graph.  `--inflight` lanes are driven by one host thread each, so the
+        host side of a step (result copy-back, arg-min, Python) overlaps the kernels of the other lane."""
+
+        def __init__(self):
+            self.ctx = _hip.Context(dev)
+            self.gmm = _hip.PackedGMM(self.ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D),
+                                      wl["w"].reshape(S, M))
+            self.batch = _hip.Batch(self.ctx, feats=wl["X"], offsets=wl["off"], dtype=npdt)
+            self.lat = _hip.Lattices(self.ctx, [stacked_graph(W, n, wl["trans"])])
+            self.ll_ms = []
+            self.decoded = None
+            self.untimed_done = ev.new()
+
+        def step(self, timed):
+            """One pass of the hot path over the batch: likelihoods, Viterbi over every word model, arg-min.
+            The likelihood kernels of different lanes are chained by events (each fills the whole GPU, so
+            overlapping two of them gains nothing and would blur the per-launch timing)."""
+            stream = self.ctx.stream
+            with chain_lock:
+                if chain["last"] is not None:
+                    ev.wait(stream, chain["last"])
+                if timed:
+                    a, b = ev.new(), ev.new()
+                    ev.record(a, stream)
+                else:
+                    b = self.untimed_done
+                self.batch.loglik(self.gmm, fetch=False)
+                ev.record(b, stream)
+                chain["last"] = b
+                if timed:
+                    self.ll_ms.append((a, b))
+            r = self.lat.viterbi(self.batch, want_path=False)
+            ec = r["end_cost_flat"].reshape(self.batch.U, W)
+            self.decoded = np.argmin(ec, axis=1)
+
+    import threading
+    chain_lock, chain = threading.Lock(), {"last": None}
+    lanes = [Lane() for _ in range(max(1, args.inflight))]
+    N_frames, U = lanes[0].batch.N, lanes[0].batch.U
+
+    def run_steps(count, timed, seconds=None):
+        """`count` steps in total (or as many as fit `seconds`), shared by the lanes' host threads."""
+        if len(lanes) == 1:
+            t0, k = time.perf_counter(), 0
+            while (k < count) if seconds is None else (time.perf_counter() - t0 < seconds):
+                lanes[0].step(timed)
+                k += 1
+            return
+        lock, state = threading.Lock(), {"next": 0, "err": None}
+        t_end = None if seconds is None else time.perf_counter() + seconds
+
+        def worker(lane):
+            try:
+                while True:
+                    with lock:
+                        k = state["next"]
+                        if (k >= count) if t_end is None else (time.perf_counter() >= t_end):
+                            return
+                        state["next"] = k + 1
+                    lane.step(timed)
+            except BaseException as e:  # surface a worker failure in the main thread
+                state["err"] = e
+        th = [threading.Thread(target=worker, args=(l,)) for l in lanes]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if state["err"] is not None:
+            raise state["err"]
 
     def fence():
-        ctx.sync()
+        for l in lanes:
+            l.ctx.sync()
         if have_torch_cuda:
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        ctx.sync()
+        for l in lanes:
+            l.ctx.sync()
         if have_torch_cuda:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        decoded = step(False)
+    run_steps(0, False, seconds=args.ramp_seconds)   # clock ramp, untimed (see --ramp-seconds)
+    run_steps(args.warmup, False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        decoded = step(True)
+    run_steps(args.steps, True)
     fence()
     dt = time.perf_counter() - t0
+    decoded = next(l.decoded for l in lanes if l.decoded is not None)
+    ll_ms = [p for l in lanes for p in l.ll_ms]
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -254,13 +321,13 @@ def main():
             "metric": "frame-state loglik/s + utterances/s Viterbi decode",
             "value": all_frames * S * args.steps / dt,
             "unit": "frame-state loglik/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_s": args.ramp_seconds,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 10-digit HMM, 5 states/digit, 8-mix GMM, 39-dim, "
                                    "%d utterances/GPU (%d frames on rank 0), isolated-word decode" % (U, N_frames),
-                       "states": S, "mixtures": M, "dim": D, "parallelism": "utterance-sharded x%d" % world},
+                       "states": S, "mixtures": M, "dim": D, "parallelism": "utterance-sharded x%d" % world, "batches_in_flight": len(lanes)},
             "utterances_per_s": all_utts * args.steps / dt,
             "frames_per_s": all_frames * args.steps / dt,
             "decode_accuracy": accuracy,

@@ -272,6 +272,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     const int lane = threadIdx.x;
     const int f = lane & 15, q = lane >> 4;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
+#ifdef GH_MF_TIMING  // diagnostic build (tools/wave_timeline.py): per-wave phase time stamps overwrite row n0 of the output
+    long long tk[5], tw[2];
+    tk[0] = clock64(); tw[0] = wall_clock64();
+#endif
     const int nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
     double* tab = reinterpret_cast<double*>(smem_raw + tab_off);  // exp / log tables (fp64 path)
     // Every load of the prologue is issued before the first wait (a load -> wait -> ds_write loop
@@ -316,6 +320,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         }
     }
     __syncthreads();
+#ifdef GH_MF_TIMING
+    tk[1] = clock64();
+#endif
 
     const int tiles_per_state = (MP <= 16) ? 1 : M_pad / 16;
     const int SC = (MP <= 16) ? chunk_tiles * (16 / (MP <= 16 ? MP : 16)) : chunk_tiles / tiles_per_state;
@@ -345,9 +352,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const T a = ring[ks % R];
+#ifdef GH_MF_NOMFMA  // diagnostic builds (tools/variant_bench.sh): loads + epilogue only / operands never refilled
+            if (ks % 8 == 0) { acc0[ks % 4] += a * b[0][ks]; acc1[ks % 4] += a * b[1][ks]; }
+            else asm volatile("" :: "v"(a));
+#else
             acc0 = Acc<T>::mfma(a, b[0][ks], acc0);
             acc1 = Acc<T>::mfma(a, b[1][ks], acc1);
+#endif
+#ifndef GH_MF_NOLOAD
             ring[ks % R] = ap[ks * 64];
+#endif
         }
         ap += KS * 64;
     };
@@ -378,6 +392,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 #define GH_MF_PIPE 1
 #endif
 #if GH_MF_PIPE
+#ifdef GH_MF_TIMING
+    tk[2] = clock64();
+#endif
     mfma_tile(0, p0, p1);
     for (int t = 1; t < n_tiles; ++t) {
         V acc0, acc1;
@@ -394,7 +411,19 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         p1 = acc1;
     }
     tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
+#ifdef GH_MF_TIMING
+    tk[3] = clock64();
+#endif
     flush();
+#ifdef GH_MF_TIMING
+    tk[4] = clock64(); tw[1] = wall_clock64();
+    if (lane == 0 && S >= 8) {
+        T* o = out + n0 * S;
+        for (int i = 0; i < 5; ++i) o[i] = (T)(double)(tk[i] - tk[0]);
+        o[5] = (T)(double)(tw[0] & 0xffffffffffll); o[6] = (T)(double)(tw[1] - tw[0]);
+        o[7] = (T)(double)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    }
+#endif
 #else
     for (int t = 0; t < n_tiles; ++t) {
         mfma_tile(t, p0, p1);

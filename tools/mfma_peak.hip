@@ -2,6 +2,7 @@
 // to price the likelihood kernel against a measured ceiling rather than the datasheet only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <int NACC>
@@ -43,9 +44,9 @@ double timeit(F launch) {
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms / 5 * 1e-3;
 }
-int main() {
+int main(int argc, char** argv) {
     void* buf; hipMalloc(&buf, 64 << 20);
-    const int iters = 20000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     for (int wpb : {64, 128, 256}) {       // waves per CU = blocks/CU * wpb/64
         for (int bpc : {4, 8}) {
             const int grid = 256 * bpc;
