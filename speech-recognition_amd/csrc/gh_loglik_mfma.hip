@@ -266,7 +266,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
                                                          const double* __restrict__ tables, int tab_off,
                                                          T* __restrict__ out) {
     typedef typename Acc<T>::type V;
-    constexpr int R = KS / 2;
+#ifndef GH_MF_RING32
+#define GH_MF_RING32 2
+#endif
+#ifndef GH_MF_RING64
+#define GH_MF_RING64 1
+#endif
+    constexpr int R = KS / (sizeof(T) == 4 ? GH_MF_RING32 : GH_MF_RING64);  // ring depth: half a tile (2) or a whole tile (1) of run-ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
     const int lane = threadIdx.x;

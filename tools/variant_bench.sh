@@ -14,7 +14,7 @@ else
   shift
   for v in "$@"; do
     for dt in f64 f32; do
-      GMMHMM_LIB=$PWD/tools/bin/libgmmhmm_$v.so timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --dtype $dt 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['dtype'], 'kernel_ms %.4f frac %.3f step_ms %.3f' % (d['roofline']['kernel_ms'], d['roofline']['frac'], d['ms_per_step']))"
+      GMMHMM_LIB=$PWD/tools/bin/libgmmhmm_$v.so timeout -k 10 200 python bench.py --no-cpu-baseline --inflight 1 --dtype $dt 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['dtype'], 'kernel_ms %.4f frac %.3f step_ms %.3f' % (d['roofline']['kernel_ms'], d['roofline']['frac'], d['ms_per_step']))"
     done
   done
 fi
