@@ -571,6 +571,53 @@ def build_state_sequences(n_states_per_word, word_trans, label_matrix):
 
 
 # -------------------------------------------------------------------------- A12
+def loop_grammar(word_transitions, n, word_penalty=0.0):
+    """N4: word LOOP grammar -- NOT in the reference (which only has the
+    exactly-K-words lattice of build_state_sequences); validated in tests as the minimum over K
+    of the reference-style K-layer decodes.
+
+    The reference's DP reads same-column origins only from rows already visited in this
+    column (decode.py:97-98,109-111), so a loop is expressible by ROW ORDER alone:
+        row 0                       non-emitting start (the reference's single start cell)
+        rows of states 1..n-1       of every word, word-major
+        one non-emitting LOOP row   collects every word's last state (same column, cost 0)
+        rows of state 0             of every word: from the start row (0), from the loop row
+                                    (word_penalty) -- both same-column hops -- and their self loop
+    A word end at frame c therefore reaches the next word's first state in the same column, which
+    scores frame c again: exactly the double emission of the K-layer lattice (SURVEY.md A6 quirk i).
+    Requires n >= 2 (a one-state word would be its own same-column ancestor).
+
+    Returns (is_nes [R], row_word [R] (-1 on non-emitting rows), row_local [R], trans [R,R], end_rows)."""
+    W = len(word_transitions)
+    assert n >= 2
+    R = 2 + W * n
+    loop_row = 1 + W * (n - 1)
+    row_word = np.full(R, -1, dtype=np.int64)
+    row_local = np.full(R, -1, dtype=np.int64)
+    row_of = np.empty((W, n), dtype=np.int64)
+    for w in range(W):
+        for i in range(1, n):
+            row_of[w, i] = 1 + w * (n - 1) + (i - 1)
+        row_of[w, 0] = loop_row + 1 + w
+    for w in range(W):
+        for i in range(n):
+            row_word[row_of[w, i]] = w
+            row_local[row_of[w, i]] = i
+    trans = np.full((R, R), np.inf)
+    ends = []
+    for w in range(W):
+        wt = np.asarray(word_transitions[w], dtype=np.float64)
+        for i in range(n):
+            for j in range(n):
+                if not np.isinf(wt[i, j]):
+                    trans[row_of[w, i], row_of[w, j]] = wt[i, j]
+        trans[row_of[w, 0], 0] = 0.0
+        trans[row_of[w, 0], loop_row] = word_penalty
+        trans[loop_row, row_of[w, n - 1]] = 0.0
+        ends.append(int(row_of[w, n - 1]))
+    return row_word < 0, row_word, row_local, trans, ends
+
+
 def path_to_words(path, is_nes, row_word):
     """main.py:59-67 (+ split_result :39-52): reversed row sequence -> drop
     consecutive duplicates -> first emitting row of every run between

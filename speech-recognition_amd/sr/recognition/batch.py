@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _hip
 from . import _pack
-from .continuous_speech import packed_lattice
+from .continuous_speech import packed_lattice, packed_loop_lattice
 
 __all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "path_to_words"]
 
@@ -79,17 +79,28 @@ def path_to_words(path, row_state, n_per_word):
 
 
 class ContinuousDecoder:
-    """Continuous-word decode through a K-layer lattice over all `models`
-    (main.py:35: build_state_sequences(models, [[0..W-1]] * K)), end points = last
-    layer's final states in the last column (main.py:60), then `path_to_words`."""
+    """Continuous-word decode over all `models`, then `path_to_words`.
 
-    def __init__(self, models, n_layers=7, device=None, dtype=np.float64):
+    grammar="layers": the reference's K-layer lattice (main.py:35: build_state_sequences(models,
+    [[0..W-1]] * K)) -- exactly `n_layers` words; end points = last layer's final states in the last
+    column (main.py:60).
+    grammar="loop": the word-loop grammar (`build_loop_grammar`) -- any number of
+    words, cost = min over K of the K-layer costs, on a graph of 2 + W*n rows instead of
+    1 + K*(W*n + 1)."""
+
+    def __init__(self, models, n_layers=7, device=None, dtype=np.float64, grammar="layers", word_penalty=0.0):
         self.ctx = _hip.default_context(device)
         self.dtype = dtype
         self.n, self.gmm = _stack_models(self.ctx, models)
         W = len(models)
-        graph, self.nes_rows = packed_lattice([m.transitions for m in models], self.n,
-                                              [list(range(W))] * n_layers)
+        wt = [m.transitions for m in models]
+        if grammar == "layers":
+            graph, self.nes_rows = packed_lattice(wt, self.n, [list(range(W))] * n_layers)
+        elif grammar == "loop":
+            graph, self.nes_rows = packed_loop_lattice(wt, self.n, word_penalty)
+        else:
+            raise ValueError("grammar must be 'layers' or 'loop', not %r" % (grammar,))
+        self.grammar = grammar
         self.row_state = graph["row_state"]
         self.lat = _hip.Lattices(self.ctx, [graph])
 

@@ -23,7 +23,7 @@ from .kmeans import kmeans
 from .hmm_state import GMM, NES, mahalanobis
 from .hmm import HMM
 
-__all__ = ["build_state_sequences", "continuous_train"]
+__all__ = ["build_state_sequences", "build_loop_grammar", "continuous_train"]
 
 
 def _layout(n_per_word, label_matrix):
@@ -90,6 +90,71 @@ def packed_lattice(word_transitions, n_per_word, label_matrix, state_base=None):
     return dict(row_state=row_state, arc_to=np.asarray(to, dtype=np.int32), arc_from=np.asarray(frm, dtype=np.int32),
                 arc_cost=np.asarray(cost, dtype=np.float64), start_rows=np.array([0], dtype=np.int32),
                 end_rows=np.asarray(ends, dtype=np.int32)), nes_rows
+
+
+def _loop_layout(W, n):
+    """Row bookkeeping of the word-loop grammar: (R, loop_row, row_of [W, n])."""
+    assert n >= 2, "a loop grammar needs words of at least two states"
+    loop_row = 1 + W * (n - 1)
+    row_of = np.empty((W, n), dtype=np.int64)
+    row_of[:, 1:] = 1 + np.arange(W)[:, None] * (n - 1) + np.arange(n - 1)[None, :]
+    row_of[:, 0] = loop_row + 1 + np.arange(W)
+    return 2 + W * n, loop_row, row_of
+
+
+def build_loop_grammar(hmms: List[HMM], word_penalty=0.0):
+    """Word LOOP grammar over `hmms` (the reference only has the exactly-K-words
+    lattice of `build_state_sequences`): any number of words, each followed by any word.
+
+    Same return convention as `build_state_sequences` -- (states [R], dense costs [R,R], end rows) --
+    and decodable by `decode_hmm_states` as is, because the loop is expressed by ROW ORDER: the DP
+    reads same-column origins only from rows it has already visited in the column
+    (decode.py:97-98,109-111), so rows are laid out as
+        0: non-emitting start | states 1..n-1 of every word | one non-emitting loop row |
+        state 0 of every word.
+    Word ends feed the loop row, the loop row (cost `word_penalty`) and the start row (cost 0) feed
+    the first states, all as same-column hops; a word boundary therefore scores its frame with both
+    words, exactly like the K-layer lattice, and the decode cost equals the minimum over K of the
+    K-layer decode costs."""
+    n = len(hmms[0].gmm_states)
+    W = len(hmms)
+    R, loop_row, row_of = _loop_layout(W, n)
+    trans = np.full((R, R), np.inf)
+    seq = [None] * R
+    seq[0], seq[loop_row] = NES(), NES()
+    ends = []
+    for w, word in enumerate(hmms):
+        assert n == len(word.gmm_states)
+        rows = row_of[w]
+        for i in range(n):
+            seq[rows[i]] = word.gmm_states[i]
+        trans[np.ix_(rows, rows)] = word.transitions
+        trans[rows[0], 0] = 0
+        trans[rows[0], loop_row] = word_penalty
+        trans[loop_row, rows[n - 1]] = 0
+        ends.append(int(rows[n - 1]))
+    return seq, trans, ends
+
+
+def packed_loop_lattice(word_transitions, n_per_word, word_penalty=0.0, state_base=None):
+    """`build_loop_grammar` as a graph dict for `_hip.Lattices` (row_state = word * n + state)."""
+    W = len(word_transitions)
+    R, loop_row, row_of = _loop_layout(W, n_per_word)
+    row_state = np.full(R, -1, dtype=np.int32)
+    to, frm, cost, ends = [], [], [], []
+    for w in range(W):
+        base = w * n_per_word if state_base is None else state_base[w]
+        rows = row_of[w]
+        row_state[rows] = base + np.arange(n_per_word)
+        wt = np.asarray(word_transitions[w])
+        i, j = np.nonzero(~np.isinf(wt))
+        to += list(rows[i]) + [rows[0], rows[0], loop_row]
+        frm += list(rows[j]) + [0, loop_row, rows[n_per_word - 1]]
+        cost += list(wt[i, j]) + [0.0, float(word_penalty), 0.0]
+        ends.append(int(rows[n_per_word - 1]))
+    return dict(row_state=row_state, arc_to=np.asarray(to, dtype=np.int32), arc_from=np.asarray(frm, dtype=np.int32),
+                arc_cost=np.asarray(cost, dtype=np.float64), start_rows=np.array([0], dtype=np.int32),
+                end_rows=np.asarray(ends, dtype=np.int32)), [0, loop_row]
 
 
 def forced_alignments(frames, models, label_seqs):

@@ -33,6 +33,7 @@ test_mahalanobis = G.test_mahalanobis
 test_decode_hmm_states_isolated = G.test_decode_hmm_states_isolated
 test_build_state_sequences_and_lattice_decode = G.test_build_state_sequences_and_lattice_decode
 test_decode_edges = G.test_decode_edges
+test_loop_grammar_decode = G.test_loop_grammar_decode
 test_dtw = G.test_dtw
 test_gmm_em = G.test_gmm_em
 test_kmeans = G.test_kmeans

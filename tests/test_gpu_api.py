@@ -131,6 +131,37 @@ def test_build_state_sequences_and_lattice_decode(R):
     np.testing.assert_array_equal(path, g["forced_path"])
 
 
+@pytest.mark.parametrize("pen", [0, 1])
+def test_loop_grammar_decode(R, pen):
+    """N4: `build_loop_grammar` lays the rows out so that the reference's decode_hmm_states decodes a word loop;
+    golden G14 holds what the reference computes on that graph."""
+    g = load_golden("G14_loop_grammar")
+    W, n = g["means"].shape[:2]
+    hmms = [make_hmm(R, g["means"][i], g["vars"][i], g["w"][i], g["word_trans"]) for i in range(W)]
+    from sr.recognition.batch import ContinuousDecoder, path_to_words
+    pp = "p%d_" % pen
+    penalty = float(g[pp + "penalty"])
+    seq, trans, ends = R.build_loop_grammar(hmms, word_penalty=penalty)
+    ref_t = np.full_like(trans, np.inf)
+    ref_t[g[pp + "arc_to"], g[pp + "arc_from"]] = g[pp + "arc_cost"]
+    np.testing.assert_array_equal(trans, ref_t)
+    assert list(ends) == list(g[pp + "ends"])
+    assert all((type(s) is R.NES) == (wd < 0) for s, wd in zip(seq, g[pp + "row_word"]))
+    dec = ContinuousDecoder(hmms, grammar="loop", word_penalty=penalty)
+    xs = [g[pp + "x%d" % u] for u in range(int(g["n_utts"]))]
+    for u, x in enumerate(xs):
+        with quiet():
+            costs, path = R.decode_hmm_states(x, seq, trans, end_points=[[e, -1] for e in ends])
+        assert_costs(costs, g[pp + "costs%d" % u])
+        np.testing.assert_array_equal(path, g[pp + "path%d" % u])
+        assert path_to_words(path, dec.row_state, n) == list(g[pp + "digits%d" % u])
+        if pen == 0:
+            np.testing.assert_allclose(min(costs[e, -1] for e in ends), np.min(g["layer_costs%d" % u]), rtol=1e-12)
+    assert dec.decode(xs) == [list(g[pp + "digits%d" % u]) for u in range(len(xs))]
+    with pytest.raises(ValueError):
+        ContinuousDecoder(hmms, grammar="ring")
+
+
 def test_decode_edges(R):
     g = load_golden("G6_decode_edges")
     h = make_hmm(R, g["means"], g["vars"], g["w"], g["trans"])

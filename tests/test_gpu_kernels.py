@@ -145,6 +145,85 @@ def test_viterbi_lattice_golden(hip, ctx, dtype):
         assert O.path_to_words(r["paths"][u], rw < 0, rw) == list(g[p + "digits"])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_viterbi_loop_grammar_golden(hip, ctx, dtype):
+    """G14 (N4): word-loop graph decoded by the reference; costs, bit-exact paths, digits."""
+    from sr.recognition.continuous_speech import packed_loop_lattice
+    g = load_golden("G14_loop_grammar")
+    means, vars_, w, wt = g["means"], g["vars"], g["w"], g["word_trans"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    U = int(g["n_utts"])
+    graphs = [packed_loop_lattice([wt] * W, n, float(g["p%d_penalty" % pen]))[0] for pen in (0, 1)]
+    for pen in (0, 1):
+        rw, rs = g["p%d_row_word" % pen], g["p%d_row_state" % pen]
+        np.testing.assert_array_equal(graphs[pen]["row_state"], np.where(rw < 0, -1, rw * n + rs))
+    lat = hip.Lattices(ctx, graphs)
+    b = hip.Batch(ctx, [g["p%d_x%d" % (pen, u)] for pen in (0, 1) for u in range(U)], dtype=dtype)
+    b.loglik(gmm, fetch=False)
+    r = lat.viterbi(b, utt_lattice=np.repeat([0, 1], U), want_costs=True)
+    for pen in (0, 1):
+        rw = g["p%d_row_word" % pen]
+        for u in range(U):
+            k = pen * U + u
+            ref = g["p%d_costs%d" % (pen, u)]
+            fin = ~np.isinf(ref)
+            np.testing.assert_array_equal(np.isinf(r["costs"][k]), ~fin)
+            np.testing.assert_allclose(r["costs"][k][fin], ref[fin], rtol=1e-10 if dtype == np.float64 else 1e-5)
+            np.testing.assert_array_equal(r["paths"][k], g["p%d_path%d" % (pen, u)])
+            assert O.path_to_words(r["paths"][k], rw < 0, rw) == list(g["p%d_digits%d" % (pen, u)])
+            if pen == 0 and dtype == np.float64:
+                np.testing.assert_allclose(np.min(r["end_cost"][k]), np.min(g["layer_costs%d" % u]), rtol=1e-12)
+
+
+def test_viterbi_loop_equals_min_over_layers_at_scale(hip, ctx):
+    """Size-independent property of N4: on every utterance the word-loop cost equals the minimum over K of the
+    exactly-K-words lattice costs (same kernels, same likelihoods), and the decoded word string equals that of
+    the best K."""
+    from sr.recognition.continuous_speech import packed_loop_lattice, packed_lattice
+    from sr.recognition.batch import path_to_words
+    rng = np.random.default_rng(77)
+    W, n, M, D, U, KMAX = 10, 5, 2, 13, 240, 6
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = -np.log(0.8) if i < n - 1 else 0.0
+        if i < n - 1:
+            trans[i + 1, i] = -np.log(0.2)
+    xs, truth = [], []
+    for u in range(U):
+        words = rng.integers(0, W, size=rng.integers(1, 6))
+        segs = []
+        for wd in words:
+            T = int(rng.integers(8, 14))
+            st = np.minimum(np.arange(T) * n // T, n - 1)
+            comp = rng.integers(0, M, size=T)
+            segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(T, D)))
+        xs.append(np.concatenate(segs))
+        truth.append([int(v) for v in words])
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    wt = [trans] * W
+    loop_graph = packed_loop_lattice(wt, n)[0]
+    graphs = [loop_graph] + [packed_lattice(wt, n, [list(range(W))] * K)[0] for K in range(1, KMAX + 1)]
+    lat = hip.Lattices(ctx, graphs)
+    res = [lat.viterbi(b, utt_lattice=np.full(U, k, dtype=np.int32)) for k in range(len(graphs))]
+    loop_cost = np.array([np.min(e) for e in res[0]["end_cost"]])
+    layer_cost = np.array([[np.min(e) for e in res[k]["end_cost"]] for k in range(1, KMAX + 1)])   # [K, U]
+    np.testing.assert_array_equal(loop_cost, layer_cost.min(axis=0))
+    best_k = layer_cost.argmin(axis=0)
+    n_right = 0
+    for u in range(U):
+        got = path_to_words(res[0]["paths"][u], loop_graph["row_state"], n)
+        ref = path_to_words(res[1 + best_k[u]]["paths"][u], graphs[1 + best_k[u]]["row_state"], n)
+        assert got == ref and len(got) == best_k[u] + 1
+        n_right += got == truth[u]
+    assert n_right >= 0.9 * U   # well-separated synthetic words: the loop decode recovers the spoken string
+
+
 def test_viterbi_edges_golden(hip, ctx):
     g = load_golden("G6_decode_edges")
     means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]

@@ -118,6 +118,45 @@ def test_G4_forced_alignment_lattice():
     assert O.path_to_words(path, nes, rw) == list(g["forced_digits"]) == labels
 
 
+@pytest.mark.parametrize("pen", [0, 1])
+def test_G14_loop_grammar(pen):
+    """N4: the word-loop graph (expressed by row order) decoded by the REFERENCE: the oracle reproduces its
+    costs / path / digits, and the loop cost equals the minimum of the reference's K-layer costs."""
+    g = load_golden("G14_loop_grammar")
+    means, vars_, w, wt = g["means"], g["vars"], g["w"], g["word_trans"]
+    W, n = means.shape[:2]
+    pp = "p%d_" % pen
+    nes, rw, rs, trans, ends = O.loop_grammar([wt] * W, n, float(g[pp + "penalty"]))
+    np.testing.assert_array_equal(rw, g[pp + "row_word"])
+    np.testing.assert_array_equal(rs, g[pp + "row_state"])
+    np.testing.assert_array_equal(ends, g[pp + "ends"])
+    np.testing.assert_array_equal(trans, _dense(len(rw), g[pp + "arc_to"], g[pp + "arc_from"], g[pp + "arc_cost"]))
+    states = [None if nes[r] else (means[rw[r], rs[r]], vars_[rw[r], rs[r]], w[rw[r], rs[r]]) for r in range(len(rw))]
+    for u in range(int(g["n_utts"])):
+        x = g[pp + "x%d" % u]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            costs, path = O.decode_states(O.emission_matrix(x, states), nes, trans, end_points=[[e, -1] for e in ends])
+        close(costs, g[pp + "costs%d" % u])
+        np.testing.assert_array_equal(path, g[pp + "path%d" % u])
+        assert O.path_to_words(path, nes, rw) == list(g[pp + "digits%d" % u])
+        if pen == 0:
+            ref = g[pp + "costs%d" % u]
+            assert min(ref[e, -1] for e in ends) == np.min(g["layer_costs%d" % u])          # reference vs reference
+            # the oracle's own K-layer lattices agree too
+            kc = []
+            for K in range(1, int(g["Kmax"]) + 1):
+                rwk, rsk, nk, tk, ek = O.build_state_sequences(n, [wt] * W, [list(range(W))] * K)
+                stk = [None if nk[r] else (means[rwk[r], rsk[r]], vars_[rwk[r], rsk[r]], w[rwk[r], rsk[r]])
+                       for r in range(len(rwk))]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    ck, _ = O.decode_states(O.emission_matrix(x, stk), nk, tk, end_points=[[e, -1] for e in ek])
+                kc.append(min(ck[e, -1] for e in ek))
+            close(kc, g["layer_costs%d" % u])
+            assert min(costs[e, -1] for e in ends) == min(kc)
+
+
 def test_G6_decode_edges():
     g = load_golden("G6_decode_edges")
     means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]

@@ -446,6 +446,65 @@ def g13(R):
 
 ALL["G13"] = g13
 
+def g14(R):
+    """N4: word LOOP grammar run through the reference's OWN decode_hmm_states.  The reference has no loop
+    grammar builder, but its DP reads same-column origins only from rows already visited in the column
+    (decode.py:97-98,109-111), so a loop is expressible by row order: [start NES | states 1..n-1 of every
+    word | loop NES | state 0 of every word].  Stored: the graph, the reference's costs / path / digits on
+    it, and the reference's K-layer end costs for K = 1..6 (the loop cost must equal their minimum)."""
+    rng = np.random.default_rng(141)
+    W, n, M, D = 4, 3, 2, 6
+    means, vars_, w, trans = synth_model(rng, W, n, M, D)
+    hmms = [make_hmm(R, means[i], vars_[i], w[i], trans) for i in range(W)]
+    Rr = 2 + W * n
+    loop_row = 1 + W * (n - 1)
+    row_of = np.empty((W, n), dtype=np.int64)
+    for wd in range(W):
+        row_of[wd, 1:] = 1 + wd * (n - 1) + np.arange(n - 1)
+        row_of[wd, 0] = loop_row + 1 + wd
+    ids = {g.id: (wi, si) for wi, h in enumerate(hmms) for si, g in enumerate(h.gmm_states)}
+    out = dict(means=means, vars=vars_, w=w, word_trans=trans, n_utts=np.array(3), Kmax=np.array(6))
+    for pen_i, penalty in enumerate((0.0, 2.5)):
+        tr = np.full((Rr, Rr), np.inf)
+        seq = [None] * Rr
+        seq[0], seq[loop_row] = R.NES(), R.NES()
+        ends = []
+        for wd, h in enumerate(hmms):
+            rows = row_of[wd]
+            for i in range(n):
+                seq[rows[i]] = h.gmm_states[i]
+            tr[np.ix_(rows, rows)] = h.transitions
+            tr[rows[0], 0] = 0
+            tr[rows[0], loop_row] = penalty
+            tr[loop_row, rows[n - 1]] = 0
+            ends.append(int(rows[n - 1]))
+        fi, fj = np.nonzero(~np.isinf(tr))
+        row_word = np.array([-1 if type(s) is R.NES else ids[s.id][0] for s in seq])
+        row_state = np.array([-1 if type(s) is R.NES else ids[s.id][1] for s in seq])
+        pp = "p%d_" % pen_i
+        out.update({pp + "penalty": np.array(penalty), pp + "arc_to": fi, pp + "arc_from": fj, pp + "arc_cost": tr[fi, fj],
+                    pp + "row_word": row_word, pp + "row_state": row_state, pp + "ends": np.array(ends)})
+        urng = np.random.default_rng(1410)
+        for u, nw in enumerate((1, 3, 5)):
+            words = urng.integers(0, W, size=nw)
+            x = synth_utt(urng, means, vars_, words, 7, 11)
+            with quiet():
+                costs, path = R.decode_hmm_states(x, seq, tr, end_points=[[e, -1] for e in ends])
+            out.update({pp + "x%d" % u: x, pp + "words%d" % u: words, pp + "costs%d" % u: costs, pp + "path%d" % u: path,
+                        pp + "digits%d" % u: np.array(reference_postprocess(R, path, seq, hmms))})
+            if pen_i == 0:   # the reference's exactly-K-words lattices on the same utterance
+                kc = []
+                for K in range(1, 7):
+                    sk, tk, ek = R.build_state_sequences(hmms, [list(range(W))] * K)
+                    with quiet():
+                        ck, _ = R.decode_hmm_states(x, sk, tk, end_points=[[e, -1] for e in ek])
+                    kc.append(min(ck[e, -1] for e in ek))
+                out["layer_costs%d" % u] = np.array(kc)
+    save("G14_loop_grammar", **out)
+
+
+ALL["G14"] = g14
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")

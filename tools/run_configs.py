@@ -19,7 +19,7 @@ for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
     sys.path.insert(0, p)
 import bench  # noqa: E402
 from sr.recognition import _hip  # noqa: E402
-from sr.recognition.continuous_speech import packed_lattice  # noqa: E402
+from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice  # noqa: E402
 from sr.recognition.batch import path_to_words  # noqa: E402
 
 
@@ -84,6 +84,17 @@ def continuous(U, K=7, W=10, n=5, M=8, D=39):
     print(json.dumps(dict(config="C5", utts=U, frames=N, lattice_rows=R, layers=K, loglik_ms=t_ll * 1e3,
                           viterbi_ms=t_vit * 1e3, utterances_per_s=U / (t_ll + t_vit),
                           dp_cells_per_s=N * R / t_vit, sequence_accuracy=acc)), flush=True)
+    # the same utterances through the word-loop grammar (N4): 2 + W*n rows, any number of words
+    lgraph, _ = packed_loop_lattice([trans] * W, n)
+    llat = _hip.Lattices(ctx, [lgraph])
+    t_loop, rl = timeit(lambda: llat.viterbi(b, want_path=True), reps=3)
+    ldec = [path_to_words(p, lgraph["row_state"], n) for p in rl["paths"]]
+    lacc = float(np.mean([d == list(wd) for d, wd in zip(ldec, words)]))
+    same = float(np.mean([np.min(a) <= np.min(c) for a, c in zip(rl["end_cost"], r["end_cost"])]))
+    print(json.dumps(dict(config="C5 loop grammar", utts=U, frames=N, lattice_rows=len(lgraph["row_state"]),
+                          viterbi_ms=t_loop * 1e3, utterances_per_s=U / (t_ll + t_loop),
+                          dp_cells_per_s=N * len(lgraph["row_state"]) / t_loop, sequence_accuracy=lacc,
+                          loop_cost_le_K_layer_cost=same)), flush=True)
 
 
 if __name__ == "__main__":
