@@ -118,12 +118,13 @@ class HipEvents:
 
 
 def profiled_traffic(dtype, n_frames):
-    """HBM bytes per launch of the likelihood kernel from the committed PMC passes
-    (profiles/r01b_pmc_traffic_f64.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-    runs of this same command); None when no profile matches this dtype / workload size."""
-    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_%s.json" % dtype)
+    """HBM bytes per launch of the likelihood kernel from the committed PMC passes (the newest
+    profiles/*_pmc_traffic_<dtype>.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this
+    same command, folded by tools/pmc_traffic.py); None when no profile matches this dtype / workload size."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % dtype)))
     try:
-        d = json.load(open(path))["kernels"]
+        d = json.load(open(paths[-1]))["kernels"]
         k = next(v for name, v in d.items() if name.startswith("loglik"))
         esz = 8 if dtype == "f64" else 4
         if abs(k["algorithmic_bytes_per_launch"] - n_frames * esz * (39 + 50)) > 1e-3 * k["algorithmic_bytes_per_launch"]:
