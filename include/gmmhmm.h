@@ -90,6 +90,24 @@ void gh_batch_destroy(gh_batch* b);
 int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
                                  const double* ceps_host, const int64_t* utt_offsets, gh_batch** out);
 int gh_batch_fetch_features(gh_ctx* ctx, const gh_batch* b, void* out_host);
+/* N3 front-end, first half: mfcc_features (sr/feature/feature.py:43-82) without the wav-file read:
+ * pre-emphasis 0.97 (:45-46) -> frames of int(frame_size*rate) samples every int(frame_stride*rate)
+ * (segment, :7-22; ceil(len/step) frames, zero-extended) -> centred zero padding to the next power of
+ * two (zero_padding, :25-40) -> Hamming window over the PADDED frame (:52) -> |rfft(., 512)|^2 / 512
+ * (:54-56) -> 40 triangular mel filters from low_freq to high_freq (<= 0: rate/2) (:58-75) -> log10, 0
+ * replaced by eps (:76-78) -> DCT-II (ortho), coefficients 1..13 (:80-81).
+ * samples: U utterances back to back, sample_fmt 0 = int16, 1 = float32, 2 = float64; sample_off[U+1];
+ * frame_off[U+1] must hold the reference's frame counts (ceil(len/step)) -- gh_mfcc_frames computes one.
+ * out_fbank [N,40] / out_mfcc [N,13] (fp64, either may be NULL) receive what mfcc_features returns.
+ * gh_batch_create_from_pcm chains the cepstra on the device into gh_batch_create_from_cepstra's
+ * kernels (delta, delta-delta, standardise; same `mode`): PCM in, resident 39-dim batch out. */
+int64_t gh_mfcc_frames(int64_t n_samples, int sample_rate, double frame_stride);
+int gh_mfcc(gh_ctx* ctx, int sample_fmt, int sample_rate, double frame_size, double frame_stride, double low_freq,
+            double high_freq, int64_t U, const void* samples, const int64_t* sample_off, const int64_t* frame_off,
+            double* out_fbank, double* out_mfcc);
+int gh_batch_create_from_pcm(gh_ctx* ctx, gh_dtype dtype, int mode, int sample_fmt, int sample_rate, double frame_size,
+                             double frame_stride, double low_freq, double high_freq, int64_t U, const void* samples,
+                             const int64_t* sample_off, const int64_t* frame_off, gh_batch** out);
 
 /* ------------------------------------------------ A3: batched GMM.evaluate
  * nll[n, s] = -log sum_m w[s,m] N(x_n; mean[s,m], diag var[s,m])  for every

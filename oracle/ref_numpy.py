@@ -84,6 +84,42 @@ def delta_feature(feat):
     return d
 
 
+def mfcc_features_signal(signal, sample_rate, frame_size=0.025, frame_stride=0.01, low_freq=80, high_freq=None):
+    """mfcc_features (sr/feature/feature.py:43-82) on an in-memory signal (the reference reads a wav file, :44):
+    pre-emphasis :45-46, segment :7-22, zero_padding :25-40, Hamming over the padded frame :52, power
+    spectrum of a 512-point rfft :54-56, 40 mel filters :58-75, log10 with eps :76-78, ortho DCT-II 1..13 :80-81.
+    Returns (filter_banks [T,40], mfcc [T,13])."""
+    from scipy.fftpack import dct
+    signal = np.asarray(signal)
+    emphasized = np.append(signal[0], signal[1:] - 0.97 * signal[:-1])
+    flen, fstep = int(frame_size * sample_rate), int(frame_stride * sample_rate)
+    num_frames = int(np.ceil(emphasized.size / fstep))          # `slen > frame_len` (seconds!) is always true
+    final_len = (num_frames - 1) * fstep + flen
+    pad_sig = np.concatenate([emphasized, np.zeros(max(0, final_len - emphasized.size))])
+    frames = np.stack([pad_sig[i * fstep:i * fstep + flen] for i in range(num_frames)])
+    width = 1 << (flen - 1).bit_length()
+    left = (width - flen) // 2
+    padded = np.zeros((num_frames, width))
+    padded[:, left:left + flen] = frames
+    padded *= np.hamming(width)
+    NFFT = 512
+    pow_frames = (1.0 / NFFT) * np.absolute(np.fft.rfft(padded, NFFT)) ** 2
+    nfilt = 40
+    high_freq = high_freq or sample_rate / 2
+    mel = np.linspace(2595 * np.log10(1 + low_freq / 700), 2595 * np.log10(1 + high_freq / 700), nfilt + 2)
+    bins = np.floor((NFFT + 1) * (700 * (10 ** (mel / 2595) - 1)) / sample_rate)
+    fbank = np.zeros((nfilt, NFFT // 2 + 1))
+    for m in range(1, nfilt + 1):
+        lo, ce, hi = int(bins[m - 1]), int(bins[m]), int(bins[m + 1])
+        for k in range(lo, ce):
+            fbank[m - 1, k] = (k - bins[m - 1]) / (bins[m] - bins[m - 1])
+        for k in range(ce, hi):
+            fbank[m - 1, k] = (bins[m + 1] - k) / (bins[m + 1] - bins[m])
+    fb = np.dot(pow_frames, fbank.T)
+    fb = np.log10(np.where(fb == 0, np.finfo(float).eps, fb))
+    return fb, dct(fb, type=2, axis=1, norm="ortho")[:, 1:14]
+
+
 def standardize(data):
     """feature.py:85-88: per-column (x - mean) / std over the frames of one utterance
     (population std, np.std's default ddof = 0)."""

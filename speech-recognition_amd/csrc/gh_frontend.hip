@@ -6,6 +6,7 @@
 // composed by load_wav_as_mfcc (sr/core.py:41-44).  fp64 arithmetic, HBM-bound.
 #include "gh_internal.h"
 #include "gh_host.h"
+#include <functional>
 
 namespace {
 
@@ -79,15 +80,17 @@ __global__ void convert_kernel(const double* __restrict__ in, int64_t n, OT* __r
 
 }  // namespace
 
-extern "C" int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
-                                            const double* ceps_host, const int64_t* utt_offsets, gh_batch** out) {
-    GH_REQUIRE(ctx && out && utt_offsets && (ceps_host || N == 0), "gh_batch_create_from_cepstra: NULL argument");
-    GH_REQUIRE(C > 0, "gh_batch_create_from_cepstra: C=%d", C);
-    GH_REQUIRE(mode >= 0 && mode <= 2, "gh_batch_create_from_cepstra: mode=%d", mode);
+// tail shared by the cepstra and the PCM entry points: d_ceps [N,C] (device) -> resident batch.
+// `fill(d_ceps, stream)` enqueues whatever produces the cepstra (an upload or the MFCC kernel).
+int gh_batch_from_device_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
+                                 const int64_t* utt_offsets, size_t extra_scratch, void** extra,
+                                 const std::function<hipError_t(double*, hipStream_t)>& fill, const char* who,
+                                 gh_batch** out) {
+    GH_REQUIRE(C > 0, "%s: C=%d", who, C);
+    GH_REQUIRE(mode >= 0 && mode <= 2, "%s: mode=%d", who, mode);
     for (int64_t u = 0; mode != 2 && u < U; ++u)
         GH_REQUIRE(utt_offsets[u + 1] - utt_offsets[u] >= 2,
-                   "gh_batch_create_from_cepstra: utterance %lld has fewer than 2 frames (delta_feature indexes feat[i + 1])",
-                   (long long)u);
+                   "%s: utterance %lld has fewer than 2 frames (delta_feature indexes feat[i + 1])", who, (long long)u);
     GH_HIP(hipSetDevice(ctx->device));
     const int D3 = mode == 2 ? C : 3 * C;  // mode 2 standardises the C input columns as they are
     const size_t esz = dtype == GH_F64 ? 8 : 4;
@@ -100,13 +103,16 @@ extern "C" int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mod
     b->owns_feats = true;
     if (N > 0) {
         double *d_ceps, *d_raw;
+        char* d_extra = nullptr;
         Carver cv;
         cv.add(&d_ceps, (size_t)N * C);
         cv.add(&d_raw, (size_t)N * D3);
+        if (extra_scratch) cv.add(&d_extra, extra_scratch);
         rc = cv.commit(ctx);
         if (rc) { gh_batch_destroy(b); return rc; }
+        if (extra) *extra = d_extra;
         hipStream_t st = ctx->stream;
-        hipError_t e = hipMemcpyAsync(d_ceps, ceps_host, (size_t)N * C * 8, hipMemcpyHostToDevice, st);
+        hipError_t e = fill(d_ceps, st);
         if (e == hipSuccess) {
             const double* src = d_ceps;  // what gets standardised / copied
             if (mode != 2) {
@@ -125,13 +131,24 @@ extern "C" int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mod
         }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
-            gh_set_error("gh_batch_create_from_cepstra: %s", hipGetErrorString(e));
+            gh_set_error("%s: %s", who, hipGetErrorString(e));
             gh_batch_destroy(b);
             return GH_ERR_HIP;
         }
     }
     *out = b;
     return GH_OK;
+}
+
+extern "C" int gh_batch_create_from_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
+                                            const double* ceps_host, const int64_t* utt_offsets, gh_batch** out) {
+    GH_REQUIRE(ctx && out && utt_offsets && (ceps_host || N == 0), "gh_batch_create_from_cepstra: NULL argument");
+    return gh_batch_from_device_cepstra(
+        ctx, dtype, mode, C, N, U, utt_offsets, 0, nullptr,
+        [&](double* d_ceps, hipStream_t st) {
+            return hipMemcpyAsync(d_ceps, ceps_host, (size_t)N * C * 8, hipMemcpyHostToDevice, st);
+        },
+        "gh_batch_create_from_cepstra", out);
 }
 
 extern "C" int gh_batch_fetch_features(gh_ctx* ctx, const gh_batch* b, void* out_host) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <utility>
 #include <vector>
@@ -35,3 +36,9 @@ template <typename T> inline int upload(T** dst, const std::vector<T>& src) {
 }
 
 
+
+// gh_frontend.hip: cepstra already on the device (scratch) -> resident batch (delta, delta-delta, standardise)
+int gh_batch_from_device_cepstra(gh_ctx* ctx, gh_dtype dtype, int mode, int C, int64_t N, int64_t U,
+                                 const int64_t* utt_offsets, size_t extra_scratch, void** extra,
+                                 const std::function<hipError_t(double*, hipStream_t)>& fill, const char* who,
+                                 gh_batch** out);

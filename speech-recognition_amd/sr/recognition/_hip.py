@@ -41,6 +41,12 @@ SIGNATURES = {
     "gh_batch_create_from_cepstra": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _c_f64p, _c_i64p,
                                                C.POINTER(C.c_void_p)]),
     "gh_batch_fetch_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gh_mfcc_frames": (C.c_int64, [C.c_int64, C.c_int, C.c_double]),
+    "gh_mfcc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                          C.c_void_p, _c_i64p, _c_i64p, _c_f64p, _c_f64p]),
+    "gh_batch_create_from_pcm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_int64, C.c_void_p, _c_i64p, _c_i64p,
+                                           C.POINTER(C.c_void_p)]),
     "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
     "gh_component_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _c_f64p, _c_f64p]),
@@ -189,13 +195,64 @@ class PackedGMM:
             pass
 
 
+_PCM_FMT = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+
+def pack_pcm(ctx, signals, sample_rate, mfcc_params=None):
+    """Concatenate audio signals for gh_mfcc / gh_batch_create_from_pcm.  int16 / float32 / float64 travel as they
+    are, anything else as float64.  mfcc_params = (frame_size, frame_stride, low_freq, high_freq), defaults of
+    mfcc_features (feature.py:43): 0.025, 0.01, 80, None.  Returns (samples, fmt, sample_off, frame_off, params)."""
+    fs, st, lo, hi = mfcc_params if mfcc_params is not None else (0.025, 0.01, 80, None)
+    prm = (float(fs), float(st), float(lo), 0.0 if hi is None else float(hi))
+    sigs = [np.asarray(x).reshape(-1) for x in signals]
+    dt = sigs[0].dtype if sigs and all(x.dtype == sigs[0].dtype for x in sigs) and sigs[0].dtype in _PCM_FMT \
+        else np.dtype(np.float64)
+    s_off = np.zeros(len(sigs) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in sigs], out=s_off[1:])
+    for x in sigs:
+        if len(x) == 0:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")  # signal[0], feature.py:46
+    samples = np.ascontiguousarray(np.concatenate(sigs).astype(dt, copy=False)) if sigs else np.zeros(0, dtype=dt)
+    f_off = np.zeros(len(sigs) + 1, dtype=np.int64)
+    np.cumsum([ctx.lib.gh_mfcc_frames(len(x), int(sample_rate), prm[1]) for x in sigs], out=f_off[1:])
+    return samples, _PCM_FMT[dt], s_off, f_off, prm
+
+
+def mfcc(ctx, signals, sample_rate=16000, mfcc_params=None):
+    """mfcc_features (feature.py:43-82) for a list of signals: ([T_u,40] log10 filterbank energies, [T_u,13] cepstra)."""
+    samples, fmt, s_off, f_off, prm = pack_pcm(ctx, signals, sample_rate, mfcc_params)
+    N = int(f_off[-1])
+    fb, mf = np.empty((N, 40)), np.empty((N, 13))
+    _check(ctx.lib, ctx.lib.gh_mfcc(ctx.h, fmt, int(sample_rate), prm[0], prm[1], prm[2], prm[3], len(s_off) - 1,
+                                    samples.ctypes.data_as(C.c_void_p), _ptr(s_off, _c_i64p), _ptr(f_off, _c_i64p),
+                                    _ptr(fb, _c_f64p), _ptr(mf, _c_f64p)))
+    U = len(s_off) - 1
+    return ([fb[f_off[u]:f_off[u + 1]] for u in range(U)], [mf[f_off[u]:f_off[u + 1]] for u in range(U)])
+
+
 class Batch:
     """Ragged batch of utterances resident in HBM (gh_batch)."""
 
-    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0):
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0,
+                 pcm=None, sample_rate=16000, mfcc_params=None):
         self.ctx = ctx
         self.np_dtype = np.dtype(dtype)
         assert self.np_dtype in (np.dtype(np.float32), np.dtype(np.float64))
+        if pcm is not None:  # N3 front-end from audio samples: MFCC -> [ceps | delta | delta-delta] -> standardise
+            samples, fmt, s_off, f_off, prm = pack_pcm(ctx, pcm, sample_rate, mfcc_params)
+            for n in np.diff(f_off):
+                if n < 2 and frontend_mode != 2:
+                    raise IndexError("index 1 is out of bounds for axis 0 with size %d" % n)  # core.py:16
+            self.offsets = f_off
+            self.N, self.D, self.U = int(f_off[-1]), (13 if frontend_mode == 2 else 39), len(f_off) - 1
+            h = C.c_void_p()
+            _check(ctx.lib, ctx.lib.gh_batch_create_from_pcm(
+                ctx.h, GH_F64 if self.np_dtype == np.float64 else GH_F32, int(frontend_mode), fmt, int(sample_rate),
+                prm[0], prm[1], prm[2], prm[3], self.U, samples.ctypes.data_as(C.c_void_p), _ptr(s_off, _c_i64p),
+                _ptr(f_off, _c_i64p), C.byref(h)))
+            self.h = h
+            self.S = None
+            return
         if cepstra is not None:  # N3 front-end: [ceps | delta | delta-delta], standardised per utterance, on the GPU
             lens = [len(u) for u in cepstra]
             for n in lens:

@@ -51,9 +51,12 @@ class PackedGMM:
 
 
 class Batch:
-    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0):
+    def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0,
+                 pcm=None, sample_rate=16000, mfcc_params=None):
         self.ctx = ctx
         self.np_dtype = np.dtype(dtype)
+        if pcm is not None:
+            cepstra = mfcc(ctx, pcm, sample_rate, mfcc_params)[1]
         if cepstra is not None:  # N3 front-end through the oracle
             outs = []
             for c in cepstra:
@@ -219,6 +222,19 @@ class Lattices:
         pass
 
 
+def mfcc(ctx, signals, sample_rate=16000, mfcc_params=None):
+    fs, st, lo, hi = mfcc_params if mfcc_params is not None else (0.025, 0.01, 80, None)
+    fbs, mfs = [], []
+    for x in signals:
+        x = np.asarray(x).reshape(-1)
+        if len(x) == 0:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        fb, mf = O.mfcc_features_signal(x, sample_rate, fs, st, lo, hi)
+        fbs.append(fb)
+        mfs.append(mf)
+    return fbs, mfs
+
+
 def distance_matrix(ctx, x, y, var=None):
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
     v = None if var is None else np.asarray(var, dtype=np.float64).reshape(-1, y.shape[1])
@@ -230,5 +246,5 @@ def distance_matrix(ctx, x, y, var=None):
 
 
 def install(monkeypatch, hip_module):
-    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context"):
+    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc"):
         monkeypatch.setattr(hip_module, name, globals()[name])

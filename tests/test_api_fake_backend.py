@@ -34,6 +34,7 @@ test_decode_hmm_states_isolated = G.test_decode_hmm_states_isolated
 test_build_state_sequences_and_lattice_decode = G.test_build_state_sequences_and_lattice_decode
 test_decode_edges = G.test_decode_edges
 test_loop_grammar_decode = G.test_loop_grammar_decode
+test_mfcc_features_matches_reference = G.test_mfcc_features_matches_reference
 test_dtw = G.test_dtw
 test_gmm_em = G.test_gmm_em
 test_kmeans = G.test_kmeans

@@ -391,3 +391,31 @@ def test_feature_stack_matches_reference(R):
         for i, f in zip(range(1, n), b.features()):
             np.testing.assert_allclose(f, g["feats%d" % i], rtol=tol, atol=tol)
         b.close()
+
+
+def test_mfcc_features_matches_reference(R, tmp_path):
+    """N3: sr.feature.mfcc_features (wav path in, like the reference) and the batched / resident entry points."""
+    from scipy.io import wavfile
+    from sr.feature import mfcc_features, mfcc_from_signals, features_from_signals
+    g = load_golden("G15_mfcc")
+    n = int(g["n"])
+    for i in (4, 5, 7, 8):
+        path = str(tmp_path / ("c%d.wav" % i))
+        wavfile.write(path, int(g["rate%d" % i]), g["signal%d" % i])
+        fb, mf = mfcc_features(path)
+        np.testing.assert_allclose(fb, g["fbank%d" % i], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mf, g["mfcc%d" % i], rtol=1e-9, atol=1e-9)
+    idx = [i for i in range(n) if int(g["rate%d" % i]) == 16000]
+    fbs, mfs = mfcc_from_signals([g["signal%d" % i] for i in idx], 16000)
+    for i, fb, mf in zip(idx, fbs, mfs):
+        np.testing.assert_allclose(fb, g["fbank%d" % i], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mf, g["mfcc%d" % i], rtol=1e-9, atol=1e-9)
+    # audio -> resident 39-dim batch == reference MFCC -> delta -> delta-delta -> standardize
+    from sr.core import stack_features
+    long = [i for i in idx if len(g["mfcc%d" % i]) >= 3 and np.all(np.std(g["mfcc%d" % i], axis=0) > 0)]
+    b = features_from_signals([g["signal%d" % i] for i in long], 16000)
+    for i, f in zip(long, b.features()):
+        np.testing.assert_allclose(f, stack_features(g["mfcc%d" % i]), rtol=1e-7, atol=1e-7)
+    b.close()
+    with pytest.raises(IndexError):
+        mfcc_from_signals([np.zeros(0, dtype=np.int16)])

@@ -497,3 +497,47 @@ def test_viterbi_chain_kernel_skip_arcs_and_stacking(hip, ctx):
         assert r["best_end"][u] == bk
         if np.isfinite(best):
             np.testing.assert_array_equal(r["paths"][u] - [bk * n, 0], ref_end[bk][1].reshape(-1, 2))
+
+
+def test_mfcc_golden(hip, ctx):
+    """G15 (N3): PCM -> log mel filterbank -> cepstra, against the reference's mfcc_features; all sample formats."""
+    g = load_golden("G15_mfcc")
+    n = int(g["n"])
+    idx16 = [i for i in range(n) if int(g["rate%d" % i]) == 16000]
+    for dt, tol in ((np.int16, 1e-9), (np.float64, 1e-9), (np.float32, 1e-9)):   # int16 values are exact in all three
+        fbs, mfs = hip.mfcc(ctx, [g["signal%d" % i].astype(dt) for i in idx16], 16000)
+        for i, fb, mf in zip(idx16, fbs, mfs):
+            assert fb.shape == g["fbank%d" % i].shape and mf.shape == g["mfcc%d" % i].shape
+            np.testing.assert_allclose(fb, g["fbank%d" % i], rtol=tol, atol=tol)
+            np.testing.assert_allclose(mf, g["mfcc%d" % i], rtol=tol, atol=tol)
+    i8 = next(i for i in range(n) if int(g["rate%d" % i]) == 8000)
+    fbs, mfs = hip.mfcc(ctx, [g["signal%d" % i8]], 8000)
+    np.testing.assert_allclose(fbs[0], g["fbank%d" % i8], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(mfs[0], g["mfcc%d" % i8], rtol=1e-9, atol=1e-9)
+    with pytest.raises(hip.BackendError):           # 48 kHz: 1200-sample frames exceed the reference's NFFT = 512
+        hip.mfcc(ctx, [np.zeros(4800, dtype=np.int16)], 48000)
+
+
+def test_mfcc_at_scale_matches_oracle(hip, ctx):
+    """10 s of audio in ragged utterances: every frame against the numpy restatement; then the resident chain
+    PCM -> 39-dim standardised features against oracle MFCC -> delta -> delta-delta -> standardize."""
+    rng = np.random.default_rng(15)
+    sigs = []
+    for n in rng.integers(2000, 24000, size=12):
+        t = np.arange(n) / 16000.0
+        f0 = rng.uniform(100, 3000)
+        sigs.append(np.round(5000 * np.sin(2 * np.pi * f0 * t * (1 + 0.3 * t)) + 1500 * rng.normal(size=n)).astype(np.int16))
+    fbs, mfs = hip.mfcc(ctx, sigs, 16000)
+    for x, fb, mf in zip(sigs, fbs, mfs):
+        rfb, rmf = O.mfcc_features_signal(x, 16000)
+        np.testing.assert_allclose(fb, rfb, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mf, rmf, rtol=1e-9, atol=1e-9)
+    for dt, tol in ((np.float64, 1e-7), (np.float32, 2e-5)):
+        b = hip.Batch(ctx, pcm=sigs, sample_rate=16000, dtype=dt)
+        assert b.D == 39 and b.U == len(sigs)
+        for x, f in zip(sigs, b.features()):
+            c = O.mfcc_features_signal(x, 16000)[1]
+            d = O.delta_feature(c)
+            ref = O.standardize(np.concatenate([c, d, O.delta_feature(d)], axis=1))
+            np.testing.assert_allclose(f, ref, rtol=tol, atol=tol)
+        b.close()

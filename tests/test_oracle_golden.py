@@ -374,3 +374,12 @@ def test_G13_feature_stack():
         close(O.stack_features(ceps), g["feats%d" % i], rtol=1e-12, atol=1e-13)
     with pytest.raises(IndexError):
         O.delta_feature(g["ceps0"][:1])
+
+
+def test_G15_mfcc():
+    """N3: mfcc_features of the reference on int16 wav files (edge lengths, 8 kHz, silence): bit-exact restatement."""
+    g = load_golden("G15_mfcc")
+    for i in range(int(g["n"])):
+        fb, mf = O.mfcc_features_signal(g["signal%d" % i], int(g["rate%d" % i]))
+        np.testing.assert_array_equal(fb, g["fbank%d" % i])
+        np.testing.assert_array_equal(mf, g["mfcc%d" % i])

@@ -505,6 +505,37 @@ def g14(R):
 
 ALL["G14"] = g14
 
+def g15(R):
+    """N3, first half: the reference's own mfcc_features (sr/feature/feature.py:43-82) on int16 wav files written
+    to a temporary directory: lengths around the frame step / frame length edges, tones + noise, one silent file
+    (log10 of eps) and one 8 kHz file (200-sample frames padded to 256, rfft zero-extends to 512)."""
+    import tempfile
+    from scipy.io import wavfile
+    mfcc_features = importlib.import_module("sr.feature").mfcc_features
+    rng = np.random.default_rng(151)
+    cases = [(16000, 1), (16000, 159), (16000, 160), (16000, 161), (16000, 400), (16000, 4001), (16000, 16000),
+             (8000, 3000)]
+    out = dict(n=np.array(len(cases) + 1))
+    with tempfile.TemporaryDirectory() as td:
+        for i, (sr_, n) in enumerate(cases):
+            t = np.arange(n) / sr_
+            sig = 6000 * np.sin(2 * np.pi * 440 * t) + 3000 * np.sin(2 * np.pi * 1870 * t + 1.0) + 800 * rng.normal(size=n)
+            sig = np.clip(np.round(sig), -32768, 32767).astype(np.int16)
+            path = os.path.join(td, "c%d.wav" % i)
+            wavfile.write(path, sr_, sig)
+            fb, mf = mfcc_features(path)
+            out.update({"rate%d" % i: np.array(sr_), "signal%d" % i: sig, "fbank%d" % i: fb, "mfcc%d" % i: mf})
+        i = len(cases)
+        sig = np.zeros(800, dtype=np.int16)
+        path = os.path.join(td, "silent.wav")
+        wavfile.write(path, 16000, sig)
+        fb, mf = mfcc_features(path)
+        out.update({"rate%d" % i: np.array(16000), "signal%d" % i: sig, "fbank%d" % i: fb, "mfcc%d" % i: mf})
+    save("G15_mfcc", **out)
+
+
+ALL["G15"] = g15
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
