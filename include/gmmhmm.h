@@ -175,6 +175,17 @@ int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
                double* out_costs, const int64_t* costs_off /*[U+1]*/);
 /* upper bound on the number of path cells of an utterance of T frames on graph l */
 int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T);
+/* A6 + A12 in one call: the same decode, but the path stays on the device and only the DECODED LABEL
+ * SEQUENCE comes back -- main.py:59-67 / split_result (main.py:39-52): reverse the path to start -> end
+ * order, and for every maximal run of emitting rows between non-emitting ones report the label of its
+ * first row.  row_label [sum_l R_l] (graphs concatenated like row_state): label of each row, < 0 on
+ * non-emitting rows (e.g. the word index).  out_labels: utterance u at label_off[u], capacity
+ * label_off[u+1]-label_off[u] (gh_viterbi_path_cap/2 + 1 always suffices); out_n_labels [U].
+ * A continuous decode of 2000 x 317 frames returns ~60 KB instead of 15 MB of (row, col) pairs. */
+int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
+                      const int32_t* utt_lattice /*[U] or NULL*/, const int32_t* row_label,
+                      double* out_end_cost, int32_t* out_best_end,
+                      int32_t* out_labels, const int64_t* label_off /*[U+1]*/, int32_t* out_n_labels);
 
 /* ------------------------------------------------------------------ A5: dtw
  * Template DP of every utterance of an fp64 batch against the n template rows y

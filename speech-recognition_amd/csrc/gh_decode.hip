@@ -6,10 +6,50 @@
 #include "gh_fb.h"
 
 // ------------------------------------------------------------------ viterbi
-extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
-                          double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
-                          const int64_t* path_off, int32_t* out_path_len, double* out_costs,
-                          const int64_t* costs_off) {
+namespace {
+
+// A12 on the device: one wave per utterance walks its path (stored end -> start) in start -> end order, 64
+// cells at a time; a cell opens a run when its row is emitting and the cell before it is not (or it is the
+// first); the run's label is written at the position given by a ballot prefix count.
+__global__ __launch_bounds__(64) void path_labels_kernel(const int32_t* __restrict__ path, const int64_t* __restrict__ path_off,
+                                                         const int32_t* __restrict__ path_len, const int32_t* __restrict__ utt_lat,
+                                                         const gh_lattices::desc* __restrict__ descs,
+                                                         const int32_t* __restrict__ row_label,
+                                                         const int64_t* __restrict__ label_off, int32_t* __restrict__ labels,
+                                                         int32_t* __restrict__ n_labels, int* __restrict__ flag) {
+    const int64_t u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int len = path_len[u];
+    const int32_t* p = path + 2 * path_off[u];
+    const int32_t* lab = row_label + descs[utt_lat ? utt_lat[u] : 0].row_base;
+    const int64_t cap = label_off[u + 1] - label_off[u];
+    int32_t* out = labels + label_off[u];
+    int count = 0, carry = -1;  // label of the cell before this chunk (-1: start / non-emitting)
+    for (int base = 0; base < len; base += 64) {
+        const int i = base + lane;
+        const int l = (i < len) ? lab[p[2 * (int64_t)(len - 1 - i)]] : -1;
+        int prev = __shfl_up(l, 1);
+        if (lane == 0) prev = carry;
+        const bool open = l >= 0 && prev < 0;
+        const unsigned long long m = __ballot(open);
+        const int pos = count + __popcll(m & ((1ull << lane) - 1));
+        if (open) {
+            if (pos < cap) out[pos] = l;
+            else atomicOr(flag, 8);
+        }
+        count += __popcll(m);
+        carry = __shfl(l, 63);
+    }
+    if (lane == 0) n_labels[u] = count;
+}
+
+}  // namespace
+
+static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                        double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
+                        const int64_t* path_off, int32_t* out_path_len, double* out_costs,
+                        const int64_t* costs_off, const int32_t* row_label, int32_t* out_labels,
+                        const int64_t* label_off, int32_t* out_n_labels) {
     GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
     GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
@@ -18,7 +58,19 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
-    const bool want_path = out_path != nullptr;
+    const bool want_labels = out_labels != nullptr;
+    std::vector<int64_t> own_path_off;  // label mode: the path lives on the device only, capacities are ours
+    if (want_labels && !out_path) {
+        own_path_off.assign(U + 1, 0);
+        for (int64_t u = 0; u < U; ++u) {
+            const int l = utt_lattice ? utt_lattice[u] : 0;
+            GH_REQUIRE(l >= 0 && l < lat->L, "gh_viterbi: utt_lattice[%lld]=%d out of range", (long long)u, l);
+            const int64_t T = b->offsets[u + 1] - b->offsets[u];
+            own_path_off[u + 1] = own_path_off[u] + (T > 1 ? T * lat->lat[l].nlev : 0);
+        }
+        path_off = own_path_off.data();
+    }
+    const bool want_path = out_path != nullptr || want_labels;
     for (int l = 0; l < lat->L; ++l)
         GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
                    lat->lat[l].max_state, S);
@@ -96,6 +148,14 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
     if (want_bp) cv.add(&d_bp, bp_max);
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+    int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
+    int64_t* d_labeloff = nullptr;
+    int64_t n_rows_total = 0;
+    for (auto& lh : lat->lat) n_rows_total = std::max<int64_t>(n_rows_total, lh.row_base + lh.R);
+    if (want_labels) {
+        cv.add(&d_rowlabel, n_rows_total); cv.add(&d_labeloff, U + 1);
+        cv.add(&d_nlabels, U); cv.add(&d_labels, label_off[U]);   // [n_labels | labels] back to back: one copy
+    }
     int rc = cv.commit(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
@@ -105,6 +165,10 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
     if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (out_costs) GH_HIP(hipMemcpyAsync(d_costsoff, costs_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (want_labels) {
+        GH_HIP(hipMemcpyAsync(d_rowlabel, row_label, n_rows_total * 4, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemcpyAsync(d_labeloff, label_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    }
 
     a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_start = lat->d_row_start;
     a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
@@ -177,8 +241,15 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     char* pin;
     rc = gh_pinned(ctx, small_bytes, (void**)&pin);
     if (rc) return rc;
+    if (want_labels) {
+        hipLaunchKernelGGL(path_labels_kernel, dim3((unsigned)U), dim3(64), 0, st, d_path, d_pathoff, d_pathlen, d_uttlat,
+                           lat->d_desc, d_rowlabel, d_labeloff, d_labels, d_nlabels, d_flag2);
+        GH_HIP(hipGetLastError());
+        GH_HIP(hipMemcpyAsync(out_n_labels, d_nlabels, U * 4, hipMemcpyDeviceToHost, st));
+        if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
+    }
     GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
-    if (want_path) {
+    if (out_path) {
         GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
         GH_HIP(hipMemcpyAsync(out_path_len, d_pathlen, U * 4, hipMemcpyDeviceToHost, st));
     }
@@ -199,7 +270,27 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
         gh_set_error("gh_viterbi: back-trace reached a cell without predecessor");
         return GH_ERR_INVALID;
     }
+    if (flag & 8) {
+        gh_set_error("gh_viterbi_labels: label capacity of an utterance too small");
+        return GH_ERR_INVALID;
+    }
     return GH_OK;
+}
+
+extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                          double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
+                          const int64_t* path_off, int32_t* out_path_len, double* out_costs,
+                          const int64_t* costs_off) {
+    return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, out_path, path_off, out_path_len, out_costs,
+                        costs_off, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                                 const int32_t* row_label, double* out_end_cost, int32_t* out_best_end,
+                                 int32_t* out_labels, const int64_t* label_off, int32_t* out_n_labels) {
+    GH_REQUIRE(row_label && out_labels && label_off && out_n_labels, "gh_viterbi_labels: NULL argument");
+    return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        row_label, out_labels, label_off, out_n_labels);
 }
 
 // ---------------------------------------------------------------------- dtw

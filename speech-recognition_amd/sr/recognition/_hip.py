@@ -58,6 +58,8 @@ SIGNATURES = {
     "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
                              _c_i32p, _c_f64p, _c_i64p]),
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
+    "gh_viterbi_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, _c_f64p, _c_i32p, _c_i32p,
+                                    _c_i64p, _c_i32p]),
     "gh_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f64p,
                          _c_f64p, _c_i32p, _c_i32p]),
     "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
@@ -448,6 +450,34 @@ class Lattices:
             out["costs"] = [costs[costs_off[u]:costs_off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u]))
                             for u in range(U)]
         return out
+
+    def viterbi_labels(self, batch, row_label, utt_lattice=None):
+        """A6 + A12 in one call: decode, keep the path on the device, return the decoded label sequences
+        (main.py:59-67: first row of every emitting run between non-emitting rows).  row_label: one int32 array per
+        graph (label per row, < 0 on non-emitting rows) or a single array when there is one graph.
+        Returns dict(labels [list of int32 arrays], best_end [U], end_cost_flat, end_off)."""
+        lib, U = self.ctx.lib, batch.U
+        lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
+        lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
+        if isinstance(row_label, np.ndarray) and row_label.ndim == 1 and self.L == 1:
+            row_label = [row_label]
+        rl = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.int32).reshape(-1) for r in row_label]))
+        assert len(rl) == int(np.sum(self.R)), "row_label must give one label per graph row"
+        T = batch.lengths
+        n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
+        end_off = np.concatenate([[0], np.cumsum(n_end)])
+        end_cost = np.empty(int(end_off[-1]), dtype=np.float64)
+        best_end = np.empty(U, dtype=np.int32)
+        nlev = np.array([self.path_cap(l, 1) for l in range(self.L)], dtype=np.int64)[lidx]
+        cap = np.where(T > 1, T * nlev // 2 + 1, 0)
+        label_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.int64)
+        labels = np.empty(int(label_off[-1]), dtype=np.int32)
+        n_labels = np.empty(U, dtype=np.int32)
+        _check(lib, lib.gh_viterbi_labels(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(rl, _c_i32p),
+                                          _ptr(end_cost, _c_f64p), _ptr(best_end, _c_i32p), _ptr(labels, _c_i32p),
+                                          _ptr(label_off, _c_i64p), _ptr(n_labels, _c_i32p)))
+        return dict(labels=[labels[label_off[u]:label_off[u] + n_labels[u]] for u in range(U)], best_end=best_end,
+                    end_off=end_off, end_cost_flat=end_cost)
 
     def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True):
         """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].

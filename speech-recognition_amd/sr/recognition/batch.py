@@ -104,11 +104,17 @@ class ContinuousDecoder:
         self.row_state = graph["row_state"]
         self.lat = _hip.Lattices(self.ctx, [graph])
 
-    def decode_batch(self, batch):
+    def decode_batch(self, batch, want_path=False):
+        """Word-index lists of every utterance (+ the raw result dict).  By default the paths stay on the device
+        and only the decoded word sequences come back (gh_viterbi_labels); want_path=True also returns the
+        reference-style (row, column) paths in `r["paths"]` and derives the words from them on the host."""
         batch.loglik(self.gmm, fetch=False)
-        r = self.lat.viterbi(batch, want_path=True)
-        words = [path_to_words(p, self.row_state, self.n) for p in r["paths"]]
-        return words, r
+        if want_path:
+            r = self.lat.viterbi(batch, want_path=True)
+            return [path_to_words(p, self.row_state, self.n) for p in r["paths"]], r
+        row_word = np.where(self.row_state >= 0, self.row_state // self.n, -1).astype(np.int32)
+        r = self.lat.viterbi_labels(batch, row_word)
+        return [[int(w) for w in l] for l in r["labels"]], r
 
     def decode(self, xs):
         """xs: list of [T_u, D] arrays -> list of word-index lists."""

@@ -218,6 +218,17 @@ class Lattices:
         out["end_cost_flat"] = np.concatenate(out["end_cost"]) if out["end_cost"] else np.zeros(0)
         return out
 
+    def viterbi_labels(self, batch, row_label, utt_lattice=None):
+        if isinstance(row_label, np.ndarray) and row_label.ndim == 1 and self.L == 1:
+            row_label = [row_label]
+        r = self.viterbi(batch, utt_lattice=utt_lattice, want_path=True)
+        lidx = np.zeros(batch.U, dtype=int) if utt_lattice is None else np.asarray(utt_lattice, dtype=int)
+        labels = []
+        for u, p in enumerate(r["paths"]):
+            rl = np.asarray(row_label[lidx[u]])
+            labels.append(np.array(O.path_to_words(p, rl < 0, rl), dtype=np.int32) if len(p) else np.zeros(0, dtype=np.int32))
+        return dict(labels=labels, best_end=r["best_end"], end_cost_flat=r["end_cost_flat"])
+
     def close(self):
         pass
 

@@ -215,6 +215,16 @@ def test_viterbi_loop_equals_min_over_layers_at_scale(hip, ctx):
     layer_cost = np.array([[np.min(e) for e in res[k]["end_cost"]] for k in range(1, KMAX + 1)])   # [K, U]
     np.testing.assert_array_equal(loop_cost, layer_cost.min(axis=0))
     best_k = layer_cost.argmin(axis=0)
+    # A12 on the device: the label sequences of gh_viterbi_labels equal path_to_words of the returned paths
+    for k in (0, 3, KMAX):
+        rw = np.where(graphs[k]["row_state"] >= 0, graphs[k]["row_state"] // n, -1)
+        full = [np.zeros(0, dtype=np.int32)] * len(graphs)
+        full = [np.where(g_["row_state"] >= 0, g_["row_state"] // n, -1) for g_ in graphs]
+        rl = lat.viterbi_labels(b, full, utt_lattice=np.full(U, k, dtype=np.int32))
+        np.testing.assert_array_equal(rl["best_end"], res[k]["best_end"])
+        np.testing.assert_array_equal(rl["end_cost_flat"], res[k]["end_cost_flat"])
+        for u in range(U):
+            assert [int(v) for v in rl["labels"][u]] == path_to_words(res[k]["paths"][u], graphs[k]["row_state"], n)
     n_right = 0
     for u in range(U):
         got = path_to_words(res[0]["paths"][u], loop_graph["row_state"], n)

@@ -90,11 +90,17 @@ def continuous(U, K=7, W=10, n=5, M=8, D=39):
     t_loop, rl = timeit(lambda: llat.viterbi(b, want_path=True), reps=3)
     ldec = [path_to_words(p, lgraph["row_state"], n) for p in rl["paths"]]
     lacc = float(np.mean([d == list(wd) for d, wd in zip(ldec, words)]))
+    row_word = np.where(lgraph["row_state"] >= 0, lgraph["row_state"] // n, -1).astype(np.int32)
+    t_lab, rlab = timeit(lambda: llat.viterbi_labels(b, row_word), reps=3)
+    lab_same = all([int(v) for v in a] == d for a, d in zip(rlab["labels"], ldec))
+    row_word_k = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+    t_labk, rlabk = timeit(lambda: lat.viterbi_labels(b, row_word_k), reps=3)
     same = float(np.mean([np.min(a) <= np.min(c) for a, c in zip(rl["end_cost"], r["end_cost"])]))
     print(json.dumps(dict(config="C5 loop grammar", utts=U, frames=N, lattice_rows=len(lgraph["row_state"]),
                           viterbi_ms=t_loop * 1e3, utterances_per_s=U / (t_ll + t_loop),
                           dp_cells_per_s=N * len(lgraph["row_state"]) / t_loop, sequence_accuracy=lacc,
-                          loop_cost_le_K_layer_cost=same)), flush=True)
+                          loop_cost_le_K_layer_cost=same, labels_only_ms=t_lab * 1e3, labels_equal_path_to_words=lab_same,
+                          labels_only_utterances_per_s=U / (t_ll + t_lab), K_layer_labels_only_ms=t_labk * 1e3)), flush=True)
 
 
 if __name__ == "__main__":
