@@ -223,6 +223,10 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
         a.arc_cap = (max_arcs + 1) & ~1;
         lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+        // back-trace: 2 KB path buffer + as many back-pointer columns as fit (at least 8)
+        if (want_path) lds = std::max(lds, (size_t)2048 + 16 + 32 + (size_t)8 * lat->max_R * 2);
+        lds = (lds + 15) & ~size_t(15);
+        a.lds_bytes = (int)lds;
     } else {
         a.em_chunk = 1;
         lds = ((size_t)2 * a.r_pad + S) * sizeof(double);

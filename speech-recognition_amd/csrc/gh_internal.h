@@ -27,6 +27,10 @@ void gh_set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 
+// lean Viterbi kernel: rows with up to this many arcs keep them in registers (one lane per row); rows with more
+// (non-emitting rows collecting every word end) get 16 lanes and an LDS-resident arc list
+#define GH_LEAN_NARROW_ARCS 3
+
 // Scaled log domain of the MFMA likelihood kernel (gh_loglik_mfma.hip): the packed operands
 // Apk / Cpk carry K * (log-density terms), K = 128/ln2 (fp64) or 1/ln2 (fp32); a component that
 // is switched off (weight 0, mixture padding) carries the finite constant OFF instead of -inf.

@@ -114,7 +114,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int r = 0; r < R; ++r) lp[level[r] + 1]++;
         int max_level_rows = 0;
         for (int k = 0; k < nlev; ++k) { max_level_rows = std::max(max_level_rows, lp[k + 1]); lp[k + 1] += lp[k]; }
-        // inside a level: rows with <= 2 arcs first, then the wide rows (the lean kernel gives those
+        // inside a level: rows with <= GH_LEAN_NARROW_ARCS arcs first, then the wide rows (the lean kernel gives those
         // 16 lanes each); ascending row index inside both groups
         h_narrow.resize(lev_base + nlev + 1, 0);
         int lean_lanes = 0;
@@ -122,7 +122,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             std::vector<int> fill(lp, lp + nlev), nwide(nlev, 0);
             for (int pass = 0; pass < 2; ++pass)
                 for (int r = 0; r < R; ++r) {
-                    const bool wide = ptr[r + 1] - ptr[r] > 2;
+                    const bool wide = ptr[r + 1] - ptr[r] > GH_LEAN_NARROW_ARCS;
                     if (wide != (pass == 1)) continue;
                     h_order[r0 + fill[level[r]]++] = r;
                     if (wide) nwide[level[r]]++; else h_narrow[lev_base + level[r]]++;

@@ -4,7 +4,7 @@
 // gh_viterbi.hip (reference: decode_hmm_states, sr/recognition/decode.py:80-146); everything a
 // lane needs per column is precomputed ONCE into registers so that the per-column work of a
 // row is ~20 instructions:
-//   * two register arcs per row (cost + 32-bit LDS byte addresses for even and odd columns; a
+//   * up to three register arcs per row (cost + 32-bit LDS byte addresses for even and odd columns; a
 //     missing / dead arc is padded with cost +inf -- it can never win the strict '<');
 //   * rows with more arcs (non-emitting rows collecting all word ends) get 16 lanes each: the
 //     lanes scan the LDS-resident arc list in parallel and a DPP row reduction (value, then
@@ -28,6 +28,13 @@ __device__ __forceinline__ double& lds_at(char* smem, unsigned off) { return *re
 template <int K> __device__ __forceinline__ int row_shl(int v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x100 | K, 0xF, 0xF, false);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL
+// store to be acknowledged (vmcnt(0)); with three barriers per column the fire-and-forget back-pointer stores
+// then cost a memory round trip each (K = 7 lattice: 1.6 -> 2.9 ms).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int K> __device__ __forceinline__ void min_step(double& best, int& idx) {
     const int lo = row_shl<K>(__double2loint(best)), hi = row_shl<K>(__double2hiint(best));
     const int oi = row_shl<K>(idx);
@@ -37,8 +44,11 @@ template <int K> __device__ __forceinline__ void min_step(double& best, int& idx
     idx = take ? oi : idx;
 }
 
-template <typename ET, bool WANT_PATH, bool WANT_COSTS, int NL>
-__global__ void viterbi_lean_kernel(gh_vit_args a) {
+// MAXB = largest block the instantiation is launched with: without it the compiler budgets registers for 1024
+// lanes (128 VGPRs per lane) and, once the three levels' row descriptors no longer fit, leaves those arrays
+// in scratch memory -- every column then reads its descriptors from global memory (measured: 0.5 -> 2.2 ms).
+template <typename ET, bool WANT_PATH, bool WANT_COSTS, int NL, int MAXB>
+__global__ __launch_bounds__(MAXB) void viterbi_lean_kernel(gh_vit_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_bi;
     __shared__ int s_state[4];
@@ -89,10 +99,10 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
     int f_r[NL], f_na[NL], f_p0[NL];
     bool f_start[NL];
     unsigned f_em[NL];           // byte offset of the row's emission inside an emission vector
-    unsigned f_a0[NL], f_a1[NL]; // LDS byte address of arc 0 / 1 at EVEN columns (prev = colA, cur = colB)
-    int f_d0[NL], f_d1[NL];      // what to add at odd columns
-    double f_c0[NL], f_c1[NL];
-    uint16_t f_b0[NL], f_b1[NL];
+    unsigned f_a0[NL], f_a1[NL], f_a2[NL]; // LDS byte address of arc 0 / 1 / 2 at EVEN columns (prev = colA, cur = colB)
+    int f_d0[NL], f_d1[NL], f_d2[NL];      // what to add at odd columns
+    double f_c0[NL], f_c1[NL], f_c2[NL];
+    int f_b0[NL], f_b1[NL], f_b2[NL];      // back-pointer codes (32-bit: with uint16_t the arrays end up in scratch memory)
     // wide rows (> 2 arcs): lane group g = tid / 16 owns wide row g of the level, lane j = tid % 16 its arcs j, j+16, ..
     int w_r[NL], w_p0[NL], w_na[NL];
     unsigned w_em[NL];
@@ -102,8 +112,9 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
         const int n_narrow = level_narrow[lev];
         const int i = level_ptr[lev] + tid;
         f_r[lev] = -1; f_na[lev] = 0; f_p0[lev] = 0; f_start[lev] = false; f_em[lev] = (unsigned)S * 8u;
-        f_a0[lev] = 0; f_a1[lev] = 0; f_d0[lev] = 0; f_d1[lev] = 0; f_c0[lev] = INF; f_c1[lev] = INF;
-        f_b0[lev] = BP_NONE; f_b1[lev] = BP_NONE;
+        f_a0[lev] = 0; f_a1[lev] = 0; f_a2[lev] = 0; f_d0[lev] = 0; f_d1[lev] = 0; f_d2[lev] = 0;
+        f_c0[lev] = INF; f_c1[lev] = INF; f_c2[lev] = INF;
+        f_b0[lev] = BP_NONE; f_b1[lev] = BP_NONE; f_b2[lev] = BP_NONE;
         w_r[lev] = -1; w_p0[lev] = 0; w_na[lev] = 0; w_em[lev] = (unsigned)S * 8u; w_start[lev] = false;
         {
             const int iw = level_ptr[lev] + n_narrow + (tid >> 4);
@@ -133,7 +144,7 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
                 f_c0[lev] = (w & GH_ARC_DEAD) ? INF : pred_cost[p0];
                 f_a0[lev] = (same ? COLB : 0u) + o * 8u;
                 f_d0[lev] = same ? -(int)COLB : (int)COLB;
-                f_b0[lev] = (uint16_t)(o | (same ? 0x8000u : 0u));
+                f_b0[lev] = (int)(o | (same ? 0x8000u : 0u));
             }
             if (na >= 2) {
                 const uint32_t w = pred_row[p0 + 1];
@@ -142,7 +153,16 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
                 f_c1[lev] = (w & GH_ARC_DEAD) ? INF : pred_cost[p0 + 1];
                 f_a1[lev] = (same ? COLB : 0u) + o * 8u;
                 f_d1[lev] = same ? -(int)COLB : (int)COLB;
-                f_b1[lev] = (uint16_t)(o | (same ? 0x8000u : 0u));
+                f_b1[lev] = (int)(o | (same ? 0x8000u : 0u));
+            }
+            if (na >= 3) {
+                const uint32_t w = pred_row[p0 + 2];
+                const unsigned o = w & GH_ARC_ROW;
+                const bool same = (w & GH_ARC_SAME) != 0;
+                f_c2[lev] = (w & GH_ARC_DEAD) ? INF : pred_cost[p0 + 2];
+                f_a2[lev] = (same ? COLB : 0u) + o * 8u;
+                f_d2[lev] = same ? -(int)COLB : (int)COLB;
+                f_b2[lev] = (int)(o | (same ? 0x8000u : 0u));
             }
         }
     }
@@ -196,83 +216,87 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
             co_p[lev] = WANT_COSTS ? costs + (int64_t)(f_r[lev] >= 0 ? f_r[lev] : 0) * T : nullptr;
         }
         int kc = 0, ci = 0;  // chunk index, column inside the chunk
-        // one column; PAR = column parity (compile time)
-        auto column = [&](int t, auto par_tag) {
-            constexpr int PAR = decltype(par_tag)::value;
-            if (ci == 0) {
-                const int64_t base = (int64_t)(kc + 1) * chunk_elems, lim = (int64_t)T * S;
+        // Columns two at a time: the inner loop is fully unrolled, so the column parity PAR (which of the two LDS
+        // cost columns is "previous") is a compile-time constant.  (Written as a plain loop on purpose: as a
+        // generic lambda called per parity the row-descriptor arrays stayed in scratch memory.)
+        for (int t0 = 0; t0 < T; t0 += 2) {
 #pragma unroll
-                for (int k = 0; k < NPRE; ++k) {
-                    const int i = tid + k * bd;
-                    pre[k] = (i < chunk_elems && base + i < lim) ? nll[base + i] : ET(0);
-                }
-            }
-            __syncthreads();
-            const unsigned emv = EM0 + (unsigned)(kc & 1) * EMCH + (unsigned)(ci * S1) * 8u;
-#pragma unroll
-            for (int lev = 0; lev < NL; ++lev) {
-                if (f_r[lev] >= 0) {
-                    const double v0 = f_c0[lev] + lds_at(smem, f_a0[lev] + (PAR ? f_d0[lev] : 0));
-                    const double v1 = f_c1[lev] + lds_at(smem, f_a1[lev] + (PAR ? f_d1[lev] : 0));
-                    const bool pick1 = v1 < v0;
-                    double best = pick1 ? v1 : v0;
-                    uint16_t b = pick1 ? f_b1[lev] : f_b0[lev];
-                    const double e = lds_at(smem, emv + f_em[lev]);
-                    double c = best + e;
-                    c = (c != c) ? INF : c;                 // min(inf, nan) keeps inf (decode.py:124)
-                    if (f_na[lev] == 0) { c = INF; b = BP_NONE; }      // rows without arcs stay +inf (:116-117)
-                    if (t == 0 && f_start[lev]) { c = e; b = BP_NONE; }  // decode.py:99-101
-                    lds_at(smem, (PAR ? 0u : COLB) + (unsigned)f_r[lev] * 8u) = c;
-                    if (WANT_PATH) { *bp_p[lev] = b; bp_p[lev] += R; }
-                    if (WANT_COSTS) { *co_p[lev] = c; co_p[lev] += 1; }
-                }
-                if (w_r[lev] >= 0) {  // wide row: 16 lanes scan its arcs, then reduce (value, lowest arc index)
-                    const unsigned prevb = PAR ? COLB : 0u, curb = PAR ? 0u : COLB;
-                    double best = INF;
-                    int bidx = 0x7fffffff;
-                    for (int p = w_p0[lev] + (tid & 15); p < w_p0[lev] + w_na[lev]; p += 16) {
-                        const uint32_t w = s_w[p];
-                        const unsigned o = w & GH_ARC_ROW;
-                        const double v = (w & GH_ARC_DEAD) ? INF : s_cost[p] + lds_at(smem, ((w & GH_ARC_SAME) ? curb : prevb) + o * 8u);
-                        if (v < best || bidx == 0x7fffffff) { best = v; bidx = p; }
+            for (int PAR = 0; PAR < 2; ++PAR) {
+                const int t = t0 + PAR;
+                if (t >= T) break;
+                if (ci == 0) {
+                    const int64_t base = (int64_t)(kc + 1) * chunk_elems, lim = (int64_t)T * S;
+    #pragma unroll
+                    for (int k = 0; k < NPRE; ++k) {
+                        const int i = tid + k * bd;
+                        pre[k] = (i < chunk_elems && base + i < lim) ? nll[base + i] : ET(0);
                     }
-                    min_step<8>(best, bidx);
-                    min_step<4>(best, bidx);
-                    min_step<2>(best, bidx);
-                    min_step<1>(best, bidx);
-                    if ((tid & 15) == 0) {
-                        const uint32_t w = s_w[bidx];
-                        uint16_t b = (uint16_t)((w & GH_ARC_ROW) | ((w & GH_ARC_SAME) ? 0x8000u : 0u));
-                        const double e = lds_at(smem, emv + w_em[lev]);
+                }
+                lds_barrier();
+                const unsigned emv = EM0 + (unsigned)(kc & 1) * EMCH + (unsigned)(ci * S1) * 8u;
+    #pragma unroll
+                for (int lev = 0; lev < NL; ++lev) {
+                    if (f_r[lev] >= 0) {
+                        const double v0 = f_c0[lev] + lds_at(smem, f_a0[lev] + (PAR ? f_d0[lev] : 0));
+                        const double v1 = f_c1[lev] + lds_at(smem, f_a1[lev] + (PAR ? f_d1[lev] : 0));
+                        const double v2 = f_c2[lev] + lds_at(smem, f_a2[lev] + (PAR ? f_d2[lev] : 0));
+                        const bool pick1 = v1 < v0;             // strict '<' in ascending origin order: np.argmin's first minimum
+                        double best = pick1 ? v1 : v0;
+                        int b = pick1 ? f_b1[lev] : f_b0[lev];
+                        const bool pick2 = v2 < best;
+                        best = pick2 ? v2 : best;
+                        b = pick2 ? f_b2[lev] : b;
+                        const double e = lds_at(smem, emv + f_em[lev]);
                         double c = best + e;
-                        c = (c != c) ? INF : c;
-                        if (t == 0 && w_start[lev]) { c = e; b = BP_NONE; }
-                        lds_at(smem, curb + (unsigned)w_r[lev] * 8u) = c;
-                        if (WANT_PATH) bp[(int64_t)t * R + w_r[lev]] = b;
-                        if (WANT_COSTS) costs[(int64_t)w_r[lev] * T + t] = c;
+                        c = (c != c) ? INF : c;                 // min(inf, nan) keeps inf (decode.py:124)
+                        if (f_na[lev] == 0) { c = INF; b = BP_NONE; }      // rows without arcs stay +inf (:116-117)
+                        if (t == 0 && f_start[lev]) { c = e; b = BP_NONE; }  // decode.py:99-101
+                        lds_at(smem, (PAR ? 0u : COLB) + (unsigned)f_r[lev] * 8u) = c;
+                        if (WANT_PATH) { *bp_p[lev] = (uint16_t)b; bp_p[lev] += R; }
+                        if (WANT_COSTS) { *co_p[lev] = c; co_p[lev] += 1; }
                     }
+                    if (w_r[lev] >= 0) {  // wide row: 16 lanes scan its arcs, then reduce (value, lowest arc index)
+                        const unsigned prevb = PAR ? COLB : 0u, curb = PAR ? 0u : COLB;
+                        double best = INF;
+                        int bidx = 0x7fffffff;
+                        for (int p = w_p0[lev] + (tid & 15); p < w_p0[lev] + w_na[lev]; p += 16) {
+                            const uint32_t w = s_w[p];
+                            const unsigned o = w & GH_ARC_ROW;
+                            const double v = (w & GH_ARC_DEAD) ? INF : s_cost[p] + lds_at(smem, ((w & GH_ARC_SAME) ? curb : prevb) + o * 8u);
+                            if (v < best || bidx == 0x7fffffff) { best = v; bidx = p; }
+                        }
+                        min_step<8>(best, bidx);
+                        min_step<4>(best, bidx);
+                        min_step<2>(best, bidx);
+                        min_step<1>(best, bidx);
+                        if ((tid & 15) == 0) {
+                            const uint32_t w = s_w[bidx];
+                            uint16_t b = (uint16_t)((w & GH_ARC_ROW) | ((w & GH_ARC_SAME) ? 0x8000u : 0u));
+                            const double e = lds_at(smem, emv + w_em[lev]);
+                            double c = best + e;
+                            c = (c != c) ? INF : c;
+                            if (t == 0 && w_start[lev]) { c = e; b = BP_NONE; }
+                            lds_at(smem, curb + (unsigned)w_r[lev] * 8u) = c;
+                            if (WANT_PATH) bp[(int64_t)t * R + w_r[lev]] = b;
+                            if (WANT_COSTS) costs[(int64_t)w_r[lev] * T + t] = c;
+                        }
+                    }
+                    if (lev + 1 < NL) lds_barrier();
                 }
-                if (lev + 1 < NL) __syncthreads();
-            }
-            if (ci == CH - 1) {  // park the prefetched chunk in the other buffer
-                const unsigned dst = EM0 + (unsigned)((kc + 1) & 1) * EMCH;
-#pragma unroll
-                for (int k = 0; k < NPRE; ++k) {
-                    const int i = tid + k * bd;
-                    if (i < chunk_elems) lds_at(smem, dst + (unsigned)((i / S) * S1 + i % S) * 8u) = (double)pre[k];
+                if (ci == CH - 1) {  // park the prefetched chunk in the other buffer
+                    const unsigned dst = EM0 + (unsigned)((kc + 1) & 1) * EMCH;
+    #pragma unroll
+                    for (int k = 0; k < NPRE; ++k) {
+                        const int i = tid + k * bd;
+                        if (i < chunk_elems) lds_at(smem, dst + (unsigned)((i / S) * S1 + i % S) * 8u) = (double)pre[k];
+                    }
+                    ci = 0;
+                    ++kc;
+                } else {
+                    ++ci;
                 }
-                ci = 0;
-                ++kc;
-            } else {
-                ++ci;
             }
-        };
-        int t = 0;
-        for (; t + 1 < T; t += 2) {
-            column(t, std::integral_constant<int, 0>{});
-            column(t + 1, std::integral_constant<int, 1>{});
         }
-        if (t < T) column(t, std::integral_constant<int, 0>{});
         __syncthreads();
     }
     // the last column is in colB if T is odd (even-parity column written last), else colA
@@ -291,8 +315,13 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
     }
     __syncthreads();
     if (WANT_PATH) {
+        // Back-trace (decode.py:143-145).  A serial walk over back-pointers in global memory costs one memory
+        // round trip per cell (~0.7 ms for a 317-frame utterance); instead ALL lanes stage the next block of
+        // back-pointer columns into LDS (coalesced) and lane 0 walks them there; the cells found are
+        // buffered in LDS and flushed by all lanes.  LDS map: [pbuf 256 cells][state][bp columns ...].
+        constexpr int PB = 255;
         int32_t* pbuf = reinterpret_cast<int32_t*>(smem);
-        const int PB = a.r_pad + CH * S1 - 1;
+        const int NB = (a.lds_bytes - 2048 - 16 - 32) / (2 * R);  // back-pointer columns per block (host: >= 8)
         int32_t* path = a.path + 2 * a.path_off[u];
         const int64_t cap = a.path_off[u + 1] - a.path_off[u];
         if (tid == 0) {
@@ -301,19 +330,39 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
             s_state[1] = T - 1;
             s_state[2] = 0;
             s_state[3] = !(T > 1 && bi >= 0);
+#ifdef GH_LEAN_NOBT  // diagnostic build: forward sweep (with back-pointer stores) only
+            s_state[3] = 1;
+#endif
         }
         __syncthreads();
         while (!s_state[3]) {
-            int n_new = 0;
+            const int j_hi = s_state[1];                          // columns (j_lo, j_hi] are staged; column 0 is never read
+            const int j_lo = (j_hi - NB > 0) ? j_hi - NB : 0;
+            // 16-byte loads from the enclosing aligned window, four per lane in flight (a 2-byte load -> wait ->
+            // LDS store loop costs one memory round trip per 64 back-pointers)
+            const uint16_t* src = bp + (int64_t)(j_lo + 1) * R;
+            const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(src) & 15u);
+            const uint4* vsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) - mis);
+            uint4* vdst = reinterpret_cast<uint4*>(smem + 2048 + 16);
+            const int nvec = (int)(((unsigned)((j_hi - j_lo) * R) * 2u + mis + 15u) >> 4);
+            for (int k0 = 0; k0 < nvec; k0 += 4 * bd) {
+                uint4 q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int k = k0 + e * bd + tid; q[e] = (k < nvec) ? vsrc[k] : uint4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int k = k0 + e * bd + tid; if (k < nvec) vdst[k] = q[e]; }
+            }
+            const uint16_t* cbp = reinterpret_cast<const uint16_t*>(smem + 2048 + 16 + mis);
+            __syncthreads();
             if (tid == 0) {
-                int i = s_state[0], j = s_state[1];
+                int i = s_state[0], j = j_hi, n_new = 0;
                 const int len = s_state[2];
-                while (j != 0 && n_new < PB) {
-                    const uint16_t b = bp[(int64_t)j * R + i];
-                    if (b == BP_NONE) { atomicOr(a.flag, 2); j = 0; break; }
+                while (j > j_lo && n_new < PB) {
+                    const uint16_t bq = cbp[(j - j_lo - 1) * R + i];
+                    if (bq == BP_NONE) { atomicOr(a.flag, 2); j = 0; break; }
                     if (len + n_new >= cap) { atomicOr(a.flag, 4); j = 0; break; }
-                    i = b & 0x7FFF;
-                    if (!(b & 0x8000u)) --j;
+                    i = bq & 0x7FFF;
+                    if (!(bq & 0x8000u)) --j;
                     pbuf[2 * n_new] = i;
                     pbuf[2 * n_new + 1] = j;
                     ++n_new;
@@ -323,7 +372,7 @@ __global__ void viterbi_lean_kernel(gh_vit_args a) {
                 pbuf[2 * PB] = n_new;
             }
             __syncthreads();
-            n_new = pbuf[2 * PB];
+            const int n_new = pbuf[2 * PB];
             const int len = s_state[2];
             for (int k = tid; k < 2 * n_new; k += bd) path[2 * (int64_t)len + k] = pbuf[k];
             __syncthreads();
@@ -341,7 +390,13 @@ int gh_launch_viterbi_lean(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, in
     if (n_utts <= 0) return GH_OK;
     dim3 grid((unsigned)n_utts), blk((unsigned)block);
     const bool wc = a.costs != nullptr;
-#define GH_VL(ET, WP, WC, NLV) hipLaunchKernelGGL((viterbi_lean_kernel<ET, WP, WC, NLV>), grid, blk, lds_bytes, ctx->stream, a)
+#define GH_VL_B(ET, WP, WC, NLV, MB) hipLaunchKernelGGL((viterbi_lean_kernel<ET, WP, WC, NLV, MB>), grid, blk, lds_bytes, ctx->stream, a)
+#define GH_VL(ET, WP, WC, NLV)                               \
+    do {                                                     \
+        if (block <= 256) GH_VL_B(ET, WP, WC, NLV, 256);     \
+        else if (block <= 512) GH_VL_B(ET, WP, WC, NLV, 512); \
+        else GH_VL_B(ET, WP, WC, NLV, 1024);                 \
+    } while (0)
 #define GH_VL_N(ET, WP, WC)                      \
     switch (levels) {                            \
         case 1: GH_VL(ET, WP, WC, 1); break;     \
@@ -356,6 +411,7 @@ int gh_launch_viterbi_lean(gh_ctx* ctx, const gh_vit_args& a, int64_t n_utts, in
     }
 #undef GH_VL_N
 #undef GH_VL
+#undef GH_VL_B
     GH_HIP(hipGetLastError());
     return GH_OK;
 }
