@@ -38,6 +38,12 @@ class StatsAllReducer:
     def __init__(self, device=None, gpu_index=None):
         """device: torch device the buffer is reduced on.  Default: the GPU `gpu_index` (or torch's
         current one) when the process group runs on RCCL ("nccl"), the host for gloo."""
+        import sys
+        self.torch = self.dist = None
+        self.enabled = False
+        self.device = device
+        if "torch" not in sys.modules:   # no process group can exist: do not pay for importing torch (seconds to minutes cold)
+            return
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
