@@ -363,6 +363,13 @@ def test_reference_pickle_scores_identically(R):
     g = load_golden("G12_reference_pickle")
     hmms = pickle.loads(g["pickle"].tobytes())
     np.testing.assert_allclose([h.evaluate(g["x"]) for h in hmms], g["evaluate"], rtol=1e-10)
+    # the packed .npz wire format carries the same models
+    import tempfile
+    from sr.recognition.model_io import save_models_npz, load_models_npz
+    with tempfile.TemporaryDirectory() as td:
+        save_models_npz(os.path.join(td, "v.npz"), hmms)
+        back = load_models_npz(os.path.join(td, "v.npz"))
+    np.testing.assert_allclose([h.evaluate(g["x"]) for h in back], g["evaluate"], rtol=1e-10)
 
 
 # ------------------------------------------------------------------ N3: front-end
