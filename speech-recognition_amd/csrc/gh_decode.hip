@@ -117,7 +117,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         for (int64_t k = 0; k < U; ++k) {
             const int64_t u = perm[k];
             const int l = utt_lattice ? utt_lattice[u] : 0;
-            const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+            // (blocks padded to 8 entries = 16 bytes: the lean kernel flushes back-pointers with 16-byte stores)
+            const size_t need = ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
             if (acc && (acc + need) * 2 > BP_BUDGET) {
                 chunk_begin.push_back(k);
                 bp_max = std::max(bp_max, acc);
@@ -223,6 +224,11 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
         a.arc_cap = (max_arcs + 1) & ~1;
         lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+        if (want_path) {  // 8 columns of back-pointers are collected in LDS and flushed with 16-byte stores
+            lds = (lds + 15) & ~size_t(15);
+            a.bpc_off = (int)lds;
+            lds += (size_t)8 * lat->max_R * 2 + 16;
+        }
         // back-trace: 2 KB path buffer + as many back-pointer columns as fit (at least 8)
         if (want_path) lds = std::max(lds, (size_t)2048 + 16 + 32 + (size_t)8 * lat->max_R * 2);
         lds = (lds + 15) & ~size_t(15);

@@ -19,6 +19,7 @@ struct gh_vit_args {
     int em_chunk;             // lean kernel: columns of emissions prefetched per chunk, >= 1
     int arc_cap;              // lean kernel: LDS slots for a graph's arc list
     int lds_bytes;            // lean kernel: dynamic LDS of the launch (the back-trace re-uses all of it)
+    int bpc_off;              // lean kernel: LDS byte offset of the 8-column back-pointer staging block
     const int64_t* utt_off;   // [U+1] frame offsets
     const int32_t* utt_lat;   // [U] graph of each utterance, or null (graph 0)
     const int64_t* perm;      // launch slot -> utterance (longest first), or null

@@ -28,9 +28,8 @@ __device__ __forceinline__ double& lds_at(char* smem, unsigned off) { return *re
 template <int K> __device__ __forceinline__ int row_shl(int v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x100 | K, 0xF, 0xF, false);
 }
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL
-// store to be acknowledged (vmcnt(0)); with three barriers per column the fire-and-forget back-pointer stores
-// then cost a memory round trip each (K = 7 lattice: 1.6 -> 2.9 ms).
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding GLOBAL
+// access, vmcnt(0) -- the emission prefetch and the back-pointer flush should stay in flight across it).
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -44,11 +43,11 @@ template <int K> __device__ __forceinline__ void min_step(double& best, int& idx
     idx = take ? oi : idx;
 }
 
-// MAXB = largest block the instantiation is launched with: without it the compiler budgets registers for 1024
-// lanes (128 VGPRs per lane) and, once the three levels' row descriptors no longer fit, leaves those arrays
-// in scratch memory -- every column then reads its descriptors from global memory (measured: 0.5 -> 2.2 ms).
+// MAXB = largest block the instantiation is launched with.  The kernel is latency bound per workgroup, so
+// what counts is workgroups per CU: the 512 variant is held to 128 VGPRs (4 waves per SIMD, three 320-lane
+// workgroups per CU for the K = 7 lattice: 3.4 -> 2.3 ms against the 141 VGPRs the compiler takes otherwise).
 template <typename ET, bool WANT_PATH, bool WANT_COSTS, int NL, int MAXB>
-__global__ __launch_bounds__(MAXB) void viterbi_lean_kernel(gh_vit_args a) {
+__global__ __launch_bounds__(MAXB, (MAXB == 512 ? 4 : 1)) void viterbi_lean_kernel(gh_vit_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_bi;
     __shared__ int s_state[4];
@@ -208,11 +207,12 @@ __global__ __launch_bounds__(MAXB) void viterbi_lean_kernel(gh_vit_args a) {
             }
             for (int c = tid; c < 2 * CH; c += bd) lds_at(smem, EM0 + (unsigned)(c * S1 + S) * 8u) = 0.0;
         }
-        uint16_t* bp_p[NL];
+        // back-pointers: 8 columns are collected in LDS ([8][R] uint16) and flushed as one contiguous block of
+        // 16-byte stores (8x fewer store instructions than one 2-byte store per row and column)
+        uint16_t* bpc = reinterpret_cast<uint16_t*>(smem + a.bpc_off);
         double* co_p[NL];
 #pragma unroll
         for (int lev = 0; lev < NL; ++lev) {
-            bp_p[lev] = WANT_PATH ? bp + (f_r[lev] >= 0 ? f_r[lev] : 0) : nullptr;
             co_p[lev] = WANT_COSTS ? costs + (int64_t)(f_r[lev] >= 0 ? f_r[lev] : 0) * T : nullptr;
         }
         int kc = 0, ci = 0;  // chunk index, column inside the chunk
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(MAXB) void viterbi_lean_kernel(gh_vit_args a) {
                         if (f_na[lev] == 0) { c = INF; b = BP_NONE; }      // rows without arcs stay +inf (:116-117)
                         if (t == 0 && f_start[lev]) { c = e; b = BP_NONE; }  // decode.py:99-101
                         lds_at(smem, (PAR ? 0u : COLB) + (unsigned)f_r[lev] * 8u) = c;
-                        if (WANT_PATH) { *bp_p[lev] = (uint16_t)b; bp_p[lev] += R; }
+                        if (WANT_PATH) bpc[(t & 7) * R + f_r[lev]] = (uint16_t)b;
                         if (WANT_COSTS) { *co_p[lev] = c; co_p[lev] += 1; }
                     }
                     if (w_r[lev] >= 0) {  // wide row: 16 lanes scan its arcs, then reduce (value, lowest arc index)
@@ -277,11 +277,21 @@ __global__ __launch_bounds__(MAXB) void viterbi_lean_kernel(gh_vit_args a) {
                             c = (c != c) ? INF : c;
                             if (t == 0 && w_start[lev]) { c = e; b = BP_NONE; }
                             lds_at(smem, curb + (unsigned)w_r[lev] * 8u) = c;
-                            if (WANT_PATH) bp[(int64_t)t * R + w_r[lev]] = b;
+                            if (WANT_PATH) bpc[(t & 7) * R + w_r[lev]] = b;
                             if (WANT_COSTS) costs[(int64_t)w_r[lev] * T + t] = c;
                         }
                     }
                     if (lev + 1 < NL) lds_barrier();
+                }
+                if (WANT_PATH && ((t & 7) == 7 || t == T - 1)) {  // flush the staged back-pointer columns
+                    lds_barrier();
+                    const int c0 = t & ~7;
+                    const int nvec = ((t - c0 + 1) * R * 2 + 15) >> 4;
+                    // 16-byte aligned: block offsets are multiples of 8 entries, c0 is a multiple of 8 columns
+                    uint4* dst = reinterpret_cast<uint4*>(bp + (int64_t)c0 * R);
+                    const uint4* srcv = reinterpret_cast<const uint4*>(bpc);
+                    for (int k = tid; k < nvec; k += bd) dst[k] = srcv[k];
+                    lds_barrier();
                 }
                 if (ci == CH - 1) {  // park the prefetched chunk in the other buffer
                     const unsigned dst = EM0 + (unsigned)((kc + 1) & 1) * EMCH;
