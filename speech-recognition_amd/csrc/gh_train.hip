@@ -180,15 +180,19 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
         const int nf = (int)((utt_off[u + 1] - n0 < F) ? (utt_off[u + 1] - n0) : F);
         __syncthreads();
         for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
-        // which states have any occupancy on this tile?  lane = state: coalesced sweeps down the
-        // [F,S] block of the occupancy matrix, ONE barrier instead of a vote per state
-        for (int s = tid; s < S; s += 256) {
-            bool any = false;
-            for (int f = 0; f < nf; ++f) {
-                const double w = occ[(n0 + f) * S + s];
-                any |= (w > occ_floor) || (w != w);
+        // which states have any occupancy on this tile?  All lanes sweep the [nf, S] block of the occupancy
+        // matrix linearly (coalesced, 4 loads in flight per lane) and raise a flag per state -- one lane per
+        // state walking down its column costs one memory round trip per frame.
+        for (int s = tid; s < S; s += 256) s_list[s] = 0;
+        __syncthreads();
+        {
+            const double* ob = occ + n0 * S;
+            const int total = nf * S;
+#pragma unroll 4
+            for (int i = tid; i < total; i += 256) {
+                const double w = ob[i];
+                if ((w > occ_floor) || (w != w)) s_list[i % S] = 1;   // benign race: every writer stores 1
             }
-            s_list[s] = any ? 1 : 0;
         }
         __syncthreads();
         if (tid == 0) {
