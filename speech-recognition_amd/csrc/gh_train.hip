@@ -156,6 +156,11 @@ __global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict_
 // states are active at all and only those are evaluated.  Accumulation is deterministic: each
 // workgroup owns a private [S,M,1+2D] slab in HBM (L2 resident), a second kernel adds the slabs
 // in a fixed order -- no float atomics.  Statistics are centred on the current means.
+constexpr int BW_MAXP = 8;  // (component, dimension) pairs per lane of bw_stats_kernel: M*(D+1) <= 8*256
+
+// workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / store acknowledgements)
+__device__ __forceinline__ void bw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict__ X, int64_t N, int D, int S, int M,
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ occ,
@@ -167,7 +172,8 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
     double* pm = rt + M * F;         // [M,D]   mean        } of the current state,
     double* pv = pm + M * D;         // [M,D]   1/variance  } staged once per (tile, state)
     double* pc = pv + M * D;         // [M]     log-constant
-    int* s_list = reinterpret_cast<int*>(pc + M);  // [S] active states of the tile, compacted
+    double* wt = pc + M;             // [F]     occupancy of the current state on the tile's frames
+    int* s_list = reinterpret_cast<int*>(wt + F);  // [S] active states of the tile, compacted
     __shared__ int s_count;
     const int tid = threadIdx.x;
     const int W = 1 + 2 * D;
@@ -205,24 +211,62 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
         const int count = s_count;
         for (int k = 0; k < count; ++k) {
             const int s = s_list[k];
+            // this lane's slab entries ((component, dimension) pairs p = tid and tid + 256) start their trip from
+            // L2 / HBM now and are added to at the end of the pair: the read-modify-write latency of the 253 KB
+            // per-workgroup slab was the largest single cost of the kernel (33 k of 80 k cycles per pair)
+            const int P = M * (D + 1);
+            double so1[BW_MAXP], so2[BW_MAXP];
+#pragma unroll
+            for (int h = 0; h < BW_MAXP; ++h) {
+                so1[h] = 0; so2[h] = 0;
+                const int p = tid + 256 * h;
+                if (p < P) {
+                    const int m = p / (D + 1), d = p % (D + 1);
+                    const double* o = slab + ((int64_t)s * M + m) * W;
+                    so1[h] = (d == D) ? o[0] : o[1 + d];
+                    so2[h] = (d == D) ? 0.0 : o[1 + D + d];
+                }
+            }
             for (int i = tid; i < M * D; i += 256) {
                 pm[i] = mean[(int64_t)s * M * D + i];
                 pv[i] = ivar[(int64_t)s * M * D + i];
             }
             if (tid < M) pc[tid] = logc[(int64_t)s * M + tid];
-            __syncthreads();
+            bw_lds_barrier();
+            // component log-densities of every (frame, component) pair of the tile on all 256 lanes (the lanes of a
+            // frame read the same feature row: LDS broadcast), four independent partial sums per pair; then one
+            // lane per frame normalises over the components
+            for (int f = tid; f < F; f += 256) wt[f] = (f < nf) ? occ[(n0 + f) * S + s] : 0.0;
+            bw_lds_barrier();
+            for (int p = tid; p < nf * M; p += 256) {
+                const int f = p / M, m = p - f * M;
+                const double wgt = wt[f];
+                double ll = 0.0;
+                if (wgt > occ_floor || wgt != wgt) {
+                    const double* x = xt + f * D;
+                    const double* mu = pm + m * D;
+                    const double* iv = pv + m * D;
+                    double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                    int d = 0;
+                    for (; d + 3 < D; d += 4) {
+                        const double t0 = x[d] - mu[d], t1 = x[d + 1] - mu[d + 1], t2 = x[d + 2] - mu[d + 2], t3 = x[d + 3] - mu[d + 3];
+                        q0 = fma(t0 * iv[d], t0, q0); q1 = fma(t1 * iv[d + 1], t1, q1);
+                        q2 = fma(t2 * iv[d + 2], t2, q2); q3 = fma(t3 * iv[d + 3], t3, q3);
+                    }
+                    for (; d < D; ++d) { const double t = x[d] - mu[d]; q0 = fma(t * iv[d], t, q0); }
+                    ll = pc[m] - 0.5 * ((q0 + q1) + (q2 + q3));
+                }
+                rt[m * F + f] = ll;
+            }
+            bw_lds_barrier();
             if (tid < F) {
                 const int f = tid;
-                const double wgt = (f < nf) ? occ[(n0 + f) * S + s] : 0.0;
+                const double wgt = wt[f];
                 if (f < nf && (wgt > occ_floor || wgt != wgt)) {
-                    const double* x = xt + f * D;
                     double mx = -INFINITY;
                     bool bad = false;
                     for (int m = 0; m < M; ++m) {
-                        double q = 0;
-                        for (int d = 0; d < D; ++d) { const double t = x[d] - pm[m * D + d]; q = fma(t * pv[m * D + d], t, q); }
-                        const double ll = pc[m] - 0.5 * q;
-                        rt[m * F + f] = ll;
+                        const double ll = rt[m * F + f];
                         bad |= (ll != ll);
                         mx = fmax(mx, ll);
                     }
@@ -238,9 +282,11 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                     for (int m = 0; m < M; ++m) rt[m * F + f] = 0.0;
                 }
             }
-            __syncthreads();
-            const int P = M * (D + 1);
-            for (int p = tid; p < P; p += 256) {
+            bw_lds_barrier();
+#pragma unroll
+            for (int h = 0; h < BW_MAXP; ++h) {
+                const int p = tid + 256 * h;
+                if (p >= P) continue;
                 const int m = p / (D + 1), d = p % (D + 1);
                 const double* r = rt + m * F;
                 double a1 = 0, a2 = 0;
@@ -256,10 +302,10 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                     }
                 }
                 double* o = slab + ((int64_t)s * M + m) * W;
-                if (d == D) o[0] += a1;
-                else { o[1 + d] += a1; o[1 + D + d] += a2; }
+                if (d == D) o[0] = so1[h] + a1;
+                else { o[1 + d] = so1[h] + a1; o[1 + D + d] = so2[h] + a2; }
             }
-            __syncthreads();  // rt / pm are rewritten by the next state
+            bw_lds_barrier();  // rt / pm are rewritten by the next state (the slab stores stay in flight)
         }
     }
 }
@@ -383,16 +429,22 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     GH_REQUIRE(b->dtype == GH_F64, "gh_bw_accumulate: needs an fp64 batch");
     GH_REQUIRE(b->occ || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
     GH_REQUIRE(g->D == b->D && g->S == b->nll_S, "gh_bw_accumulate: model / batch mismatch");
+    GH_REQUIRE(g->M * (g->D + 1) <= BW_MAXP * 256, "gh_bw_accumulate: M=%d x D=%d unsupported", g->M, g->D);
     GH_HIP(hipSetDevice(ctx->device));
     const int S = g->S, M = g->M, D = g->D, W = 1 + 2 * D;
     const int64_t len = (int64_t)S * M * W;
     hipStream_t st = ctx->stream;
-    int F = 128;
-    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f + 2 * (size_t)M * D + M) * 8 + (size_t)S * 4 + 16; };
-    while (F > 32 && lds_need(F) > 64 * 1024) F >>= 1;
+    // The kernel is latency bound per workgroup (global round trips between barriers), so workgroups per CU
+    // decide: frame tiles are sized for as many resident workgroups as the 160 KB of LDS allow (a tile one
+    // entry too large silently drops a CU from 3 to 2 workgroups: measured 4.4 -> 5.0 ms).
+    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f + 2 * (size_t)M * D + M + f) * 8 + (size_t)S * 4 + 16; };
+    int F = (int)std::max<int64_t>(32, std::min<int64_t>(160, (b->max_T + 7) & ~int64_t(7)));  // one tile per utterance when it fits
+    if (const char* e = getenv("GMMHMM_BW_F")) F = std::max(16, std::min(256, atoi(e)));   // tuning knob
+    while (F > 16 && lds_need(F) > 80 * 1024) F >>= 1;
     GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_bw_accumulate: D=%d M=%d does not fit LDS", D, M);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / (lds_need(F) + 256)));
     const int64_t ntiles = b->U;  // one utterance (in chunks of F frames) per workgroup pass
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 3 * (int64_t)ctx->n_cu));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, per_cu * (int64_t)ctx->n_cu));
     void* base;
     const size_t slab_bytes = (size_t)grid * len * 8, out_bytes = ((size_t)len * 8 + 255) & ~size_t(255);
     int rc = gh_scratch(ctx, out_bytes + slab_bytes, &base);
