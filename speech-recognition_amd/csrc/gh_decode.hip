@@ -444,7 +444,13 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
-    const size_t lds = ((size_t)2 * a.r_pad + 3 * (size_t)S) * sizeof(double);
+    // LDS: two cost columns, three emission / occupancy vectors, and the whole graph (both CSRs, row tables)
+    int fb_max_arcs = 0;
+    for (auto& lh : lat->lat) fb_max_arcs = std::max(fb_max_arcs, lh.A);
+    a.arc_cap = (fb_max_arcs + 2) & ~1;
+    a.lev_cap = lat->max_nlev + 1;
+    const size_t lds = ((size_t)2 * a.r_pad + 4 * (size_t)S + 2 * (size_t)a.arc_cap) * sizeof(double) +
+                       ((size_t)2 * a.arc_cap + 2 * (size_t)(a.r_pad + 2) + 3 * (size_t)a.r_pad + a.lev_cap + 4) * sizeof(int32_t);
     if (lds > 150 * 1024) {
         gh_set_error("gh_forward_backward: %d rows + %d states need %zu B of LDS", lat->max_R, S, lds);
         return GH_ERR_UNSUPPORTED;

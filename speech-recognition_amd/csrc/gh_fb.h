@@ -18,6 +18,8 @@ struct gh_fb_args {
     const void* nll;
     int S;
     int r_pad;
+    int arc_cap;                 // LDS slots for a graph's arc lists (even)
+    int lev_cap;                 // LDS slots for a graph's level offsets
     const int64_t* utt_off;
     const int32_t* utt_lat;
     const int64_t* perm;

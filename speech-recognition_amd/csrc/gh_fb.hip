@@ -27,6 +27,12 @@ __device__ __forceinline__ void lse_add(double v, double& m, double& s) {
 }
 __device__ __forceinline__ double lse_val(double m, double s) { return (s > 0.0) ? m + log(s) : -INFINITY; }
 
+// workgroup barrier that orders LDS traffic only (the alpha / occupancy stores and the prefetch loads stay in flight)
+__device__ __forceinline__ void fb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The graph (both CSRs, row tables, level offsets) is staged into LDS once per workgroup and the next column's
+// emissions / alpha column travel from HBM while the current column is processed: walking the CSR and fetching the
+// emissions from global memory inside the column loop cost 2-3 memory round trips per level (2.6 us per column).
 template <typename ET>
 __global__ void fb_kernel(gh_fb_args a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -36,16 +42,6 @@ __global__ void fb_kernel(gh_fb_args a) {
     const int l = a.utt_lat ? a.utt_lat[u] : 0;
     const gh_lattices::desc dsc = a.descs[l];
     const int R = dsc.R, nlev = dsc.nlev, n_end = dsc.n_end;
-    const int32_t* row_state = a.row_state + dsc.row_base;
-    const uint8_t* row_flag = a.row_flag + dsc.row_base;
-    const int32_t* pred_ptr = a.pred_ptr + dsc.ptr_base;
-    const uint32_t* pred_row = a.pred_row + dsc.arc_base;
-    const double* pred_cost = a.pred_cost + dsc.arc_base;
-    const int32_t* succ_ptr = a.succ_ptr + dsc.ptr_base;
-    const uint32_t* succ_row = a.succ_row + dsc.arc_base;
-    const double* succ_cost = a.succ_cost + dsc.arc_base;
-    const int32_t* order = a.order + dsc.row_base;
-    const int32_t* level_ptr = a.level_ptr + dsc.lev_base;
     const int32_t* end_rows = a.end_rows + dsc.end_base;
     const int64_t f0 = a.utt_off[u];
     const int T = (int)(a.utt_off[u + 1] - f0);
@@ -55,9 +51,20 @@ __global__ void fb_kernel(gh_fb_args a) {
 
     double* colA = lds;                  // alpha prev / beta next
     double* colB = lds + a.r_pad;        // alpha cur  / beta cur
-    double* em0 = lds + 2 * a.r_pad;     // emissions of the current column
-    double* em1 = em0 + S;               // emissions of column c+1 (backward)
-    double* occ = em1 + S;               // [S] occupancy of the current column
+    double* emA = lds + 2 * a.r_pad;     // emission vectors (rotating)
+    double* emB = emA + S;
+    double* emC = emB + S;
+    double* occ = emC + S;               // [S] occupancy of the current column
+    double* g_pcost = occ + S;           // [arc_cap]
+    double* g_scost = g_pcost + a.arc_cap;
+    int32_t* g_prow = reinterpret_cast<int32_t*>(g_scost + a.arc_cap);   // [arc_cap]
+    int32_t* g_srow = g_prow + a.arc_cap;
+    int32_t* g_pptr = g_srow + a.arc_cap;     // [R + 1]
+    int32_t* g_sptr = g_pptr + a.r_pad + 2;
+    int32_t* g_order = g_sptr + a.r_pad + 2;  // [R]
+    int32_t* g_state = g_order + a.r_pad;
+    int32_t* g_flag = g_state + a.r_pad;
+    int32_t* g_lev = g_flag + a.r_pad;        // [nlev + 1]
     __shared__ double s_logp;
     double* alpha = a.alpha_scratch + a.scratch_off[slot];  // [T,R]
     double* o_alpha = a.out_alpha ? a.out_alpha + a.mat_off[u] : nullptr;  // [R,T]
@@ -68,30 +75,69 @@ __global__ void fb_kernel(gh_fb_args a) {
         if (tid == 0 && a.logp) a.logp[u] = NEG;
         return;
     }
-    for (int r = tid; r < R; r += bd) { colA[r] = NEG; colB[r] = NEG; }
+    {   // ---- graph -> LDS
+        const int32_t* pred_ptr = a.pred_ptr + dsc.ptr_base;
+        const int32_t* succ_ptr = a.succ_ptr + dsc.ptr_base;
+        const int n_arcs = pred_ptr[R];
+        for (int p = tid; p < n_arcs; p += bd) {
+            g_pcost[p] = a.pred_cost[dsc.arc_base + p]; g_prow[p] = (int32_t)a.pred_row[dsc.arc_base + p];
+            g_scost[p] = a.succ_cost[dsc.arc_base + p]; g_srow[p] = (int32_t)a.succ_row[dsc.arc_base + p];
+        }
+        for (int r = tid; r <= R; r += bd) { g_pptr[r] = pred_ptr[r]; g_sptr[r] = succ_ptr[r]; }
+        for (int r = tid; r < R; r += bd) {
+            g_order[r] = a.order[dsc.row_base + r];
+            g_state[r] = a.row_state[dsc.row_base + r];
+            g_flag[r] = a.row_flag[dsc.row_base + r];
+            colA[r] = NEG; colB[r] = NEG;
+        }
+        for (int k = tid; k <= nlev; k += bd) g_lev[k] = a.level_ptr[dsc.lev_base + k];
+    }
+    // emissions: every lane owns the states tid, tid + bd, ... (at most FB_EM per lane; larger S falls back to a loop)
+    constexpr int FB_EM = 4;
+    const bool em_regs = S <= FB_EM * bd;
+    ET epre[FB_EM];
+    auto em_prefetch = [&](int t) {   // column t -> registers (issued early, parked later)
+        if (!em_regs) return;
+#pragma unroll
+        for (int k = 0; k < FB_EM; ++k) {
+            const int s = tid + k * bd;
+            epre[k] = (t >= 0 && t < T && s < S) ? nll[(int64_t)t * S + s] : ET(0);
+        }
+    };
+    auto em_park = [&](double* dst, int t) {
+        if (em_regs) {
+#pragma unroll
+            for (int k = 0; k < FB_EM; ++k) { const int s = tid + k * bd; if (s < S) dst[s] = (double)epre[k]; }
+        } else {
+            for (int s = tid; s < S; s += bd) dst[s] = (t >= 0 && t < T) ? (double)nll[(int64_t)t * S + s] : 0.0;
+        }
+    };
+    em_prefetch(0);
+    em_park(emA, 0);
     __syncthreads();
     double* prev = colA;
     double* cur = colB;
+    double* em0 = emA;     // emissions of the current column
+    double* emn = emB;     // being filled for the next one
     // ------------------------------------------------------------------ forward
     for (int t = 0; t < T; ++t) {
-        for (int s = tid; s < S; s += bd) em0[s] = (double)nll[(int64_t)t * S + s];
-        __syncthreads();
+        em_prefetch(t + 1);
         for (int lev = 0; lev < nlev; ++lev) {
-            const int i1 = level_ptr[lev + 1];
-            for (int i = level_ptr[lev] + tid; i < i1; i += bd) {
-                const int r = order[i];
-                const int st = row_state[r];
+            const int i1 = g_lev[lev + 1];
+            for (int i = g_lev[lev] + tid; i < i1; i += bd) {
+                const int r = g_order[i];
+                const int st = g_state[r];
                 const double e = st >= 0 ? em0[st] : 0.0;
                 double v;
-                if (t == 0 && (row_flag[r] & 1)) {
+                if (t == 0 && (g_flag[r] & 1)) {
                     v = -e;
                 } else {
                     double m = NEG, sm = 0.0;
-                    for (int p = pred_ptr[r]; p < pred_ptr[r + 1]; ++p) {
-                        const uint32_t w = pred_row[p];
+                    for (int p = g_pptr[r]; p < g_pptr[r + 1]; ++p) {
+                        const uint32_t w = (uint32_t)g_prow[p];
                         if (w & GH_ARC_DEAD) continue;  // same-column origin not yet computed: +inf cost
                         const int o = (int)(w & GH_ARC_ROW);
-                        lse_add(((w & GH_ARC_SAME) ? cur[o] : prev[o]) - pred_cost[p], m, sm);
+                        lse_add(((w & GH_ARC_SAME) ? cur[o] : prev[o]) - g_pcost[p], m, sm);
                     }
                     v = lse_val(m, sm) - e;
                 }
@@ -99,9 +145,12 @@ __global__ void fb_kernel(gh_fb_args a) {
                 alpha[(int64_t)t * R + r] = v;
                 if (o_alpha) o_alpha[(int64_t)r * T + t] = v;
             }
-            __syncthreads();
+            fb_lds_barrier();
         }
-        double* t_ = prev; prev = cur; cur = t_;
+        em_park(emn, t + 1);
+        fb_lds_barrier();
+        { double* t_ = prev; prev = cur; cur = t_; }
+        { double* t_ = em0; em0 = emn; emn = t_; }
     }
     if (tid == 0) {  // `prev` holds the last alpha column
         double m = NEG, sm = 0.0;
@@ -109,57 +158,86 @@ __global__ void fb_kernel(gh_fb_args a) {
         s_logp = lse_val(m, sm);
         if (a.logp) a.logp[u] = s_logp;
     }
-    __syncthreads();
+    __syncthreads();   // (full barrier: the alpha columns written above are read back below)
     const double logp = s_logp;
     // ----------------------------------------------------------------- backward
     double* nxt = colA;  // beta of column c+1
     cur = colB;
     for (int r = tid; r < R; r += bd) { nxt[r] = NEG; cur[r] = NEG; }
-    __syncthreads();
-    for (int t = T - 1; t >= 0; --t) {
-        for (int s = tid; s < S; s += bd) {
-            em0[s] = (double)nll[(int64_t)t * S + s];
-            em1[s] = (t + 1 < T) ? (double)nll[(int64_t)(t + 1) * S + s] : 0.0;
-            occ[s] = 0.0;
+    // emission window: em0 = column t, em1 = column t + 1, emn = being filled with column t - 1
+    double* em1 = emC;
+    em0 = emA; emn = emB;
+    em_prefetch(T - 1);
+    em_park(em0, T - 1);
+    for (int s = tid; s < S; s += bd) em1[s] = 0.0;
+    // alpha column of every row this lane owns (rows i = tid, tid + bd, ... of the level order), one column ahead
+    constexpr int FB_AL = 4;
+    const bool al_regs = R <= FB_AL * bd;
+    double apre[FB_AL];
+    auto alpha_prefetch = [&](int t) {
+        if (!al_regs) return;
+#pragma unroll
+        for (int k = 0; k < FB_AL; ++k) {
+            const int i = tid + k * bd;
+            apre[k] = (t >= 0 && i < R) ? alpha[(int64_t)t * R + g_order[i]] : 0.0;
         }
-        __syncthreads();
-        for (int lev = nlev - 1; lev >= 0; --lev) {
-            const int i1 = level_ptr[lev + 1];
-            for (int i = level_ptr[lev] + tid; i < i1; i += bd) {
-                const int r = order[i];
-                double m = NEG, sm = 0.0;
-                if (t == T - 1 && (row_flag[r] & 2)) lse_add(0.0, m, sm);
-                for (int p = succ_ptr[r]; p < succ_ptr[r + 1]; ++p) {
-                    const uint32_t w = succ_row[p];
-                    if (w & GH_ARC_DEAD) continue;
-                    const int s2 = (int)(w & GH_ARC_ROW);
-                    const int st2 = row_state[s2];
-                    if (w & GH_ARC_SAME) {
-                        lse_add(cur[s2] - succ_cost[p] - (st2 >= 0 ? em0[st2] : 0.0), m, sm);
-                    } else if (t + 1 < T) {
-                        lse_add(nxt[s2] - succ_cost[p] - (st2 >= 0 ? em1[st2] : 0.0), m, sm);
-                    }
+    };
+    __syncthreads();
+    alpha_prefetch(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+        double acur[FB_AL];
+#pragma unroll
+        for (int k = 0; k < FB_AL; ++k) acur[k] = apre[k];
+        alpha_prefetch(t - 1);
+        em_prefetch(t - 1);
+        for (int s = tid; s < S; s += bd) occ[s] = 0.0;
+        fb_lds_barrier();
+        auto beta_row = [&](int i, double av) {   // row i of the level order; av = its alpha in this column
+            const int r = g_order[i];
+            double m = NEG, sm = 0.0;
+            if (t == T - 1 && (g_flag[r] & 2)) lse_add(0.0, m, sm);
+            for (int p = g_sptr[r]; p < g_sptr[r + 1]; ++p) {
+                const uint32_t w = (uint32_t)g_srow[p];
+                if (w & GH_ARC_DEAD) continue;
+                const int s2 = (int)(w & GH_ARC_ROW);
+                const int st2 = g_state[s2];
+                if (w & GH_ARC_SAME) {
+                    lse_add(cur[s2] - g_scost[p] - (st2 >= 0 ? em0[st2] : 0.0), m, sm);
+                } else if (t + 1 < T) {
+                    lse_add(nxt[s2] - g_scost[p] - (st2 >= 0 ? em1[st2] : 0.0), m, sm);
                 }
-                const double bv = lse_val(m, sm);
-                cur[r] = bv;
-                const double av = alpha[(int64_t)t * R + r];
-                double g = exp(av + bv - logp);
-                if (!(g == g)) g = 0.0;  // -inf - -inf, or logP == -inf
-                if (o_beta) o_beta[(int64_t)r * T + t] = bv;
-                if (o_gamma) o_gamma[(int64_t)r * T + t] = g;
-                const int st = row_state[r];
-                if (a.occ && st >= 0 && g != 0.0) atomicAdd(&occ[st], g);
             }
-            __syncthreads();
+            const double bv = lse_val(m, sm);
+            cur[r] = bv;
+            double g = exp(av + bv - logp);
+            if (!(g == g)) g = 0.0;  // -inf - -inf, or logP == -inf
+            if (o_beta) o_beta[(int64_t)r * T + t] = bv;
+            if (o_gamma) o_gamma[(int64_t)r * T + t] = g;
+            const int st = g_state[r];
+            if (a.occ && st >= 0 && g != 0.0) atomicAdd(&occ[st], g);
+        };
+        for (int lev = nlev - 1; lev >= 0; --lev) {
+            const int i0 = g_lev[lev], i1 = g_lev[lev + 1];
+            if (al_regs) {
+#pragma unroll
+                for (int k = 0; k < FB_AL; ++k) {
+                    const int i = tid + k * bd;
+                    if (i >= i0 && i < i1) beta_row(i, acur[k]);
+                }
+            } else {
+                for (int i = i0 + tid; i < i1; i += bd) beta_row(i, alpha[(int64_t)t * R + g_order[i]]);
+            }
+            fb_lds_barrier();
         }
         if (a.occ) {
             double* orow = a.occ + (f0 + t) * S;
             for (int s = tid; s < S; s += bd) orow[s] = occ[s];
         }
-        __syncthreads();
-        double* t_ = nxt; nxt = cur; cur = t_;
+        em_park(emn, t - 1);
+        { double* t_ = nxt; nxt = cur; cur = t_; }
+        { double* t_ = em1; em1 = em0; em0 = emn; emn = t_; }   // window slides down: (t, t+1) -> (t-1, t)
+        fb_lds_barrier();
         for (int r = tid; r < R; r += bd) cur[r] = NEG;  // same-column reads see only rows of this column
-        __syncthreads();
     }
 }
 
