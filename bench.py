@@ -153,10 +153,22 @@ def cpu_baseline(wl, n_utts=20):
         correct += int(np.argmin(ev) == wl["words"][u])
         frames += len(x)
     dt = time.perf_counter() - t0
-    return dict(value=frames * W * n / dt, unit="frame-state loglik/s", cores=1, kind="port",
-                sample="first %d utterances (%d frames) of the same workload, oracle/ref_numpy.py "
-                       "(emission_matrix dense=True + decode_states), %.1f s" % (n_utts, frames, dt),
-                utterances_per_s=n_utts / dt, accuracy=correct / n_utts)
+    out = dict(value=frames * W * n / dt, unit="frame-state loglik/s", cores=1, kind="port",
+               sample="first %d utterances (%d frames) of the same workload, oracle/ref_numpy.py "
+                      "(emission_matrix dense=True + decode_states), %.1f s" % (n_utts, frames, dt),
+               utterances_per_s=n_utts / dt, accuracy=correct / n_utts)
+    # beside it: the same arithmetic VECTORISED with numpy (log-domain batch likelihoods, oracle.gmm_neg_loglik_batch;
+    # the DP stays per cell), i.e. what a CPU user who is not bound to the reference's per-frame objects would run
+    nv = min(len(wl["words"]), 3 * n_utts)
+    Xs = wl["X"][:wl["off"][nv]]
+    S = W * n
+    t1 = time.perf_counter()
+    O.gmm_neg_loglik_batch(Xs, wl["means"].reshape(S, *wl["means"].shape[2:]), wl["vars"].reshape(S, *wl["vars"].shape[2:]),
+                           wl["w"].reshape(S, -1))
+    dv = time.perf_counter() - t1
+    out["vectorized_numpy_loglik"] = dict(value=len(Xs) * S / dv, unit="frame-state loglik/s", frames=int(len(Xs)),
+                                          seconds=dv, threads="numpy default")
+    return out
 
 
 def main():
