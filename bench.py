@@ -354,7 +354,7 @@ def main():
                 "note": "algorithmic flops = 2*(2D)*S*M per frame; peak = dense %s rate" % args.dtype,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is a rank-0, single-GPU-run measurement
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_utts)
         print(json.dumps(out), flush=True)
     if dist is not None:
