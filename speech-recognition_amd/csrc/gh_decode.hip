@@ -414,6 +414,42 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     chunk_begin.push_back(U);
     const bool mats = out_alpha || out_beta || out_gamma;
     const int64_t n_mat = mats ? mat_off[U] : 0;
+    // one-word chain graphs and no matrices asked for: one lane per utterance (GMMHMM_FB=generic forces the other)
+    {
+        const char* e = getenv("GMMHMM_FB");
+        if (lat->fbchain_ok && !mats && !(e && !strcmp(e, "generic"))) {
+            std::vector<int64_t> coff(U, 0);
+            size_t cacc = 0;
+            for (int64_t k = 0; k < U; ++k) {
+                const int64_t u = b->perm[k];
+                coff[k] = (int64_t)cacc;
+                cacc += (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0].n;
+            }
+            int64_t* d_coff;
+            int32_t* d_ul = nullptr;
+            double *d_al, *d_lp;
+            Carver cc;
+            cc.add(&d_coff, U); cc.add(&d_lp, U); cc.add(&d_al, cacc);
+            if (utt_lattice) cc.add(&d_ul, U);
+            int rc2 = cc.commit(ctx);
+            if (rc2) return rc2;
+            hipStream_t s2 = ctx->stream;
+            GH_HIP(hipMemcpyAsync(d_coff, coff.data(), U * 8, hipMemcpyHostToDevice, s2));
+            if (utt_lattice) GH_HIP(hipMemcpyAsync(d_ul, utt_lattice, U * 4, hipMemcpyHostToDevice, s2));
+            if (want_occ && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, s2));
+            gh_fbchain_args ca;
+            memset(&ca, 0, sizeof ca);
+            ca.chains = lat->d_fbchain; ca.nll = b->nll; ca.S = S; ca.utt_off = b->d_offsets; ca.utt_lat = d_ul;
+            ca.perm = b->d_perm; ca.U = U; ca.alpha_scratch = d_al; ca.scratch_off = d_coff; ca.logp = d_lp;
+            ca.occ = want_occ ? b->occ : nullptr;
+            rc2 = gh_launch_fb_chain(ctx, ca, b->dtype == GH_F64);
+            if (rc2) return rc2;
+            if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_lp, U * 8, hipMemcpyDeviceToHost, s2));
+            if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, s2));
+            GH_HIP(hipStreamSynchronize(s2));
+            return GH_OK;
+        }
+    }
     int64_t *d_soff, *d_matoff = nullptr;
     int32_t* d_uttlat = nullptr;
     double *d_scratch, *d_logp, *d_alpha = nullptr, *d_beta = nullptr, *d_gamma = nullptr;

@@ -35,3 +35,19 @@ struct gh_fb_args {
 };
 
 int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, size_t lds_bytes, bool f64);
+
+// one-word chain graphs: one lane per utterance (fb_chain_kernel)
+struct gh_fbchain_args {
+    const gh_fbchain* chains;    // [L]
+    const void* nll;
+    int S;
+    const int64_t* utt_off;
+    const int32_t* utt_lat;      // or null (graph 0)
+    const int64_t* perm;         // launch slot -> utterance (longest first)
+    int64_t U;
+    double* alpha_scratch;       // [T, n] per launch slot
+    const int64_t* scratch_off;  // [slots]
+    double* logp;                // [U]
+    double* occ;                 // optional [N,S], zeroed by the caller
+};
+int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);

@@ -103,6 +103,18 @@ struct gh_lattice_host {
     int max_state;
 };
 
+// A graph that is ONE left-to-right chain of <= 8 emitting rows with distinct states (arcs from r, r-1, r-2 in the
+// previous column), started at its first row (directly, or through a non-emitting start row: cost c0) and ended
+// at its last row -- what a one-word forced-alignment lattice is.  gh_forward_backward runs these with one LANE
+// per utterance (fb_chain_kernel): the whole recursion lives in registers.
+#define GH_FBCHAIN_MAX 8
+struct gh_fbchain {
+    int32_t n, pad;
+    int32_t state[GH_FBCHAIN_MAX];
+    double c0;
+    double self_c[GH_FBCHAIN_MAX], next_c[GH_FBCHAIN_MAX], skip_c[GH_FBCHAIN_MAX];   // +inf = no such arc
+};
+
 struct gh_lattices {
     gh_ctx* ctx;
     int L;
@@ -136,6 +148,9 @@ struct gh_lattices {
     double *d_ch_cost0, *d_ch_cost1, *d_ch_cost2;
     uint8_t* d_ch_info;
     int32_t *d_ch_end_slot, *d_ch_group_row0;
+    bool fbchain_ok;                 // every graph is a gh_fbchain
+    std::vector<gh_fbchain> h_fbchain;
+    gh_fbchain* d_fbchain;
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };

@@ -31,6 +31,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     lt->d_ch_cost0 = lt->d_ch_cost1 = lt->d_ch_cost2 = nullptr; lt->d_ch_info = nullptr;
     lt->d_ch_end_slot = nullptr; lt->d_ch_group_row0 = nullptr;
     lt->d_desc = nullptr;
+    lt->d_fbchain = nullptr; lt->fbchain_ok = true;
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
         const int64_t r0 = row_off[l], a0 = arc_off[l];
@@ -142,6 +143,51 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         lt->h_desc.push_back(d);
         lt->max_R = std::max(lt->max_R, R);
         lt->max_nlev = std::max(lt->max_nlev, nlev);
+
+        // ---- one-word chain form for the forward-backward kernel (see gh_fbchain) ----
+        if (lt->fbchain_ok) {
+            gh_fbchain fc;
+            memset(&fc, 0, sizeof fc);
+            std::vector<int> em;  // emitting rows, ascending
+            for (int r = 0; r < R; ++r) if (h_state[r0 + r] >= 0) em.push_back(r);
+            bool ok = !em.empty() && (int)em.size() <= GH_FBCHAIN_MAX && ne == 1 && end_rows[end_off[l]] == em.back();
+            std::vector<int> pos(R, -1);
+            for (int j = 0; ok && j < (int)em.size(); ++j) {
+                pos[em[j]] = j;
+                fc.state[j] = h_state[r0 + em[j]];
+                fc.self_c[j] = fc.next_c[j] = fc.skip_c[j] = INFINITY;
+                for (int i = 0; i < j; ++i) ok = ok && fc.state[i] != fc.state[j];
+            }
+            fc.n = (int)em.size();
+            fc.c0 = INFINITY;
+            int start_row = -1;
+            for (int k = 0; ok && k < ns; ++k) {
+                if (start_row >= 0) ok = false;
+                start_row = start_rows[start_off[l] + k];
+            }
+            ok = ok && start_row >= 0;
+            if (ok && start_row == em[0]) fc.c0 = 0.0;
+            else if (ok && h_state[r0 + start_row] >= 0) ok = false;  // starts at an emitting row that is not the first
+            for (int k = 0; ok && k < A; ++k) {
+                const int to = arc_to[a0 + k], fr = arc_from[a0 + k];
+                const double c = arc_cost[a0 + k];
+                if (c != c) { ok = false; break; }
+                if (pos[to] >= 0 && pos[fr] >= 0) {           // emitting -> emitting: previous column
+                    const int dlt = pos[to] - pos[fr];
+                    double* slot = dlt == 0 ? &fc.self_c[pos[to]] : dlt == 1 ? &fc.next_c[pos[to]] : dlt == 2 ? &fc.skip_c[pos[to]] : nullptr;
+                    if (!slot || !std::isinf(*slot)) ok = false; else *slot = c;
+                } else if (pos[to] >= 0) {                    // non-emitting -> emitting: only start row -> first row
+                    if (fr == start_row && to == em[0] && std::isinf(fc.c0) && fr < to) fc.c0 = c; else ok = false;
+                } else {                                      // anything -> non-emitting row: must not lead anywhere
+                    if (pos[fr] < 0) ok = false;              // (non-emitting chains are not modelled)
+                }
+            }
+            // a non-emitting row that is fed may not feed an emitting row (checked above: only the start row does),
+            // and the start row must not be fed
+            for (int k = 0; ok && k < A; ++k) if (arc_to[a0 + k] == start_row && start_row != em[0]) ok = false;
+            ok = ok && !std::isinf(fc.c0);
+            if (ok) lt->h_fbchain.push_back(fc); else { lt->fbchain_ok = false; lt->h_fbchain.clear(); }
+        }
 #undef GH_LFAIL
     }
     // ---- chain form: one graph, one level, arcs only from r, r-1, r-2, distinct end rows ----
@@ -201,7 +247,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         (rc = upload(&lt->d_succ_cost, h_scost)) ||
         (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_level_narrow, h_narrow)) ||
         (rc = upload(&lt->d_end_rows, h_end)) ||
-        (rc = upload(&lt->d_desc, lt->h_desc))) {
+        (rc = upload(&lt->d_desc, lt->h_desc)) || (lt->fbchain_ok && (rc = upload(&lt->d_fbchain, lt->h_fbchain)))) {
         gh_lattices_destroy(lt);
         return rc;
     }
@@ -219,6 +265,7 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipFree(l->d_ch_end_slot); hipFree(l->d_ch_group_row0);
     hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
     hipFree(l->d_desc);
+    hipFree(l->d_fbchain);
     delete l;
 }
 

@@ -551,3 +551,59 @@ def test_mfcc_at_scale_matches_oracle(hip, ctx):
             ref = O.standardize(np.concatenate([c, d, O.delta_feature(d)], axis=1))
             np.testing.assert_allclose(f, ref, rtol=tol, atol=tol)
         b.close()
+
+
+def test_forward_backward_chain_kernel_vs_generic_and_oracle(hip, ctx, monkeypatch):
+    """One-word graphs (plain chains and the NES-wrapped forced-alignment lattices of packed_lattice) take the
+    one-lane-per-utterance kernel when no matrices are requested: log P and the frame x state occupancies must equal
+    the generic kernel's (GMMHMM_FB=generic) and the oracle's."""
+    from sr.recognition.continuous_speech import packed_lattice
+    g = load_golden("G3_isolated_decode_c2")
+    means, vars_, w, trans = g["means"], g["vars"], g["w"], g["trans"]
+    W, n, M, D = means.shape
+    S = W * n
+    gmm = hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), w.reshape(S, M))
+    rng = np.random.default_rng(5)
+    xs, words = [], []
+    for u in range(70):                       # more than one wave of utterances, ragged lengths incl. T = 1 and 2
+        wd = int(rng.integers(0, W))
+        T = [1, 2, 3][u] if u < 3 else int(rng.integers(6, 40))
+        st = np.minimum(np.arange(T) * n // T, n - 1)
+        xs.append(means[wd, st, 0] + np.sqrt(vars_[wd, st, 0]) * rng.normal(size=(T, D)))
+        words.append(wd)
+    plain = [graph(np.arange(n) + i * n, trans, [0], [n - 1]) for i in range(W)]
+    wrapped = [packed_lattice([trans] * W, n, [[i]])[0] for i in range(W)]
+    for graphs in (plain, wrapped):
+        lat = hip.Lattices(ctx, graphs)
+        b = hip.Batch(ctx, xs)
+        nll = b.loglik(gmm)
+        monkeypatch.delenv("GMMHMM_FB", raising=False)
+        r_chain = lat.forward_backward(b, utt_lattice=words, want_occ=True)
+        monkeypatch.setenv("GMMHMM_FB", "generic")
+        r_gen = lat.forward_backward(b, utt_lattice=words, want_occ=True)
+        monkeypatch.delenv("GMMHMM_FB", raising=False)
+        np.testing.assert_allclose(r_chain["logp"], r_gen["logp"], rtol=1e-11)
+        np.testing.assert_allclose(r_chain["occ"], r_gen["occ"], rtol=1e-9, atol=1e-12)
+        long_enough = np.repeat(b.lengths >= n, b.lengths)     # a chain of n states needs n frames to reach its end
+        np.testing.assert_allclose(r_chain["occ"][long_enough].sum(axis=1), 1.0, rtol=1e-9)
+        assert np.all(r_chain["occ"][~long_enough] == 0) and np.all(np.isinf(r_chain["logp"][:3]))
+        for u in (0, 1, 2, 5, 69):            # oracle on a few utterances
+            gr = graphs[words[u]]
+            rs = np.asarray(gr["row_state"])
+            R = len(rs)
+            dense = np.full((R, R), np.inf)
+            dense[np.asarray(gr["arc_to"]), np.asarray(gr["arc_from"])] = gr["arc_cost"]
+            x_nll = nll[b.offsets[u]:b.offsets[u + 1]]
+            E = np.where(rs[:, None] >= 0, x_nll[:, np.maximum(rs, 0)].T, 0.0)
+            al, be, ga, logp = O.forward_backward(E, rs < 0, dense, gr["end_rows"])
+            if np.isinf(logp):
+                assert np.isinf(r_chain["logp"][u])
+                continue
+            np.testing.assert_allclose(r_chain["logp"][u], logp, rtol=1e-10)
+            occ = np.zeros((len(x_nll), S))
+            for r in range(R):
+                if rs[r] >= 0:
+                    occ[:, rs[r]] += ga[r]
+            np.testing.assert_allclose(r_chain["occ"][b.offsets[u]:b.offsets[u + 1]], occ, rtol=1e-8, atol=1e-12)
+        b.close()
+        lat.close()
