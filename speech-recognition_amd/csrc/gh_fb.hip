@@ -253,89 +253,100 @@ __device__ __forceinline__ double lse3(double x, double y, double z) {
     return m + log(exp(x - m) + exp(y - m) + exp(z - m));
 }
 
+__device__ __forceinline__ double lse2(double x, double y) {
+    const double m = fmax(x, y);
+    if (m == -INFINITY) return -INFINITY;
+    return m + log1p(exp(fmin(x, y) - m));   // one exp + one log1p (three exps + a log in lse3)
+}
+
+// Lane layout: 8 lanes per utterance (lane j of the group = chain row j, idle when j >= n), 8 utterances per wave.
+// A first version with one lane per utterance and all rows in registers had U/64 waves of ~800 dependent
+// instructions per column (0.85 ms for 12 500 utterances); one row per lane gives 8x the waves and 1/5 of the
+// serial work per lane.  Neighbouring rows are one __shfl_up / __shfl_down (width 8) away.
 template <typename ET>
 __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
-    constexpr int NMAX = GH_FBCHAIN_MAX;
-    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (slot >= a.U) return;
-    const int64_t u = a.perm ? a.perm[slot] : slot;
-    const gh_fbchain ch = a.chains[a.utt_lat ? a.utt_lat[u] : 0];
-    const int n = ch.n;
-    const int64_t f0 = a.utt_off[u];
-    const int T = (int)(a.utt_off[u + 1] - f0);
+    constexpr int NMAX = GH_FBCHAIN_MAX;   // == 8 == lanes per utterance
+    constexpr int PD = 4;                  // columns of loads in flight per lane
+    const int j = threadIdx.x & (NMAX - 1);
+    const int64_t slot = (int64_t)blockIdx.x * (64 / NMAX) + (threadIdx.x / NMAX);
+    const bool has_utt = slot < a.U;
+    const int64_t u = has_utt ? (a.perm ? a.perm[slot] : slot) : 0;
+    const gh_fbchain* chp = a.chains + ((has_utt && a.utt_lat) ? a.utt_lat[u] : 0);
+    const int n = chp->n;
+    const bool act = has_utt && j < n;     // this lane owns a row
+    const bool skip = chp->pad != 0;
+    const int st = act ? chp->state[j] : 0;
     const double NEG = -INFINITY;
-    if (T <= 0) { if (a.logp) a.logp[u] = NEG; return; }
+    const double c_self = act ? chp->self_c[j] : INFINITY, c_next = act ? chp->next_c[j] : INFINITY,
+                 c_skip = act ? chp->skip_c[j] : INFINITY;
+    // costs of the arcs LEAVING this row towards j+1 / j+2 (stored at their destination)
+    const double c_out1 = (act && j + 1 < n) ? chp->next_c[(j + 1 < NMAX) ? j + 1 : j] : INFINITY;
+    const double c_out2 = (act && j + 2 < n) ? chp->skip_c[(j + 2 < NMAX) ? j + 2 : j] : INFINITY;
+    const int64_t f0 = has_utt ? a.utt_off[u] : 0;
+    const int T = has_utt ? (int)(a.utt_off[u + 1] - f0) : 0;
+    // every lane of the wave runs to the longest utterance of the wave (shuffles need converged lanes)
+    int Tmax = T;
+#pragma unroll
+    for (int o = 32; o >= NMAX; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
+    if (has_utt && j == 0 && T <= 0 && a.logp) a.logp[u] = NEG;
     const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
-    double* alpha = a.alpha_scratch + a.scratch_off[slot];   // [T, n]
-    double al[NMAX], e[NMAX], en[NMAX];
+    double* alpha = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0);   // [T, n]
+    auto load_e = [&](int t) -> ET { return (act && t >= 0 && t < T) ? nll[(int64_t)t * a.S + st] : ET(0); };
+    ET ering[PD];
+    double e = (double)load_e(0);
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) { al[j] = NEG; e[j] = (j < n) ? (double)nll[ch.state[j]] : 0.0; }
+    for (int k = 0; k < PD; ++k) ering[k] = load_e(1 + k);
     // ---- forward ----
-    al[0] = -ch.c0 - e[0];
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) {
+    double al = (act && j == 0 && T > 0) ? -chp->c0 - e : NEG;
+    double al_last = NEG;   // alpha of this row in column T - 1
+    for (int t0 = 0; t0 < Tmax; t0 += PD) {
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) en[j] = (j < n) ? (double)nll[(int64_t)(t + 1) * a.S + ch.state[j]] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) if (j < n) alpha[(int64_t)t * n + j] = al[j];
-        if (t + 1 < T) {
-            double nx[NMAX];
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                const double a0 = al[j] - ch.self_c[j];
-                const double a1 = (j >= 1) ? al[j - 1] - ch.next_c[j] : NEG;
-                const double a2 = (j >= 2) ? al[j - 2] - ch.skip_c[j] : NEG;
-                nx[j] = (j < n) ? lse3(a0, a1, a2) - en[j] : NEG;
-            }
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) { al[j] = nx[j]; e[j] = en[j]; }
+        for (int k = 0; k < PD; ++k) {
+            const int t = t0 + k;
+            if (t >= Tmax) break;
+            if (act && t < T) alpha[(int64_t)t * n + j] = al;
+            if (t == T - 1) al_last = al;
+            const double up1 = __shfl_up(al, 1, NMAX), up2 = __shfl_up(al, 2, NMAX);
+            const double a0 = al - c_self;
+            const double a1 = (j >= 1) ? up1 - c_next : NEG;
+            const double a2 = (j >= 2) ? up2 - c_skip : NEG;
+            const double en = (double)ering[k];
+            const double nx = (skip ? lse3(a0, a1, a2) : lse2(a0, a1)) - en;
+            if (act && t + 1 < T) { al = nx; e = en; }
+            ering[k] = load_e(t + 1 + PD);   // slot k next serves column t + 1 + PD
         }
     }
-    double logp = NEG;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) if (j == n - 1) logp = al[j];
-    if (a.logp) a.logp[u] = logp;
+    const double logp = __shfl(al_last, (n > 0 ? n - 1 : 0), NMAX);
+    if (has_utt && j == 0 && T > 0 && a.logp) a.logp[u] = logp;
     if (!a.occ) return;
-    // ---- backward: beta in registers, gamma straight into the occupancy rows (e[] holds column T-1) ----
-    double be[NMAX];
+    // ---- backward: beta in a register, gamma straight into the occupancy rows (e holds column T-1) ----
+    auto load_a = [&](int t) -> double { return (act && t >= 0 && t < T) ? alpha[(int64_t)t * n + j] : NEG; };
+    double be = (act && j == n - 1) ? 0.0 : NEG;
+    double ap = load_a(T - 1);
+    double aring[PD];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) be[j] = (j == n - 1) ? 0.0 : NEG;
-    double ap[NMAX];
+    for (int k = 0; k < PD; ++k) { aring[k] = load_a(T - 2 - k); ering[k] = load_e(T - 2 - k); }
+    // lanes of shorter utterances idle (be = -inf, no stores) until the wave's column index reaches their T - 1
+    for (int t0 = Tmax - 1; t0 >= 0; t0 -= PD) {
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) ap[j] = (j < n) ? alpha[(int64_t)(T - 1) * n + j] : NEG;
-    for (int t = T - 1; t >= 0; --t) {
-        double apn[NMAX];
-        if (t > 0) {   // next iteration's alpha column and emissions travel while this column is processed
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                apn[j] = (j < n) ? alpha[(int64_t)(t - 1) * n + j] : NEG;
-                en[j] = (j < n) ? (double)nll[(int64_t)(t - 1) * a.S + ch.state[j]] : 0.0;
-            }
-        }
-        double* orow = a.occ + (f0 + t) * a.S;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            if (j < n) {
-                double g = exp(ap[j] + be[j] - logp);
+        for (int k = 0; k < PD; ++k) {
+            const int tw = t0 - k;              // column index of the wave's longest utterance
+            if (tw < 0) break;
+            const int t = tw - (Tmax - T);      // this utterance's column (negative: it has not started yet)
+            if (act && t >= 0) {
+                double g = exp(ap + be - logp);
                 if (!(g == g)) g = 0.0;
-                orow[ch.state[j]] = g;
+                a.occ[(f0 + t) * a.S + st] = g;
             }
-        }
-        if (t > 0) {
             // beta_{t-1}(j) = lse over successors j, j+1, j+2 of (beta_t(s) - cost(j -> s) - e_t(s))
-            double w[NMAX], nb[NMAX];
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) w[j] = (j < n) ? be[j] - e[j] : NEG;
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                const double b0 = w[j] - ch.self_c[j];
-                const double b1 = (j + 1 < NMAX) ? w[(j + 1 < NMAX) ? j + 1 : j] - ch.next_c[(j + 1 < NMAX) ? j + 1 : j] : NEG;
-                const double b2 = (j + 2 < NMAX) ? w[(j + 2 < NMAX) ? j + 2 : j] - ch.skip_c[(j + 2 < NMAX) ? j + 2 : j] : NEG;
-                nb[j] = (j < n) ? lse3(b0, (j + 1 < n) ? b1 : NEG, (j + 2 < n) ? b2 : NEG) : NEG;
-            }
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j) { be[j] = nb[j]; ap[j] = apn[j]; e[j] = en[j]; }
+            const double w = act ? be - e : NEG;
+            const double d1 = __shfl_down(w, 1, NMAX), d2 = __shfl_down(w, 2, NMAX);
+            const double b0 = w - c_self;
+            const double b1 = (j + 1 < n) ? d1 - c_out1 : NEG;
+            const double b2 = (j + 2 < n) ? d2 - c_out2 : NEG;
+            const double nb = skip ? lse3(b0, b1, b2) : lse2(b0, b1);
+            if (act && t > 0) { be = nb; ap = aring[k]; e = (double)ering[k]; }
+            if (t >= 0) { aring[k] = load_a(t - 1 - PD); ering[k] = load_e(t - 1 - PD); }
         }
     }
 }
@@ -352,7 +363,7 @@ int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, si
 
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64) {
     if (a.U <= 0) return GH_OK;
-    const dim3 grid((unsigned)((a.U + 63) / 64)), blk(64);
+    const dim3 grid((unsigned)((a.U + 7) / 8)), blk(64);   // 8 utterances per wave, 8 lanes each
     if (f64) hipLaunchKernelGGL((fb_chain_kernel<double>), grid, blk, 0, ctx->stream, a);
     else hipLaunchKernelGGL((fb_chain_kernel<float>), grid, blk, 0, ctx->stream, a);
     GH_HIP(hipGetLastError());

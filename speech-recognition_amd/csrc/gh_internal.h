@@ -109,7 +109,7 @@ struct gh_lattice_host {
 // per utterance (fb_chain_kernel): the whole recursion lives in registers.
 #define GH_FBCHAIN_MAX 8
 struct gh_fbchain {
-    int32_t n, pad;
+    int32_t n, pad;                       // pad = 1 when the chain has r-2 -> r (skip) arcs
     int32_t state[GH_FBCHAIN_MAX];
     double c0;
     double self_c[GH_FBCHAIN_MAX], next_c[GH_FBCHAIN_MAX], skip_c[GH_FBCHAIN_MAX];   // +inf = no such arc

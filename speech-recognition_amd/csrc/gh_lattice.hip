@@ -186,6 +186,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             // and the start row must not be fed
             for (int k = 0; ok && k < A; ++k) if (arc_to[a0 + k] == start_row && start_row != em[0]) ok = false;
             ok = ok && !std::isinf(fc.c0);
+            for (int j = 0; j < fc.n; ++j) if (!std::isinf(fc.skip_c[j])) fc.pad = 1;   // pad = "has skip arcs"
             if (ok) lt->h_fbchain.push_back(fc); else { lt->fbchain_ok = false; lt->h_fbchain.clear(); }
         }
 #undef GH_LFAIL
