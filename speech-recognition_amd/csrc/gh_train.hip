@@ -161,22 +161,28 @@ constexpr int BW_MAXP = 8;  // (component, dimension) pairs per lane of bw_stats
 // workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / store acknowledgements)
 __device__ __forceinline__ void bw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// MF = accumulate on the matrix cores (needs M <= 8 and 2D + 1 <= 128): see the accumulation phase below.
+// MAXCT / MAXP bound the column tiles and the (component, dimension) pairs per lane at compile time (register arrays).
+template <bool MF, int MAXCT, int MAXP>
 __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict__ X, int64_t N, int D, int S, int M,
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ occ,
                                                        double occ_floor, int F, const int64_t* __restrict__ utt_off,
                                                        int64_t U, double* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* xt = sm;                 // [F,D]   frames of the tile
-    double* rt = xt + F * D;         // [M,F]   weighted responsibilities of the current state
-    double* pm = rt + M * F;         // [M,D]   mean        } of the current state,
+    double* xt = sm;                 // [F,D]   frames of the tile (MF: rows >= nf zeroed up to a multiple of 4)
+    double* rt = xt + F * D;         // [M,F]   weighted responsibilities of the current state (MF: [F,8], frame major)
+    double* pm = rt + (MF ? 8 : M) * F;  // [M,D] mean      } of the current state,
     double* pv = pm + M * D;         // [M,D]   1/variance  } staged once per (tile, state)
     double* pc = pv + M * D;         // [M]     log-constant
     double* wt = pc + M;             // [F]     occupancy of the current state on the tile's frames
-    int* s_list = reinterpret_cast<int*>(wt + F);  // [S] active states of the tile, compacted
+    const int NCT = (2 * D + 1 + 15) / 16;                    // MF: 16-column tiles of Z = [1 | x - c | (x - c)^2]
+    double* gt = wt + F;                                       // MF: [8][NCT*16] product tile
+    int* s_list = reinterpret_cast<int*>(gt + (MF ? 8 * NCT * 16 : 0));  // [S] active states of the tile, compacted
     __shared__ int s_count;
     const int tid = threadIdx.x;
     const int W = 1 + 2 * D;
+    const int RS = MF ? 8 : 0;                                 // MF: row stride of rt
     double* slab = slabs + (int64_t)blockIdx.x * S * M * W;
     // tiles never straddle utterances: an utterance only occupies the states of its own graph, so a
     // tile's active set stays small (5 states for an isolated word instead of the 10-15 of a 128-frame
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
     for (int64_t n0 = utt_off[u]; n0 < utt_off[u + 1]; n0 += F) {
         const int nf = (int)((utt_off[u + 1] - n0 < F) ? (utt_off[u + 1] - n0) : F);
         __syncthreads();
-        for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];
+#pragma unroll 8
+        for (int i = tid; i < nf * D; i += 256) xt[i] = X[n0 * D + i];   // (unrolled: 8 loads in flight per lane)
+        if (MF) for (int i = nf * D + tid; i < ((nf + 3) & ~3) * D; i += 256) xt[i] = 0.0;   // 0 * garbage could be NaN
         // which states have any occupancy on this tile?  All lanes sweep the [nf, S] block of the occupancy
         // matrix linearly (coalesced, 4 loads in flight per lane) and raise a flag per state -- one lane per
         // state walking down its column costs one memory round trip per frame.
@@ -215,9 +223,9 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
             // L2 / HBM now and are added to at the end of the pair: the read-modify-write latency of the 253 KB
             // per-workgroup slab was the largest single cost of the kernel (33 k of 80 k cycles per pair)
             const int P = M * (D + 1);
-            double so1[BW_MAXP], so2[BW_MAXP];
+            double so1[MAXP], so2[MAXP];
 #pragma unroll
-            for (int h = 0; h < BW_MAXP; ++h) {
+            for (int h = 0; h < MAXP; ++h) {
                 so1[h] = 0; so2[h] = 0;
                 const int p = tid + 256 * h;
                 if (p < P) {
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                 pv[i] = ivar[(int64_t)s * M * D + i];
             }
             if (tid < M) pc[tid] = logc[(int64_t)s * M + tid];
+            if (MF) for (int i = tid; i < 8 * NCT * 16; i += 256) gt[i] = 0.0;
             bw_lds_barrier();
             // component log-densities of every (frame, component) pair of the tile on all 256 lanes (the lanes of a
             // frame read the same feature row: LDS broadcast), four independent partial sums per pair; then one
@@ -256,35 +265,108 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                     for (; d < D; ++d) { const double t = x[d] - mu[d]; q0 = fma(t * iv[d], t, q0); }
                     ll = pc[m] - 0.5 * ((q0 + q1) + (q2 + q3));
                 }
-                rt[m * F + f] = ll;
+                rt[MF ? f * RS + m : m * F + f] = ll;
             }
             bw_lds_barrier();
             if (tid < F) {
                 const int f = tid;
                 const double wgt = wt[f];
+                double* rf = MF ? rt + f * RS : rt + f;          // this frame's responsibilities, stride rs
+                const int rs = MF ? 1 : F;
                 if (f < nf && (wgt > occ_floor || wgt != wgt)) {
                     double mx = -INFINITY;
                     bool bad = false;
                     for (int m = 0; m < M; ++m) {
-                        const double ll = rt[m * F + f];
+                        const double ll = rf[m * rs];
                         bad |= (ll != ll);
                         mx = fmax(mx, ll);
                     }
                     double sum = 0;
                     for (int m = 0; m < M; ++m) {
-                        const double e = (mx == -INFINITY) ? 0.0 : exp(rt[m * F + f] - mx);
-                        rt[m * F + f] = e;
+                        const double e = (mx == -INFINITY) ? 0.0 : exp(rf[m * rs] - mx);
+                        rf[m * rs] = e;
                         sum += e;
                     }
                     const double inv = bad ? NAN : (sum > 0 ? wgt / sum : 0.0);
-                    for (int m = 0; m < M; ++m) rt[m * F + f] = bad ? NAN : rt[m * F + f] * inv;
+                    for (int m = 0; m < M; ++m) rf[m * rs] = bad ? NAN : rf[m * rs] * inv;
+                    if (MF) for (int m = M; m < 8; ++m) rf[m] = 0.0;
+                } else if (MF) {
+                    if (f < ((nf + 3) & ~3)) for (int m = 0; m < 8; ++m) rf[m] = 0.0;
                 } else {
-                    for (int m = 0; m < M; ++m) rt[m * F + f] = 0.0;
+                    for (int m = 0; m < M; ++m) rf[m * rs] = 0.0;
                 }
             }
             bw_lds_barrier();
+            if (MF) {
+                // ---- accumulation on the matrix cores: G[m, c] = sum_f r[f, m] Z[f, c] with ONE operand for all
+                // components, Z[f] = [1 | x_f - c_s | (x_f - c_s)^2] centred on the state's first component mean
+                // c_s; the component-centred sums follow in the epilogue: with delta = mean_m - c_s,
+                //   S1 = G1 - delta S0,   S2 = G2 - 2 delta G1 + delta^2 S0.
+                // v_mfma_f64_16x16x4: A[i, k] = r[f0 + k][i] (rows 8..15 zero), B[k, j] = Z[f0 + k][16 ct + j]; wave w
+                // owns column tiles w, w + 4.  (The per-lane frame loops of the vector version were 33 k cycles per
+                // tile and state.)
+                // Work split: wave w takes the k-steps (groups of 4 frames) w, w + 4, ... for ALL column tiles -- one A
+                // fragment feeds NCT independent MFMAs, whose issue time hides the LDS latency of the next operands --
+                // and adds its partial tile into the shared product tile with LDS fp64 atomics.
+                typedef double v4d __attribute__((ext_vector_type(4)));
+                const int lane = tid & 63, wv = tid >> 6;
+                const int i = lane & 15, kq = lane >> 4;
+                const int nk = (nf + 3) >> 2;
+                int kind[MAXCT], dd[MAXCT];
+                double cs[MAXCT];
+                v4d acc[MAXCT];
 #pragma unroll
-            for (int h = 0; h < BW_MAXP; ++h) {
+                for (int ct = 0; ct < MAXCT; ++ct) {
+                    const int c = ct * 16 + i;                       // column of Z this lane feeds in tile ct
+                    kind[ct] = (ct >= NCT) ? 3 : (c == 0) ? 0 : (c <= D) ? 1 : (c <= 2 * D) ? 2 : 3;
+                    dd[ct] = (kind[ct] == 1) ? c - 1 : (kind[ct] == 2) ? c - 1 - D : 0;
+                    cs[ct] = pm[dd[ct]];
+                    acc[ct] = (v4d){0, 0, 0, 0};
+                }
+                for (int k = wv; k < nk; k += 4) {
+                    const int f = 4 * k + kq;
+                    const double av = (i < 8) ? rt[f * RS + i] : 0.0;
+                    const double* xr = xt + f * D;
+#pragma unroll
+                    for (int ct = 0; ct < MAXCT; ++ct) {
+                        if (ct < NCT) {
+                            const double xv = xr[dd[ct]] - cs[ct];
+                            const double bv = (kind[ct] == 0) ? 1.0 : (kind[ct] == 1) ? xv : (kind[ct] == 2) ? xv * xv : 0.0;
+                            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ct], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < MAXCT; ++ct) {
+                    if (ct < NCT) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {             // D[row = kq + 4 r4][col = i]
+                            const int row = kq + 4 * r4;
+                            if (row < 8) atomicAdd(&gt[row * (NCT * 16) + ct * 16 + i], acc[ct][r4]);
+                        }
+                    }
+                }
+                bw_lds_barrier();
+#pragma unroll
+                for (int h = 0; h < MAXP; ++h) {
+                    const int p = tid + 256 * h;
+                    if (p >= P) continue;
+                    const int m = p / (D + 1), d = p % (D + 1);
+                    const double* g = gt + m * (NCT * 16);
+                    double* o = slab + ((int64_t)s * M + m) * W;
+                    if (d == D) {
+                        o[0] = so1[h] + g[0];
+                    } else {
+                        const double dl = pm[m * D + d] - pm[d], s0 = g[0], g1 = g[1 + d], g2 = g[1 + D + d];
+                        o[1 + d] = so1[h] + (g1 - dl * s0);
+                        o[1 + D + d] = so2[h] + (g2 - dl * (2.0 * g1 - dl * s0));
+                    }
+                }
+                bw_lds_barrier();
+                continue;
+            }
+#pragma unroll
+            for (int h = 0; h < MAXP; ++h) {
                 const int p = tid + 256 * h;
                 if (p >= P) continue;
                 const int m = p / (D + 1), d = p % (D + 1);
@@ -437,9 +519,14 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     // The kernel is latency bound per workgroup (global round trips between barriers), so workgroups per CU
     // decide: frame tiles are sized for as many resident workgroups as the 160 KB of LDS allow (a tile one
     // entry too large silently drops a CU from 3 to 2 workgroups: measured 4.4 -> 5.0 ms).
-    auto lds_need = [&](int f) { return ((size_t)f * D + (size_t)M * f + 2 * (size_t)M * D + M + f) * 8 + (size_t)S * 4 + 16; };
+    const bool mf = M <= 8 && 2 * D + 1 <= 128;   // accumulation on the matrix cores
+    const int nct = (2 * D + 1 + 15) / 16;
+    auto lds_need = [&](int f) {
+        return ((size_t)f * D + (size_t)(mf ? 8 : M) * f + 2 * (size_t)M * D + M + f + (mf ? 8 * nct * 16 : 0)) * 8 + (size_t)S * 4 + 16;
+    };
     int F = (int)std::max<int64_t>(32, std::min<int64_t>(160, (b->max_T + 7) & ~int64_t(7)));  // one tile per utterance when it fits
     if (const char* e = getenv("GMMHMM_BW_F")) F = std::max(16, std::min(256, atoi(e)));   // tuning knob
+    F = (F + 3) & ~3;
     while (F > 16 && lds_need(F) > 80 * 1024) F >>= 1;
     GH_REQUIRE(lds_need(F) <= 150 * 1024, "gh_bw_accumulate: D=%d M=%d does not fit LDS", D, M);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / (lds_need(F) + 256)));
@@ -453,7 +540,9 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     double* d_slabs = (double*)((char*)base + out_bytes);
     GH_HIP(hipMemsetAsync(d_slabs, 0, slab_bytes, st));
     if (ntiles > 0) {
-        hipLaunchKernelGGL(bw_stats_kernel, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats, b->N, D, S, M,
+        auto kern = !mf ? bw_stats_kernel<false, 1, BW_MAXP>
+                        : (nct <= 5 && M * (D + 1) <= 512) ? bw_stats_kernel<true, 5, 2> : bw_stats_kernel<true, 8, BW_MAXP>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats, b->N, D, S, M,
                            g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, b->d_offsets, b->U, d_slabs);
         GH_HIP(hipGetLastError());
     }
