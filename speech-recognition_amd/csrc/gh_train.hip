@@ -247,6 +247,42 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
             // lane per frame normalises over the components
             for (int f = tid; f < F; f += 256) wt[f] = (f < nf) ? occ[(n0 + f) * S + s] : 0.0;
             bw_lds_barrier();
+            if (MF) {
+                // densities AND the normalisation over the components in one phase: lane = (frame, component slot of
+                // 8); max / sum over the 8 slots by xor shuffles -- no intermediate LDS round trip, no second barrier
+                const int npair = ((nf + 3) & ~3) * 8;
+                for (int p = tid; p < npair; p += 256) {
+                    const int f = p >> 3, m = p & 7;
+                    const double wgt = (f < nf) ? wt[f] : 0.0;
+                    const bool on = (wgt > occ_floor || wgt != wgt);
+                    double ll = -INFINITY;
+                    if (on && m < M) {
+                        const double* x = xt + f * D;
+                        const double* mu = pm + m * D;
+                        const double* iv = pv + m * D;
+                        double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                        int d = 0;
+                        for (; d + 3 < D; d += 4) {
+                            const double t0 = x[d] - mu[d], t1 = x[d + 1] - mu[d + 1], t2 = x[d + 2] - mu[d + 2], t3 = x[d + 3] - mu[d + 3];
+                            q0 = fma(t0 * iv[d], t0, q0); q1 = fma(t1 * iv[d + 1], t1, q1);
+                            q2 = fma(t2 * iv[d + 2], t2, q2); q3 = fma(t3 * iv[d + 3], t3, q3);
+                        }
+                        for (; d < D; ++d) { const double t = x[d] - mu[d]; q0 = fma(t * iv[d], t, q0); }
+                        ll = pc[m] - 0.5 * ((q0 + q1) + (q2 + q3));
+                    }
+                    // NaN anywhere in the frame's densities poisons the frame (as the sequential version did)
+                    double bad = (ll != ll) ? 1.0 : 0.0, mx = (ll != ll) ? -INFINITY : ll;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) { mx = fmax(mx, __shfl_xor(mx, o)); bad += __shfl_xor(bad, o); }
+                    double e = (mx == -INFINITY || m >= M || ll != ll) ? 0.0 : exp(ll - mx);
+                    double sum = e;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o);
+                    double r = 0.0;
+                    if (on && m < M) r = (bad > 0.0) ? NAN : (sum > 0 ? e * (wgt / sum) : 0.0);
+                    rt[f * RS + m] = r;
+                }
+            } else {
             for (int p = tid; p < nf * M; p += 256) {
                 const int f = p / M, m = p - f * M;
                 const double wgt = wt[f];
@@ -296,6 +332,7 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                     for (int m = 0; m < M; ++m) rf[m * rs] = 0.0;
                 }
             }
+            }   // !MF
             bw_lds_barrier();
             if (MF) {
                 // ---- accumulation on the matrix cores: G[m, c] = sum_f r[f, m] Z[f, c] with ONE operand for all
