@@ -52,7 +52,8 @@ def test_loglik_golden(hip, ctx, tag, dtype, rtol):
         np.testing.assert_allclose(np.exp(comp), g["comp"][:, 7], rtol=1e-9)
 
 
-@pytest.mark.parametrize("S,M,D,N", [(3, 1, 6, 130), (50, 8, 39, 1000), (7, 5, 13, 257), (4, 3, 50, 64), (2, 9, 24, 63)])
+@pytest.mark.parametrize("S,M,D,N", [(3, 1, 6, 130), (50, 8, 39, 1000), (7, 5, 13, 257), (4, 3, 50, 64), (2, 9, 24, 63),
+                                     (5, 32, 39, 100), (3, 20, 13, 70), (70, 2, 13, 300), (130, 4, 39, 65), (9, 48, 7, 33)])
 def test_loglik_vs_oracle_shapes(hip, ctx, S, M, D, N):
     rng = np.random.default_rng(S * 100 + M)
     means = rng.normal(size=(S, M, D))
