@@ -218,26 +218,41 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             block = lb;
         }
     }
-    size_t lds;
-    if (lean_levels) {
-        a.em_chunk = std::max(1, std::min(8, 8 * block / std::max(S, 1)));
-        if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
-        a.arc_cap = (max_arcs + 1) & ~1;
-        lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+    size_t lds = 0;
+    auto lean_lds = [&](int ch) {
+        size_t v = (size_t)2 * a.r_pad * 8 + (size_t)2 * ch * (S + 1) * 8 + (size_t)(((max_arcs + 1) & ~1)) * 12 + 16;
         if (want_path) {  // 8 columns of back-pointers are collected in LDS and flushed with 16-byte stores
-            lds = (lds + 15) & ~size_t(15);
-            a.bpc_off = (int)lds;
-            lds += (size_t)8 * lat->max_R * 2 + 16;
+            v = (v + 15) & ~size_t(15);
+            v += (size_t)8 * lat->max_R * 2 + 16;
         }
         // back-trace: 2 KB path buffer + as many back-pointer columns as fit (at least 8)
-        if (want_path) lds = std::max(lds, (size_t)2048 + 16 + 32 + (size_t)8 * lat->max_R * 2);
-        lds = (lds + 15) & ~size_t(15);
+        if (want_path) v = std::max(v, (size_t)2048 + 16 + 32 + (size_t)8 * lat->max_R * 2);
+        return (v + 15) & ~size_t(15);
+    };
+    if (lean_levels && !use_chain) {
+        a.em_chunk = std::max(1, std::min(8, 8 * block / std::max(S, 1)));
+        if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
+        while (a.em_chunk > 1 && lean_lds(a.em_chunk) > 96 * 1024) a.em_chunk >>= 1;   // keep >= 1 workgroup pair per CU
+        if (lean_lds(a.em_chunk) > 160 * 1024) lean_levels = 0;                         // does not fit: generic kernel
+    }
+    if (lean_levels && !use_chain) {
+        a.arc_cap = (max_arcs + 1) & ~1;
+        lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
+        if (want_path) {
+            lds = (lds + 15) & ~size_t(15);
+            a.bpc_off = (int)lds;
+        }
+        lds = lean_lds(a.em_chunk);
         a.lds_bytes = (int)lds;
-    } else {
+    } else if (!use_chain) {
+        lean_levels = 0;
+        int max_level_rows2 = 1;
+        for (auto& d : lat->h_desc) max_level_rows2 = std::max(max_level_rows2, d.pad);
+        block = std::min(512, std::max(64, (max_level_rows2 + 63) & ~63));
         a.em_chunk = 1;
         lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
     }
-    if (lds > 160 * 1024) {
+    if (!use_chain && lds > 160 * 1024) {
         gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
         return GH_ERR_UNSUPPORTED;
     }

@@ -608,3 +608,46 @@ def test_forward_backward_chain_kernel_vs_generic_and_oracle(hip, ctx, monkeypat
             np.testing.assert_allclose(r_chain["occ"][b.offsets[u]:b.offsets[u + 1]], occ, rtol=1e-8, atol=1e-12)
         b.close()
         lat.close()
+
+
+def test_viterbi_configs3_shape_1024_rows(hip, ctx):
+    """configs[3] shape (64 word models x 16 states = 1024 rows / 1024 states): the stacked chain graph through
+    the chain kernel, and the same graph per utterance (lean / generic kernel selection with its LDS budget)."""
+    rng = np.random.default_rng(64)
+    W, n, M, D = 64, 16, 1, 4
+    S = W * n
+    means = rng.normal(size=(S, M, D)) * 3
+    vars_ = rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = np.ones((S, M))
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = -np.log(0.7) if i < n - 1 else 0.0
+        if i < n - 1:
+            trans[i + 1, i] = -np.log(0.3)
+    big = np.full((S, S), np.inf)
+    for i in range(W):
+        big[i * n:(i + 1) * n, i * n:(i + 1) * n] = trans
+    g = graph(np.arange(S), big, [i * n for i in range(W)], [i * n + n - 1 for i in range(W)])
+    xs, words = [], []
+    for u in range(6):
+        wd = int(rng.integers(0, W))
+        T = int(rng.integers(20, 40))
+        st = np.minimum(np.arange(T) * n // T, n - 1)
+        xs.append(means[wd * n + st, 0] + np.sqrt(vars_[wd * n + st, 0]) * rng.normal(size=(T, D)))
+        words.append(wd)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, xs)
+    nll = b.loglik(gmm)
+    lat = hip.Lattices(ctx, [g])
+    r1 = lat.viterbi(b, want_path=False)
+    r2 = lat.viterbi(b, utt_lattice=np.zeros(len(xs), dtype=np.int32), want_path=True)
+    np.testing.assert_array_equal(r1["end_cost_flat"], r2["end_cost_flat"])
+    ec = r1["end_cost_flat"].reshape(len(xs), W)
+    assert list(np.argmin(ec, axis=1)) == words
+    for u, wd in enumerate(words):
+        E = nll[b.offsets[u]:b.offsets[u + 1], wd * n:(wd + 1) * n].T
+        costs, path = O.decode_states(E, np.zeros(n, dtype=bool), trans)
+        np.testing.assert_allclose(ec[u, wd], costs[-1, -1], rtol=1e-12)
+        got = r2["paths"][u]
+        assert r2["best_end"][u] == wd
+        np.testing.assert_array_equal(got[:, 0] - wd * n, path[:, 0])

@@ -23,8 +23,13 @@ from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
 from sr.recognition.batch import path_to_words  # noqa: E402
 
 
-def timeit(fn, reps=5):
+def timeit(fn, reps=5, ramp=0.4):
+    """Mean wall time of fn() over `reps` calls, after keeping the GPU busy with it for `ramp` seconds (a cold
+    MI355X runs ~20 % below its sustained clock for the first few hundred ms)."""
+    t_r = time.perf_counter()
     fn()
+    while time.perf_counter() - t_r < ramp:
+        fn()
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fn()
