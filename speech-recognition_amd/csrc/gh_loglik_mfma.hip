@@ -259,12 +259,13 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
 #ifndef GH_MF_SGB
 #define GH_MF_SGB 0
 #endif
-template <typename T, int KS, int MP>
+// MULTI: the wave walks `bpw` blocks (light models); false = one block per wave, the block loop folds away.
+template <typename T, int KS, int MP, bool MULTI>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
                                                          const double* __restrict__ tables, int tab_off,
-                                                         T* __restrict__ out) {
+                                                         T* __restrict__ out, int bpw) {
     typedef typename Acc<T>::type V;
 #ifndef GH_MF_RING32
 #define GH_MF_RING32 2
@@ -277,21 +278,28 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     T* lds = reinterpret_cast<T*>(smem_raw);
     const int lane = threadIdx.x;
     const int f = lane & 15, q = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    // A wave processes `bpw` consecutive 32-frame blocks (1 for models with enough work per block; several for
+    // light models -- M = 1, few states -- where launching one wave per 32 frames and re-priming the operand ring
+    // cost more than the block's 64 MFMAs).  The Gaussian tiles stream in a closed loop: the last tile's run-ahead
+    // loads fetch tile 0 again, so the ring is primed when the wave moves to its next block.
+    const int64_t n_blocks = (N + 31) / 32;
+    int64_t n0 = (int64_t)blockIdx.x * (MULTI ? bpw : 1) * 32;
 #ifdef GH_MF_TIMING  // diagnostic build (tools/wave_timeline.py): per-wave phase time stamps overwrite row n0 of the output
     long long tk[5], tw[2];
     tk[0] = clock64(); tw[0] = wall_clock64();
 #endif
-    const int nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
+    int nrows = 0;
     double* tab = reinterpret_cast<double*>(smem_raw + tab_off);  // exp / log tables (fp64 path)
-    // Every load of the prologue is issued before the first wait (a load -> wait -> ds_write loop
-    // costs one HBM round trip per 64 elements: 20 in a row for a 32 x 39 tile).
-    {
+    if (sizeof(T) == 8 && MP != 1) {   // (a single-component state needs no exp / log)
         double tr[6];
-        if (sizeof(T) == 8) {
 #pragma unroll
-            for (int it = 0; it < 6; ++it) tr[it] = tables[lane + 64 * it];
-        }
+        for (int it = 0; it < 6; ++it) tr[it] = tables[lane + 64 * it];
+#pragma unroll
+        for (int it = 0; it < 6; ++it) tab[lane + 64 * it] = tr[it];
+    }
+    // Every load of a block's prologue is issued before the first wait (a load -> wait -> ds_write loop
+    // costs one HBM round trip per 64 elements: 20 in a row for a 32 x 39 tile).
+    auto stage_frames = [&]() {
         // ---- frames: global -> LDS (coalesced) -> B fragments in registers ----------------
         const int nelem = nrows * D;  // <= 32 * KP = 64 * KS
         const T* src = X + n0 * D;
@@ -301,34 +309,29 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             const int i = lane + 64 * it;
             xr[it] = (i < nelem) ? src[i] : T(0);
         }
-        if (sizeof(T) == 8) {
-#pragma unroll
-            for (int it = 0; it < 6; ++it) tab[lane + 64 * it] = tr[it];
-        }
 #pragma unroll
         for (int it = 0; it < KS; ++it) {
             const int i = lane + 64 * it;
             if (i < nelem) lds[i] = xr[it];
         }
         __syncthreads();
-    }
+    };
     constexpr int KQ = KS / 2;  // k-steps of the x^2 half == of the x half (KP = 4*KQ)
     T b[2][KS];
+    auto build_b = [&]() {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int row = 16 * c + f;
+        for (int c = 0; c < 2; ++c) {
+            const int row = 16 * c + f;
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const int d = 4 * j + q;
-            const T v = (row < nrows && d < D) ? lds[row * D + d] : T(0);
-            b[c][j] = v * v;
-            b[c][KQ + j] = v;
+            for (int j = 0; j < KQ; ++j) {
+                const int d = 4 * j + q;
+                const T v = (row < nrows && d < D) ? lds[row * D + d] : T(0);
+                b[c][j] = v * v;
+                b[c][KQ + j] = v;
+            }
         }
-    }
-    __syncthreads();
-#ifdef GH_MF_TIMING
-    tk[1] = clock64();
-#endif
+        __syncthreads();
+    };
 
     const int tiles_per_state = (MP <= 16) ? 1 : M_pad / 16;
     const int SC = (MP <= 16) ? chunk_tiles * (16 / (MP <= 16 ? MP : 16)) : chunk_tiles / tiles_per_state;
@@ -340,10 +343,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     // ---- stream the Gaussian tiles; the epilogue of tile t-1 runs under the MFMAs of tile t ----
     // (the host pads Apk / Cpk with one all-zero tile, so the run-ahead loads stay in bounds)
     T ring[R];
-    const T* ap = Apk + lane;  // next fragment to fetch
 #pragma unroll
-    for (int j = 0; j < R; ++j) ring[j] = ap[j * 64];
-    ap += R * 64;
+    for (int j = 0; j < R; ++j) ring[j] = Apk[j * 64 + lane];
     V c_nxt, p0, p1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) c_nxt[r] = Cpk[4 * q + r];
@@ -352,9 +353,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     auto mfma_tile = [&](int t, V& acc0, V& acc1) {
         acc0 = c_nxt;
         acc1 = c_nxt;
-        const T* cp = Cpk + (t + 1) * 16 + 4 * q;
+        const int tn = (t + 1 < n_tiles) ? t + 1 : 0;
+        const T* cp = Cpk + tn * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c_nxt[r] = cp[r];
+        // slot j serves k-step j [and j + R], refilled R k-steps ahead: from this tile while that stays inside it,
+        // from the next tile (tile 0 after the last) otherwise
+        const T* a_cur = Apk + (int64_t)t * (KS * 64) + lane;
+        const T* a_nxt = Apk + (int64_t)tn * (KS * 64) + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const T a = ring[ks % R];
@@ -366,10 +372,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             acc1 = Acc<T>::mfma(a, b[1][ks], acc1);
 #endif
 #ifndef GH_MF_NOLOAD
-            ring[ks % R] = ap[ks * 64];
+            ring[ks % R] = (ks + R < KS) ? a_cur[(ks + R) * 64] : a_nxt[(ks + R - KS) * 64];
 #endif
         }
-        ap += KS * 64;
     };
     auto flush = [&]() {
         const int cnt = ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
@@ -394,50 +399,47 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         chunk_s0 += SC;
     };
 
-#ifndef GH_MF_PIPE
-#define GH_MF_PIPE 1
-#endif
-#if GH_MF_PIPE
+    const int nb = MULTI ? bpw : 1;
+    for (int ib = 0; ib < nb; ++ib, n0 += 32) {
+        if (MULTI && n0 >= N) break;
+        nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
+        stage_frames();
+        build_b();
+        chunk_s0 = 0;
 #ifdef GH_MF_TIMING
-    tk[2] = clock64();
+        tk[1] = clock64();
+        tk[2] = tk[1];
 #endif
-    mfma_tile(0, p0, p1);
-    for (int t = 1; t < n_tiles; ++t) {
-        V acc0, acc1;
-        mfma_tile(t, acc0, acc1);
-        tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
-        // schedule: one MFMA, then a slice of the previous tile's epilogue VALU work
+        mfma_tile(0, p0, p1);
+        for (int t = 1; t < n_tiles; ++t) {
+            V acc0, acc1;
+            mfma_tile(t, acc0, acc1);
+            tile_epilogue<T, V, MP>(p0, p1, t - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
+            // (GH_MF_SGB: forced MFMA / VALU interleave, measured slower than back-to-back MFMAs)
 #pragma unroll
-        for (int i = 0; i < (GH_MF_SGB ? 2 * KS : 0); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, sizeof(T) == 8 ? 5 : 3, 0);  // VALU
+            for (int i = 0; i < (GH_MF_SGB ? 2 * KS : 0); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, sizeof(T) == 8 ? 5 : 3, 0);  // VALU
+            }
+            if (t % chunk_tiles == 0) flush();
+            p0 = acc0;
+            p1 = acc1;
         }
-        if (t % chunk_tiles == 0) flush();
-        p0 = acc0;
-        p1 = acc1;
-    }
-    tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
+        tile_epilogue<T, V, MP>(p0, p1, n_tiles - 1, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
 #ifdef GH_MF_TIMING
-    tk[3] = clock64();
+        tk[3] = clock64();
 #endif
-    flush();
+        flush();
 #ifdef GH_MF_TIMING
-    tk[4] = clock64(); tw[1] = wall_clock64();
-    if (lane == 0 && S >= 8) {
-        T* o = out + n0 * S;
-        for (int i = 0; i < 5; ++i) o[i] = (T)(double)(tk[i] - tk[0]);
-        o[5] = (T)(double)(tw[0] & 0xffffffffffll); o[6] = (T)(double)(tw[1] - tw[0]);
-        o[7] = (T)(double)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-    }
+        tk[4] = clock64(); tw[1] = wall_clock64();
+        if (lane == 0 && S >= 8) {
+            T* o = out + n0 * S;
+            for (int i = 0; i < 5; ++i) o[i] = (T)(double)(tk[i] - tk[0]);
+            o[5] = (T)(double)(tw[0] & 0xffffffffffll); o[6] = (T)(double)(tw[1] - tw[0]);
+            o[7] = (T)(double)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+        }
 #endif
-#else
-    for (int t = 0; t < n_tiles; ++t) {
-        mfma_tile(t, p0, p1);
-        tile_epilogue<T, V, MP>(p0, p1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
-        if ((t + 1) % chunk_tiles == 0 && t + 1 < n_tiles) flush();
     }
-    flush();
-#endif
 }
 
 template <typename T>
@@ -461,12 +463,22 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     const int tab_off = (int)lds;
     if (sizeof(T) == 8) lds += 384 * sizeof(double);
     const double* tables = ctx->d_fp64_tables;
-    const unsigned grid = (unsigned)((N + 31) / 32);
+    // blocks per wave: enough MFMAs per wave (>= ~512) to amortise its launch and the ring priming
+    const int64_t n_blocks = (N + 31) / 32;
+    const int per_block = std::max(1, n_tiles * KS * 2);
+    const int bpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (512 + per_block - 1) / per_block));
+    const unsigned grid = (unsigned)((n_blocks + bpw - 1) / bpw);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
-#define GH_MF_LAUNCH(ks, mp)                                                                                \
-    hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                       Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out)
+#define GH_MF_LAUNCH(ks, mp)                                                                                             \
+    do {                                                                                                                 \
+        if (bpw > 1)                                                                                                     \
+            hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw);                     \
+        else                                                                                                             \
+            hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, false>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw);                     \
+    } while (0)
 #define GH_MF_CASE(ks)                                   \
     case ks:                                             \
         switch (M_pad) {                                 \
