@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     auto mfma_tile = [&](int t, V& acc0, V& acc1) {
         acc0 = c_nxt;
         acc1 = c_nxt;
-        const int tn = (t + 1 < n_tiles) ? t + 1 : 0;
+        const int tn = (!MULTI || t + 1 < n_tiles) ? t + 1 : 0;   // one block per wave: run on into the zero pad tile
         const T* cp = Cpk + tn * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c_nxt[r] = cp[r];
