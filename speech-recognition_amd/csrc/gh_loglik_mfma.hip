@@ -461,7 +461,7 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     size_t lds = ((size_t)32 * std::max(std::min(SC, S), g->D) + 64) * sizeof(T);
     lds = (lds + 15) & ~size_t(15);
     const int tab_off = (int)lds;
-    if (sizeof(T) == 8) lds += 384 * sizeof(double);
+    if (sizeof(T) == 8 && M_pad != 1) lds += 384 * sizeof(double);   // exp / log tables (not needed for M = 1)
     const double* tables = ctx->d_fp64_tables;
     // blocks per wave: enough MFMAs per wave (>= ~512) to amortise its launch and the ring priming
     const int64_t n_blocks = (N + 31) / 32;
