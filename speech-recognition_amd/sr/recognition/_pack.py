@@ -7,6 +7,7 @@ models and arc lists.  Everything here is host-side bookkeeping; no likelihood
 or DP arithmetic happens in this file.
 """
 import hashlib
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -73,22 +74,33 @@ def _digest(*arrays):
 
 
 class _LRU(OrderedDict):
+    """Small content-addressed cache of device handles; keys start with id(ctx): a handle is never shared between
+    contexts (it is bound to the context it was created with).  Thread-safe."""
+
     def __init__(self, cap):
         super().__init__()
         self.cap = cap
+        self.lock = threading.RLock()
 
     def lookup(self, key, make):
-        if key in self:
-            self.move_to_end(key)
-            return self[key]
-        val = make()
-        self[key] = val
-        while len(self) > self.cap:
-            _, old = self.popitem(last=False)
-            close = getattr(old, "close", None)
-            if close:
-                close()
-        return val
+        with self.lock:
+            if key in self:
+                self.move_to_end(key)
+                return self[key]
+            val = make()
+            self[key] = val
+            while len(self) > self.cap:
+                _, old = self.popitem(last=False)
+                close = getattr(old, "close", None)
+                if close:
+                    close()
+            return val
+
+    def purge(self, ctx):
+        """Close and drop every handle created with `ctx` (before the context itself is closed)."""
+        with self.lock:
+            for key in [k for k in self if k[0] == id(ctx)]:
+                self.pop(key).close()
 
 
 _gmm_cache = _LRU(8)
@@ -98,7 +110,7 @@ _lat_cache = _LRU(16)
 def device_gmm(ctx, gmms):
     """PackedGMM for a list of GMM objects (cached on parameter content)."""
     means, vars_, w = stack_gmms(gmms)
-    key = (ctx.device, _digest(means, vars_, w))
+    key = (id(ctx), _digest(means, vars_, w))
     return _gmm_cache.lookup(key, lambda: _hip.PackedGMM(ctx, means, vars_, w))
 
 
@@ -115,7 +127,7 @@ def device_lattices(ctx, graphs):
     parts = []
     for g in graphs:
         parts += [g["row_state"], g["arc_to"], g["arc_from"], g["arc_cost"], g["start_rows"], g["end_rows"]]
-    key = (ctx.device, _digest(*[np.asarray(p) for p in parts]))
+    key = (id(ctx), _digest(*[np.asarray(p) for p in parts]))
     return _lat_cache.lookup(key, lambda: _hip.Lattices(ctx, graphs))
 
 

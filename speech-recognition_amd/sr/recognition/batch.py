@@ -13,7 +13,7 @@ from . import _hip
 from . import _pack
 from .continuous_speech import packed_lattice, packed_loop_lattice
 
-__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "path_to_words"]
+__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_words"]
 
 
 def _stack_models(ctx, models):
@@ -30,8 +30,8 @@ class IsolatedWordRecognizer:
     The W word chains are stacked into one graph (W start rows, W end rows), so one
     gh_loglik + one gh_viterbi launch replaces U x W calls of HMM.evaluate."""
 
-    def __init__(self, models, device=None, dtype=np.float64):
-        self.ctx = _hip.default_context(device)
+    def __init__(self, models, device=None, dtype=np.float64, ctx=None):
+        self.ctx = ctx if ctx is not None else _hip.default_context(device)
         self.dtype = dtype
         self.W = len(models)
         self.n, self.gmm = _stack_models(self.ctx, models)
@@ -88,8 +88,8 @@ class ContinuousDecoder:
     words, cost = min over K of the K-layer costs, on a graph of 2 + W*n rows instead of
     1 + K*(W*n + 1)."""
 
-    def __init__(self, models, n_layers=7, device=None, dtype=np.float64, grammar="layers", word_penalty=0.0):
-        self.ctx = _hip.default_context(device)
+    def __init__(self, models, n_layers=7, device=None, dtype=np.float64, grammar="layers", word_penalty=0.0, ctx=None):
+        self.ctx = ctx if ctx is not None else _hip.default_context(device)
         self.dtype = dtype
         self.n, self.gmm = _stack_models(self.ctx, models)
         W = len(models)
@@ -123,3 +123,55 @@ class ContinuousDecoder:
             return self.decode_batch(batch)[0]
         finally:
             batch.close()
+
+
+class InFlight:
+    """Several batches in flight on ONE GPU: `n_lanes` contexts (HIP stream, scratch, pinned buffers), one host
+    thread each, every lane with its own resident copy of whatever `make_worker(ctx)` builds (e.g. a recogniser).
+    The host side of a batch (result copy-back, arg-min, Python) then overlaps the other lanes' kernels -- what
+    `bench.py --inflight 2` measures (+17 % throughput on configs[1]).  ctypes releases the GIL during calls.
+
+        pool = InFlight(lambda ctx: IsolatedWordRecognizer(models, ctx=ctx))
+        results = pool.map(lambda rec, xs: rec.recognize(xs), list_of_utterance_lists)      # in input order
+    """
+
+    def __init__(self, make_worker, n_lanes=2, device=None):
+        dev = _hip.default_context(device).device
+        self.ctxs = [_hip.Context(dev) for _ in range(max(1, int(n_lanes)))]
+        self.workers = [make_worker(c) for c in self.ctxs]
+
+    def map(self, fn, items):
+        import threading
+        items = list(items)
+        out = [None] * len(items)
+        lock, state = threading.Lock(), {"next": 0, "err": None}
+
+        def run(worker):
+            try:
+                while True:
+                    with lock:
+                        k = state["next"]
+                        if k >= len(items) or state["err"] is not None:
+                            return
+                        state["next"] = k + 1
+                    out[k] = fn(worker, items[k])
+            except BaseException as e:  # surfaced in the caller's thread
+                state["err"] = e
+        threads = [threading.Thread(target=run, args=(w,)) for w in self.workers]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if state["err"] is not None:
+            raise state["err"]
+        return out
+
+    def close(self):
+        for w in self.workers:
+            h = getattr(w, "lat", None)
+            if h is not None and hasattr(h, "close"):
+                h.close()
+        for c in self.ctxs:
+            _pack._gmm_cache.purge(c)     # handles are bound to the context they were created with
+            _pack._lat_cache.purge(c)
+            c.close()

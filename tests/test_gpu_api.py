@@ -426,3 +426,24 @@ def test_mfcc_features_matches_reference(R, tmp_path):
     b.close()
     with pytest.raises(IndexError):
         mfcc_from_signals([np.zeros(0, dtype=np.int16)])
+
+
+def test_in_flight_lanes_give_the_same_results(R):
+    """batch.InFlight: two contexts / host threads on one GPU decode a stream of batches; results equal the single-lane
+    ones, in input order."""
+    from sr.recognition.batch import IsolatedWordRecognizer, InFlight
+    g = load_golden("G3_isolated_decode_c2")
+    W = g["means"].shape[0]
+    hmms = [make_hmm(R, g["means"][i], g["vars"][i], g["w"][i], g["trans"]) for i in range(W)]
+    xs = [g["x%d" % u] for u in range(len(g["words"]))]
+    batches = [xs, xs[::-1], xs[:1], xs[1:], xs]
+    single = IsolatedWordRecognizer(hmms)
+    ref = [single.recognize(b) for b in batches]
+    pool = InFlight(lambda ctx: IsolatedWordRecognizer(hmms, ctx=ctx), n_lanes=2)
+    got = pool.map(lambda rec, b: rec.recognize(b), batches)
+    for (w0, c0), (w1, c1) in zip(ref, got):
+        np.testing.assert_array_equal(w0, w1)
+        np.testing.assert_array_equal(c0, c1)
+    with pytest.raises(ZeroDivisionError):
+        pool.map(lambda rec, b: 1 // 0, batches)
+    pool.close()
