@@ -606,6 +606,18 @@ def test_forward_backward_chain_kernel_vs_generic_and_oracle(hip, ctx, monkeypat
                 if rs[r] >= 0:
                     occ[:, rs[r]] += ga[r]
             np.testing.assert_allclose(r_chain["occ"][b.offsets[u]:b.offsets[u + 1]], occ, rtol=1e-8, atol=1e-12)
+        # fp32 likelihood matrix through both kernels
+        b32 = hip.Batch(ctx, xs, dtype=np.float32)
+        b32.loglik(gmm, fetch=False)
+        c32 = lat.forward_backward(b32, utt_lattice=words, want_occ=True)
+        monkeypatch.setenv("GMMHMM_FB", "generic")
+        g32 = lat.forward_backward(b32, utt_lattice=words, want_occ=True)
+        monkeypatch.delenv("GMMHMM_FB", raising=False)
+        np.testing.assert_allclose(c32["logp"], g32["logp"], rtol=1e-11)
+        np.testing.assert_allclose(c32["occ"], g32["occ"], rtol=1e-9, atol=1e-12)
+        fin = np.isfinite(r_chain["logp"])
+        np.testing.assert_allclose(c32["logp"][fin], r_chain["logp"][fin], rtol=1e-5)
+        b32.close()
         b.close()
         lat.close()
 
