@@ -345,18 +345,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     T ring[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) ring[j] = Apk[j * 64 + lane];
-    V c_nxt, p0, p1;
+    V c_a, c_b, p0, p1;   // C values of the current / the next tile (roles alternate)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c_nxt[r] = Cpk[4 * q + r];
+    for (int r = 0; r < 4; ++r) c_a[r] = Cpk[4 * q + r];
 
-    // one tile of MFMAs: accumulators start at C (prefetched), ring refilled as it is consumed
-    auto mfma_tile = [&](int t, V& acc0, V& acc1) {
-        acc0 = c_nxt;
-        acc1 = c_nxt;
+    // one tile of MFMAs: the first k-step takes the (prefetched) C values as its addend -- no accumulator
+    // initialisation copies --, the next tile's C travels into the other register set; ring refilled as it is consumed
+    auto mfma_tile = [&](int t, V& acc0, V& acc1, const V& c_use, V& c_load) {
         const int tn = (!MULTI || t + 1 < n_tiles) ? t + 1 : 0;   // one block per wave: run on into the zero pad tile
         const T* cp = Cpk + tn * 16 + 4 * q;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c_nxt[r] = cp[r];
+        for (int r = 0; r < 4; ++r) c_load[r] = cp[r];
         // slot j serves k-step j [and j + R], refilled R k-steps ahead: from this tile while that stays inside it,
         // from the next tile (tile 0 after the last) otherwise
         const T* a_cur = Apk + (int64_t)t * (KS * 64) + lane;
@@ -365,11 +364,12 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         for (int ks = 0; ks < KS; ++ks) {
             const T a = ring[ks % R];
 #ifdef GH_MF_NOMFMA  // diagnostic builds (tools/variant_bench.sh): loads + epilogue only / operands never refilled
+            if (ks == 0) { acc0 = c_use; acc1 = c_use; }
             if (ks % 8 == 0) { acc0[ks % 4] += a * b[0][ks]; acc1[ks % 4] += a * b[1][ks]; }
             else asm volatile("" :: "v"(a));
 #else
-            acc0 = Acc<T>::mfma(a, b[0][ks], acc0);
-            acc1 = Acc<T>::mfma(a, b[1][ks], acc1);
+            acc0 = Acc<T>::mfma(a, b[0][ks], ks == 0 ? c_use : acc0);
+            acc1 = Acc<T>::mfma(a, b[1][ks], ks == 0 ? c_use : acc1);
 #endif
 #ifndef GH_MF_NOLOAD
             ring[ks % R] = (ks + R < KS) ? a_cur[(ks + R) * 64] : a_nxt[(ks + R - KS) * 64];
@@ -422,30 +422,35 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             if ((t + 1) % chunk_tiles == 0 && t + 1 < n_tiles) flush();
         };
         V r0, r1;
-        mfma_tile(0, p0, p1);
+        // (every block starts with c_a holding tile 0's C: n_tiles tiles alternate c_a / c_b, so the wrap-around load
+        //  of a multi-block wave lands in c_a only when n_tiles is even -- it is reloaded below when it is odd)
+        mfma_tile(0, p0, p1, c_a, c_b);
         if (sizeof(T) == 8) {
             int t = 1;
             for (; t + 1 < n_tiles; t += 2) {
-                mfma_tile(t, r0, r1);
+                mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
-                mfma_tile(t + 1, p0, p1);
+                mfma_tile(t + 1, p0, p1, c_a, c_b);
                 epi(r0, r1, t);
             }
             if (t < n_tiles) {
-                mfma_tile(t, r0, r1);
+                mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
                 epi(r0, r1, t);
             } else {
                 epi(p0, p1, n_tiles - 1);
+                if (MULTI) c_a = c_b;
             }
         } else {   // fp32: the copying loop schedules better (measured 0.65 vs 0.67 ms)
             for (int t = 1; t < n_tiles; ++t) {
-                mfma_tile(t, r0, r1);
+                mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
                 p0 = r0;
                 p1 = r1;
+                c_b = c_a;
             }
             epi(p0, p1, n_tiles - 1);
+            if (MULTI) c_a = c_b;
         }
 #ifdef GH_MF_TIMING
         tk[3] = clock64();
