@@ -72,6 +72,12 @@ def test_fullsize_viterbi_kernels_agree_and_decode(full):
     ec = r_chain["end_cost_flat"].reshape(U, W)
     decoded = np.argmin(ec, axis=1)
     assert np.mean(decoded == wl["words"]) == 1.0
+    # decode + post-processing on the device (gh_viterbi_labels) through the chain kernel: one label = the word
+    row_word = (np.arange(len(full["graph"]["row_state"])) // wl["n"]).astype(np.int32)
+    rl = lat.viterbi_labels(batch, row_word)
+    np.testing.assert_array_equal(rl["best_end"], r_chain["best_end"])
+    assert all(len(l) == 1 for l in rl["labels"])
+    np.testing.assert_array_equal(np.array([l[0] for l in rl["labels"]]), decoded)
     # a sample of utterances through the oracle's reference-shaped DP: costs and paths
     nll = full["nll"]
     sub = [0, 1, U // 2, U - 1]
