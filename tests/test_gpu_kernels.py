@@ -663,3 +663,41 @@ def test_viterbi_configs3_shape_1024_rows(hip, ctx):
         got = r2["paths"][u]
         assert r2["best_end"][u] == wd
         np.testing.assert_array_equal(got[:, 0] - wd * n, path[:, 0])
+
+
+def test_empty_and_degenerate_batches(hip, ctx):
+    """No utterances at all, utterances without frames, one-frame utterances: every entry point returns empty / the
+    reference's degenerate results instead of faulting."""
+    rng = np.random.default_rng(9)
+    S, M, D, n = 6, 2, 5, 3
+    gmm = hip.PackedGMM(ctx, rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D)), rng.dirichlet(np.ones(M), size=S))
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = 0.2
+        if i + 1 < n:
+            trans[i + 1, i] = 1.0
+    lat = hip.Lattices(ctx, [graph(np.arange(n), trans, [0], [n - 1])])
+    # (a) an empty batch
+    b0 = hip.Batch(ctx, feats=np.zeros((0, D)), offsets=np.array([0], dtype=np.int64))
+    assert b0.U == 0 and b0.N == 0
+    assert b0.loglik(gmm).shape == (0, S)
+    r = lat.viterbi(b0)
+    assert len(r["paths"]) == 0 and len(r["best_end"]) == 0
+    assert len(lat.forward_backward(b0)["logp"]) == 0
+    b0.close()
+    # (b) empty and one-frame utterances between ordinary ones
+    xs = [rng.normal(size=(7, D)), np.zeros((0, D)), rng.normal(size=(1, D)), np.zeros((0, D)), rng.normal(size=(4, D))]
+    b = hip.Batch(ctx, xs)
+    nll = b.loglik(gmm)
+    assert nll.shape == (12, S)
+    r = lat.viterbi(b, want_path=True)
+    assert r["best_end"][1] == -1 and r["best_end"][3] == -1 and len(r["paths"][1]) == 0 and len(r["paths"][2]) == 0
+    rl = lat.viterbi_labels(b, np.zeros(n, dtype=np.int32))
+    assert [len(l) for l in rl["labels"]] == [1, 0, 0, 0, 1]
+    fb = lat.forward_backward(b, want_occ=True)
+    assert np.isneginf(fb["logp"][1]) and np.isneginf(fb["logp"][3]) and np.isneginf(fb["logp"][2])   # 1 frame < 3 states
+    assert np.isfinite(fb["logp"][0]) and np.isfinite(fb["logp"][4])
+    np.testing.assert_allclose(fb["occ"][:7].sum(axis=1), 1.0, rtol=1e-9)
+    b.close()
+    lat.close()
+    gmm.close()
