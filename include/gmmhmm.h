@@ -116,6 +116,12 @@ int gh_batch_create_from_pcm(gh_ctx* ctx, gh_dtype dtype, int mode, int sample_f
  * dynamic programs; `out_host` (may be NULL) receives a copy.
  * gh_loglik_dev_ptr returns the resident matrix (device pointer, [N,S]). */
 int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host /*[N,S] or NULL*/);
+/* Same, restricted: utterance u only needs the states [state_lo[u], state_hi[u]) -- forced alignment and EM with a known
+ * transcript never look at the other words' states (the reference evaluates exactly the states of the lattice it was
+ * given, decode.py:123).  Entries outside an utterance's range are unspecified (zero after the first call).  10 word
+ * models: a tenth of the work of gh_loglik. */
+int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo /*[U]*/,
+                     const int32_t* state_hi /*[U]*/);
 void* gh_loglik_dev_ptr(gh_batch* b);
 /* weighted component densities in the log domain, log(w_m pdf_m(x)) for one
  * state over arbitrary frames (hmm_state.py:114-116 with

@@ -157,4 +157,6 @@ struct gh_lattices {
 
 // kernels (gh_loglik.hip / gh_viterbi.hip)
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
-int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);  // 1 = shape not covered
+// 1 = shape not covered; st_lo / st_hi (per utterance, or null): only the states [lo, hi) of every utterance are needed
+int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
+                          const int32_t* st_hi = nullptr);

@@ -30,6 +30,9 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// block table entry of gh_loglik_subset: frames [n0, n0 + nrows) (one utterance), Gaussian tiles [t0, t1)
+struct gh_loglik_blk { int64_t n0; int32_t nrows, t0, t1, pad; };
+
 template <typename T> struct Acc;
 template <> struct Acc<double> {
     typedef v4d type;
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
                                                          const double* __restrict__ tables, int tab_off,
-                                                         T* __restrict__ out, int bpw) {
+                                                         T* __restrict__ out, int bpw,
+                                                         const gh_loglik_blk* __restrict__ blk_tab, int64_t n_blk) {
     typedef typename Acc<T>::type V;
 #ifndef GH_MF_RING32
 #define GH_MF_RING32 2
@@ -289,6 +293,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     tk[0] = clock64(); tw[0] = wall_clock64();
 #endif
     int nrows = 0;
+    // (MULTI only) a block table restricts every block to the tiles [t_lo, t_hi) of its utterance's states
+    const bool subset = MULTI && blk_tab != nullptr;
+    const int64_t kb0 = (int64_t)blockIdx.x * (MULTI ? bpw : 1);
+    int t_lo = subset ? blk_tab[kb0].t0 : 0, t_hi = n_tiles, nxt_t0 = 0;
     double* tab = reinterpret_cast<double*>(smem_raw + tab_off);  // exp / log tables (fp64 path)
     if (sizeof(T) == 8 && MP != 1) {   // (a single-component state needs no exp / log)
         double tr[6];
@@ -339,20 +347,21 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     T* dummy = lds + 32 * RS + lane;    // per-lane slot behind the output tile
     T run_mx[2] = {Dom<T>::off, Dom<T>::off}, run_sm[2] = {T(0), T(0)};
     int chunk_s0 = 0;  // first state held in the LDS output tile
+    int subset_cnt = 0;  // (block table) number of states the block's tile range covers
 
     // ---- stream the Gaussian tiles; the epilogue of tile t-1 runs under the MFMAs of tile t ----
     // (the host pads Apk / Cpk with one all-zero tile, so the run-ahead loads stay in bounds)
     T ring[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) ring[j] = Apk[j * 64 + lane];
+    for (int j = 0; j < R; ++j) ring[j] = Apk[((int64_t)t_lo * KS + j) * 64 + lane];
     V c_a, c_b, p0, p1;   // C values of the current / the next tile (roles alternate)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c_a[r] = Cpk[4 * q + r];
+    for (int r = 0; r < 4; ++r) c_a[r] = Cpk[t_lo * 16 + 4 * q + r];
 
     // one tile of MFMAs: the first k-step takes the (prefetched) C values as its addend -- no accumulator
     // initialisation copies --, the next tile's C travels into the other register set; ring refilled as it is consumed
     auto mfma_tile = [&](int t, V& acc0, V& acc1, const V& c_use, V& c_load) {
-        const int tn = (!MULTI || t + 1 < n_tiles) ? t + 1 : 0;   // one block per wave: run on into the zero pad tile
+        const int tn = (!MULTI || t + 1 < t_hi) ? t + 1 : nxt_t0;   // one block per wave: run on into the zero pad tile
         const T* cp = Cpk + tn * 16 + 4 * q;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c_load[r] = cp[r];
@@ -377,9 +386,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         }
     };
     auto flush = [&]() {
-        const int cnt = ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
+        const int cnt = subset ? subset_cnt : ((chunk_s0 + SC < S) ? chunk_s0 + SC : S) - chunk_s0;  // states in this chunk
         __syncthreads();
-        if (cnt == S) {  // whole rows: the [nrows, S] block is contiguous in memory (16 bytes per lane)
+        if (cnt == S && !subset) {  // whole rows: the [nrows, S] block is contiguous in memory (16 bytes per lane)
             typedef T V16 __attribute__((ext_vector_type(16 / sizeof(T))));
             constexpr int VE = 16 / sizeof(T);
             T* dst = out + n0 * S;  // 32 * S * sizeof(T) bytes per block: always 16-byte aligned
@@ -389,10 +398,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             for (int i = lane; i < nvec; i += 64)
                 reinterpret_cast<V16*>(dst)[i] = reinterpret_cast<const V16*>(lds)[i];
             for (int i = nvec * VE + lane; i < total; i += 64) dst[i] = lds[i];
-        } else if (cnt > 0) {
-            for (int r = 0; r < nrows; ++r) {
-                T* dst = out + (n0 + r) * S + chunk_s0;
-                for (int j = lane; j < cnt; j += 64) dst[j] = lds[r * RS + j];
+        } else if (cnt > 0) {   // a column range of the rows: (row, column) pairs flattened over the lanes
+            const int total = nrows * cnt;
+            for (int i = lane; i < total; i += 64) {
+                const int r = i / cnt, j = i - r * cnt;
+                out[(n0 + r) * S + chunk_s0 + j] = lds[r * RS + j];
             }
         }
         __syncthreads();
@@ -401,11 +411,23 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 
     const int nb = MULTI ? bpw : 1;
     for (int ib = 0; ib < nb; ++ib, n0 += 32) {
-        if (MULTI && n0 >= N) break;
-        nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
+        if (subset) {
+            const int64_t k = kb0 + ib;
+            if (k >= n_blk) break;
+            const gh_loglik_blk bd = blk_tab[k];
+            n0 = bd.n0; nrows = bd.nrows; t_lo = bd.t0; t_hi = bd.t1;
+            nxt_t0 = (ib + 1 < nb && k + 1 < n_blk) ? blk_tab[k + 1].t0 : bd.t0;
+        } else {
+            if (MULTI && n0 >= N) break;
+            nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
+        }
         stage_frames();
         build_b();
-        chunk_s0 = 0;
+        chunk_s0 = (MP <= 16) ? t_lo * (16 / (MP <= 16 ? MP : 16)) : t_lo / tiles_per_state;   // 0 without a block table
+        if (subset) {
+            const int s_end = (MP <= 16) ? t_hi * (16 / (MP <= 16 ? MP : 16)) : t_hi / tiles_per_state;
+            subset_cnt = ((s_end < S) ? s_end : S) - chunk_s0;
+        }
 #ifdef GH_MF_TIMING
         tk[1] = clock64();
         tk[2] = tk[1];
@@ -419,37 +441,38 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, sizeof(T) == 8 ? 5 : 3, 0);
             }
-            if ((t + 1) % chunk_tiles == 0 && t + 1 < n_tiles) flush();
+            if (!subset && (t + 1) % chunk_tiles == 0 && t + 1 < n_tiles) flush();
         };
         V r0, r1;
         // (every block starts with c_a holding tile 0's C: n_tiles tiles alternate c_a / c_b, so the wrap-around load
         //  of a multi-block wave lands in c_a only when n_tiles is even -- it is reloaded below when it is odd)
-        mfma_tile(0, p0, p1, c_a, c_b);
+        const int tb = MULTI ? t_lo : 0, te = MULTI ? t_hi : n_tiles;   // tile range of this block
+        mfma_tile(tb, p0, p1, c_a, c_b);
         if (sizeof(T) == 8) {
-            int t = 1;
-            for (; t + 1 < n_tiles; t += 2) {
+            int t = tb + 1;
+            for (; t + 1 < te; t += 2) {
                 mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
                 mfma_tile(t + 1, p0, p1, c_a, c_b);
                 epi(r0, r1, t);
             }
-            if (t < n_tiles) {
+            if (t < te) {
                 mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
                 epi(r0, r1, t);
             } else {
-                epi(p0, p1, n_tiles - 1);
+                epi(p0, p1, te - 1);
                 if (MULTI) c_a = c_b;
             }
         } else {   // fp32: the copying loop schedules better (measured 0.65 vs 0.67 ms)
-            for (int t = 1; t < n_tiles; ++t) {
+            for (int t = tb + 1; t < te; ++t) {
                 mfma_tile(t, r0, r1, c_b, c_a);
                 epi(p0, p1, t - 1);
                 p0 = r0;
                 p1 = r1;
                 c_b = c_a;
             }
-            epi(p0, p1, n_tiles - 1);
+            epi(p0, p1, te - 1);
             if (MULTI) c_a = c_b;
         }
 #ifdef GH_MF_TIMING
@@ -469,7 +492,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 }
 
 template <typename T>
-int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk) {
+int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk, const int32_t* st_lo,
+                  const int32_t* st_hi) {
     const int64_t N = b->N;
     if (N == 0) return GH_OK;
     const int KS = g->KP / 2;
@@ -489,10 +513,39 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     const int tab_off = (int)lds;
     if (sizeof(T) == 8 && M_pad != 1) lds += 384 * sizeof(double);   // exp / log tables (not needed for M = 1)
     const double* tables = ctx->d_fp64_tables;
+    // ---- optional block table: every utterance in blocks of <= 32 frames, only the tiles of its state range ----
+    gh_loglik_blk* d_blk = nullptr;
+    int64_t n_blk = 0;
+    int max_tiles = n_tiles;
+    if (st_lo) {
+        std::vector<gh_loglik_blk> tabv;
+        max_tiles = 1;
+        for (int64_t u = 0; u < b->U; ++u) {
+            const int lo = st_lo[u], hi = st_hi[u];
+            if (lo < 0 || hi > S || lo >= hi) { gh_set_error("gh_loglik_subset: utterance %lld has state range [%d, %d)", (long long)u, lo, hi); return GH_ERR_INVALID; }
+            int t0, t1;
+            if (M_pad <= 16) { const int spt = 16 / M_pad; t0 = lo / spt; t1 = (hi + spt - 1) / spt; }
+            else { const int tps = M_pad / 16; t0 = lo * tps; t1 = hi * tps; }
+            const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
+            if (span > SC) return 1;   // range wider than one LDS chunk: the caller computes the full matrix
+            max_tiles = std::max(max_tiles, t1 - t0);
+            for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
+                tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), t0, t1, 0});
+        }
+        n_blk = (int64_t)tabv.size();
+        if (n_blk == 0) return GH_OK;
+        void* base;
+        int rc = gh_scratch(ctx, tabv.size() * sizeof(gh_loglik_blk), &base);
+        if (rc) return rc;
+        d_blk = static_cast<gh_loglik_blk*>(base);
+        GH_HIP(hipMemcpyAsync(d_blk, tabv.data(), tabv.size() * sizeof(gh_loglik_blk), hipMemcpyHostToDevice, ctx->stream));
+        GH_HIP(hipStreamSynchronize(ctx->stream));   // tabv goes out of scope
+    }
     // blocks per wave: enough MFMAs per wave (>= ~512) to amortise its launch and the ring priming
-    const int64_t n_blocks = (N + 31) / 32;
-    const int per_block = std::max(1, n_tiles * KS * 2);
-    const int bpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (512 + per_block - 1) / per_block));
+    const int64_t n_blocks = st_lo ? n_blk : (N + 31) / 32;
+    const int per_block = std::max(1, max_tiles * KS * 2);
+    int bpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (512 + per_block - 1) / per_block));
+    if (st_lo) bpw = std::max(bpw, 2);   // the block table lives in the multi-block instantiation
     const unsigned grid = (unsigned)((n_blocks + bpw - 1) / bpw);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
@@ -500,10 +553,10 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     do {                                                                                                                 \
         if (bpw > 1)                                                                                                     \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw);                     \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk);       \
         else                                                                                                             \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, false>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw);                     \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk);       \
     } while (0)
 #define GH_MF_CASE(ks)                                   \
     case ks:                                             \
@@ -534,8 +587,8 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
 }  // namespace
 
 // returns 1 when the shape is not covered (caller uses the VALU kernel), <0 on error
-int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b) {
+int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi) {
     if (!g->dApk64) return 1;
-    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64);
-    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32);
+    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi);
+    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi);
 }

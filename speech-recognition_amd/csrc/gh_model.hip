@@ -195,5 +195,25 @@ extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_ho
     return GH_OK;
 }
 
+extern "C" int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo, const int32_t* state_hi) {
+    GH_REQUIRE(ctx && g && b && state_lo && state_hi, "gh_loglik_subset: NULL argument");
+    GH_REQUIRE(g->D == b->D, "gh_loglik_subset: feature dim %d != model dim %d (hmm_state.py:45)", b->D, g->D);
+    GH_HIP(hipSetDevice(ctx->device));
+    const size_t esz = b->dtype == GH_F64 ? 8 : 4;
+    if (b->nll && b->nll_S != g->S) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        GH_HIP(hipFree(b->nll));
+        b->nll = nullptr;
+    }
+    if (!b->nll && b->N > 0) {
+        GH_HIP(hipMalloc(&b->nll, (size_t)b->N * g->S * esz));
+        GH_HIP(hipMemsetAsync(b->nll, 0, (size_t)b->N * g->S * esz, ctx->stream));   // entries outside the ranges stay defined
+        b->nll_S = g->S;
+    }
+    int rc = gh_launch_loglik_mfma(ctx, g, b, state_lo, state_hi);
+    if (rc == 1) return gh_loglik(ctx, g, b, nullptr);   // shape / range not covered: the full matrix is a superset
+    return rc;
+}
+
 extern "C" void* gh_loglik_dev_ptr(gh_batch* b) { return b ? b->nll : nullptr; }
 

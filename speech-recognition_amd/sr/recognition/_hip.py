@@ -48,6 +48,7 @@ SIGNATURES = {
                                            C.c_double, C.c_double, C.c_int64, C.c_void_p, _c_i64p, _c_i64p,
                                            C.POINTER(C.c_void_p)]),
     "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gh_loglik_subset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p]),
     "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
     "gh_component_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _c_f64p, _c_f64p]),
     "gh_distance_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p,
@@ -302,8 +303,25 @@ class Batch:
         _check(self.ctx.lib, self.ctx.lib.gh_batch_fetch_features(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
         return [out[self.offsets[u]:self.offsets[u + 1]] for u in range(self.U)]
 
-    def loglik(self, gmm, fetch=True):
-        """A3 for every frame x state; the [N,S] matrix stays resident for the DPs."""
+    def loglik(self, gmm, fetch=True, state_ranges=None):
+        """A3 for every frame x state; the [N,S] matrix stays resident for the DPs.
+        state_ranges = (lo [U], hi [U]): only the states [lo[u], hi[u]) of utterance u are needed (forced alignment /
+        EM with known transcripts); the other entries of the matrix are then unspecified."""
+        if state_ranges is not None:
+            lo = np.ascontiguousarray(state_ranges[0], dtype=np.int32)
+            hi = np.ascontiguousarray(state_ranges[1], dtype=np.int32)
+            assert len(lo) == self.U and len(hi) == self.U
+            _check(self.ctx.lib, self.ctx.lib.gh_loglik_subset(self.ctx.h, gmm.h, self.h, _ptr(lo, _c_i32p), _ptr(hi, _c_i32p)))
+            self.S = gmm.S
+            if not fetch:
+                return None
+            out = np.empty((self.N, gmm.S), dtype=self.np_dtype)
+            esz = out.itemsize
+            hipmem = C.CDLL("libamdhip64.so")
+            self.ctx.sync()
+            assert hipmem.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ctx.lib.gh_loglik_dev_ptr(self.h)),
+                                    C.c_size_t(out.size * esz), 2) == 0
+            return out
         out = np.empty((self.N, gmm.S), dtype=self.np_dtype) if fetch else None
         _check(self.ctx.lib, self.ctx.lib.gh_loglik(self.ctx.h, gmm.h, self.h,
                                                     None if out is None else out.ctypes.data_as(C.c_void_p)))

@@ -51,6 +51,11 @@ class BaumWelchTrainer:
                 graphs.append(packed_lattice(transitions, self.n, [[l] for l in key])[0])
             self.utt_graph[u] = keys[key]
         self.lat = _hip.Lattices(self.ctx, graphs) if graphs else None
+        # an utterance's alignment only involves the states of its own words: likelihoods for that range only
+        lo = np.array([min(int(l) for l in labels) * self.n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
+        hi = np.array([(max(int(l) for l in labels) + 1) * self.n if len(labels) else self.S for labels in label_seqs],
+                      dtype=np.int32)
+        self.state_ranges = (lo, hi)
         self.history = []
 
     def e_step(self):
@@ -59,7 +64,7 @@ class BaumWelchTrainer:
         try:
             if self.batch.U == 0:
                 return np.zeros((self.S, self.M, 1 + 2 * self.D)), np.zeros(self.S), 0.0
-            self.batch.loglik(gmm, fetch=False)
+            self.batch.loglik(gmm, fetch=False, state_ranges=self.state_ranges)
             r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False)
             stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor)
             counts = stats[:, :, 0].sum(axis=1)  # sum_n occ[n,s]: responsibilities of a state add up to its occupancy

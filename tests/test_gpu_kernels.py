@@ -701,3 +701,27 @@ def test_empty_and_degenerate_batches(hip, ctx):
     b.close()
     lat.close()
     gmm.close()
+
+
+@pytest.mark.parametrize("S,M,D", [(50, 8, 39), (12, 3, 13), (40, 1, 13), (9, 32, 7), (30, 16, 24)])
+def test_loglik_subset_equals_full_on_the_ranges(hip, ctx, S, M, D):
+    """gh_loglik_subset: every utterance gets the likelihoods of its own state range, bit-identical to gh_loglik."""
+    rng = np.random.default_rng(S + M)
+    gmm = hip.PackedGMM(ctx, rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D)), rng.dirichlet(np.ones(M), size=S))
+    lens = [1, 31, 32, 33, 64, 100, 7, 150]
+    xs = [rng.normal(size=(t, D)) for t in lens]
+    lo = rng.integers(0, S - 1, size=len(xs)).astype(np.int32)
+    hi = np.minimum(S, lo + rng.integers(1, 7, size=len(xs))).astype(np.int32)
+    lo[0], hi[0] = 0, min(S, 5)
+    lo[-1], hi[-1] = max(0, S - 5), S
+    for dt in (np.float64, np.float32):
+        full = hip.Batch(ctx, xs, dtype=dt)
+        ref = full.loglik(gmm)
+        sub = hip.Batch(ctx, xs, dtype=dt)
+        got = sub.loglik(gmm, state_ranges=(lo, hi))
+        for u in range(len(xs)):
+            a, b_ = sub.offsets[u], sub.offsets[u + 1]
+            np.testing.assert_array_equal(got[a:b_, lo[u]:hi[u]], ref[a:b_, lo[u]:hi[u]])
+        full.close()
+        sub.close()
+    gmm.close()
