@@ -165,7 +165,10 @@ def forced_alignments(frames, models, label_seqs):
     ctx = frames.ctx
     n = len(models[0].gmm_states)
     gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
-    frames.loglik(gmm, fetch=False)
+    # an utterance's lattice only contains the states of its own words: likelihoods for that state range only
+    lo = np.array([min(labels) * n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
+    hi = np.array([(max(labels) + 1) * n if len(labels) else len(models) * n for labels in label_seqs], dtype=np.int32)
+    frames.loglik(gmm, fetch=False, state_ranges=(lo, hi))
     keys, graphs, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
     wt = [m.transitions for m in models]
     for u, labels in enumerate(label_seqs):
