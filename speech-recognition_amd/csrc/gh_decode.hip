@@ -452,6 +452,15 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             GH_HIP(hipMemcpyAsync(d_coff, coff.data(), U * 8, hipMemcpyHostToDevice, s2));
             if (utt_lattice) GH_HIP(hipMemcpyAsync(d_ul, utt_lattice, U * 4, hipMemcpyHostToDevice, s2));
             if (want_occ && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, s2));
+            if (want_occ) {   // the only states that can carry occupancy: each utterance's chain
+                std::vector<int32_t> st((size_t)U * GH_FBCHAIN_MAX, -1);
+                for (int64_t u = 0; u < U; ++u) {
+                    const gh_fbchain& fc = lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0];
+                    for (int j = 0; j < fc.n; ++j) st[(size_t)u * GH_FBCHAIN_MAX + j] = fc.state[j];
+                }
+                if (!b->d_occ_states) GH_HIP(hipMalloc((void**)&b->d_occ_states, st.size() * 4));
+                GH_HIP(hipMemcpy(b->d_occ_states, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+            }
             gh_fbchain_args ca;
             memset(&ca, 0, sizeof ca);
             ca.chains = lat->d_fbchain; ca.nll = b->nll; ca.S = S; ca.utt_off = b->d_offsets; ca.utt_lat = d_ul;
@@ -492,6 +501,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     a.alpha_scratch = d_scratch; a.scratch_off = d_soff; a.logp = d_logp;
     a.out_alpha = d_alpha; a.out_beta = d_beta; a.out_gamma = d_gamma; a.mat_off = d_matoff;
     a.occ = want_occ ? b->occ : nullptr;
+    if (want_occ && b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }   // any state may be occupied
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));

@@ -87,6 +87,9 @@ struct gh_batch {
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
     double* occ;  // device [N,S] fp64 frame x state occupancies after gh_forward_backward(want_occ)
+    // after a chain-form forward-backward: the states that can carry occupancy in each utterance ([U][8], -1 padded),
+    // so that gh_bw_accumulate need not scan the occupancy matrix for them; null otherwise
+    int32_t* d_occ_states;
     // launch order of the DP kernels: utterances sorted longest first (computed once)
     std::vector<int64_t> perm;
     int64_t* d_perm;

@@ -110,6 +110,7 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     b->ctx = ctx; b->dtype = dtype; b->D = D; b->N = N; b->U = U;
     b->feats = nullptr; b->owns_feats = false; b->nll = nullptr; b->nll_S = 0; b->d_offsets = nullptr;
     b->occ = nullptr;
+    b->d_occ_states = nullptr;
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;
     for (int64_t u = 0; u < U; ++u) b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
@@ -163,6 +164,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
     if (b->owns_feats && b->feats) hipFree(b->feats);
     if (b->nll) hipFree(b->nll);
     if (b->occ) hipFree(b->occ);
+    if (b->d_occ_states) hipFree(b->d_occ_states);
     if (b->d_offsets) hipFree(b->d_offsets);
     if (b->d_perm) hipFree(b->d_perm);
     delete b;

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ occ,
                                                        double occ_floor, int F, const int64_t* __restrict__ utt_off,
-                                                       int64_t U, double* __restrict__ slabs) {
+                                                       int64_t U, double* __restrict__ slabs,
+                                                       const int32_t* __restrict__ utt_states) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* xt = sm;                 // [F,D]   frames of the tile (MF: rows >= nf zeroed up to a multiple of 4)
     double* rt = xt + F * D;         // [M,F]   weighted responsibilities of the current state (MF: [F,8], frame major)
@@ -197,6 +198,15 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
         // which states have any occupancy on this tile?  All lanes sweep the [nf, S] block of the occupancy
         // matrix linearly (coalesced, 4 loads in flight per lane) and raise a flag per state -- one lane per
         // state walking down its column costs one memory round trip per frame.
+        if (utt_states) {   // a chain-form forward-backward left the list of states that can be occupied (<= 8)
+            __syncthreads();
+            if (tid == 0) {
+                int c = 0;
+                for (int j = 0; j < 8; ++j) { const int s = utt_states[u * 8 + j]; if (s >= 0) s_list[c++] = s; }
+                s_count = c;
+            }
+            __syncthreads();
+        } else {
         for (int s = tid; s < S; s += 256) s_list[s] = 0;
         __syncthreads();
         {
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
             s_count = c;
         }
         __syncthreads();
+        }
         const int count = s_count;
         for (int k = 0; k < count; ++k) {
             const int s = s_list[k];
@@ -580,7 +591,7 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
         auto kern = !mf ? bw_stats_kernel<false, 1, BW_MAXP>
                         : (nct <= 5 && M * (D + 1) <= 512) ? bw_stats_kernel<true, 5, 2> : bw_stats_kernel<true, 8, BW_MAXP>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_need(F), st, (const double*)b->feats, b->N, D, S, M,
-                           g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, b->d_offsets, b->U, d_slabs);
+                           g->dMean, g->dIvar, g->dLogc, b->occ, occ_floor, F, b->d_offsets, b->U, d_slabs, b->d_occ_states);
         GH_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, d_slabs, grid, len, d_out);
