@@ -725,3 +725,27 @@ def test_loglik_subset_equals_full_on_the_ranges(hip, ctx, S, M, D):
         full.close()
         sub.close()
     gmm.close()
+
+
+def test_loglik_extreme_parameter_ranges(hip, ctx):
+    """Tiny and huge variances, offsets far from zero, weights spanning 12 decades, far-away frames: the scaled-log-domain
+    epilogue of the MFMA kernel against the oracle's log-domain arithmetic (fp64)."""
+    rng = np.random.default_rng(77)
+    S, M, D, N = 6, 8, 13, 200
+    means = rng.normal(size=(S, M, D)) * np.array([1e-3, 1.0, 30.0, 1e3, 1.0, 1.0])[:, None, None]
+    vars_ = 10.0 ** rng.uniform(-6, 6, size=(S, M, D))
+    vars_[4] = 10.0 ** rng.uniform(-1, 1, size=(M, D))
+    w = 10.0 ** rng.uniform(-12, 0, size=(S, M))
+    X = rng.normal(size=(N, D)) * 3.0
+    X[:50] += means[3, 0]            # near the far-away state
+    X[50:60] *= 1e3                  # very unlikely frames: costs of ~1e6 and more
+    ref = O.gmm_neg_loglik_batch(X, means, vars_, w)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, feats=X, offsets=[0, N])
+    got = b.loglik(gmm)
+    assert np.all(np.isfinite(got))
+    # the contraction sum_k P_k z_k cancels terms of size ~max|x^2/var|: compare to that scale
+    scale = np.maximum(np.abs(ref), ((X[:, None, None, :] ** 2 + means[None] ** 2) / vars_[None]).sum(axis=3).max(axis=2))
+    assert np.max(np.abs(got - ref) / scale) < 1e-12
+    b.close()
+    gmm.close()
