@@ -9,20 +9,26 @@
 // components is the epilogue.
 //
 // gfx950 mapping (one wave per workgroup, no inter-wave traffic):
-//   * a wave owns 32 frames.  Their Z operand (B fragments of both 16-frame column tiles,
-//     all K) is loaded ONCE -- coalesced global -> LDS tile -> registers -- and stays in
-//     VGPRs for the whole kernel;
-//   * the Gaussians stream past as 16-row tiles.  The host packs P so that every A
-//     fragment is 64 consecutive elements in lane order (one coalesced 512-byte /
-//     256-byte load per k-step); all waves read the same 256 KB, which lives in L2/L1.
-//     The next tile's fragments are fetched into a second register set while the
-//     current tile's MFMAs issue;
-//   * accumulators start at C[g], so they finish as component log-densities.  The row
-//     order inside a tile is chosen per dtype (host side) such that lane group q = lane>>4
-//     holds components 4q..4q+3 of the tile in its 4 accumulator registers -- for M = 8
-//     the log-sum-exp is 4 in-register terms + one xor-16 exchange;
-//   * results are staged in LDS as a [32 frames, states] tile and written back as one
-//     contiguous block (the [N,S] matrix is row-major), 16 bytes per lane.
+//   * a wave owns 32 frames at a time.  Their Z operand (B fragments of both 16-frame column
+//     tiles, all K) is loaded ONCE -- coalesced global -> LDS tile -> registers, every load in
+//     flight before the first wait -- and stays in VGPRs while the Gaussians stream past;
+//   * the Gaussians stream past as 16-row tiles.  The host packs P so that every A fragment is 64
+//     consecutive elements in lane order (one coalesced 512-byte / 256-byte load per k-step); all
+//     waves read the same 256 KB, which lives in L2 (~60 % of it is served by the CU's L1).  The
+//     fragments travel through a register ring a whole tile (fp64) / half a tile (fp32) ahead;
+//   * the first k-step of a tile takes C[g] as its addend, so the accumulators finish as component
+//     log-densities -- in a SCALED log domain (see below) that makes the log-sum-exp cheap.  The
+//     row order inside a tile is chosen per dtype (host side) such that lane group q = lane>>4
+//     holds components 4q..4q+3 of the tile in its 4 accumulator registers -- for M = 8 the
+//     log-sum-exp is 4 in-register terms + one xor-16 exchange;
+//   * the epilogue of tile t-1 is scheduled with the MFMAs of tile t (fp64: two accumulator pairs
+//     swap roles, nothing is copied);
+//   * results are staged in LDS as a [32 frames, states] tile and written back as one contiguous
+//     block (the [N,S] matrix is row-major), 16 bytes per lane;
+//   * light models (few MFMAs per 32 frames: M = 1, or a state subset) use the MULTI instantiation:
+//     a wave walks several blocks with the operand ring kept primed (closed loop over the tiles),
+//     optionally driven by a block table that restricts every utterance to its own state range
+//     (gh_loglik_subset).
 #include "gh_internal.h"
 
 namespace {
