@@ -68,12 +68,13 @@ __device__ __forceinline__ void dft8(c2 (&v)[8]) {
 template <int FMT>
 __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
     constexpr int S1 = 72, S2 = 9;                       // padded strides of the two transposes (elements)
-    __shared__ c2 s_x[4][8 * S1];                        // 9216 B per wave, reused by every phase
+    __shared__ double s_x[4][8 * S1];                    // 4608 B per wave (the transposes move re and im one after
+                                                         // the other: half the LDS, twice the resident waves), reused by every phase
     __shared__ double s_lfb[4][2][NFILT];
     __shared__ double s_wup[NBIN], s_wdn[NBIN];          // per-bin filter weights, shared by the block
     for (int k = threadIdx.x; k < NBIN; k += 256) { s_wup[k] = a.t.wup[k]; s_wdn[k] = a.t.wdn[k]; }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    c2* ex = s_x[wv];
+    double* ex = s_x[wv];
     const int64_t n0 = ((int64_t)blockIdx.x * 4 + wv) * 2;   // frames n0 (A) and n0 + 1 (B)
     int64_t s0[2] = {0, 0}, slen[2] = {0, 0}, sbase[2] = {0, 0};
     bool live[2];
@@ -129,46 +130,56 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
     dft8(v);
 #pragma unroll
     for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], *reinterpret_cast<const c2*>(a.t.tw + 2 * (lane * q)));
+    // component-wise transpose through LDS: v[i] goes to slot wr(i), comes back from slot rd(i)
+    auto transpose = [&](auto wr, auto rd) {
+        double tx[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ex[q * S1 + lane] = v[q];
-    __syncthreads();
+        for (int i = 0; i < 8; ++i) ex[wr(i)] = v[i].x;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tx[i] = ex[rd(i)];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ex[wr(i)] = v[i].y;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (c2){tx[i], ex[rd(i)]};
+        __syncthreads();
+    };
     const int l1 = lane & 7, qq = lane >> 3;
-#pragma unroll
-    for (int l2 = 0; l2 < 8; ++l2) v[l2] = ex[qq * S1 + l1 + 8 * l2];
-    __syncthreads();
+    transpose([&](int q) { return q * S1 + lane; }, [&](int l2) { return qq * S1 + l1 + 8 * l2; });
     // ---- pass 2: DFT over l2, twiddle W64^(l1 q'); transpose so that lane (q + 8 q') holds l1 = 0..7 ----
     dft8(v);
 #pragma unroll
     for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], *reinterpret_cast<const c2*>(a.t.tw + 2 * (8 * l1 * q2)));
-#pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) ex[(qq + 8 * q2) * S2 + l1] = v[q2];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = ex[lane * S2 + i];
-    __syncthreads();
+    transpose([&](int q2) { return (qq + 8 * q2) * S2 + l1; }, [&](int i) { return lane * S2 + i; });
     // ---- pass 3: DFT over l1: register p holds Z[lane + 64 p] ----
     dft8(v);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) ex[lane + 64 * p] = v[p];
-    __syncthreads();
     TK();
-    // ---- separate the two real spectra, power / NFFT for bins 0..256 ----
-    double pa[5], pb[5];
+    // ---- separate the two real spectra, power / NFFT for bins 0..256: the partner Z[N - k] comes through LDS ----
+    double wx[5], wy[5];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) ex[lane + 64 * p] = v[p].x;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wx[i] = ex[(NFFT - (lane + 64 * i)) & (NFFT - 1)];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) ex[lane + 64 * p] = v[p].y;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wy[i] = ex[(NFFT - (lane + 64 * i)) & (NFFT - 1)];
+    __syncthreads();
+    double* pw = ex;                                         // [2][NBIN + pad]
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int k = lane + 64 * i;
         const c2 z = (i < 4) ? v[i] : v[4];                  // k = 256 sits in lane 0, register 4
-        const c2 w = ex[(NFFT - k) & (NFFT - 1)];
-        const double ar = z.x + w.x, ai = z.y - w.y, br = z.x - w.x, bi = z.y + w.y;
-        pa[i] = (ar * ar + ai * ai) * (0.25 / NFFT);
-        pb[i] = (br * br + bi * bi) * (0.25 / NFFT);
-    }
-    __syncthreads();
-    double* pw = reinterpret_cast<double*>(ex);              // [2][NBIN + pad]
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int k = lane + 64 * i;
-        if (k < NBIN) { pw[k] = pa[i]; pw[264 + k] = pb[i]; }
+        const double ar = z.x + wx[i], ai = z.y - wy[i], br = z.x - wx[i], bi = z.y + wy[i];
+        if (k < NBIN) {
+            pw[k] = (ar * ar + ai * ai) * (0.25 / NFFT);
+            pw[264 + k] = (br * br + bi * bi) * (0.25 / NFFT);
+        }
     }
     __syncthreads();
     TK();
