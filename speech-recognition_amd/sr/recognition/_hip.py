@@ -469,10 +469,11 @@ class Lattices:
                             for u in range(U)]
         return out
 
-    def viterbi_labels(self, batch, row_label, utt_lattice=None):
+    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None):
         """A6 + A12 in one call: decode, keep the path on the device, return the decoded label sequences
         (main.py:59-67: first row of every emitting run between non-emitting rows).  row_label: one int32 array per
         graph (label per row, < 0 on non-emitting rows) or a single array when there is one graph.
+        max_labels (scalar or [U]): upper bound on the labels per utterance; exceeding it raises BackendError.
         Returns dict(labels [list of int32 arrays], best_end [U], end_cost_flat, end_off)."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
@@ -488,6 +489,8 @@ class Lattices:
         best_end = np.empty(U, dtype=np.int32)
         nlev = np.array([self.path_cap(l, 1) for l in range(self.L)], dtype=np.int64)[lidx]
         cap = np.where(T > 1, T * nlev // 2 + 1, 0)
+        if max_labels is not None:   # the caller knows a tighter bound (e.g. K + 1 for a K-layer lattice): smaller copy-back
+            cap = np.minimum(cap, np.asarray(max_labels, dtype=np.int64))
         label_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.int64)
         labels = np.empty(int(label_off[-1]), dtype=np.int32)
         n_labels = np.empty(U, dtype=np.int32)

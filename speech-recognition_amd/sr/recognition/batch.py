@@ -96,8 +96,10 @@ class ContinuousDecoder:
         wt = [m.transitions for m in models]
         if grammar == "layers":
             graph, self.nes_rows = packed_lattice(wt, self.n, [list(range(W))] * n_layers)
+            self._max_labels = lambda T: n_layers + 1
         elif grammar == "loop":
             graph, self.nes_rows = packed_loop_lattice(wt, self.n, word_penalty)
+            self._max_labels = lambda T: T // max(1, self.n - 1) + 2      # a word spans at least n - 1 column steps
         else:
             raise ValueError("grammar must be 'layers' or 'loop', not %r" % (grammar,))
         self.grammar = grammar
@@ -113,7 +115,7 @@ class ContinuousDecoder:
             r = self.lat.viterbi(batch, want_path=True)
             return [path_to_words(p, self.row_state, self.n) for p in r["paths"]], r
         row_word = np.where(self.row_state >= 0, self.row_state // self.n, -1).astype(np.int32)
-        r = self.lat.viterbi_labels(batch, row_word)
+        r = self.lat.viterbi_labels(batch, row_word, max_labels=self._max_labels(batch.lengths))
         return [[int(w) for w in l] for l in r["labels"]], r
 
     def decode(self, xs):
