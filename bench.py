@@ -4,7 +4,12 @@
 Headline benchmark: frame-state log-likelihoods/s + utterances/s Viterbi decode
 (BASELINE.json) of the GMM-HMM hot path on MI355X, through the C ABI.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or started directly -- then this process only spawns the N rank
+processes (before anything touches HIP or torch.cuda) and relays their exit code.  One rank per GPU, backend
+"nccl" (= RCCL over xGMI); `--backend gloo --device 0` rehearses the N-rank path on a one-GPU box.
 
 One "step" = one pass of the hot path over the batch: batched GMM log-likelihood
 of every frame against every state (A3) + isolated-word Viterbi of every
@@ -16,10 +21,15 @@ collective -- decode shards by utterance).  Features are resident in HBM before
 the timed region.  Arithmetic: fp64 (the reference's), which is what keeps the
 Viterbi paths bit-identical; --dtype f32 runs the fp32 likelihood kernel.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra
 objects: "roofline" for the dominant kernel (the likelihood kernel; HIP-event
-timed live on the library's stream) and "cpu_baseline" (the numpy oracle,
-reference-shaped scalar loops, 1 core, on a bounded sample).
+timed live on the library's stream), "cpu_baseline" (the numpy oracle,
+reference-shaped scalar loops, 1 core, on a bounded sample), "em" (configs[2]: soft-EM
+iterations on every rank's shard with ONE all-reduce of the device-resident statistics
+per iteration -- em_utterances_per_s, allreduce_ms, rccl_ranks), "configs" (the other
+BASELINE.json configs timed after the headline region: C1 x1000, C4, C5 K-layer and
+loop grammar at the per-GPU size) and "pcie_inclusive" (the headline step with the
+feature upload inside the step).  None of these touch `value` / `ms_per_step`.
 """
 import argparse
 import ctypes as C
@@ -171,6 +181,264 @@ def cpu_baseline(wl, n_utts=20):
     return out
 
 
+# ------------------------------------------------------------------------------------------ N-rank launch
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started without a launcher: start N rank processes with the torchrun environment and
+    relay the worst exit code.  This parent never imports torch and never calls HIP (a process that has touched the
+    GPU must not fork / exec rank processes on this pool)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ EM leg
+def em_leg(args, rank, world, dev, backend):
+    """configs[2]: soft-EM iterations (E-step = own-state likelihoods -> forward-backward -> statistics, all HIP;
+    ONE all-reduce of the packed fp64 statistics buffer per iteration; host M-step) on this rank's shard of
+    `--em-utts` utterances (100k / 8 GPUs = 12 500 by default; weak scaling).  With backend nccl the buffer is
+    reduced where the kernels left it (torch tensor in HBM handed to gh_bw_accumulate as `stats_dev`)."""
+    import torch
+    import torch.distributed as dist
+    from sr.recognition.train import BaumWelchTrainer
+    from sr.recognition.parallel import StatsAllReducer
+    info = {}
+    own_group = False
+    if not dist.is_initialized() and backend == "nccl" and torch.cuda.is_available():
+        # single-GPU run: a one-rank RCCL group, so that the collective of the training path runs on every bench
+        try:
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                    device_id=torch.device("cuda", dev))
+            own_group = True
+        except Exception as e:  # reported, not fatal: the EM leg then runs without a process group
+            info["rccl_error"] = repr(e)[:200]
+    wl = synth_workload(1003, args.em_utts, utt_seed=None if rank == 0 else 1003 + 7919 * rank)
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    U = args.em_utts
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    labels = [[int(w)] for w in wl["words"]]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)   # perturbed start, same on every rank
+    red = StatsAllReducer(gpu_index=dev)
+    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=dev, reducer=red)
+    del data
+    sync_dev = "cuda" if (dist.is_initialized() and dist.get_backend() == "nccl") else "cpu"
+
+    def fence():
+        tr.ctx.sync()
+        if dist.is_initialized():
+            if sync_dev == "cuda":
+                torch.cuda.synchronize()
+            dist.barrier()
+    hist = [tr.iteration()]                       # warm-up iteration (allocations, RCCL channel set-up)
+    red.calls, red.seconds = 0, 0.0
+    fence()
+    t0 = time.perf_counter()
+    e_s = 0.0
+    for _ in range(args.em_iters):
+        hist.append(tr.iteration())
+        e_s += tr.last_timing["e_step_s"]
+    fence()
+    dt = time.perf_counter() - t0
+    frames = float(tr.batch.N)
+    if dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([float(U), frames], dtype=torch.float64, device=sync_dev)
+        dist.all_reduce(tot)
+        dt, all_utts, all_frames = float(t.item()), float(tot[0].item()), float(tot[1].item())
+    else:
+        all_utts, all_frames = float(U), frames
+    info.update({
+        "workload": "configs[2]: soft EM (fwd-bwd E-step + all-reduced statistics + M-step), 10x5 states, 8-mix, 39-dim, "
+                    "%d utterances per GPU" % U,
+        "iterations": args.em_iters, "ms_per_iteration": dt / args.em_iters * 1e3,
+        "em_utterances_per_s": all_utts * args.em_iters / dt, "em_frames_per_s": all_frames * args.em_iters / dt,
+        "e_step_ms": e_s / args.em_iters * 1e3,
+        "allreduce_ms": (red.seconds / red.calls * 1e3) if red.calls else None,
+        "allreduce_bytes": tr._packed_len() * 8,
+        "allreduce_on_device_buffer": bool(red.on_gpu),
+        "backend": dist.get_backend() if dist.is_initialized() else None,
+        "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+        "loglik_per_frame": [h / all_frames for h in hist],
+        "loglik_monotone": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(hist, hist[1:]))),
+    })
+    tr.close()
+    if own_group:
+        dist.destroy_process_group()
+    return info
+
+
+# ----------------------------------------------------------------------------- the other BASELINE configs
+def _timeit(fn, reps=3, ramp=0.3):
+    """Mean wall time of fn() (each call synchronises) after `ramp` seconds of the same work (clock governor)."""
+    t_r = time.perf_counter()
+    out = fn()
+    while time.perf_counter() - t_r < ramp:
+        out = fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def _isolated_config(ctx, name, seed, U, W, n, M, D, npdt, peak_flops):
+    from sr.recognition import _hip
+    wl = synth_workload(seed, U, W=W, n=n, M=M, D=D)
+    S = W * n
+    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
+    b = _hip.Batch(ctx, feats=wl["X"], offsets=wl["off"], dtype=npdt)
+    lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
+    t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()))
+    t_vit, r = _timeit(lambda: lat.viterbi(b, want_path=False))
+    words = np.argmin(r["end_cost_flat"].reshape(U, W), axis=1)
+    esz = np.dtype(npdt).itemsize
+    N = b.N
+    flops, bytes_ll, bytes_vit = 2.0 * 2 * D * S * M * N, float(esz * (D + S) * N), float(esz * S * N)
+    hbm_bound = flops / bytes_ll < peak_flops / PEAK_HBM
+    out = {"workload": name, "utterances": U, "frames": int(N), "states": S, "mixtures": M, "dim": D,
+           "ms": (t_ll + t_vit) * 1e3, "loglik_ms": t_ll * 1e3, "viterbi_ms": t_vit * 1e3,
+           "value": N * S / (t_ll + t_vit), "unit": "frame-state loglik/s", "utterances_per_s": U / (t_ll + t_vit),
+           "decode_accuracy": float(np.mean(words == wl["words"])),
+           "roofline": ({"kernel": "loglik", "bound": "hbm", "achieved": bytes_ll / t_ll / 1e9, "peak": PEAK_HBM / 1e9,
+                         "unit": "GB/s", "frac": bytes_ll / t_ll / PEAK_HBM} if hbm_bound else
+                        {"kernel": "loglik", "bound": "mfma", "achieved": flops / t_ll / 1e12, "peak": peak_flops / 1e12,
+                         "unit": "TFLOP/s", "frac": flops / t_ll / peak_flops}),
+           "viterbi_roofline": {"kernel": "viterbi_chain", "bound": "hbm", "achieved": bytes_vit / t_vit / 1e9,
+                                "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_vit / t_vit / PEAK_HBM},
+           "timing": "wall time of the synchronous C-ABI calls (includes their host side), mean of 3 after a 0.3 s ramp"}
+    lat.close(); b.close(); gmm.close()
+    return out
+
+
+def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
+    """configs[4] at its per-GPU size (1 M utterances / 8 GPUs): `U_base` distinct synthetic K-word utterances,
+    tiled on the device to `U_total`; K-layer lattice (the reference's grammar, main.py:35) and the word-loop
+    grammar, decoded to label sequences on the device (gh_viterbi_labels)."""
+    import torch
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    rng = np.random.default_rng(1005)
+    wl = synth_workload(1005, 1, W=W, n=n, M=M, D=D)
+    means, vars_, trans = wl["means"], wl["vars"], wl["trans"]
+    S = W * n
+    words = rng.integers(0, W, size=(U_base, K))
+    Tw = rng.integers(30, 61, size=(U_base, K))
+    seg_len = Tw.reshape(-1)
+    seg_off = np.concatenate([[0], np.cumsum(seg_len)])
+    Nb = int(seg_off[-1])
+    seg = np.repeat(np.arange(len(seg_len)), seg_len)
+    t = np.arange(Nb) - seg_off[seg]
+    st = np.minimum(t * n // seg_len[seg], n - 1)
+    idx = (words.reshape(-1)[seg] * n + st) * M + rng.integers(0, M, size=Nb)
+    X = means.reshape(-1, D)[idx] + np.sqrt(vars_).reshape(-1, D)[idx] * rng.standard_normal((Nb, D))
+    T = Tw.sum(axis=1)
+    reps = max(1, int(round(U_total / U_base)))
+    U = U_base * reps
+    dev = torch.device("cuda", ctx.device)
+    tdt = torch.float64 if npdt == np.float64 else torch.float32
+    xb = torch.from_numpy(np.ascontiguousarray(X, dtype=npdt)).to(dev)
+    xt = xb.repeat(reps, 1).contiguous()
+    del xb
+    torch.cuda.synchronize(dev)
+    off = np.concatenate([[0], np.cumsum(np.tile(T, reps))]).astype(np.int64)
+    N = int(off[-1])
+    b = _hip.Batch(ctx, feats_dev=xt.data_ptr(), dim=D, offsets=off, dtype=npdt)
+    gmm = _hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), wl["w"].reshape(S, M))
+    t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()), reps=2, ramp=0.0)
+    esz = np.dtype(npdt).itemsize
+    out = {}
+    truth = [list(w) for w in words]
+    for key, (graph, _nes), max_labels in (
+            ("C5_K7_lattice", packed_lattice([trans] * W, n, [list(range(W))] * K), K + 1),
+            ("C5_loop_grammar", packed_loop_lattice([trans] * W, n), None)):
+        lat = _hip.Lattices(ctx, [graph])
+        R = len(graph["row_state"])
+        row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+        ml = max_labels if max_labels is not None else b.lengths // (n - 1) + 2
+        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml), reps=2, ramp=0.0)
+        acc = float(np.mean([[int(v) for v in r["labels"][u]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
+        bytes_dp = float((esz * S + 4) * N)     # SURVEY 8(d): un-fused Viterbi over materialised likelihoods
+        out[key] = {"workload": "configs[4] per-GPU share: %d utterances (%d distinct, tiled x%d on the device), K=%d words, "
+                                "%d lattice rows" % (U, U_base, reps, K, R),
+                    "utterances": U, "frames": N, "lattice_rows": R,
+                    "ms": (t_ll + t_dec) * 1e3, "loglik_ms": t_ll * 1e3, "viterbi_labels_ms": t_dec * 1e3,
+                    "value": U / (t_ll + t_dec), "unit": "utterances/s", "dp_cells_per_s": N * R / t_dec,
+                    "sequence_accuracy_sampled": acc,
+                    "roofline": {"kernel": "viterbi (lattice)", "bound": "hbm", "achieved": bytes_dp / t_dec / 1e9,
+                                 "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_dp / t_dec / PEAK_HBM,
+                                 "note": "algorithmic bytes (esz*S + 4) per frame over the wall time of gh_viterbi_labels "
+                                         "(kernels + label copy-back + host slicing)"}}
+        lat.close()
+    b.close(); gmm.close()
+    del xt
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_configs(args, dev, npdt, peak_flops):
+    from sr.recognition import _hip
+    ctx = _hip.Context(dev)
+    out = {}
+    for key, fn in (
+            ("C1x1000", lambda: _isolated_config(ctx, "configs[0] x1000: 10x5 states, 1 Gaussian, 13-dim, 100 000 utterances",
+                                                 1001, 100000, 10, 5, 1, 13, npdt, peak_flops)),
+            ("C4", lambda: _isolated_config(ctx, "configs[3] (reduced utterance count): 64 HMMs x 16 states x 32 mixtures, 39-dim",
+                                            1004, args.c4_utts, 64, 16, 32, 39, npdt, peak_flops)),
+            ("C5", lambda: _continuous_config(ctx, args.c5_utts, min(args.c5_utts, 5000), npdt))):
+        t0 = time.perf_counter()
+        try:
+            r = fn()
+            if key == "C5":
+                out.update(r)
+            else:
+                out[key] = r
+        except Exception as e:   # an extra must never take the headline line down with it
+            out[key] = {"error": repr(e)[:300]}
+        out.setdefault("_seconds", {})[key] = round(time.perf_counter() - t0, 1)
+    ctx.close()
+    return out
+
+
+def pcie_inclusive(dev, wl, npdt, steps=5):
+    """The headline step with the feature upload INSIDE the step (gh_batch_create from pageable host memory, not
+    overlapped): what a caller pays who hands over host buffers every time.  Never part of `value`."""
+    from sr.recognition import _hip
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    S = W * n
+    ctx = _hip.Context(dev)
+    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
+    lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
+    X = np.ascontiguousarray(wl["X"], dtype=npdt)
+
+    def step():
+        b = _hip.Batch(ctx, feats=X, offsets=wl["off"], dtype=npdt)
+        b.loglik(gmm, fetch=False)
+        lat.viterbi(b, want_path=False)
+        b.close()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    lat.close(); gmm.close(); ctx.close()
+    return {"ms_per_step": dt * 1e3, "value": X.shape[0] * S / dt, "unit": "frame-state loglik/s",
+            "h2d_bytes_per_step": int(X.nbytes), "note": "upload + likelihoods + Viterbi per step, one stream, no overlap"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,11 +458,23 @@ def main():
     # rehearsal of the N > 1 path on a box with fewer GPUs: --backend gloo --device 0 lets every rank share GPU 0
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (default: LOCAL_RANK)")
+    ap.add_argument("--no-em", action="store_true", help="skip the EM leg (configs[2])")
+    ap.add_argument("--em-utts", type=int, default=12500, help="utterances per GPU of the EM leg (100k / 8 GPUs)")
+    ap.add_argument("--em-iters", type=int, default=5)
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip C1 x1000 / C4 / C5 / PCIe legs (single-GPU runs only)")
+    ap.add_argument("--c4-utts", type=int, default=10000, help="utterances of the C4 leg (~1 M frames)")
+    ap.add_argument("--c5-utts", type=int, default=125000, help="utterances of the C5 legs (1 M / 8 GPUs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing above this line touches HIP or torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: torch.distributed.run "
+                 "--nproc-per-node %d, or start bench.py --gpus %d without a launcher)" % (args.gpus, world, args.gpus, args.gpus))
     dist = None
     dev = local_rank if args.device is None else args.device
     if world > 1:
@@ -211,7 +491,6 @@ def main():
     except Exception:
         torch, have_torch_cuda = None, False
     red_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
-
     from sr.recognition import _hip
     npdt = np.float64 if args.dtype == "f64" else np.float32
     wl = synth_workload(1002, args.utts, utt_seed=None if rank == 0 else 1002 + 7919 * rank)
@@ -356,6 +635,28 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a rank-0, single-GPU-run measurement
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_utts)
+    # ---- everything below runs after (and outside) the timed region; it never changes value / ms_per_step
+    for l in lanes:
+        l.lat.close(); l.batch.close(); l.gmm.close(); l.ctx.close()
+    lanes.clear()
+    em = None
+    if not args.no_em:
+        try:
+            em = em_leg(args, rank, world, dev, args.backend)
+        except Exception as e:
+            if world > 1:
+                raise             # a rank that drops out of a collective would hang the others: fail loudly
+            em = {"error": repr(e)[:300]}
+    if rank == 0:
+        if em is not None:
+            out["em"] = em
+        if world == 1 and not args.no_extra_configs:
+            peak = PEAK_F64 if args.dtype == "f64" else PEAK_F32
+            out["configs"] = extra_configs(args, dev, npdt, peak)
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(dev, wl, npdt)
+            except Exception as e:
+                out["pcie_inclusive"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -412,7 +412,12 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         for (int64_t u = 0; u < U; ++u)
             GH_REQUIRE(utt_lattice[u] >= 0 && utt_lattice[u] < lat->L, "gh_forward_backward: utt_lattice[%lld] out of range",
                        (long long)u);
-    if (want_occ && !b->occ && b->N > 0) GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
+    if (want_occ && b->N > 0 && (!b->occ || b->occ_S != S)) {   // sized for the model in use, not for the first one seen
+        if (b->occ) { GH_HIP(hipStreamSynchronize(ctx->stream)); GH_HIP(hipFree(b->occ)); b->occ = nullptr; }
+        if (b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }
+        GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
+        b->occ_S = S;
+    }
     // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
     const size_t BUDGET = (size_t)4 << 30;
     std::vector<int64_t> soff(U, 0), chunk_begin{0};

@@ -64,7 +64,12 @@ struct gh_gmm {
     int S, M, D, KP;
     std::vector<double> hA, hB, hC;  // host fp64 master copies [G,KP], [G,KP], [G]
     double *dA64, *dB64, *dC64;      // device fp64
-    float *dA32, *dB32, *dC32;       // device fp32
+    float *dA32, *dB32, *dC32;       // device fp32 -- for CENTRED features x - cen (see dCen32)
+    // fp32 only: the GEMM form cancels terms of size (x^2 + mean^2)/var, which costs fp32 its digits once the
+    // features sit far from zero.  The likelihood is shift invariant, so the fp32 operands are packed for
+    // x' = x - cen, mean' = mean - cen with cen = the average component mean per dimension (rounded to fp32: the
+    // kernels subtract exactly the value the host packed for); fp64 operands stay un-centred (cen = 0).
+    float* dCen32;                   // [KP]
     // plain parameters (fp64) for the training kernels: mean, inv_var [G,D], logc [G]
     double *dMean, *dIvar, *dLogc;
     // MFMA operand packing (gh_loglik_mfma.hip): mixtures padded to M_pad components,
@@ -86,7 +91,8 @@ struct gh_batch {
     int64_t max_T;
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
-    double* occ;  // device [N,S] fp64 frame x state occupancies after gh_forward_backward(want_occ)
+    double* occ;  // device [N,occ_S] fp64 frame x state occupancies after gh_forward_backward(want_occ)
+    int occ_S;    // state count `occ` was allocated for (reallocated when a model of another size is used)
     // after a chain-form forward-backward: the states that can carry occupancy in each utterance ([U][8], -1 padded),
     // so that gh_bw_accumulate need not scan the occupancy matrix for them; null otherwise
     int32_t* d_occ_states;

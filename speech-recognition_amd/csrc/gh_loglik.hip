@@ -49,7 +49,7 @@ template <typename T, int KP>
 __global__ __launch_bounds__(64) void loglik_kernel(const T* __restrict__ X, int64_t N, int D,
                                                     const T* __restrict__ A, const T* __restrict__ B,
                                                     const T* __restrict__ C, int S, int M,
-                                                    T* __restrict__ out) {
+                                                    T* __restrict__ out, const T* __restrict__ cen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);  // [64][D] frames of this wave, row-major
     const int lane = threadIdx.x;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void loglik_kernel(const T* __restrict__ X, int
 #pragma unroll
     for (int d = 0; d < KP; ++d) {
         T v = (d < D) ? tile[row * D + d] : T(0);
+        if (cen) v -= cen[d];   // fp32: operands are packed for centred features (gh_internal.h, dCen32)
         x[d] = v;
         x2[d] = v * v;
     }
@@ -117,7 +118,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X, int64_t N, int D, int KP,
                                                         const T* __restrict__ A, const T* __restrict__ B,
                                                         const T* __restrict__ C, int S, int M,
-                                                        T* __restrict__ out) {
+                                                        T* __restrict__ out, const T* __restrict__ cen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
     const int lane = threadIdx.x;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X,
     const int64_t nrows = (N - n0 < 64) ? (N - n0) : 64;
     const int64_t nelem = nrows * D;
     const T* src = X + n0 * D;
-    for (int64_t i = lane; i < nelem; i += 64) tile[i] = src[i];
+    for (int64_t i = lane; i < nelem; i += 64) tile[i] = src[i] - (cen ? cen[i % D] : T(0));
     __syncthreads();
     const int row = (lane < nrows) ? lane : 0;
     const T* xr = tile + row * D;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X,
 }
 
 template <typename T>
-int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, const T* C) {
+int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, const T* C, const T* cen) {
     const int64_t N = b->N;
     if (N == 0) return GH_OK;
     const unsigned grid = (unsigned)((N + 63) / 64);
@@ -160,7 +161,7 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
 #define GH_LL_CASE(kp)                                                                              \
     case kp:                                                                                        \
         hipLaunchKernelGGL((loglik_kernel<T, kp>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                           A, B, C, g->S, g->M, out);                                               \
+                           A, B, C, g->S, g->M, out, cen);                                          \
         break;
     switch (g->KP) {
         GH_LL_CASE(4)
@@ -170,7 +171,7 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
         GH_LL_CASE(40)
         default:
             hipLaunchKernelGGL((loglik_kernel_any<T>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D,
-                               g->KP, A, B, C, g->S, g->M, out);
+                               g->KP, A, B, C, g->S, g->M, out, cen);
     }
 #undef GH_LL_CASE
     GH_HIP(hipGetLastError());
@@ -180,6 +181,6 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
 }  // namespace
 
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b) {
-    if (b->dtype == GH_F64) return launch_t<double>(ctx, g, b, g->dA64, g->dB64, g->dC64);
-    return launch_t<float>(ctx, g, b, g->dA32, g->dB32, g->dC32);
+    if (b->dtype == GH_F64) return launch_t<double>(ctx, g, b, g->dA64, g->dB64, g->dC64, nullptr);
+    return launch_t<float>(ctx, g, b, g->dA32, g->dB32, g->dC32, g->dCen32);
 }

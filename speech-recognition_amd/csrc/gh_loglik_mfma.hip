@@ -275,7 +275,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
                                                          const double* __restrict__ tables, int tab_off,
                                                          T* __restrict__ out, int bpw,
-                                                         const gh_loglik_blk* __restrict__ blk_tab, int64_t n_blk) {
+                                                         const gh_loglik_blk* __restrict__ blk_tab, int64_t n_blk,
+                                                         const T* __restrict__ cen) {
     typedef typename Acc<T>::type V;
 #ifndef GH_MF_RING32
 #define GH_MF_RING32 2
@@ -332,6 +333,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     };
     constexpr int KQ = KS / 2;  // k-steps of the x^2 half == of the x half (KP = 4*KQ)
     T b[2][KS];
+    // fp32: the operands are packed for centred features x - cen (gh_internal.h, dCen32): this lane's dimensions
+    T cen_r[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) cen_r[j] = (sizeof(T) == 4 && cen) ? cen[4 * j + q] : T(0);
     auto build_b = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -339,7 +344,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 #pragma unroll
             for (int j = 0; j < KQ; ++j) {
                 const int d = 4 * j + q;
-                const T v = (row < nrows && d < D) ? lds[row * D + d] : T(0);
+                T v = (row < nrows && d < D) ? lds[row * D + d] : T(0);
+                if (sizeof(T) == 4) v = (row < nrows && d < D) ? v - cen_r[j] : T(0);
                 b[c][j] = v * v;
                 b[c][KQ + j] = v;
             }
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 
 template <typename T>
 int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk, const int32_t* st_lo,
-                  const int32_t* st_hi) {
+                  const int32_t* st_hi, const T* cen) {
     const int64_t N = b->N;
     if (N == 0) return GH_OK;
     const int KS = g->KP / 2;
@@ -559,10 +565,10 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     do {                                                                                                                 \
         if (bpw > 1)                                                                                                     \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk);       \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen); \
         else                                                                                                             \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, false>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk);       \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen); \
     } while (0)
 #define GH_MF_CASE(ks)                                   \
     case ks:                                             \
@@ -595,6 +601,6 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
 // returns 1 when the shape is not covered (caller uses the VALU kernel), <0 on error
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi) {
     if (!g->dApk64) return 1;
-    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi);
-    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi);
+    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr);
+    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32);
 }

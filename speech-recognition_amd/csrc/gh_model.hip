@@ -40,15 +40,36 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
         logc[i] = std::log(weight[i]) - 0.5 * (D * log2pi + sum_logv);  // log(0) = -inf: component off
         g->hC[i] = logc[i] - 0.5 * sum_m2;
     }
-    std::vector<float> fA(g->hA.begin(), g->hA.end()), fB(g->hB.begin(), g->hB.end()),
-        fC(g->hC.begin(), g->hC.end());
+    // fp32 operands: packed for centred features (gh_internal.h, dCen32)
+    std::vector<float> cen32(KP, 0.f);
+    for (int d = 0; d < D; ++d) {
+        long double acc = 0;
+        int cnt = 0;
+        for (int i = 0; i < G; ++i) {
+            const double mu = mean[(size_t)i * D + d];
+            if (std::isfinite(mu)) { acc += mu; ++cnt; }
+        }
+        cen32[d] = cnt ? (float)(double)(acc / cnt) : 0.f;
+        if (!std::isfinite(cen32[d])) cen32[d] = 0.f;
+    }
+    std::vector<double> hB32((size_t)G * KP, 0.0), hC32(G, 0.0);   // fp64 master copies of the centred B and C
+    for (int i = 0; i < G; ++i) {
+        double sum_m2 = 0;
+        for (int d = 0; d < D; ++d) {
+            const double iv = ivar[(size_t)i * D + d], mu = mean[(size_t)i * D + d] - (double)cen32[d];
+            hB32[(size_t)i * KP + d] = mu * iv;
+            sum_m2 += mu * mu * iv;
+        }
+        hC32[i] = logc[i] - 0.5 * sum_m2;
+    }
+    std::vector<float> fA(g->hA.begin(), g->hA.end()), fB(hB32.begin(), hB32.end()), fC(hC32.begin(), hC32.end());
     // ---- MFMA operand packing (see gh_loglik_mfma.hip) ----
     int M_pad = 1;
     if (M <= 16) { while (M_pad < M) M_pad <<= 1; } else { M_pad = (M + 15) & ~15; }
     const int n_tiles = (S * M_pad + 15) / 16, KS = KP / 2;
     g->M_pad = M_pad;
     g->n_tiles = n_tiles;
-    g->dApk64 = nullptr; g->dCpk64 = nullptr; g->dApk32 = nullptr; g->dCpk32 = nullptr;
+    g->dApk64 = nullptr; g->dCpk64 = nullptr; g->dApk32 = nullptr; g->dCpk32 = nullptr; g->dCen32 = nullptr;
     // (+2 all-zero tiles: the kernel's run-ahead operand loads stay in bounds)
     std::vector<double> apk64((size_t)(n_tiles + 2) * KS * 64, 0.0), cpk64((size_t)(n_tiles + 2) * 16, GH_LSE_OFF64);
     std::vector<float> apk32(apk64.size(), 0.f), cpk32(cpk64.size(), GH_LSE_OFF32);
@@ -58,9 +79,9 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
             if (s >= S || m >= M) continue;  // padding component: switched off (C = OFF, P = 0)
             const int go = s * M + m;
             // scaled log domain; a weight-0 component (C = -inf) gets the finite OFF constant, NaN stays NaN
-            const double c = g->hC[go];
+            const double c = g->hC[go], c32 = hC32[go];
             cpk64[gp] = (c == -INFINITY) ? GH_LSE_OFF64 : std::max(c * GH_LSE_SCALE64, GH_LSE_OFF64);
-            cpk32[gp] = (c == -INFINITY) ? GH_LSE_OFF32 : (float)std::max(c * GH_LSE_SCALE32, (double)GH_LSE_OFF32);
+            cpk32[gp] = (c32 == -INFINITY) ? GH_LSE_OFF32 : (float)std::max(c32 * GH_LSE_SCALE32, (double)GH_LSE_OFF32);
             // accumulator row that makes lane group q = j/4 hold this component in register j%4:
             // f64 16x16x4: row = (lane>>4) + 4*reg  ->  row = j/4 + 4*(j%4); f32: row = 4*(lane>>4) + reg = j
             const int row64 = (j >> 2) + 4 * (j & 3), row32 = j;
@@ -68,14 +89,15 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
                 for (int kq = 0; kq < 4; ++kq) {
                     const int kk = 4 * ks + kq;
                     const double v = kk < KP ? g->hA[(size_t)go * KP + kk] : g->hB[(size_t)go * KP + kk - KP];
+                    const double v32 = kk < KP ? v : hB32[(size_t)go * KP + kk - KP];
                     apk64[((size_t)t * KS + ks) * 64 + kq * 16 + row64] = v * GH_LSE_SCALE64;
-                    apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)(v * GH_LSE_SCALE32);
+                    apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)(v32 * GH_LSE_SCALE32);
                 }
         }
     std::vector<double> vmean(mean, mean + (size_t)G * D);
     int rc = GH_OK;
     if ((rc = upload(&g->dA64, g->hA)) || (rc = upload(&g->dB64, g->hB)) || (rc = upload(&g->dC64, g->hC)) ||
-        (rc = upload(&g->dA32, fA)) || (rc = upload(&g->dB32, fB)) || (rc = upload(&g->dC32, fC)) ||
+        (rc = upload(&g->dA32, fA)) || (rc = upload(&g->dB32, fB)) || (rc = upload(&g->dC32, fC)) || (rc = upload(&g->dCen32, cen32)) ||
         (rc = upload(&g->dMean, vmean)) || (rc = upload(&g->dIvar, ivar)) || (rc = upload(&g->dLogc, logc)) ||
         (rc = upload(&g->dApk64, apk64)) || (rc = upload(&g->dCpk64, cpk64)) ||
         (rc = upload(&g->dApk32, apk32)) || (rc = upload(&g->dCpk32, cpk32))) {
@@ -90,7 +112,7 @@ extern "C" void gh_gmm_destroy(gh_gmm* g) {
     if (!g) return;
     hipSetDevice(g->ctx->device);
     hipFree(g->dA64); hipFree(g->dB64); hipFree(g->dC64);
-    hipFree(g->dA32); hipFree(g->dB32); hipFree(g->dC32);
+    hipFree(g->dA32); hipFree(g->dB32); hipFree(g->dC32); hipFree(g->dCen32);
     hipFree(g->dMean); hipFree(g->dIvar); hipFree(g->dLogc);
     hipFree(g->dApk64); hipFree(g->dCpk64); hipFree(g->dApk32); hipFree(g->dCpk32);
     delete g;
@@ -110,6 +132,7 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     b->ctx = ctx; b->dtype = dtype; b->D = D; b->N = N; b->U = U;
     b->feats = nullptr; b->owns_feats = false; b->nll = nullptr; b->nll_S = 0; b->d_offsets = nullptr;
     b->occ = nullptr;
+    b->occ_S = 0;
     b->d_occ_states = nullptr;
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;

@@ -42,13 +42,14 @@ __global__ void kmeans_assign_kernel(const double* __restrict__ X, int64_t N, in
 // ------------------------------------------------------------------ EM statistics
 // Tile of F frames per iteration.  Phase 1 (lane = frame): weighted component log
 // densities of the first k components, responsibilities r = softmax over those k
-// (hmm_state.py:128-133) into LDS.  Phase 2 (lane = (component, dim) pair):
+// (hmm_state.py:128-133; components the reference's linear-domain product rounds to 0 get none) into LDS.  Phase 2 (lane = (component, dim) pair):
 // S0[c] += r, S1[c,d] += r (x_d - mean_cd), S2[c,d] += r (x_d - mean_cd)^2 from the LDS tile
 // -- no shuffles, no atomics.  Centring on the component's current mean keeps the
 // single-pass variance S2/S0 - (S1/S0)^2 free of cancellation (the reference makes a
 // second pass over the data around the new mean, hmm_state.py:141-143).  Each workgroup writes one partial [k, 1+2D]; the host adds the partials in
 // a fixed order (deterministic).
 constexpr int EM_MAXP = 8;  // pairs per lane: k*(D+1) <= 8*256
+constexpr double EM_LN_UNDERFLOW = -745.1332191019412;  // exp(x) rounds to +0 in fp64 below this
 
 __global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict__ X, int64_t N, int D, int k,
                                                        const double* __restrict__ mean,
@@ -84,9 +85,13 @@ __global__ __launch_bounds__(256) void em_stats_kernel(const double* __restrict_
                 for (int c = 0; c < k; ++c) {
                     double q = 0;
                     for (int d = 0; d < D; ++d) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
-                    const double ll = pc[c] - 0.5 * q;
-                    rt[c * F + f] = ll;
+                    double ll = pc[c] - 0.5 * q;
                     bad |= (ll != ll);
+                    // The reference forms w * norm * np.exp(-0.5 q) in the LINEAR domain (hmm_state.py:42-43,115): once
+                    // exp() -- or the product -- rounds to 0 the component gets no share of the frame, and a frame whose
+                    // every component underflowed keeps an all-zero row (row sum 0 -> 1e-5, :130-133): it moves nothing.
+                    if (-0.5 * q < EM_LN_UNDERFLOW || ll < EM_LN_UNDERFLOW) ll = -INFINITY;
+                    rt[c * F + f] = ll;
                     mx = fmax(mx, ll);
                 }
                 double sum = 0;
@@ -558,6 +563,7 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
     GH_REQUIRE(ctx && g && b && (out_stats || stats_dev), "gh_bw_accumulate: NULL argument");
     GH_REQUIRE(b->dtype == GH_F64, "gh_bw_accumulate: needs an fp64 batch");
     GH_REQUIRE(b->occ || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
+    GH_REQUIRE(b->N == 0 || b->occ_S == g->S, "gh_bw_accumulate: occupancies were computed for %d states, the model has %d", b->occ_S, g->S);
     GH_REQUIRE(g->D == b->D && g->S == b->nll_S, "gh_bw_accumulate: model / batch mismatch");
     GH_REQUIRE(g->M * (g->D + 1) <= BW_MAXP * 256, "gh_bw_accumulate: M=%d x D=%d unsupported", g->M, g->D);
     GH_HIP(hipSetDevice(ctx->device));

@@ -237,10 +237,20 @@ class Batch:
     """Ragged batch of utterances resident in HBM (gh_batch)."""
 
     def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0,
-                 pcm=None, sample_rate=16000, mfcc_params=None):
+                 pcm=None, sample_rate=16000, mfcc_params=None, feats_dev=None, dim=None):
         self.ctx = ctx
         self.np_dtype = np.dtype(dtype)
         assert self.np_dtype in (np.dtype(np.float32), np.dtype(np.float64))
+        if feats_dev is not None:  # features already in HBM (gh_batch_wrap): device pointer of a row-major [N, dim] matrix
+            self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            self.N, self.D, self.U = int(self.offsets[-1]), int(dim), len(self.offsets) - 1
+            h = C.c_void_p()
+            _check(ctx.lib, ctx.lib.gh_batch_wrap(ctx.h, GH_F64 if self.np_dtype == np.float64 else GH_F32, self.D,
+                                                  self.N, self.U, C.c_void_p(int(feats_dev)),
+                                                  _ptr(self.offsets, _c_i64p), C.byref(h)))
+            self.h = h
+            self.S = None
+            return
         if pcm is not None:  # N3 front-end from audio samples: MFCC -> [ceps | delta | delta-delta] -> standardise
             samples, fmt, s_off, f_off, prm = pack_pcm(ctx, pcm, sample_rate, mfcc_params)
             for n in np.diff(f_off):
@@ -363,10 +373,13 @@ class Batch:
                                                            _ptr(v, _c_f64p), _ptr(out, _c_i32p)))
         return out.astype(np.int64)
 
-    def bw_accumulate(self, gmm, occ_floor=0.0, stats_dev=None):
+    def bw_accumulate(self, gmm, occ_floor=0.0, stats_dev=None, fetch=True):
         """Baum-Welch statistics [S, M, 1+2D] of the whole batch from the resident occupancies
-        (run Lattices.forward_backward(..., want_occ=True) first)."""
-        out = np.empty((gmm.S, gmm.M, 1 + 2 * self.D))
+        (run Lattices.forward_backward(..., want_occ=True) first).  stats_dev: device pointer (e.g. a torch
+        tensor's data_ptr() that RCCL is about to all-reduce) that receives them; with fetch=False nothing is
+        copied to the host and None is returned."""
+        assert fetch or stats_dev, "bw_accumulate: nowhere to put the statistics"
+        out = np.empty((gmm.S, gmm.M, 1 + 2 * self.D)) if fetch else None
         _check(self.ctx.lib, self.ctx.lib.gh_bw_accumulate(self.ctx.h, gmm.h, self.h, float(occ_floor),
                                                            _ptr(out, _c_f64p), stats_dev))
         return out

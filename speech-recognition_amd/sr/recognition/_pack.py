@@ -75,7 +75,8 @@ def _digest(*arrays):
 
 class _LRU(OrderedDict):
     """Small content-addressed cache of device handles; keys start with id(ctx): a handle is never shared between
-    contexts (it is bound to the context it was created with).  Thread-safe."""
+    contexts (it is bound to the context it was created with).  Thread-safe.  The cache never destroys a handle that
+    somebody else may still hold: eviction forgets it, the handle's own finaliser frees it."""
 
     def __init__(self, cap):
         super().__init__()
@@ -90,10 +91,10 @@ class _LRU(OrderedDict):
             val = make()
             self[key] = val
             while len(self) > self.cap:
-                _, old = self.popitem(last=False)
-                close = getattr(old, "close", None)
-                if close:
-                    close()
+                # Evicting only drops the cache's reference.  Long-lived holders (a recogniser keeps the handle of its
+                # stacked models) and threads that are inside a library call with the GIL released still use the
+                # object; the device memory goes when the last of them lets go (PackedGMM / Lattices.__del__).
+                self.popitem(last=False)
             return val
 
     def purge(self, ctx):

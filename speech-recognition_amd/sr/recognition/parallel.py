@@ -33,7 +33,12 @@ def shard_utterances(lengths, world_size):
 
 
 class StatsAllReducer:
-    """Sum a packed fp64 statistics buffer over all ranks (one collective per call)."""
+    """Sum a packed fp64 statistics buffer over all ranks (one collective per call).
+
+    Two forms.  `device_buffer(n)` + `reduce_device()`: the buffer lives in HBM (a torch tensor whose
+    `data_ptr()` is handed to `gh_bw_accumulate(stats_dev=...)`), RCCL reduces it where the kernels left
+    it and only the reduced result crosses to the host -- the path of a multi-GPU run (backend "nccl").
+    `__call__(ndarray)`: host buffer through the process group's backend (gloo in the CPU tests)."""
 
     def __init__(self, device=None, gpu_index=None):
         """device: torch device the buffer is reduced on.  Default: the GPU `gpu_index` (or torch's
@@ -42,25 +47,58 @@ class StatsAllReducer:
         self.torch = self.dist = None
         self.enabled = False
         self.device = device
+        self.calls, self.seconds = 0, 0.0          # collectives issued / host time spent in them (bench.py reports it)
+        self._buf = None
         if "torch" not in sys.modules:   # no process group can exist: do not pay for importing torch (seconds to minutes cold)
             return
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.enabled = dist.is_available() and dist.is_initialized()
         if device is None and self.enabled and dist.get_backend() == "nccl":
             device = torch.device("cuda", torch.cuda.current_device() if gpu_index is None else int(gpu_index))
         self.device = device
 
+    @property
+    def world_size(self):
+        return self.dist.get_world_size() if self.enabled else 1
+
+    @property
+    def on_gpu(self):
+        """True when the collective runs on device memory (RCCL): use device_buffer / reduce_device."""
+        return bool(self.enabled and self.device is not None and getattr(self.device, "type", str(self.device)) == "cuda")
+
+    def device_buffer(self, n):
+        """(tensor, device pointer) of an fp64 buffer of n entries on the reduce device (reused between calls)."""
+        if self._buf is None or self._buf.numel() != n:
+            self._buf = self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        return self._buf, int(self._buf.data_ptr())
+
+    def reduce_device(self, tensor=None):
+        """All-reduce (sum) the device buffer in place; returns the reduced buffer as a host ndarray."""
+        import time
+        t = self._buf if tensor is None else tensor
+        t0 = time.perf_counter()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        out = t.cpu().numpy()                      # waits for the collective
+        self.calls += 1
+        self.seconds += time.perf_counter() - t0
+        return out
+
     def __call__(self, stats):
         """stats: numpy fp64 array (any shape) -> summed over ranks, same shape."""
-        if not self.enabled:
+        if not self.enabled or self.world_size == 1 and not self.on_gpu:
             return stats
+        import time
+        t0 = time.perf_counter()
         t = self.torch.from_numpy(np.ascontiguousarray(stats, dtype=np.float64))
         if self.device is not None:
             t = t.to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy().reshape(stats.shape)
+        out = t.cpu().numpy().reshape(stats.shape)
+        self.calls += 1
+        self.seconds += time.perf_counter() - t0
+        return out
 
 
 def m_step(stats, counts, means):

@@ -29,17 +29,21 @@ class BaumWelchTrainer:
 
     means / vars_ / weights: [W, n, M, D] / [W, n, M, D] / [W, n, M] word-state mixtures;
     transitions: list of W [n, n] cost matrices (kept fixed);
-    data: list of [T_u, D] utterances of THIS rank; label_seqs: word indices per utterance."""
+    data: list of [T_u, D] utterances of THIS rank; label_seqs: word indices per utterance.
+    var_floor: lower bound of the re-estimated variances; None (default) = 1e-6 x the mean variance of the
+    initial model -- the centred single-pass variance can cancel to 0 (or slightly below) for a component
+    that holds on to a single frame, and a non-positive variance is a LinAlgError in the next E-step."""
 
     def __init__(self, means, vars_, weights, transitions, data, label_seqs, device=None, reducer=None,
-                 var_floor=0.0, occ_floor=0.0):
+                 var_floor=None, occ_floor=0.0, min_occupancy=1e-8):
         self.ctx = _hip.default_context(device)
         self.W, self.n, self.M, self.D = means.shape
         self.S = self.W * self.n
         self.means = np.array(means, dtype=np.float64).reshape(self.S, self.M, self.D)
         self.vars = np.array(vars_, dtype=np.float64).reshape(self.S, self.M, self.D)
         self.weights = np.array(weights, dtype=np.float64).reshape(self.S, self.M)
-        self.var_floor, self.occ_floor = var_floor, occ_floor
+        self.var_floor = 1e-6 * float(np.mean(self.vars)) if var_floor is None else float(var_floor)
+        self.occ_floor, self.min_occupancy = occ_floor, float(min_occupancy)
         self.reducer = reducer if reducer is not None else StatsAllReducer(gpu_index=self.ctx.device)
         self.batch = _hip.Batch(self.ctx, data)
         keys, graphs = {}, []
@@ -57,40 +61,59 @@ class BaumWelchTrainer:
                       dtype=np.int32)
         self.state_ranges = (lo, hi)
         self.history = []
+        self.n_stats = self.S * self.M * (1 + 2 * self.D)
+        self.last_timing = {}
 
-    def e_step(self):
-        """Returns (stats [S,M,1+2D], counts [S], total log-likelihood) of this rank."""
+    # layout of the ONE buffer that crosses ranks: [statistics S*M*(1+2D) | total log-likelihood | utterances]
+    def _packed_len(self):
+        return self.n_stats + 2
+
+    def e_step(self, stats_dev=None):
+        """Returns (stats [S,M,1+2D] or None when they were left in `stats_dev`, total log-likelihood) of this rank."""
         gmm = _hip.PackedGMM(self.ctx, self.means, self.vars, self.weights)
         try:
             if self.batch.U == 0:
-                return np.zeros((self.S, self.M, 1 + 2 * self.D)), np.zeros(self.S), 0.0
+                return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), 0.0
             self.batch.loglik(gmm, fetch=False, state_ranges=self.state_ranges)
             r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False)
-            stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor)
-            counts = stats[:, :, 0].sum(axis=1)  # sum_n occ[n,s]: responsibilities of a state add up to its occupancy
+            stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor, stats_dev=stats_dev, fetch=stats_dev is None)
             logp = r["logp"]
-            return stats, counts, float(np.sum(logp[np.isfinite(logp)]))
+            return stats, float(np.sum(logp[np.isfinite(logp)]))
         finally:
             gmm.close()
 
     def iteration(self):
         """One EM iteration over all ranks; returns the total log-likelihood BEFORE the update."""
-        stats, counts, ll = self.e_step()
-        S = self.S
-        packed = np.concatenate([stats.reshape(S, -1), counts.reshape(S, 1), np.full((S, 1), ll / S)], axis=1)
-        packed = self.reducer(packed)                       # the ONE collective of the iteration
-        stats = packed[:, :-2].reshape(stats.shape)
-        counts = packed[:, -2]
-        ll = float(packed[:, -1].sum())
+        import time
+        t0 = time.perf_counter()
+        red = self.reducer
+        if red.on_gpu:
+            # statistics go from the kernel's slabs straight into the tensor RCCL reduces: no host bounce
+            buf, ptr = red.device_buffer(self._packed_len())
+            if self.batch.U == 0:
+                buf.zero_()
+            _, ll = self.e_step(stats_dev=ptr)
+            buf[self.n_stats:] = red.torch.tensor([ll, float(self.batch.U)], dtype=red.torch.float64)
+            t1 = time.perf_counter()
+            packed = red.reduce_device()                     # the ONE collective of the iteration
+        else:
+            stats, ll = self.e_step()
+            packed = np.concatenate([stats.reshape(-1), [ll, float(self.batch.U)]])
+            t1 = time.perf_counter()
+            packed = red(packed)                            # the ONE collective of the iteration (gloo / single rank)
+        t2 = time.perf_counter()
+        stats = packed[:self.n_stats].reshape(self.S, self.M, 1 + 2 * self.D)
+        ll = float(packed[self.n_stats])
+        counts = stats[:, :, 0].sum(axis=1)                  # responsibilities of a state add up to its occupancy
         seen = counts > 0
         mu, sigma, w = m_step(stats[seen], counts[seen], self.means[seen])
-        if self.var_floor > 0:
-            sigma = np.maximum(sigma, self.var_floor)
-        ok = stats[seen][:, :, 0] > 0                       # components that received mass
+        sigma = np.maximum(sigma, self.var_floor)
+        ok = stats[seen][:, :, 0] > self.min_occupancy       # components that received mass
         self.means[seen] = np.where(ok[:, :, None], mu, self.means[seen])
         self.vars[seen] = np.where(ok[:, :, None], sigma, self.vars[seen])
         self.weights[seen] = np.where(ok, w, self.weights[seen])
         self.history.append(ll)
+        self.last_timing = dict(e_step_s=t1 - t0, allreduce_s=t2 - t1, m_step_s=time.perf_counter() - t2)
         return ll
 
     def fit(self, n_iterations=5):

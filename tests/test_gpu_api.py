@@ -227,6 +227,21 @@ def test_gmm_em(R, k, tag, iters):
     np.testing.assert_allclose(st.mu_old, g[p + "mu_old"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_gmm_em_linear_domain_underflow(R, k):
+    """the E-step keeps the reference's linear-domain semantics -- a frame whose every weighted density
+    rounds to 0 moves nothing, an underflowed component gets no share (golden G16, captured from the reference)."""
+    g = load_golden("G16_gmm_em_underflow")
+    for tag, iters in (("it1", 1), ("it3", 3)):
+        st = R.GMM(g["mu0"].copy(), g["var0"].copy(), len(g["init_w"]))
+        st.update_models(g["init_means"].copy(), g["init_vars"].copy(), g["init_w"].copy())
+        with contextlib.redirect_stdout(io.StringIO()):
+            st.em(g["data"], k, max_iteration=iters)
+        np.testing.assert_allclose(np.array([d.mean for d in st.dists]), g["k%d_%s_means" % (k, tag)], rtol=1e-8)
+        np.testing.assert_allclose(np.array([d.cov for d in st.dists]), g["k%d_%s_vars" % (k, tag)], rtol=1e-8)
+        np.testing.assert_allclose(st.w, g["k%d_%s_w" % (k, tag)], rtol=1e-8)
+
+
 # ------------------------------------------------------------------------ A14
 @pytest.mark.parametrize("tag,k,dist", [("k2m", 2, "m"), ("k4m", 4, "m"), ("k4e", 4, "e")])
 def test_kmeans(R, tag, k, dist):

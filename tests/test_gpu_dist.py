@@ -1,9 +1,14 @@
 # -*- coding: utf-8 -*-
-"""Two ranks sharing the one GPU of the test box: the sharded EM iteration (HIP E-step per
-rank + ONE all-reduce of the packed statistics, gloo here / RCCL in production) gives the same
-model as the single-process iteration, and sharded decode needs no collective."""
+"""The sharded EM iteration (HIP E-step per rank + ONE all-reduce of the packed statistics) gives the same model as
+the single-process iteration.  With two or more GPUs visible the ranks take one GPU each and the collective is RCCL
+("nccl") on the device-resident buffer; on a one-GPU box two ranks share GPU 0 over gloo, and a ONE-rank RCCL group
+still drives the device-buffer path (gh_bw_accumulate(stats_dev) -> dist.all_reduce on that tensor).  `bench.py
+--gpus 2` is run as ONE command, the way the driver starts it."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -33,7 +38,17 @@ def _problem():
     return means, vars_, w, trans, data, labels
 
 
-def _worker(rank, world, port, out_dir):
+def _n_gpus():
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
+    except OSError:
+        return 0
+    return n.value
+
+
+def _worker(rank, world, port, out_dir, backend):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "speech-recognition_amd"), here):
@@ -42,18 +57,25 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["GMMHMM_DEVICE"] = "0"  # both ranks on the single GPU of the box
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0     # gloo: both ranks on the single GPU of the box
+    os.environ["GMMHMM_DEVICE"] = str(dev)
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sr.recognition.train import BaumWelchTrainer
         from sr.recognition.parallel import shard_utterances, StatsAllReducer
         means, vars_, w, trans, data, labels = _problem()
         mine = shard_utterances([len(x) for x in data], world)[rank]
         tr = BaumWelchTrainer(means, vars_, w, trans, [data[i] for i in mine], [labels[i] for i in mine],
-                              device=0, reducer=StatsAllReducer(), var_floor=1e-3)
+                              device=dev, reducer=StatsAllReducer(gpu_index=dev), var_floor=1e-3)
+        assert tr.reducer.on_gpu == (backend == "nccl")
         hist = tr.fit(2)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), means=tr.means, vars=tr.vars, w=tr.weights,
-                 hist=np.array(hist), mine=mine)
+                 hist=np.array(hist), mine=mine, collectives=tr.reducer.calls)
         tr.close()
     finally:
         dist.destroy_process_group()
@@ -62,15 +84,97 @@ def _worker(rank, world, port, out_dir):
 def test_sharded_em_equals_single_process(tmp_path):
     import torch.multiprocessing as mp
     from sr.recognition.train import BaumWelchTrainer
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    backend = "nccl" if _n_gpus() >= 2 else "gloo"    # RCCL whenever the box has a GPU per rank
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
     means, vars_, w, trans, data, labels = _problem()
     tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, var_floor=1e-3)
     hist = tr.fit(2)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert sorted(np.concatenate([r0["mine"], r1["mine"]]).tolist()) == list(range(len(data)))
     for r in (r0, r1):
+        assert int(r["collectives"]) == 2                      # ONE collective per EM iteration
         np.testing.assert_allclose(r["hist"], hist, rtol=1e-10)
         np.testing.assert_allclose(r["means"], tr.means, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(r["vars"], tr.vars, rtol=1e-7)
         np.testing.assert_allclose(r["w"], tr.weights, rtol=1e-8, atol=1e-12)
     tr.close()
+
+
+def _one_rank_rccl(port, out_dir):
+    """A ONE-rank RCCL group: the device-buffer path of the trainer on whatever single GPU is there."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "speech-recognition_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        from sr.recognition.train import BaumWelchTrainer
+        from sr.recognition.parallel import StatsAllReducer
+        means, vars_, w, trans, data, labels = _problem()
+        red = StatsAllReducer(gpu_index=0)
+        assert red.enabled and red.on_gpu and dist.get_backend() == "nccl"
+        tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, device=0, reducer=red, var_floor=1e-3)
+        hist = tr.fit(2)
+        np.savez(os.path.join(out_dir, "rccl1.npz"), means=tr.means, vars=tr.vars, w=tr.weights, hist=np.array(hist),
+                 collectives=red.calls)
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_allreduce_on_the_device_resident_statistics(tmp_path):
+    """gh_bw_accumulate writes into a torch tensor in HBM, RCCL ("nccl") all-reduces THAT tensor, the M-step reads
+    the reduced copy: same model as the trainer without a process group (host-buffer path)."""
+    import torch.multiprocessing as mp
+    from sr.recognition.train import BaumWelchTrainer
+    mp.spawn(_one_rank_rccl, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    means, vars_, w, trans, data, labels = _problem()
+    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, var_floor=1e-3)
+    hist = tr.fit(2)
+    r = np.load(tmp_path / "rccl1.npz")
+    assert int(r["collectives"]) == 2
+    np.testing.assert_allclose(r["hist"], hist, rtol=1e-12)
+    np.testing.assert_allclose(r["means"], tr.means, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r["vars"], tr.vars, rtol=1e-12)
+    np.testing.assert_allclose(r["w"], tr.weights, rtol=1e-12, atol=1e-14)
+    tr.close()
+
+
+def _run_bench(extra):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--ramp-seconds", "0.1",
+           "--utts", "400", "--em-utts", "300", "--em-iters", "2", "--no-cpu-baseline", "--no-extra-configs"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_is_one_command():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks.  RCCL when the box
+    has two GPUs, otherwise the gloo rehearsal with both ranks on GPU 0."""
+    two = _n_gpus() >= 2
+    out = _run_bench(["--gpus", "2"] + ([] if two else ["--backend", "gloo", "--device", "0"]))
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"].endswith("x2")
+    assert out["decode_accuracy"] == 1.0
+    em = out["em"]
+    assert em["backend"] == ("nccl" if two else "gloo") and em["rccl_ranks"] == (2 if two else 0)
+    assert em["loglik_monotone"] and em["em_utterances_per_s"] > 0 and em["allreduce_ms"] > 0
+
+
+def test_bench_single_gpu_runs_the_collective_on_rccl():
+    out = _run_bench(["--gpus", "1"])
+    assert out["n_gpus"] == 1
+    em = out["em"]
+    assert "rccl_error" not in em, em
+    assert em["backend"] == "nccl" and em["rccl_ranks"] == 1 and em["allreduce_on_device_buffer"]
+    assert em["loglik_monotone"]

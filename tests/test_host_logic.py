@@ -222,3 +222,12 @@ def test_reference_pickles_load_into_the_mirror(R):
     # and they round-trip through the mirror's own pickling
     again = pickle.loads(pickle.dumps(hmms))
     assert again[0] == hmms[0] and again[1].gmm_states[2].id == hmms[1].gmm_states[2].id
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

@@ -231,6 +231,25 @@ def test_G7_gmm_em(k, tag, iters):
     close(st["w_old"], g[p + "w_old"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_G16_gmm_em_linear_domain_underflow(k):
+    """Frames whose weighted densities round to 0 in the reference's linear domain get an all-zero responsibility
+    row (hmm_state.py:130-133) / no share of an underflowed component."""
+    g = load_golden("G16_gmm_em_underflow")
+    p0 = np.array([O.gmm_evaluate(x, g["init_means"], g["init_vars"], g["init_w"], neg_log=False)[:k] for x in g["data"]])
+    np.testing.assert_array_equal(p0 == 0, g["k%d_p0" % k] == 0)
+    assert (p0.sum(axis=1) == 0).sum() == 3
+    for tag, iters in (("it1", 1), ("it3", 3)):
+        M = len(g["init_w"])
+        st = O.new_gmm_state(g["mu0"], g["var0"], M)
+        st["means"][:], st["vars"][:], st["w"][:] = g["init_means"], g["init_vars"], g["init_w"]
+        O.gmm_em(g["data"], st["means"], st["vars"], st["w"], k, max_iteration=iters,
+                 old=(st["mu_old"], st["sigma_old"], st["w_old"]))
+        close(st["means"], g["k%d_%s_means" % (k, tag)], rtol=1e-9)
+        close(st["vars"], g["k%d_%s_vars" % (k, tag)], rtol=1e-9)
+        close(st["w"], g["k%d_%s_w" % (k, tag)], rtol=1e-9)
+
+
 # --------------------------------------------------------------------------- A14
 @pytest.mark.parametrize("tag,k,dist", [("k2m", 2, "mahalanobis"), ("k4m", 4, "mahalanobis"), ("k4e", 4, "euclid")])
 def test_G8_kmeans(tag, k, dist):

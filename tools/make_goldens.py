@@ -299,6 +299,39 @@ def g7(R):
     save("G7_gmm_em", **out)
 
 
+def g16(R):
+    """GMM.em with frames whose weighted densities underflow in the reference's LINEAR domain (hmm_state.py:42-43,
+    128-133): three frames far from every component (all-zero responsibility row, row sum 0 -> 1e-5) and three
+    frames that only one component still resolves."""
+    rng = np.random.default_rng(716)
+    D, M, N = 6, 4, 120
+    cm = rng.normal(size=(2, D)) * 2
+    data = np.concatenate([cm[i] + rng.normal(size=(N // 2, D)) * (0.6 + 0.3 * i) for i in range(2)])
+    far = data.mean(0) + 90.0 * np.sqrt(data.var(0)) * np.array([1, -1, 1, 1, -1, 1.0])      # every component -> 0
+    data = np.concatenate([data[:40], far[None] * np.array([[1.0], [1.1], [0.9]]), data[40:]])
+    mu0, var0 = data[:40].mean(0), data[:40].var(0)
+    init_means = np.concatenate([cm + rng.normal(size=(2, D)) * 0.3, mu0 + rng.normal(size=(2, D))])
+    init_vars = np.tile(var0, (M, 1))
+    init_vars[1] *= 30.0                                                                      # a wide component
+    half = init_means[0] + 38.0 * np.sqrt(init_vars[0])                                       # only the wide one resolves
+    data = np.concatenate([data, half[None] + rng.normal(size=(3, D)) * 0.1])
+    init_w = np.array([0.3, 0.2, 0.25, 0.25])
+    out = dict(data=data, mu0=mu0, var0=var0, init_means=init_means, init_vars=init_vars, init_w=init_w)
+    for k in (2, 3):
+        g = R.GMM(mu0.copy(), var0.copy(), M)
+        g.update_models(init_means.copy(), init_vars.copy(), init_w.copy())
+        p = np.array([g.evaluate(x, return_neg_log_likelihood=False)[:k] for x in data])
+        out["k%d_p0" % k] = p                                                                  # first E-step, linear domain
+        for iters, tag in ((1, "it1"), (3, "it3")):
+            g = R.GMM(mu0.copy(), var0.copy(), M)
+            g.update_models(init_means.copy(), init_vars.copy(), init_w.copy())
+            with quiet():
+                g.em(data, k, max_iteration=iters)
+            m, v, w = pack_gmm(g)
+            out.update({"k%d_%s_means" % (k, tag): m, "k%d_%s_vars" % (k, tag): v, "k%d_%s_w" % (k, tag): w})
+    save("G16_gmm_em_underflow", **out)
+
+
 def g8(R):
     rng = np.random.default_rng(81)
     D = 8
@@ -401,7 +434,7 @@ def g11(R):
     save("G11_continuous_train", **out)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G16=g16)
 
 
 def g12(R):
