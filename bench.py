@@ -23,7 +23,7 @@ Viterbi paths bit-identical; --dtype f32 runs the fp32 likelihood kernel.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra
 objects: "roofline" for the dominant kernel (the likelihood kernel; HIP-event
-timed live on the library's stream), "cpu_baseline" (the numpy oracle,
+timed live on the library's stream, gh_event_*), "cpu_baseline" (the numpy oracle,
 reference-shaped scalar loops, 1 core, on a bounded sample), "em" (configs[2]: soft-EM
 iterations on every rank's shard with ONE all-reduce of the device-resident statistics
 per iteration -- em_utterances_per_s, allreduce_ms, rccl_ranks), "configs" (the other
@@ -97,36 +97,6 @@ def stacked_graph(W, n, trans):
                 start_rows=[i * n for i in range(W)], end_rows=[i * n + n - 1 for i in range(W)])
 
 
-class HipEvents:
-    """hipEvent timing on an explicit stream (torch.cuda.Event would only see torch's stream)."""
-
-    def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
-        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
-        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
-        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
-        self.hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
-        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
-
-    def new(self):
-        e = C.c_void_p()
-        assert self.hip.hipEventCreate(C.byref(e)) == 0
-        return e
-
-    def record(self, e, stream):
-        assert self.hip.hipEventRecord(e, C.c_void_p(stream)) == 0
-
-    def wait(self, stream, e):
-        """Work submitted to `stream` after this call starts only when `e` has completed."""
-        assert self.hip.hipStreamWaitEvent(C.c_void_p(stream), e, 0) == 0
-
-    def elapsed_ms(self, a, b):
-        assert self.hip.hipEventSynchronize(b) == 0
-        ms = C.c_float()
-        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
-        return float(ms.value)
-
-
 def profiled_traffic(dtype, n_frames):
     """HBM bytes per launch of the likelihood kernel from the committed PMC passes (the newest
     profiles/*_pmc_traffic_<dtype>.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this
@@ -181,6 +151,21 @@ def cpu_baseline(wl, n_utts=20):
     return out
 
 
+class native_stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; the contract of this
+    script is ONE JSON line on stdout, so native writes to fd 1 are sent to stderr while a process group starts."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 # ------------------------------------------------------------------------------------------ N-rank launch
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` started without a launcher: start N rank processes with the torchrun environment and
@@ -221,8 +206,10 @@ def em_leg(args, rank, world, dev, backend):
             import socket
             s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
             torch.cuda.set_device(dev)
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                                    device_id=torch.device("cuda", dev))
+            with native_stdout_to_stderr():
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                        device_id=torch.device("cuda", dev))
+                dist.barrier()
             own_group = True
         except Exception as e:  # reported, not fatal: the EM leg then runs without a process group
             info["rccl_error"] = repr(e)[:200]
@@ -480,11 +467,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(dev)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
+        with native_stdout_to_stderr():
+            if args.backend == "nccl":
+                torch.cuda.set_device(dev)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()      # communicators come up here (and RCCL's banner is printed), not inside the timed region
     try:
         import torch
         have_torch_cuda = torch.cuda.is_available()
@@ -496,7 +485,6 @@ def main():
     wl = synth_workload(1002, args.utts, utt_seed=None if rank == 0 else 1002 + 7919 * rank)
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
     S = W * n
-    ev = HipEvents()
 
     class Lane:
         """One in-flight batch: its own context (HIP stream, scratch, pinned buffers) and resident copies of the
@@ -511,23 +499,22 @@ def main():
             self.lat = _hip.Lattices(self.ctx, [stacked_graph(W, n, wl["trans"])])
             self.ll_ms = []
             self.decoded = None
-            self.untimed_done = ev.new()
+            self.untimed_done = self.ctx.new_event()
 
         def step(self, timed):
             """One pass of the hot path over the batch: likelihoods, Viterbi over every word model, arg-min.
             The likelihood kernels of different lanes are chained by events (each fills the whole GPU, so
             overlapping two of them gains nothing and would blur the per-launch timing)."""
-            stream = self.ctx.stream
             with chain_lock:
                 if chain["last"] is not None:
-                    ev.wait(stream, chain["last"])
+                    self.ctx.wait_event(chain["last"])
                 if timed:
-                    a, b = ev.new(), ev.new()
-                    ev.record(a, stream)
+                    a, b = self.ctx.new_event(), self.ctx.new_event()
+                    self.ctx.record(a)
                 else:
                     b = self.untimed_done
                 self.batch.loglik(self.gmm, fetch=False)
-                ev.record(b, stream)
+                self.ctx.record(b)
                 chain["last"] = b
                 if timed:
                     self.ll_ms.append((a, b))
@@ -590,7 +577,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     decoded = next(l.decoded for l in lanes if l.decoded is not None)
-    ll_ms = [p for l in lanes for p in l.ll_ms]
+    ll_times = [lanes[0].ctx.elapsed_ms(a, b) for l in lanes for a, b in l.ll_ms]   # HIP events, the library's own runtime
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -603,7 +590,7 @@ def main():
     accuracy = float(np.mean(decoded == wl["words"]))
 
     if rank == 0:
-        ll_avg_s = float(np.mean([ev.elapsed_ms(a, b) for a, b in ll_ms])) * 1e-3
+        ll_avg_s = float(np.mean(ll_times)) * 1e-3
         esz = 8 if args.dtype == "f64" else 4
         flops_per_frame = 2.0 * (2 * D) * S * M          # GEMM-form contraction
         bytes_per_frame = esz * D + esz * S              # features in once + likelihoods out once

@@ -56,8 +56,19 @@ int gh_version(void);
 int gh_ctx_create(int device, gh_ctx** out);
 void gh_ctx_destroy(gh_ctx* ctx);
 int gh_ctx_sync(gh_ctx* ctx);
-/* raw hipStream_t of the context (for hipEvent timing / torch interop) */
+/* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);
+/* number of GPUs the library's HIP runtime sees (<= 0: none).  Callers must not dlopen a HIP runtime of their own
+ * to find out: a second runtime in the process does not know this library's streams and allocations. */
+int gh_device_count(void);
+/* hipEvent timing on the context's stream, through the library's own runtime (measurement plumbing of bench.py; no
+ * reference counterpart): record an event behind the work submitted so far, make the stream wait for an event of
+ * another context, elapsed milliseconds between two completed events (waits for the second). */
+int gh_event_create(gh_ctx* ctx, void** out_event);
+void gh_event_destroy(void* event);
+int gh_event_record(gh_ctx* ctx, void* event);
+int gh_ctx_wait_event(gh_ctx* ctx, void* event);
+int gh_event_elapsed_ms(void* start, void* stop, float* out_ms);
 
 /* ----------------------------------------------------------- emission model
  * Packs S states x M components x D dims.  Replaces the per-state object graph
@@ -123,6 +134,8 @@ int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host /*[N,S] 
 int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo /*[U]*/,
                      const int32_t* state_hi /*[U]*/);
 void* gh_loglik_dev_ptr(gh_batch* b);
+/* copy of the resident [N,S] likelihood matrix (dtype of the batch) after gh_loglik / gh_loglik_subset */
+int gh_loglik_fetch(gh_ctx* ctx, const gh_batch* b, void* out_host /*[N,S]*/);
 /* weighted component densities in the log domain, log(w_m pdf_m(x)) for one
  * state over arbitrary frames (hmm_state.py:114-116 with
  * return_neg_log_likelihood=False, in logs): out[n, m], fp64. */

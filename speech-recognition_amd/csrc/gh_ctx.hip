@@ -76,6 +76,44 @@ extern "C" int gh_ctx_sync(gh_ctx* c) {
 
 extern "C" void* gh_ctx_stream(gh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+extern "C" int gh_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// ------------------------------------------------------------------- events
+extern "C" int gh_event_create(gh_ctx* c, void** out_event) {
+    GH_REQUIRE(c && out_event, "gh_event_create: NULL argument");
+    GH_HIP(hipSetDevice(c->device));
+    hipEvent_t e;
+    GH_HIP(hipEventCreate(&e));
+    *out_event = (void*)e;
+    return GH_OK;
+}
+
+extern "C" void gh_event_destroy(void* event) {
+    if (event) hipEventDestroy((hipEvent_t)event);
+}
+
+extern "C" int gh_event_record(gh_ctx* c, void* event) {
+    GH_REQUIRE(c && event, "gh_event_record: NULL argument");
+    GH_HIP(hipEventRecord((hipEvent_t)event, c->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_ctx_wait_event(gh_ctx* c, void* event) {
+    GH_REQUIRE(c && event, "gh_ctx_wait_event: NULL argument");
+    GH_HIP(hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return GH_OK;
+}
+
+extern "C" int gh_event_elapsed_ms(void* start, void* stop, float* out_ms) {
+    GH_REQUIRE(start && stop && out_ms, "gh_event_elapsed_ms: NULL argument");
+    GH_HIP(hipEventSynchronize((hipEvent_t)stop));
+    GH_HIP(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GH_OK;
+}
+
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->scratch_bytes) {
         GH_HIP(hipStreamSynchronize(ctx->stream));

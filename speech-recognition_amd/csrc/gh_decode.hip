@@ -111,6 +111,14 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         for (int64_t u = 0; use_chain && u < U; ++u)
             if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
     }
+    // layer-form kernel: one K-layer word lattice for the whole batch (GMMHMM_VITERBI=lean / generic force the others)
+    bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs;
+    {
+        static const bool no_layers = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        if (no_layers) use_layers = false;
+        for (int64_t u = 0; use_layers && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
+    }
     const bool want_bp = want_path || (use_chain && out_costs);
     if (want_bp) {
         size_t acc = 0;
@@ -118,7 +126,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             const int64_t u = perm[k];
             const int l = utt_lattice ? utt_lattice[u] : 0;
             // (blocks padded to 8 entries = 16 bytes: the lean kernel flushes back-pointers with 16-byte stores)
-            const size_t need = ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
+            const size_t need = use_layers ? gh_layers_bp_entries(lat->h_layers, b->offsets[u + 1] - b->offsets[u])
+                                           : ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
             if (acc && (acc + need) * 2 > BP_BUDGET) {
                 chunk_begin.push_back(k);
                 bp_max = std::max(bp_max, acc);
@@ -198,6 +207,19 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             if (rc) return rc;
         }
     }
+    if (use_layers) {
+        gh_layers_args c;
+        memset(&c, 0, sizeof c);
+        c.lf = lat->d_layers; c.end_slot = lat->d_lf_end_slot; c.n_end = lat->lat[0].n_end; c.S = S;
+        c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm; c.bp = d_bp; c.bp_off = d_bpoff;
+        c.end_cost = d_endcost; c.best_end = d_bestend; c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen;
+        c.flag = d_flag2;
+        for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
+            rc = gh_launch_viterbi_layers(ctx, c, lat->h_layers, chunk_begin[k], chunk_begin[k + 1] - chunk_begin[k],
+                                          b->dtype == GH_F64, want_path);
+            if (rc) return rc;
+        }
+    }
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
@@ -229,13 +251,13 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         if (want_path) v = std::max(v, (size_t)2048 + 16 + 32 + (size_t)8 * lat->max_R * 2);
         return (v + 15) & ~size_t(15);
     };
-    if (lean_levels && !use_chain) {
+    if (lean_levels && !use_chain && !use_layers) {
         a.em_chunk = std::max(1, std::min(8, 8 * block / std::max(S, 1)));
         if (const char* e = getenv("GMMHMM_EMCHUNK")) a.em_chunk = std::max(1, std::min(a.em_chunk, atoi(e)));  // tuning knob
         while (a.em_chunk > 1 && lean_lds(a.em_chunk) > 96 * 1024) a.em_chunk >>= 1;   // keep >= 1 workgroup pair per CU
         if (lean_lds(a.em_chunk) > 160 * 1024) lean_levels = 0;                         // does not fit: generic kernel
     }
-    if (lean_levels && !use_chain) {
+    if (lean_levels && !use_chain && !use_layers) {
         a.arc_cap = (max_arcs + 1) & ~1;
         lds = (size_t)2 * a.r_pad * 8 + (size_t)2 * a.em_chunk * (S + 1) * 8 + (size_t)a.arc_cap * 12 + 16;
         if (want_path) {
@@ -244,7 +266,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         }
         lds = lean_lds(a.em_chunk);
         a.lds_bytes = (int)lds;
-    } else if (!use_chain) {
+    } else if (!use_chain && !use_layers) {
         lean_levels = 0;
         int max_level_rows2 = 1;
         for (auto& d : lat->h_desc) max_level_rows2 = std::max(max_level_rows2, d.pad);
@@ -252,11 +274,11 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         a.em_chunk = 1;
         lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
     }
-    if (!use_chain && lds > 160 * 1024) {
+    if (!use_chain && !use_layers && lds > 160 * 1024) {
         gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);
         return GH_ERR_UNSUPPORTED;
     }
-    for (size_t c = 0; !use_chain && c + 1 < chunk_begin.size(); ++c) {
+    for (size_t c = 0; !use_chain && !use_layers && c + 1 < chunk_begin.size(); ++c) {
         a.u_begin = chunk_begin[c];
         const int64_t nu = chunk_begin[c + 1] - chunk_begin[c];
         rc = lean_levels ? gh_launch_viterbi_lean(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path, lean_levels)

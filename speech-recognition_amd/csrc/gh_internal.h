@@ -124,6 +124,25 @@ struct gh_fbchain {
     double self_c[GH_FBCHAIN_MAX], next_c[GH_FBCHAIN_MAX], skip_c[GH_FBCHAIN_MAX];   // +inf = no such arc
 };
 
+// Layer form of a word lattice (build_state_sequences, continuous_speech.py:13-53, with the SAME W words in each of
+// its K layers -- the decode lattice of main.py:35): row 0 = non-emitting start; layer k = rows
+// k*(P+1)+1 .. k*(P+1)+P (P = W*N: word w, state s at offset w*N + s), followed by one non-emitting row (k+1)*(P+1);
+// inside a word only arcs from s, s-1, s-2 (previous column); non-emitting row k -> state 0 of every word of layer k
+// and last state of every word of layer k -> non-emitting row k+1 (same column, decode.py:109-111); identical costs
+// and states in every layer.  gh_viterbi runs such graphs with one WAVE per utterance: lane = (layer mod 4, word),
+// the N states of a word in registers (gh_viterbi_layers.hip).
+#define GH_LAYERS_MAXW 16
+#define GH_LAYERS_MAXN 8
+#define GH_LAYERS_MAXK 8
+struct gh_layerform {
+    int32_t K, W, N, skip;      // layers, words per layer, states per word, any s-2 arc
+    int32_t P, R, pad0, pad1;
+    int32_t state[GH_LAYERS_MAXW][GH_LAYERS_MAXN];
+    uint8_t arcs[GH_LAYERS_MAXW][GH_LAYERS_MAXN];   // bit0 self, bit1 from s-1, bit2 from s-2, bit3 from the non-emitting row
+    double c0[GH_LAYERS_MAXW][GH_LAYERS_MAXN], c1[GH_LAYERS_MAXW][GH_LAYERS_MAXN], c2[GH_LAYERS_MAXW][GH_LAYERS_MAXN];
+    double cin[GH_LAYERS_MAXW], cout[GH_LAYERS_MAXW];   // +inf = no such arc
+};
+
 struct gh_lattices {
     gh_ctx* ctx;
     int L;
@@ -160,6 +179,10 @@ struct gh_lattices {
     bool fbchain_ok;                 // every graph is a gh_fbchain
     std::vector<gh_fbchain> h_fbchain;
     gh_fbchain* d_fbchain;
+    bool layers_ok;                  // L == 1 and the graph is a gh_layerform
+    gh_layerform h_layers;
+    gh_layerform* d_layers;
+    int32_t* d_lf_end_slot;          // [R] position of a row in the end list or -1
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };

@@ -32,6 +32,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     lt->d_ch_end_slot = nullptr; lt->d_ch_group_row0 = nullptr;
     lt->d_desc = nullptr;
     lt->d_fbchain = nullptr; lt->fbchain_ok = true;
+    lt->layers_ok = false; lt->d_layers = nullptr; lt->d_lf_end_slot = nullptr;
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
         const int64_t r0 = row_off[l], a0 = arc_off[l];
@@ -233,7 +234,114 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         }
         if (ok) { lt->chain_ok = true; lt->chain_skip = skip; lt->chain_groups = (int)chgroups.size() - 1; }
     }
+    // ---- layer form (gh_layerform): K identical layers of W left-to-right words, non-emitting rows between them ----
+    std::vector<int32_t> lf_slot;
+    if (L == 1 && !lt->has_nan_arc && !lt->has_self_arc) {
+        const int R = lt->lat[0].R, A = lt->lat[0].A;
+        gh_layerform& f = lt->h_layers;
+        memset(&f, 0, sizeof f);
+        bool ok = R >= 4 && h_state[0] < 0;
+        int P = 0;
+        if (ok) {   // P = rows up to the next non-emitting row
+            int r = 1;
+            while (r < R && h_state[r] >= 0) ++r;
+            P = r - 1;
+            ok = P >= 2 && r < R && (R - 1) % (P + 1) == 0;
+        }
+        const int K = ok ? (R - 1) / (P + 1) : 0;
+        ok = ok && K >= 1 && K <= GH_LAYERS_MAXK;
+        for (int r = 0; ok && r < R; ++r) {
+            const bool nes = r % (P + 1) == 0;
+            if (nes != (h_state[r] < 0)) ok = false;
+            if (!nes && h_state[r] != h_state[1 + (r - 1) % (P + 1)]) ok = false;   // same states in every layer
+        }
+        ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);
+        // words: a new word starts where the non-emitting row has an arc into the row
+        std::vector<int> word_of(P + 1, -1), pos_of(P + 1, -1);
+        std::vector<double> tc0(P, INFINITY), tc1(P, INFINITY), tc2(P, INFINITY), tin(P, INFINITY), tout(P, INFINITY);
+        std::vector<char> seen(5 * (size_t)std::max(P, 1) * std::max(K, 1), 0);   // every (layer, slot, position) arc at most once
+        const int32_t* ptr = h_ptr.data();
+        for (int r = 0; ok && r < R; ++r)
+            for (int p = ptr[r]; ok && p < ptr[r + 1]; ++p) {
+                const int o = (int)(h_prow[p] & GH_ARC_ROW);
+                const double c = h_pcost[p];
+                const bool r_nes = r % (P + 1) == 0, o_nes = o % (P + 1) == 0;
+                int slot, k, pos;
+                if (!r_nes && !o_nes) {              // emitting -> emitting: same layer, from s, s-1 or s-2
+                    k = (r - 1) / (P + 1); pos = (r - 1) % (P + 1);
+                    if ((o - 1) / (P + 1) != k || r - o < 0 || r - o > 2) { ok = false; break; }
+                    slot = r - o;
+                } else if (o_nes && !r_nes) {        // non-emitting row k -> a row of layer k
+                    k = (r - 1) / (P + 1); pos = (r - 1) % (P + 1);
+                    if (o != k * (P + 1)) { ok = false; break; }
+                    slot = 3;
+                } else if (r_nes && !o_nes) {        // a row of layer k -> non-emitting row k + 1
+                    k = (o - 1) / (P + 1); pos = (o - 1) % (P + 1);
+                    if (r != (k + 1) * (P + 1)) { ok = false; break; }
+                    slot = 4;
+                } else { ok = false; break; }
+                double& t = slot == 0 ? tc0[pos] : slot == 1 ? tc1[pos] : slot == 2 ? tc2[pos] : slot == 3 ? tin[pos] : tout[pos];
+                char& sn = seen[((size_t)k * 5 + slot) * P + pos];
+                if (sn) { ok = false; break; }
+                sn = 1;
+                if (k == 0) t = c;
+                else if (!(t == c)) { ok = false; break; }   // layers must be identical (bit-equal costs)
+            }
+        // every layer must have every arc of layer 0
+        for (int k = 1; ok && k < K; ++k)
+            for (int slot = 0; ok && slot < 5; ++slot)
+                for (int pos = 0; ok && pos < P; ++pos)
+                    if (seen[((size_t)k * 5 + slot) * P + pos] != seen[(size_t)slot * P + pos]) ok = false;
+        int W = 0, N = 0;
+        if (ok) {   // cut the layer into words at the rows fed by the non-emitting row
+            for (int pos = 0; pos < P; ++pos) {
+                if (!std::isinf(tin[pos])) { ++W; if (W == 2) N = pos; }
+                if (W == 0) { ok = false; break; }
+            }
+            if (ok && W == 1) N = P;
+            ok = ok && N >= 2 && N <= GH_LAYERS_MAXN && W <= GH_LAYERS_MAXW && W * N == P;
+        }
+        bool skip = false;
+        for (int pos = 0; ok && pos < P; ++pos) {
+            const int w = pos / N, sx = pos % N;
+            if ((sx == 0) != !std::isinf(tin[pos])) ok = false;                                   // entries exactly at state 0
+            if (sx == 0 && (!std::isinf(tc1[pos]) || !std::isinf(tc2[pos]))) ok = false;          // no arc across words
+            if (sx == 1 && !std::isinf(tc2[pos])) ok = false;
+            if (!std::isinf(tout[pos]) && sx == 0) ok = false;                                    // an exit is never an entry
+            if (!std::isinf(tout[pos]) && sx != N - 1) ok = false;                                // exits at the last state only
+            if (!std::isinf(tc2[pos])) skip = true;
+            f.state[w][sx] = h_state[1 + pos];
+            f.c0[w][sx] = tc0[pos]; f.c1[w][sx] = tc1[pos]; f.c2[w][sx] = tc2[pos];
+            f.arcs[w][sx] = (uint8_t)((!std::isinf(tc0[pos]) ? 1 : 0) | (!std::isinf(tc1[pos]) ? 2 : 0) |
+                                      (!std::isinf(tc2[pos]) ? 4 : 0) | (!std::isinf(tin[pos]) ? 8 : 0));
+            if (sx == 0) f.cin[w] = tin[pos];
+            if (sx == N - 1) f.cout[w] = tout[pos];
+        }
+        if (ok) {
+            lf_slot.assign(R, -1);
+            for (int k = 0; ok && k < (int)h_end.size(); ++k) {
+                const int r = h_end[k];
+                if (r % (P + 1) == 0 || lf_slot[r] >= 0) ok = false;    // a non-emitting or duplicated end row: other kernels
+                else lf_slot[r] = k;
+            }
+        }
+        if (ok) {
+            f.K = K; f.W = W; f.N = N; f.skip = skip ? 1 : 0; f.P = P; f.R = R;
+            for (int w = W; w < GH_LAYERS_MAXW; ++w) {
+                f.cin[w] = f.cout[w] = INFINITY;
+                for (int sx = 0; sx < GH_LAYERS_MAXN; ++sx) f.c0[w][sx] = f.c1[w][sx] = f.c2[w][sx] = INFINITY;
+            }
+            lt->layers_ok = true;
+        }
+    }
     int rc = GH_OK;
+    if (lt->layers_ok) {
+        std::vector<gh_layerform> one(1, lt->h_layers);
+        if ((rc = upload(&lt->d_layers, one)) || (rc = upload(&lt->d_lf_end_slot, lf_slot))) {
+            gh_lattices_destroy(lt);
+            return rc;
+        }
+    }
     if (lt->chain_ok &&
         ((rc = upload(&lt->d_ch_cost0, ch0)) || (rc = upload(&lt->d_ch_cost1, ch1)) || (rc = upload(&lt->d_ch_cost2, ch2)) ||
          (rc = upload(&lt->d_ch_info, chinfo)) || (rc = upload(&lt->d_ch_end_slot, chslot)) ||
@@ -267,6 +375,7 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
     hipFree(l->d_desc);
     hipFree(l->d_fbchain);
+    hipFree(l->d_layers); hipFree(l->d_lf_end_slot);
     delete l;
 }
 

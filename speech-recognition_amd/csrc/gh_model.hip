@@ -242,3 +242,14 @@ extern "C" int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const
 
 extern "C" void* gh_loglik_dev_ptr(gh_batch* b) { return b ? b->nll : nullptr; }
 
+extern "C" int gh_loglik_fetch(gh_ctx* ctx, const gh_batch* b, void* out_host) {
+    GH_REQUIRE(ctx && b && out_host, "gh_loglik_fetch: NULL argument");
+    GH_REQUIRE(b->nll || b->N == 0, "gh_loglik_fetch: gh_loglik has not been run on this batch");
+    GH_HIP(hipSetDevice(ctx->device));
+    if (b->N == 0) return GH_OK;
+    GH_HIP(hipMemcpyAsync(out_host, b->nll, (size_t)b->N * b->nll_S * (b->dtype == GH_F64 ? 8 : 4), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+}
+

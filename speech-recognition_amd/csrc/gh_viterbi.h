@@ -73,3 +73,26 @@ struct gh_chain_args {
 int gh_launch_viterbi_chain(gh_ctx* ctx, const gh_chain_args& a, int64_t u_begin, int64_t n_utts, bool f64,
                             bool want_bp, bool want_costs, bool skip);
 int gh_launch_chain_backtrace(gh_ctx* ctx, const gh_chain_args& a, int64_t u_begin, int64_t n_utts);
+
+// Layer-form kernel (gh_viterbi_layers.hip): K identical layers of W words x N states (gh_layerform), one graph for
+// the whole batch, one wave per utterance.  All pointers are device pointers.
+struct gh_layers_args {
+    const gh_layerform* lf;
+    const int32_t* end_slot;   // [R] position of a row in the end list or -1
+    int n_end, S;
+    const void* nll;
+    const int64_t* utt_off;
+    const int64_t* perm;
+    int64_t slot0;
+    uint16_t* bp;              // decision words; bp_off in uint16 units (multiples of 8)
+    const int64_t* bp_off;
+    double* end_cost;          // [U, n_end]
+    int32_t* best_end;         // [U]
+    int32_t* path;
+    const int64_t* path_off;
+    int32_t* path_len;
+    int* flag;
+};
+size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T);
+int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
+                             bool f64, bool want_path);

@@ -30,6 +30,12 @@ SIGNATURES = {
     "gh_ctx_destroy": (None, [C.c_void_p]),
     "gh_ctx_sync": (C.c_int, [C.c_void_p]),
     "gh_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "gh_device_count": (C.c_int, []),
+    "gh_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gh_event_destroy": (None, [C.c_void_p]),
+    "gh_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gh_ctx_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gh_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "gh_gmm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_gmm_destroy": (None, [C.c_void_p]),
@@ -50,6 +56,7 @@ SIGNATURES = {
     "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gh_loglik_subset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p]),
     "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
+    "gh_loglik_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gh_component_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _c_f64p, _c_f64p]),
     "gh_distance_matrix": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p,
                                      C.c_int, _c_f64p]),
@@ -105,6 +112,14 @@ def load_library(path=None):
         return lib
 
 
+def device_count():
+    """GPUs visible to the library's HIP runtime (0 when the library or a GPU is missing)."""
+    try:
+        return max(0, int(load_library().gh_device_count()))
+    except BackendError:
+        return 0
+
+
 def _check(lib, rc):
     if rc != 0:
         msg = lib.gh_last_error().decode("utf-8", "replace")
@@ -137,6 +152,24 @@ class Context:
     @property
     def stream(self):
         return self.lib.gh_ctx_stream(self.h)
+
+    # hipEvent timing on this context's stream, through the library's own HIP runtime
+    def new_event(self):
+        e = C.c_void_p()
+        _check(self.lib, self.lib.gh_event_create(self.h, C.byref(e)))
+        return e
+
+    def record(self, event):
+        _check(self.lib, self.lib.gh_event_record(self.h, event))
+
+    def wait_event(self, event):
+        """Work submitted to this context after the call starts only when `event` (of any context) has completed."""
+        _check(self.lib, self.lib.gh_ctx_wait_event(self.h, event))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        _check(self.lib, self.lib.gh_event_elapsed_ms(start, stop, C.byref(ms)))
+        return float(ms.value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -326,11 +359,7 @@ class Batch:
             if not fetch:
                 return None
             out = np.empty((self.N, gmm.S), dtype=self.np_dtype)
-            esz = out.itemsize
-            hipmem = C.CDLL("libamdhip64.so")
-            self.ctx.sync()
-            assert hipmem.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ctx.lib.gh_loglik_dev_ptr(self.h)),
-                                    C.c_size_t(out.size * esz), 2) == 0
+            _check(self.ctx.lib, self.ctx.lib.gh_loglik_fetch(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
             return out
         out = np.empty((self.N, gmm.S), dtype=self.np_dtype) if fetch else None
         _check(self.ctx.lib, self.ctx.lib.gh_loglik(self.ctx.h, gmm.h, self.h,

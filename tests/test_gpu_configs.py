@@ -27,7 +27,7 @@ def c4():
     import bench
     from sr.recognition import _hip
     ctx = _hip.default_context()
-    wl = bench.synth_workload(1004, 1000, W=64, n=16, M=32, D=39)      # ~100 k frames
+    wl = bench.synth_workload(1004, 1040, W=64, n=16, M=32, D=39)      # > 100 k frames
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
     S = W * n
     fm, fv, fw = wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M)

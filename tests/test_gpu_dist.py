@@ -39,13 +39,8 @@ def _problem():
 
 
 def _n_gpus():
-    import ctypes
-    n = ctypes.c_int(0)
-    try:
-        ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n))
-    except OSError:
-        return 0
-    return n.value
+    from sr.recognition import _hip
+    return _hip.device_count()
 
 
 def _worker(rank, world, port, out_dir, backend):
@@ -100,7 +95,7 @@ def test_sharded_em_equals_single_process(tmp_path):
     tr.close()
 
 
-def _one_rank_rccl(port, out_dir):
+def _one_rank_rccl(rank, port, out_dir):
     """A ONE-rank RCCL group: the device-buffer path of the trainer on whatever single GPU is there."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

@@ -1,0 +1,211 @@
+# -*- coding: utf-8 -*-
+"""The layer-form lattice kernel (gh_viterbi_layers.hip: one wave per utterance, lane = (layer, word), states in
+registers, decision bits as back-pointers) against the reference's goldens, the oracle and the row-per-lane lean
+kernel, which implements the same decode_hmm_states semantics (decode.py:80-146) by an entirely different route.
+
+`Lattices.viterbi(batch)` with ONE graph for the whole batch takes the layer-form kernel when the graph is a K-layer
+word lattice; passing `utt_lattice` (all zeros) makes the call non-uniform and routes it to the lean kernel."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sr.recognition import _hip
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    return hip.default_context()
+
+
+def word_trans(rng, n, skip=False, last_self=0.0):
+    t = np.full((n, n), np.inf)
+    for i in range(n):
+        t[i, i] = rng.uniform(0.05, 0.6) if i < n - 1 else last_self
+        if i < n - 1:
+            t[i + 1, i] = rng.uniform(0.8, 2.5)
+        if skip and i < n - 2 and rng.random() < 0.6:
+            t[i + 2, i] = rng.uniform(1.5, 4.0)
+    return t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_layers_kernel_reference_goldens(hip, ctx, dtype):
+    """G4 (captured from the reference's decode_hmm_states): end costs, chosen end and BIT-EXACT paths for the
+    K = 1, 2, 3, 7 lattices, each decoded as a one-graph batch (layer-form kernel)."""
+    g = load_golden("G4_lattice_decode")
+    means, vars_, w = g["means"], g["vars"], g["w"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    for K in (1, 2, 3, 7):
+        p = "K%d_" % K
+        rw, rs = g[p + "row_word"], g[p + "row_state"]
+        graph = dict(row_state=np.where(rw < 0, -1, rw * n + rs), arc_to=g[p + "arc_to"], arc_from=g[p + "arc_from"],
+                     arc_cost=g[p + "arc_cost"], start_rows=[0], end_rows=g[p + "ends"])
+        lat = hip.Lattices(ctx, [graph])
+        b = hip.Batch(ctx, [g[p + "x"]], dtype=dtype)
+        b.loglik(gmm, fetch=False)
+        r = lat.viterbi(b, want_path=True)
+        ref = g[p + "costs"]
+        ends = np.asarray(g[p + "ends"])
+        np.testing.assert_allclose(r["end_cost"][0], ref[ends, -1], rtol=1e-10 if dtype == np.float64 else 1e-5)
+        np.testing.assert_array_equal(r["paths"][0], g[p + "path"])
+        assert O.path_to_words(r["paths"][0], rw < 0, rw) == list(g[p + "digits"])
+        row_word = np.where(rw < 0, -1, rw).astype(np.int32)
+        rl = lat.viterbi_labels(b, row_word, max_labels=K + 1)
+        assert [int(v) for v in rl["labels"][0]] == list(g[p + "digits"])
+        b.close()
+        lat.close()
+
+
+@pytest.mark.parametrize("W,n,K,skip", [(10, 5, 7, False), (11, 5, 7, False), (1, 2, 1, False), (3, 2, 8, False),
+                                        (16, 3, 4, True), (5, 8, 5, True), (7, 4, 3, False), (10, 5, 2, True),
+                                        (4, 6, 6, False), (2, 7, 8, True)])
+def test_layers_kernel_equals_lean_kernel(hip, ctx, W, n, K, skip):
+    """Random word models (per-word transition costs, optional skip arcs), utterances from far too short to long:
+    end costs BITWISE equal, same chosen end, same paths -- including the unreachable cases, where every candidate is
+    +inf and the winner is decided by the candidate order alone."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(1000 * W + 10 * n + K)
+    M, D = 2, 6
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    wt = [word_trans(rng, n, skip, last_self=rng.uniform(0.0, 0.3)) for _ in range(W)]
+    xs = []
+    for u in range(60):
+        if u < 12:
+            T = int(rng.integers(2, K * (n - 1) + 2))              # too short for K words: unreachable ends
+            xs.append(rng.normal(size=(T, D)) * 2.0)
+            continue
+        words = rng.integers(0, W, size=K)
+        segs = []
+        for wd in words:
+            Tw = int(rng.integers(n, 3 * n + 4))
+            st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+            comp = rng.integers(0, M, size=Tw)
+            segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    graph = packed_lattice(wt, n, [list(range(W))] * K)[0]
+    lat = hip.Lattices(ctx, [graph])
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    U = b.U
+    lean = lat.viterbi(b, utt_lattice=np.zeros(U, dtype=np.int32), want_path=True)
+    fast = lat.viterbi(b, want_path=True)
+    np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+    np.testing.assert_array_equal(fast["best_end"], lean["best_end"])
+    assert np.isfinite(lean["end_cost_flat"]).any()
+    if K * (n - 1) >= 4:
+        assert np.isinf(lean["end_cost_flat"]).any()          # the short utterances cannot hold K words
+    for u in range(U):
+        np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+    nopath = lat.viterbi(b, want_path=False)                          # the variant without decision bits
+    np.testing.assert_array_equal(nopath["end_cost_flat"], lean["end_cost_flat"])
+    np.testing.assert_array_equal(nopath["best_end"], lean["best_end"])
+    row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+    la = lat.viterbi_labels(b, row_word)
+    lb = lat.viterbi_labels(b, row_word, utt_lattice=np.zeros(U, dtype=np.int32))
+    for u in range(U):
+        np.testing.assert_array_equal(la["labels"][u], lb["labels"][u])
+    # and against the oracle's reference-shaped DP on a few utterances (costs 1e-12, paths exact)
+    nll = b.loglik(gmm, fetch=True)
+    R = len(graph["row_state"])
+    dense = np.full((R, R), np.inf)
+    dense[graph["arc_to"], graph["arc_from"]] = graph["arc_cost"]
+    is_nes = graph["row_state"] < 0
+    for u in (0, 13, 40, U - 1):
+        E = np.zeros((R, len(xs[u])))
+        E[~is_nes] = nll[b.offsets[u]:b.offsets[u + 1]][:, graph["row_state"][~is_nes]].T
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            costs, path = O.decode_states(E, is_nes, dense, end_points=[[int(e), -1] for e in graph["end_rows"]])
+        ec = costs[np.asarray(graph["end_rows"]), -1]
+        fin = np.isfinite(ec)
+        np.testing.assert_array_equal(np.isfinite(fast["end_cost"][u]), fin)
+        np.testing.assert_allclose(fast["end_cost"][u][fin], ec[fin], rtol=1e-12)
+        if fin.any():
+            np.testing.assert_array_equal(fast["paths"][u], path)
+    b.close()
+    lat.close()
+    gmm.close()
+
+
+def test_layers_kernel_fp32_likelihoods_and_long_utterances(hip, ctx):
+    """fp32 resident likelihoods (the DP itself stays fp64), utterances of several hundred frames (many decision
+    words, several register chunks in the back-trace), ragged lengths in one launch."""
+    from sr.recognition.continuous_speech import packed_lattice
+    from sr.recognition.batch import path_to_words
+    rng = np.random.default_rng(5)
+    W, n, K, M, D = 10, 5, 7, 4, 13
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    trans = word_trans(rng, n)
+    xs, truth = [], []
+    for u in range(96):
+        words = rng.integers(0, W, size=K)
+        segs = []
+        for wd in words:
+            Tw = int(rng.integers(6, 140 if u % 5 == 0 else 40))
+            st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+            comp = rng.integers(0, M, size=Tw)
+            segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+        truth.append([int(v) for v in words])
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    graph = packed_lattice([trans] * W, n, [list(range(W))] * K)[0]
+    lat = hip.Lattices(ctx, [graph])
+    for dtype in (np.float32, np.float64):
+        b = hip.Batch(ctx, xs, dtype=dtype)
+        b.loglik(gmm, fetch=False)
+        lean = lat.viterbi(b, utt_lattice=np.zeros(b.U, dtype=np.int32), want_path=True)
+        fast = lat.viterbi(b, want_path=True)
+        np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+        np.testing.assert_array_equal(fast["best_end"], lean["best_end"])
+        ok = 0
+        for u in range(b.U):
+            np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+            ok += path_to_words(fast["paths"][u], graph["row_state"], n) == truth[u]
+        assert ok >= 0.9 * b.U
+        assert max(len(x) for x in xs) > 400
+        b.close()
+    lat.close()
+    gmm.close()
+
+
+def test_layers_kernel_is_not_taken_for_other_graphs(hip, ctx):
+    """Graphs that are not in layer form (different words per layer, a non-emitting end row, the loop grammar) keep
+    working through the other kernels -- and a layer-form batch with a one-frame utterance falls back as a whole
+    (the reference's column wrap at T == 1)."""
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    rng = np.random.default_rng(9)
+    W, n, M, D = 4, 3, 1, 4
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = np.ones((W, n, M, D))
+    w = np.ones((W, n, M))
+    wt = [word_trans(rng, n) for _ in range(W)]
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    xs = [rng.normal(size=(int(T), D)) for T in (9, 1, 14, 30)]
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    for graph in (packed_lattice(wt, n, [[0, 1], [2, 3, 1]])[0], packed_loop_lattice(wt, n)[0],
+                  packed_lattice(wt, n, [list(range(W))] * 3)[0]):
+        lat = hip.Lattices(ctx, [graph])
+        a = lat.viterbi(b, want_path=True)
+        c = lat.viterbi(b, utt_lattice=np.zeros(b.U, dtype=np.int32), want_path=True)
+        np.testing.assert_array_equal(a["end_cost_flat"], c["end_cost_flat"])
+        for u in range(b.U):
+            np.testing.assert_array_equal(a["paths"][u], c["paths"][u])
+        lat.close()
+    b.close()
+    gmm.close()
