@@ -356,8 +356,9 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
         R = len(graph["row_state"])
         row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
         ml = max_labels if max_labels is not None else b.lengths // (n - 1) + 2
-        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml), reps=2, ramp=0.0)
-        acc = float(np.mean([[int(v) for v in r["labels"][u]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
+        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False), reps=2, ramp=0.0)
+        lf, lo, ln = r["labels_flat"], r["label_off"], r["n_labels"]
+        acc = float(np.mean([[int(v) for v in lf[lo[u]:lo[u] + ln[u]]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
         bytes_dp = float((esz * S + 4) * N)     # un-fused Viterbi over materialised likelihoods
         out[key] = {"workload": "configs[4] per-GPU share: %d utterances (%d distinct, tiled x%d on the device), K=%d words, "
                                 "%d lattice rows" % (U, U_base, reps, K, R),

@@ -59,8 +59,29 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
     const bool want_labels = out_labels != nullptr;
+    const bool uniform = utt_lattice == nullptr;
+    // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
+    // the reference's wrap-around semantics, which only the lean / generic kernels implement)
+    bool use_chain = lat->chain_ok && uniform;
+    {
+        static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        if (no_chain) use_chain = false;
+        for (int64_t u = 0; use_chain && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
+    }
+    // layer-form kernels: one K-layer word lattice / word-loop grammar for the whole batch (GMMHMM_VITERBI=lean /
+    // generic force the others)
+    bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs;
+    {
+        static const bool no_layers = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        if (no_layers) use_layers = false;
+        for (int64_t u = 0; use_layers && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
+    }
+    // layer-form kernels in label mode: the back-trace writes the label sequences itself, no path is materialised
+    const bool labels_direct = use_layers && want_labels && !out_path;
     std::vector<int64_t> own_path_off;  // label mode: the path lives on the device only, capacities are ours
-    if (want_labels && !out_path) {
+    if (want_labels && !out_path && !labels_direct) {
         own_path_off.assign(U + 1, 0);
         for (int64_t u = 0; u < U; ++u) {
             const int l = utt_lattice ? utt_lattice[u] : 0;
@@ -75,7 +96,6 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
                    lat->lat[l].max_state, S);
     // per-utterance bookkeeping (host); with one graph for all utterances everything is implicit
-    const bool uniform = utt_lattice == nullptr;
     const std::vector<int64_t>& perm = b->perm;
     std::vector<int64_t> end_off;
     int64_t n_end_total = 0;
@@ -90,7 +110,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         }
         n_end_total = end_off[U];
     }
-    if (want_path)
+    if (want_path && !labels_direct)
         for (int64_t u = 0; u < U; ++u) {
             const int l = uniform ? 0 : utt_lattice[u];
             const int64_t T = b->offsets[u + 1] - b->offsets[u];
@@ -102,23 +122,6 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     std::vector<int64_t> bp_off(U, 0);
     std::vector<int64_t> chunk_begin{0};
     size_t bp_max = 0;
-    // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
-    // the reference's wrap-around semantics, which only the lean / generic kernels implement)
-    bool use_chain = lat->chain_ok && uniform;
-    {
-        static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
-        if (no_chain) use_chain = false;
-        for (int64_t u = 0; use_chain && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
-    }
-    // layer-form kernel: one K-layer word lattice for the whole batch (GMMHMM_VITERBI=lean / generic force the others)
-    bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs;
-    {
-        static const bool no_layers = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
-        if (no_layers) use_layers = false;
-        for (int64_t u = 0; use_layers && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
-    }
     const bool want_bp = want_path || (use_chain && out_costs);
     if (want_bp) {
         size_t acc = 0;
@@ -139,7 +142,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         bp_max = std::max(bp_max, acc);
     }
     chunk_begin.push_back(U);
-    const int64_t n_path = want_path ? path_off[U] : 0;
+    const int64_t n_path = (want_path && !labels_direct) ? path_off[U] : 0;
     const int64_t n_costs = out_costs ? costs_off[U] : 0;
 
     gh_vit_args a;
@@ -155,7 +158,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (want_bp) cv.add(&d_bpoff, U);
     if (!uniform) cv.add(&d_endoff, U + 1);
     if (utt_lattice) cv.add(&d_uttlat, U);
-    if (want_path) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
+    if (want_path && !labels_direct) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
     if (want_bp) cv.add(&d_bp, bp_max);
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
@@ -173,7 +176,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (want_bp) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
     if (!uniform) GH_HIP(hipMemcpyAsync(d_endoff, end_off.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (utt_lattice) GH_HIP(hipMemcpyAsync(d_uttlat, utt_lattice, U * 4, hipMemcpyHostToDevice, st));
-    if (want_path) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
+    if (want_path && !labels_direct) GH_HIP(hipMemcpyAsync(d_pathoff, path_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (out_costs) GH_HIP(hipMemcpyAsync(d_costsoff, costs_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     if (want_labels) {
         GH_HIP(hipMemcpyAsync(d_rowlabel, row_label, n_rows_total * 4, hipMemcpyHostToDevice, st));
@@ -210,13 +213,15 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (use_layers) {
         gh_layers_args c;
         memset(&c, 0, sizeof c);
-        c.lf = lat->d_layers; c.end_slot = lat->d_lf_end_slot; c.n_end = lat->lat[0].n_end; c.S = S;
+        c.lf = lat->d_layers; c.end_slot = lat->d_lf_end_slot; c.end_rows = lat->d_end_rows; c.n_end = lat->lat[0].n_end; c.S = S;
         c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm; c.bp = d_bp; c.bp_off = d_bpoff;
         c.end_cost = d_endcost; c.best_end = d_bestend; c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen;
         c.flag = d_flag2;
+        if (labels_direct) { c.row_label = d_rowlabel; c.labels = d_labels; c.label_off = d_labeloff; c.n_labels = d_nlabels; }
         for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
             rc = gh_launch_viterbi_layers(ctx, c, lat->h_layers, chunk_begin[k], chunk_begin[k + 1] - chunk_begin[k],
                                           b->dtype == GH_F64, want_path);
+            if (!rc && want_path) rc = gh_launch_lattice_backtrace(ctx, c, lat->h_layers, chunk_begin[k], chunk_begin[k + 1] - chunk_begin[k]);
             if (rc) return rc;
         }
     }
@@ -289,9 +294,11 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     rc = gh_pinned(ctx, small_bytes, (void**)&pin);
     if (rc) return rc;
     if (want_labels) {
-        hipLaunchKernelGGL(path_labels_kernel, dim3((unsigned)U), dim3(64), 0, st, d_path, d_pathoff, d_pathlen, d_uttlat,
-                           lat->d_desc, d_rowlabel, d_labeloff, d_labels, d_nlabels, d_flag2);
-        GH_HIP(hipGetLastError());
+        if (!labels_direct) {
+            hipLaunchKernelGGL(path_labels_kernel, dim3((unsigned)U), dim3(64), 0, st, d_path, d_pathoff, d_pathlen, d_uttlat,
+                               lat->d_desc, d_rowlabel, d_labeloff, d_labels, d_nlabels, d_flag2);
+            GH_HIP(hipGetLastError());
+        }
         GH_HIP(hipMemcpyAsync(out_n_labels, d_nlabels, U * 4, hipMemcpyDeviceToHost, st));
         if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
     }

@@ -134,13 +134,19 @@ struct gh_fbchain {
 #define GH_LAYERS_MAXW 16
 #define GH_LAYERS_MAXN 8
 #define GH_LAYERS_MAXK 8
+// LOOP form (K = 1, loop = 1): the word-loop grammar of continuous_speech.build_loop_grammar -- row 0 = non-emitting
+// start; rows 1 .. W*(N-1) = states 1..N-1 of every word; row loop_row = 1 + W*(N-1) = the non-emitting loop row;
+// rows loop_row+1+w = state 0 of word w.  Last states feed the loop row, the start row (cost cin0) and the loop row
+// (cost cin) feed the first states, all in the same column.  gh_viterbi runs it with FOUR utterances per wave: DPP
+// row = utterance, lane = word (gh_viterbi_layers.hip, viterbi_loop_kernel).
 struct gh_layerform {
     int32_t K, W, N, skip;      // layers, words per layer, states per word, any s-2 arc
-    int32_t P, R, pad0, pad1;
+    int32_t P, R, loop, loop_row;
     int32_t state[GH_LAYERS_MAXW][GH_LAYERS_MAXN];
     uint8_t arcs[GH_LAYERS_MAXW][GH_LAYERS_MAXN];   // bit0 self, bit1 from s-1, bit2 from s-2, bit3 from the non-emitting row
     double c0[GH_LAYERS_MAXW][GH_LAYERS_MAXN], c1[GH_LAYERS_MAXW][GH_LAYERS_MAXN], c2[GH_LAYERS_MAXW][GH_LAYERS_MAXN];
     double cin[GH_LAYERS_MAXW], cout[GH_LAYERS_MAXW];   // +inf = no such arc
+    double cin0[GH_LAYERS_MAXW];                        // loop form: arc from the start row into state 0 (arcs bit4)
 };
 
 struct gh_lattices {
@@ -179,7 +185,7 @@ struct gh_lattices {
     bool fbchain_ok;                 // every graph is a gh_fbchain
     std::vector<gh_fbchain> h_fbchain;
     gh_fbchain* d_fbchain;
-    bool layers_ok;                  // L == 1 and the graph is a gh_layerform
+    bool layers_ok;                  // L == 1 and the graph is a gh_layerform (layers or loop: h_layers.loop)
     gh_layerform h_layers;
     gh_layerform* d_layers;
     int32_t* d_lf_end_slot;          // [R] position of a row in the end list or -1

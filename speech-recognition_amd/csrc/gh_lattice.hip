@@ -326,11 +326,74 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             }
         }
         if (ok) {
-            f.K = K; f.W = W; f.N = N; f.skip = skip ? 1 : 0; f.P = P; f.R = R;
+            f.K = K; f.W = W; f.N = N; f.skip = skip ? 1 : 0; f.P = P; f.R = R; f.loop = 0; f.loop_row = 0;
+            for (int w = 0; w < GH_LAYERS_MAXW; ++w) f.cin0[w] = INFINITY;
             for (int w = W; w < GH_LAYERS_MAXW; ++w) {
                 f.cin[w] = f.cout[w] = INFINITY;
                 for (int sx = 0; sx < GH_LAYERS_MAXN; ++sx) f.c0[w][sx] = f.c1[w][sx] = f.c2[w][sx] = INFINITY;
             }
+            lt->layers_ok = true;
+        }
+    }
+    // ---- loop form (gh_layerform with loop = 1): the word-loop grammar ----
+    if (!lt->layers_ok && L == 1 && !lt->has_nan_arc && !lt->has_self_arc) {
+        const int R = lt->lat[0].R;
+        gh_layerform& f = lt->h_layers;
+        memset(&f, 0, sizeof f);
+        int Lr = -1, n_nes = 0;
+        for (int r = 0; r < R; ++r) if (h_state[r] < 0) { ++n_nes; if (r > 0) Lr = r; }
+        bool ok = R >= 4 && h_state[0] < 0 && n_nes == 2 && Lr > 1 && Lr < R - 1;
+        const int W = ok ? R - 1 - Lr : 0;
+        ok = ok && W >= 1 && W <= GH_LAYERS_MAXW && (Lr - 1) % W == 0;
+        const int N = ok ? (Lr - 1) / W + 1 : 0;
+        ok = ok && N >= 2 && N <= GH_LAYERS_MAXN;
+        ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);
+        auto row_of = [&](int w, int sx) { return sx == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (sx - 1); };
+        std::vector<int> wof(R, -1), sof(R, -1);
+        for (int w = 0; ok && w < W; ++w)
+            for (int sx = 0; sx < N; ++sx) { wof[row_of(w, sx)] = w; sof[row_of(w, sx)] = sx; }
+        for (int w = 0; w < GH_LAYERS_MAXW; ++w) {
+            f.cin[w] = f.cout[w] = f.cin0[w] = INFINITY;
+            for (int sx = 0; sx < GH_LAYERS_MAXN; ++sx) f.c0[w][sx] = f.c1[w][sx] = f.c2[w][sx] = INFINITY;
+        }
+        bool skip = false;
+        const int32_t* ptr = h_ptr.data();
+        for (int r = 0; ok && r < R; ++r)
+            for (int p = ptr[r]; ok && p < ptr[r + 1]; ++p) {
+                const int o = (int)(h_prow[p] & GH_ARC_ROW);
+                const double c = h_pcost[p];
+                if (r == 0) { ok = false; break; }                                   // nothing enters the start row
+                if (r == Lr) {                                                       // last state of a word -> loop row
+                    if (wof[o] < 0 || sof[o] != N - 1 || !std::isinf(f.cout[wof[o]])) { ok = false; break; }
+                    f.cout[wof[o]] = c;
+                } else if (o == 0 || o == Lr) {                                      // start / loop row -> state 0
+                    if (sof[r] != 0) { ok = false; break; }
+                    double& t = o == 0 ? f.cin0[wof[r]] : f.cin[wof[r]];
+                    if (!std::isinf(t)) { ok = false; break; }
+                    t = c;
+                    f.arcs[wof[r]][0] |= o == 0 ? 16 : 8;
+                } else {                                                             // inside a word: from s, s-1, s-2
+                    const int w = wof[r], d = sof[r] - sof[o];
+                    if (w < 0 || wof[o] != w || d < 0 || d > 2) { ok = false; break; }
+                    double& t = d == 0 ? f.c0[w][sof[r]] : d == 1 ? f.c1[w][sof[r]] : f.c2[w][sof[r]];
+                    if (!std::isinf(t)) { ok = false; break; }
+                    t = c;
+                    f.arcs[w][sof[r]] |= (uint8_t)(1 << d);
+                    if (d == 2) skip = true;
+                }
+            }
+        if (ok) {
+            lf_slot.assign(R, -1);
+            for (int k = 0; ok && k < (int)h_end.size(); ++k) {
+                const int r = h_end[k];
+                if (h_state[r] < 0 || lf_slot[r] >= 0) ok = false;
+                else lf_slot[r] = k;
+            }
+        }
+        if (ok) {
+            for (int w = 0; w < W; ++w)
+                for (int sx = 0; sx < N; ++sx) f.state[w][sx] = h_state[row_of(w, sx)];
+            f.K = 1; f.W = W; f.N = N; f.skip = skip ? 1 : 0; f.P = W * N; f.R = R; f.loop = 1; f.loop_row = Lr;
             lt->layers_ok = true;
         }
     }

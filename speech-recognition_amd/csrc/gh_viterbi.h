@@ -79,6 +79,7 @@ int gh_launch_chain_backtrace(gh_ctx* ctx, const gh_chain_args& a, int64_t u_beg
 struct gh_layers_args {
     const gh_layerform* lf;
     const int32_t* end_slot;   // [R] position of a row in the end list or -1
+    const int32_t* end_rows;   // [n_end]
     int n_end, S;
     const void* nll;
     const int64_t* utt_off;
@@ -91,8 +92,13 @@ struct gh_layers_args {
     int32_t* path;
     const int64_t* path_off;
     int32_t* path_len;
+    const int32_t* row_label;  // label mode (gh_viterbi_labels): label per row, < 0 on non-emitting rows
+    int32_t* labels;           // utterance u at label_off[u]
+    const int64_t* label_off;  // [U+1]
+    int32_t* n_labels;         // [U]
     int* flag;
 };
 size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T);
 int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                              bool f64, bool want_path);
+int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);

@@ -23,8 +23,8 @@
 //     N = 5 against 716 B of uint16 back-pointers per column in the row-per-lane kernel;
 //   * each lane streams the N emissions of its word from the resident [N, S] matrix (saddr + per-lane byte offset,
 //     PF columns in flight);
-//   * end selection and back-trace run in the same wave: the walk is wave-uniform (scalar registers), the decision
-//     words of 16 words x CPW columns sit in registers (v_readlane), the next 16 are in flight.
+//   * end selection runs in the same wave; the back-trace is a second kernel with one LANE per utterance
+//     (lattice_backtrace_kernel below).
 // ~110 VALU instructions per column for all 8 layer slots (the row-per-lane kernel: three LDS phases with
 // barriers, ~5 900 cycles per column).
 #include "gh_internal.h"
@@ -211,147 +211,373 @@ __global__ __launch_bounds__(64) void viterbi_layers_kernel(gh_layers_args a) {
         if (ov < best_v || (ov == best_v && os > best_slot)) { best_v = ov; best_slot = os; best_row = orow; }
     }
     if (lane == 0 && a.best_end) a.best_end[u] = best_slot;
-    if (!WANT_BP) return;
-    if (!a.path) return;
-    if (T <= 1 || best_slot < 0) {
-        if (lane == 0) a.path_len[u] = 0;
-        return;
-    }
+}
 
-    // ---- back-trace (decode.py:143-145): wave-uniform walk, decision words in registers ----
-    int32_t* path = a.path + 2 * a.path_off[u];
-    const int64_t cap = a.path_off[u + 1] - a.path_off[u];
-    int j = T - 1;
-    bool on_nes = false;
-    int kn = 0;                                               // non-emitting row index (0 .. K) while on_nes
-    int bk, bw, bs;                                           // emitting cell: layer, word, state
-    {
-        const int r = __builtin_amdgcn_readfirstlane(best_row);
-        bk = (r - 1) / (P + 1);
-        const int pos = (r - 1) % (P + 1);
-        bw = pos / N;
-        bs = pos % N;
+
+// =====================================================================================================================
+// LOOP form (gh_layerform.loop): the word-loop grammar.  One "layer" whose non-emitting row feeds its own first states
+// (same column), so a DPP row is a complete decode: FOUR UTTERANCES PER WAVE (row = utterance, lane = word, the N
+// states of the word in registers).  Per column and row: the states from the previous column, the loop row = row
+// minimum over the last states (row_ror), the first states from (start row, loop row, self) in that candidate
+// order.  Rows whose utterance has ended are switched off by EXEC (DPP row operations never cross rows).  Decision
+// bits: N + 2 (+ N - 2 with skip arcs) per column and lane, 16 lanes x 4 B per CPW columns and utterance.
+// The back-trace is a second kernel (lattice_backtrace_kernel, one lane per utterance).
+template <int N, bool SKIP> struct LoopBits {
+    static constexpr int HB = N + 2 + (SKIP ? N - 2 : 0);
+    static constexpr int CPW = 32 / HB;
+};
+
+template <typename ET, int N, bool SKIP, bool WANT_BP>
+__global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int64_t slot_end) {
+    constexpr int HB = LoopBits<N, SKIP>::HB, CPW = LoopBits<N, SKIP>::CPW;
+    constexpr int PF = 4;
+    static_assert(CPW >= 1, "decision bits of a column must fit one word");
+    const int lane = threadIdx.x, kk = lane >> 4, w = lane & 15;
+    const gh_layerform* __restrict__ lf = a.lf;
+    const int W = lf->W, Lr = lf->loop_row;
+    const int64_t slot = a.slot0 + (int64_t)blockIdx.x * 4 + kk;
+    const bool has_utt = slot < slot_end;
+    const int64_t u = has_utt ? (a.perm ? a.perm[slot] : slot) : 0;
+    const int64_t f0 = has_utt ? a.utt_off[u] : 0;
+    const int T = has_utt ? (int)(a.utt_off[u + 1] - f0) : 0;
+    const double INF = INFINITY;
+    int Tmax = T;
+    Tmax = max(Tmax, __shfl_xor(Tmax, 16));
+    Tmax = max(Tmax, __shfl_xor(Tmax, 32));
+    const bool wact = w < W;
+    const int wc = wact ? w : 0;
+    double c0[N], c1[N], c2[N];
+    unsigned sto[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        c0[s] = wact ? lf->c0[wc][s] : INF;
+        c1[s] = wact ? lf->c1[wc][s] : INF;
+        c2[s] = (SKIP && wact) ? lf->c2[wc][s] : INF;
+        sto[s] = (unsigned)lf->state[wc][s] * (unsigned)sizeof(ET);
     }
-    int pr = 0, pc = 0, nbuf = 0;                             // path cells parked in lanes 0 .. nbuf-1
-    int64_t len = 0;
-    bool stop = false;
-    auto emit = [&](int row, int col) {
-        pr = (lane == nbuf) ? row : pr;
-        pc = (lane == nbuf) ? col : pc;
-        ++nbuf;
-        if (len + nbuf > cap) { if (lane == 0) atomicOr(a.flag, 4); stop = true; --nbuf; return; }
-        if (nbuf == 64) {
-            reinterpret_cast<int2*>(path)[len + lane] = make_int2(pr, pc);
-            len += 64;
-            nbuf = 0;
-        }
-    };
-    constexpr int WCH = 8;                                    // decision words per register chunk
-    const uint32_t* bpr = reinterpret_cast<const uint32_t*>(a.bp + a.bp_off[slot]) + lane;
-    const int wi_hi = (T - 1) / CPW;
-    uint32_t wr[WCH], nx[WCH];
-    int cb = wi_hi & ~(WCH - 1);
+    const double cin = wact ? lf->cin[wc] : INF, cin0 = wact ? lf->cin0[wc] : INF, cout = wact ? lf->cout[wc] : INF;
+    const char* nllb = static_cast<const char*>(a.nll) + f0 * a.S * (int64_t)sizeof(ET);   // per row
+    const int64_t rowb = (int64_t)a.S * (int64_t)sizeof(ET);
+    ET ring[PF][N];
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) wr[i] = (cb + i <= wi_hi) ? bpr[(int64_t)(cb + i) * 64] : 0u;
-    for (; cb >= 0 && !stop && j != 0; cb -= WCH) {
+    for (int k = 0; k < PF; ++k)
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) nx[i] = (cb - WCH + i >= 0) ? bpr[(int64_t)(cb - WCH + i) * 64] : 0u;
+        for (int s = 0; s < N; ++s)
+            ring[k][s] = (k < T) ? *reinterpret_cast<const ET*>(nllb + k * rowb + sto[s]) : ET(0);
+    double prev[N];
 #pragma unroll
-        for (int i = WCH - 1; i >= 0; --i) {
-            const int wi = cb + i;
-            while (!stop && j != 0 && j / CPW == wi) {
-                const int shift = (CPW - 1 - j % CPW) * BITS;
-                if (!on_nes) {
-                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)wr[i], (bk & 3) * 16 + bw);
-                    const uint32_t hb = (x >> (shift + (H - 1 - (bk >> 2)) * HB)) & ((1u << HB) - 1u);
-                    const int arcs = lf->arcs[bw][bs];
-                    if (bs >= 1) {
-                        // pushes before state bs: states N-1 .. bs+1 (two bits each when they have a skip arc slot)
-                        int before = 0;
-                        for (int s2 = N - 1; s2 > bs; --s2) before += (SKIP && s2 >= 2) ? 2 : 1;
-                        int code;
-                        if (SKIP && bs >= 2) {
-                            const int b_a = (hb >> (HB - 1 - before)) & 1, b_b = (hb >> (HB - 2 - before)) & 1;
-                            code = b_b ? 0 : (b_a ? 1 : 2);
-                        } else {
-                            code = ((hb >> (HB - 1 - before)) & 1) ? 0 : 1;
-                        }
-                        if (!((arcs >> code) & 1)) {          // every candidate was +inf: the first existing arc (lowest origin)
-                            code = (arcs & 4) ? 2 : (arcs & 2) ? 1 : (arcs & 1) ? 0 : -1;
-                        }
-                        if (code < 0) { if (lane == 0) atomicOr(a.flag, 2); stop = true; break; }
-                        bs -= code;
-                        --j;
-                        emit(bk * (P + 1) + 1 + bw * N + bs, j);
+    for (int s = 0; s < N; ++s) prev[s] = INF;
+    uint32_t word = 0;
+    uint32_t* bp = (WANT_BP && has_utt) ? reinterpret_cast<uint32_t*>(a.bp + a.bp_off[slot]) + w : nullptr;
+
+    for (int t0 = 0; t0 < Tmax; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            if (t >= Tmax) break;
+            if (t < T) {                                       // row-uniform: the rows of finished utterances sit out
+                double e[N];
+#pragma unroll
+                for (int s = 0; s < N; ++s) e[s] = (double)ring[k][s];
+                if (t + PF < T) {
+                    const char* colp = nllb + (int64_t)(t + PF) * rowb;
+#pragma unroll
+                    for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
+                }
+                const double base0 = c0[0] + prev[0];
+#pragma unroll
+                for (int s = N - 1; s >= 1; --s) {
+                    const double v0 = c0[s] + prev[s];
+                    const double v1 = c1[s] + prev[s - 1];
+                    double best;
+                    if (SKIP && s >= 2) {
+                        const double v2 = c2[s] + prev[s - 2];
+                        const bool b_a = v1 < v2;
+                        const double m = vmin(v1, v2);
+                        const bool b_b = v0 < m;
+                        best = vmin(v0, m);
+                        if (WANT_BP) { push_bit(word, __ballot(b_a)); push_bit(word, __ballot(b_b)); }
                     } else {
-                        const int self_better = hb & 1;
-                        const bool take_self = (self_better && (arcs & 1)) || !(arcs & 8);
-                        if (take_self && !(arcs & 1)) { if (lane == 0) atomicOr(a.flag, 2); stop = true; break; }
-                        if (take_self) {
-                            --j;
-                            emit(bk * (P + 1) + 1 + bw * N, j);
-                        } else {                              // the non-emitting row in front of the layer, same column
-                            on_nes = true;
-                            kn = bk;
-                            emit(kn * (P + 1), j);
-                        }
+                        const bool b = v0 < v1;
+                        best = vmin(v0, v1);
+                        if (WANT_BP) push_bit(word, __ballot(b));
                     }
-                } else {
-                    if (kn == 0) { if (lane == 0) atomicOr(a.flag, 2); stop = true; break; }   // the start row has no origin
-                    const int kp = kn - 1;
-                    const uint32_t eq = (wr[i] >> (shift + (H - 1 - (kp >> 2)) * HB + 1)) & 1u;
-                    const unsigned long long m = __ballot(eq != 0);
-                    const unsigned sl = (unsigned)(m >> (16 * (kp & 3))) & ((1u << W) - 1u);
-                    if (sl == 0) { if (lane == 0) atomicOr(a.flag, 2); stop = true; break; }
-                    bw = __builtin_ctz(sl);                   // lowest word index = lowest origin row: np.argmin's first minimum
-                    bk = kp;
-                    bs = N - 1;
-                    on_nes = false;
-                    emit(bk * (P + 1) + 1 + bw * N + bs, j);
+                    prev[s] = vmin(best + e[s], INF);
+                }
+                // the loop row: minimum over the words' last states of THIS column
+                const double cand = prev[N - 1] + cout;
+                const double rm = row_min16(cand);
+                if (WANT_BP) push_bit(word, __ballot(cand == rm));
+                // state 0: start row (row 0), loop row, self -- ascending origin, strict '<'
+                const double cs = ((t == 0) ? 0.0 : INF) + cin0;
+                const double cl = rm + cin;
+                const bool b_l = cl < cs;
+                const double m2 = vmin(cl, cs);
+                const bool b_s = base0 < m2;
+                if (WANT_BP) { push_bit(word, __ballot(b_l)); push_bit(word, __ballot(b_s)); }
+                prev[0] = vmin(vmin(base0, m2) + e[0], INF);
+                if (WANT_BP) {
+                    const int ci = t % CPW;
+                    if (ci == CPW - 1 || t == T - 1) {
+                        if (CPW > 1 && ci < CPW - 1) word <<= HB * (CPW - 1 - ci);
+                        bp[(int64_t)(t / CPW) * 16] = word;
+                        word = 0;
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) wr[i] = nx[i];
     }
-    if (nbuf > 0 && lane < nbuf) reinterpret_cast<int2*>(path)[len + lane] = make_int2(pr, pc);
-    if (lane == 0) a.path_len[u] = (int32_t)(len + nbuf);
+    if (!has_utt) return;
+    // ---- end costs + end selection inside the row ('>=': the last of equal minima) ----
+    double best_v = INF;
+    int best_slot = -1;
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        if (wact) {
+            const int r = s == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (s - 1);
+            const int es = a.end_slot[r];
+            if (es >= 0) {
+                const double v = T > 0 ? prev[s] : INF;
+                if (a.end_cost) a.end_cost[u * a.n_end + es] = v;
+                if (v < best_v || (v == best_v && es > best_slot)) { best_v = v; best_slot = es; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(best_v, o);
+        const int os = __shfl_xor(best_slot, o);
+        if (ov < best_v || (ov == best_v && os > best_slot)) { best_v = ov; best_slot = os; }
+    }
+    if (w == 0 && a.best_end) a.best_end[u] = T > 0 ? best_slot : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Back-trace of both forms (decode.py:143-145): ONE LANE PER UTTERANCE.  A first version walked one utterance per
+// wave with wave-uniform (scalar) code and v_readlane on register-resident decision words; correct, but a CU has ONE
+// scalar unit for its four SIMDs, and ~100 scalar instructions per cell x 330 cells x 125 000 utterances is 6 ms of
+// pure SALU issue (measured: 5.5 ms, more than the forward sweep).  Per-lane walks put the same work on the vector
+// units, 64 utterances per wave.  A lane keeps the decision word of its current (word index, word) in a register and
+// the one below it prefetched, so a memory round trip is only exposed when the path changes words.
+// MODE 0: the (row, column) path as decode_hmm_states returns it; MODE 1: only the label sequence of main.py:59-67
+// (gh_viterbi_labels) -- cells are visited end -> start, a run of labelled rows reports the label of its first row
+// in start -> end order, i.e. of the last one visited before an unlabelled row; labels are collected from the back of
+// the utterance's slot and moved to its front at the end.
+template <int N, bool SKIP, bool LOOP, int MODE>
+__global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a, int64_t slot_end) {
+    constexpr int HB = LOOP ? LoopBits<N, SKIP>::HB : N + 1 + (SKIP ? N - 2 : 0);
+    constexpr int BITS = LOOP ? HB : 2 * HB;
+    constexpr int CPW = 32 / BITS;
+    constexpr int LPW = LOOP ? 16 : 64;                       // dwords per word index
+    __shared__ uint8_t s_arcs[GH_LAYERS_MAXW * GH_LAYERS_MAXN];
+    const gh_layerform* __restrict__ lf = a.lf;
+    for (int i = threadIdx.x; i < GH_LAYERS_MAXW * GH_LAYERS_MAXN; i += 64) s_arcs[i] = (&lf->arcs[0][0])[i];
+    __syncthreads();
+    const int W = lf->W, P = lf->P, Lr = lf->loop_row;
+    const int64_t slot = a.slot0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= slot_end) return;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const int T = (int)(a.utt_off[u + 1] - a.utt_off[u]);
+    const int be = a.best_end[u];
+    int32_t* out_n = MODE == 0 ? a.path_len : a.n_labels;
+    if (T <= 1 || be < 0) { out_n[u] = 0; return; }
+    auto row_of = [&](int k, int ww, int ss) {
+        return LOOP ? (ss == 0 ? Lr + 1 + ww : 1 + ww * (N - 1) + (ss - 1)) : k * (P + 1) + 1 + ww * N + ss;
+    };
+    int bk = 0, bw, bs;
+    {
+        const int r = a.end_rows[be];
+        if (LOOP) {
+            if (r > Lr) { bw = r - Lr - 1; bs = 0; } else { bw = (r - 1) / (N - 1); bs = (r - 1) % (N - 1) + 1; }
+        } else {
+            bk = (r - 1) / (P + 1);
+            const int pos = (r - 1) % (P + 1);
+            bw = pos / N;
+            bs = pos % N;
+        }
+    }
+    const uint32_t* bpu = reinterpret_cast<const uint32_t*>(a.bp + a.bp_off[slot]);
+    int32_t* path = MODE == 0 ? a.path + 2 * a.path_off[u] : nullptr;
+    int32_t* labs = MODE == 1 ? a.labels + a.label_off[u] : nullptr;
+    const int64_t cap = MODE == 0 ? a.path_off[u + 1] - a.path_off[u] : a.label_off[u + 1] - a.label_off[u];
+    int64_t len = 0;
+    int prev_label = -1;                                      // MODE 1: label of the cell visited last
+    int j = T - 1, kind = 0, kn = 0;                          // kind 0 emitting (bk, bw, bs); 1 non-emitting row kn; 2 start row
+    int flag = 0;
+    int64_t key = -1;                                         // dword index of the decision word held in `cw`
+    uint32_t cw = 0, pw = 0;                                  // current word, and the one LPW dwords below it
+    auto visit = [&](int row, int col) {
+        if (MODE == 0) {
+            if (len >= cap) { flag |= 4; return; }
+            reinterpret_cast<int2*>(path)[len] = make_int2(row, col);
+            ++len;
+        } else {
+            const int l = a.row_label[row];
+            if (prev_label >= 0 && l < 0) {
+                if (len >= cap) { flag |= 8; return; }
+                labs[cap - 1 - len] = prev_label;
+                ++len;
+            }
+            prev_label = l;
+        }
+    };
+    while (j != 0 && !flag) {
+        const int wi = j / CPW;
+        const int shift = (CPW - 1 - j % CPW) * BITS;
+        if (kind == 0) {
+            const int64_t want = (int64_t)wi * LPW + (LOOP ? bw : (bk & 3) * 16 + bw);
+            if (want != key) {
+                if (want == key - LPW) cw = pw; else cw = bpu[want];
+                key = want;
+                pw = (wi > 0) ? bpu[want - LPW] : 0u;
+            }
+            const uint32_t hb = (cw >> (shift + (LOOP ? 0 : (1 - (bk >> 2)) * HB))) & ((1u << HB) - 1u);
+            const int arcs = s_arcs[bw * GH_LAYERS_MAXN + bs];
+            if (bs >= 1) {
+                int before = 0;
+                for (int s2 = N - 1; s2 > bs; --s2) before += (SKIP && s2 >= 2) ? 2 : 1;
+                int code;
+                if (SKIP && bs >= 2) {
+                    const int b_a = (hb >> (HB - 1 - before)) & 1, b_b = (hb >> (HB - 2 - before)) & 1;
+                    code = b_b ? 0 : (b_a ? 1 : 2);
+                } else {
+                    code = ((hb >> (HB - 1 - before)) & 1) ? 0 : 1;
+                }
+                // every candidate was +inf: the first existing arc (lowest origin) -- or none at all
+                if (!((arcs >> code) & 1)) code = (arcs & 4) ? 2 : (arcs & 2) ? 1 : (arcs & 1) ? 0 : -1;
+                if (code < 0) { flag |= 2; break; }
+                bs -= code;
+                --j;
+                visit(row_of(bk, bw, bs), j);
+            } else if (LOOP) {
+                // candidates in ascending origin order: start row (arcs bit4), loop row (bit3), self (bit0)
+                const int b_l = (hb >> 1) & 1, b_s = hb & 1;
+                int pick = b_s ? 0 : (b_l ? 3 : 4);
+                if (!((arcs >> pick) & 1)) pick = (arcs & 16) ? 4 : (arcs & 8) ? 3 : (arcs & 1) ? 0 : -1;
+                if (pick < 0) { flag |= 2; break; }
+                if (pick == 0) { --j; visit(row_of(0, bw, 0), j); }
+                else if (pick == 3) { kind = 1; visit(Lr, j); }
+                else { kind = 2; visit(0, j); }
+            } else {
+                const bool self_better = hb & 1;
+                const bool take_self = (self_better && (arcs & 1)) || !(arcs & 8);
+                if (take_self && !(arcs & 1)) { flag |= 2; break; }
+                if (take_self) { --j; visit(row_of(bk, bw, 0), j); }
+                else { kind = 1; kn = bk; visit(kn * (P + 1), j); }          // the non-emitting row in front of the layer
+            }
+        } else if (kind == 1) {
+            if (!LOOP && kn == 0) { flag |= 2; break; }                       // the start row has no origin
+            const int kp = LOOP ? 0 : kn - 1;
+            const int eq_shift = shift + (LOOP ? 2 : (1 - (kp >> 2)) * HB + 1);
+            const uint4* rowp = reinterpret_cast<const uint4*>(bpu + (int64_t)wi * LPW + (LOOP ? 0 : (kp & 3) * 16));
+            int found = -1;
+#pragma unroll
+            for (int q4 = 3; q4 >= 0; --q4) {                                   // 16 word lanes = 64 contiguous bytes
+                const uint4 v = rowp[q4];
+                if ((v.w >> eq_shift) & 1u) found = 4 * q4 + 3;
+                if ((v.z >> eq_shift) & 1u) found = 4 * q4 + 2;
+                if ((v.y >> eq_shift) & 1u) found = 4 * q4 + 1;
+                if ((v.x >> eq_shift) & 1u) found = 4 * q4;
+            }
+            if (found < 0 || found >= W) { flag |= 2; break; }                 // lowest word = lowest origin row (np.argmin)
+            bw = found;
+            bk = kp;
+            bs = N - 1;
+            kind = 0;
+            visit(row_of(bk, bw, bs), j);
+        } else {
+            flag |= 2;                                                          // the start row, reached in a column > 0
+            break;
+        }
+    }
+    if (flag) atomicOr(a.flag, flag);
+    if (MODE == 1) {
+        if (!flag && prev_label >= 0) {
+            if (len >= cap) atomicOr(a.flag, 8);
+            else { labs[cap - 1 - len] = prev_label; ++len; }
+        }
+        for (int64_t i = 0; i < len; ++i) labs[i] = labs[cap - len + i];       // to the front, start -> end order
+    }
+    out_n[u] = (int32_t)len;
 }
 
 }  // namespace
 
 // back-pointer scratch of one utterance of T frames, in uint16 units (the lattice kernels' common unit)
 size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
+    if (f.loop) {
+        const int hb = f.N + 2 + (f.skip ? f.N - 2 : 0);
+        const int cpw = 32 / hb;
+        return (size_t)((T + cpw - 1) / cpw) * 16 * 2;
+    }
     const int hb = f.N + 1 + (f.skip ? f.N - 2 : 0);
     const int cpw = 32 / (2 * hb);
     return (size_t)((T + cpw - 1) / cpw) * 64 * 2;
 }
+
+#define GH_LY_CASES(ET, MACRO)                   \
+    switch (f.N) {                               \
+        case 2: MACRO(ET, 2, false); break;      \
+        case 3: if (f.skip) MACRO(ET, 3, true); else MACRO(ET, 3, false); break; \
+        case 4: if (f.skip) MACRO(ET, 4, true); else MACRO(ET, 4, false); break; \
+        case 5: if (f.skip) MACRO(ET, 5, true); else MACRO(ET, 5, false); break; \
+        case 6: if (f.skip) MACRO(ET, 6, true); else MACRO(ET, 6, false); break; \
+        case 7: if (f.skip) MACRO(ET, 7, true); else MACRO(ET, 7, false); break; \
+        case 8: if (f.skip) MACRO(ET, 8, true); else MACRO(ET, 8, false); break; \
+        default: gh_set_error("gh_viterbi: layer form with %d states per word", f.N); return GH_ERR_UNSUPPORTED; \
+    }
 
 int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                              bool f64, bool want_path) {
     if (n_utts <= 0) return GH_OK;
     gh_layers_args b = a;
     b.slot0 = u_begin;
-    const dim3 grid((unsigned)n_utts), blk(64);
-#define GH_LY(ET, NN, SK, BP) hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, BP>), grid, blk, 0, ctx->stream, b)
-#define GH_LY_B(ET, NN, SK) do { if (want_path) GH_LY(ET, NN, SK, true); else GH_LY(ET, NN, SK, false); } while (0)
-#define GH_LY_S(ET, NN) do { if (f.skip) GH_LY_B(ET, NN, true); else GH_LY_B(ET, NN, false); } while (0)
-#define GH_LY_N(ET)                              \
-    switch (f.N) {                               \
-        case 2: GH_LY_B(ET, 2, false); break;    \
-        case 3: GH_LY_S(ET, 3); break;           \
-        case 4: GH_LY_S(ET, 4); break;           \
-        case 5: GH_LY_S(ET, 5); break;           \
-        case 6: GH_LY_S(ET, 6); break;           \
-        case 7: GH_LY_S(ET, 7); break;           \
-        case 8: GH_LY_S(ET, 8); break;           \
-        default: gh_set_error("gh_viterbi: layer form with %d states per word", f.N); return GH_ERR_UNSUPPORTED; \
+    const dim3 blk(64);
+    if (f.loop) {
+        const dim3 grid((unsigned)((n_utts + 3) / 4));
+        const int64_t slot_end = u_begin + n_utts;
+#define GH_LP(ET, NN, SK)                                                                                                  \
+    do {                                                                                                                   \
+        if (want_path) hipLaunchKernelGGL((viterbi_loop_kernel<ET, NN, SK, true>), grid, blk, 0, ctx->stream, b, slot_end);  \
+        else hipLaunchKernelGGL((viterbi_loop_kernel<ET, NN, SK, false>), grid, blk, 0, ctx->stream, b, slot_end);           \
+    } while (0)
+        if (f64) { GH_LY_CASES(double, GH_LP) } else { GH_LY_CASES(float, GH_LP) }
+#undef GH_LP
+        GH_HIP(hipGetLastError());
+        return GH_OK;
     }
-    if (f64) { GH_LY_N(double) } else { GH_LY_N(float) }
-#undef GH_LY_N
-#undef GH_LY_S
-#undef GH_LY_B
+    const dim3 grid((unsigned)n_utts);
+#define GH_LY(ET, NN, SK)                                                                                      \
+    do {                                                                                                       \
+        if (want_path) hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, true>), grid, blk, 0, ctx->stream, b); \
+        else hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, false>), grid, blk, 0, ctx->stream, b);          \
+    } while (0)
+    if (f64) { GH_LY_CASES(double, GH_LY) } else { GH_LY_CASES(float, GH_LY) }
 #undef GH_LY
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
+
+// the path (a.path) or the label sequences (a.labels) of the utterances [u_begin, u_begin + n_utts) from the decision words
+int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts) {
+    if (n_utts <= 0 || !(a.path || a.labels)) return GH_OK;
+    gh_layers_args b = a;
+    b.slot0 = u_begin;
+    const dim3 grid((unsigned)((n_utts + 63) / 64)), blk(64);
+    const int64_t slot_end = u_begin + n_utts;
+    const bool labels = a.labels != nullptr;
+#define GH_BT(ET, NN, SK)                                                                                               \
+    do {                                                                                                                \
+        if (f.loop) {                                                                                                   \
+            if (labels) hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, true, 1>), grid, blk, 0, ctx->stream, b, slot_end);  \
+            else hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, true, 0>), grid, blk, 0, ctx->stream, b, slot_end);         \
+        } else {                                                                                                        \
+            if (labels) hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 1>), grid, blk, 0, ctx->stream, b, slot_end); \
+            else hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 0>), grid, blk, 0, ctx->stream, b, slot_end);        \
+        }                                                                                                               \
+    } while (0)
+    GH_LY_CASES(double, GH_BT)
+#undef GH_BT
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

@@ -511,12 +511,14 @@ class Lattices:
                             for u in range(U)]
         return out
 
-    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None):
+    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True):
         """A6 + A12 in one call: decode, keep the path on the device, return the decoded label sequences
         (main.py:59-67: first row of every emitting run between non-emitting rows).  row_label: one int32 array per
         graph (label per row, < 0 on non-emitting rows) or a single array when there is one graph.
         max_labels (scalar or [U]): upper bound on the labels per utterance; exceeding it raises BackendError.
-        Returns dict(labels [list of int32 arrays], best_end [U], end_cost_flat, end_off)."""
+        Returns dict(labels [list of int32 arrays], best_end [U], end_cost_flat, end_off, labels_flat, label_off,
+        n_labels); as_lists=False leaves out the per-utterance list (at 10^5 utterances building it costs more host
+        time than the decode takes on the GPU): utterance u is labels_flat[label_off[u] : label_off[u] + n_labels[u]]."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
         lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
@@ -539,8 +541,11 @@ class Lattices:
         _check(lib, lib.gh_viterbi_labels(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(rl, _c_i32p),
                                           _ptr(end_cost, _c_f64p), _ptr(best_end, _c_i32p), _ptr(labels, _c_i32p),
                                           _ptr(label_off, _c_i64p), _ptr(n_labels, _c_i32p)))
-        return dict(labels=[labels[label_off[u]:label_off[u] + n_labels[u]] for u in range(U)], best_end=best_end,
-                    end_off=end_off, end_cost_flat=end_cost)
+        out = dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost, labels_flat=labels, label_off=label_off,
+                   n_labels=n_labels)
+        if as_lists:
+            out["labels"] = [labels[label_off[u]:label_off[u] + n_labels[u]] for u in range(U)]
+        return out
 
     def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True):
         """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].

@@ -183,6 +183,84 @@ def test_layers_kernel_fp32_likelihoods_and_long_utterances(hip, ctx):
     gmm.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_loop_kernel_reference_goldens(hip, ctx, dtype):
+    """G14: the word-loop graph decoded by the reference's own decode_hmm_states -- end costs, BIT-EXACT paths and
+    digits through the loop-form kernel (four utterances per wave, one launch for all utterances of a penalty)."""
+    from sr.recognition.continuous_speech import packed_loop_lattice
+    g = load_golden("G14_loop_grammar")
+    means, vars_, w, wt = g["means"], g["vars"], g["w"], g["word_trans"]
+    W, n, M, D = means.shape
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    U = int(g["n_utts"])
+    for pen in (0, 1):
+        graph = packed_loop_lattice([wt] * W, n, float(g["p%d_penalty" % pen]))[0]
+        lat = hip.Lattices(ctx, [graph])
+        b = hip.Batch(ctx, [g["p%d_x%d" % (pen, u)] for u in range(U)], dtype=dtype)
+        b.loglik(gmm, fetch=False)
+        r = lat.viterbi(b, want_path=True)
+        rw = g["p%d_row_word" % pen]
+        ends = np.asarray(graph["end_rows"])
+        for u in range(U):
+            ref = g["p%d_costs%d" % (pen, u)]
+            np.testing.assert_allclose(r["end_cost"][u], ref[ends, -1], rtol=1e-10 if dtype == np.float64 else 1e-5)
+            np.testing.assert_array_equal(r["paths"][u], g["p%d_path%d" % (pen, u)])
+            assert O.path_to_words(r["paths"][u], rw < 0, rw) == list(g["p%d_digits%d" % (pen, u)])
+        b.close()
+        lat.close()
+
+
+@pytest.mark.parametrize("W,n,skip,penalty", [(10, 5, False, 0.0), (11, 5, False, 2.5), (1, 2, False, 0.0), (16, 3, True, 1.0),
+                                              (5, 8, True, 0.0), (7, 4, False, 0.7), (3, 6, True, 3.0), (2, 7, False, 0.0)])
+def test_loop_kernel_equals_lean_kernel(hip, ctx, W, n, skip, penalty):
+    """Random word models through the loop grammar: ragged utterances (1 .. 6 words, a few too short for even one
+    word, counts that are not a multiple of the four utterances a wave holds): end costs BITWISE, chosen ends, paths
+    and labels equal to the row-per-lane lean kernel."""
+    from sr.recognition.continuous_speech import packed_loop_lattice
+    rng = np.random.default_rng(77 * W + n)
+    M, D = 2, 6
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    wt = [word_trans(rng, n, skip, last_self=rng.uniform(0.0, 0.3)) for _ in range(W)]
+    xs = []
+    for u in range(61):
+        if u % 9 == 0:
+            xs.append(rng.normal(size=(int(rng.integers(2, max(3, n))), D)) * 2.0)      # shorter than any word
+            continue
+        segs = []
+        for wd in rng.integers(0, W, size=rng.integers(1, 7)):
+            Tw = int(rng.integers(n, 3 * n + 4))
+            st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+            comp = rng.integers(0, M, size=Tw)
+            segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    graph = packed_loop_lattice(wt, n, penalty)[0]
+    lat = hip.Lattices(ctx, [graph])
+    for dtype in (np.float64, np.float32):
+        b = hip.Batch(ctx, xs, dtype=dtype)
+        b.loglik(gmm, fetch=False)
+        U = b.U
+        lean = lat.viterbi(b, utt_lattice=np.zeros(U, dtype=np.int32), want_path=True)
+        fast = lat.viterbi(b, want_path=True)
+        np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+        np.testing.assert_array_equal(fast["best_end"], lean["best_end"])
+        for u in range(U):
+            np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+        nopath = lat.viterbi(b, want_path=False)
+        np.testing.assert_array_equal(nopath["end_cost_flat"], lean["end_cost_flat"])
+        np.testing.assert_array_equal(nopath["best_end"], lean["best_end"])
+        row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+        la = lat.viterbi_labels(b, row_word)
+        lb = lat.viterbi_labels(b, row_word, utt_lattice=np.zeros(U, dtype=np.int32))
+        for u in range(U):
+            np.testing.assert_array_equal(la["labels"][u], lb["labels"][u])
+        b.close()
+    lat.close()
+    gmm.close()
+
+
 def test_layers_kernel_is_not_taken_for_other_graphs(hip, ctx):
     """Graphs that are not in layer form (different words per layer, a non-emitting end row, the loop grammar) keep
     working through the other kernels -- and a layer-form batch with a one-frame utterance falls back as a whole
