@@ -243,6 +243,30 @@ int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t coun
                      const double* mean /*[k,D]*/, const double* var /*[k,D]*/, const double* weight /*[k]*/,
                      double* out_stats /*[k, 1+2D]*/, double* out_loglik);
 
+/* ------------------------------------- A9 / A11: every state refit in lock-step
+ * The reference refits the states one after the other (hmm.py:97-124, continuous_speech.py:114-142): split k-means
+ * (kmeans.py:167-193), then mixture EM (hmm_state.py:122-159), each iteration a pass over the state's frames.  Here
+ * the frames of ALL states sit back to back in one fp64 batch -- state s owns frames [seg_off[s], seg_off[s+1]) --
+ * and one call advances every state whose `active[s]` is non-zero (NULL: all): the sharded trainer runs all states in
+ * lock-step with a converged mask and all-reduces one buffer per lock-step iteration.
+ *
+ * gh_kmeans_assign_multi: clusters_io[i] = argmin_c dist(centroids[s,c], x_i) under var[s] ([S,D]: the shared
+ *   variance cov[0] of kmeans.py:183, mahalanobis; NULL: Euclidean) for every frame of every active state; frames of
+ *   inactive states keep their entry.  out_changed[s] (may be NULL) = number of frames of s whose entry changed;
+ *   out_sums (may be NULL) [S,k,D+1] = per cluster the sum of its frames and, in column D, their number (the centroid
+ *   update of kmeans.py:158-164 as sufficient statistics).
+ * gh_em_accumulate_multi: gh_em_accumulate for every active state in one launch: the first k components of state s are
+ *   mean/var/weight[s, 0..k-1]; out_stats [S,k,1+2D] (centred on the means given), out_loglik [S] (either may be NULL);
+ *   stats_dev (may be NULL): device buffer [S,k,1+2D] that receives the statistics, e.g. a tensor RCCL all-reduces. */
+int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off /*[S+1]*/,
+                           const uint8_t* active /*[S] or NULL*/, int k, const double* centroids /*[S,k,D]*/,
+                           const double* var /*[S,D] or NULL*/, int32_t* clusters_io /*[N]*/, int32_t* out_changed /*[S]*/,
+                           double* out_sums /*[S,k,D+1]*/);
+int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off /*[S+1]*/,
+                           const uint8_t* active /*[S] or NULL*/, int k, const double* mean /*[S,k,D]*/,
+                           const double* var /*[S,k,D]*/, const double* weight /*[S,k]*/, double* out_stats,
+                           double* out_loglik, double* stats_dev);
+
 /* ----------------------------------------------- A13: forward-backward
  * NOT in the reference (it trains by Viterbi alignment only); the sum-product twin of
  * gh_viterbi: same graphs, same same-column rule for arcs touching a non-emitting row,

@@ -72,6 +72,10 @@ SIGNATURES = {
                          _c_f64p, _c_i32p, _c_i32p]),
     "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_i32p]),
+    "gh_kmeans_assign_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.POINTER(C.c_uint8), C.c_int, _c_f64p,
+                                         _c_f64p, _c_i32p, _c_i32p, _c_f64p]),
+    "gh_em_accumulate_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.POINTER(C.c_uint8), C.c_int, _c_f64p,
+                                         _c_f64p, _c_f64p, _c_f64p, _c_f64p, C.c_void_p]),
     "gh_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, C.c_int, _c_f64p, _c_f64p, _c_f64p,
                                       _c_f64p, _c_i64p, _c_f64p]),
     "gh_bw_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _c_f64p, C.c_void_p]),
@@ -401,6 +405,46 @@ class Batch:
                                                            centroids.shape[0], _ptr(centroids, _c_f64p),
                                                            _ptr(v, _c_f64p), _ptr(out, _c_i32p)))
         return out.astype(np.int64)
+
+    def kmeans_assign_multi(self, seg_off, centroids, var=None, clusters=None, active=None, want_sums=False):
+        """A14 for every state at once: frames [seg_off[s], seg_off[s+1]) belong to state s; centroids [S,k,D]; var [S,D]
+        (mahalanobis under the state's shared variance) or None (Euclidean).  `clusters` (int32 [N]) is updated in
+        place for the frames of active states.  Returns (clusters, changed [S], sums [S,k,D+1] or None)."""
+        centroids = _f64(centroids)
+        S, k, D = centroids.shape
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        assert len(seg_off) == S + 1 and D == self.D
+        if clusters is None:
+            clusters = np.full(self.N, -1, dtype=np.int32)
+        assert clusters.dtype == np.int32 and clusters.flags.c_contiguous and len(clusters) == self.N
+        v = None if var is None else _f64(var).reshape(S, D)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        changed = np.zeros(S, dtype=np.int32)
+        sums = np.zeros((S, k, D + 1)) if want_sums else None
+        _check(self.ctx.lib, self.ctx.lib.gh_kmeans_assign_multi(
+            self.ctx.h, self.h, S, _ptr(seg_off, _c_i64p), None if act is None else act.ctypes.data_as(C.POINTER(C.c_uint8)),
+            k, _ptr(centroids, _c_f64p), _ptr(v, _c_f64p), _ptr(clusters, _c_i32p), _ptr(changed, _c_i32p),
+            _ptr(sums, _c_f64p)))
+        return clusters, changed, sums
+
+    def em_accumulate_multi(self, seg_off, mean, var, weight, active=None, stats_dev=None):
+        """A7 E-step statistics of every (active) state in one launch: mean / var [S,k,D], weight [S,k].
+        Returns (stats [S,k,1+2D], loglik [S])."""
+        mean, var, weight = _f64(mean), _f64(var), _f64(weight)
+        S, k, D = mean.shape
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        assert len(seg_off) == S + 1 and D == self.D and var.shape == (S, k, D) and weight.shape == (S, k)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        stats = np.zeros((S, k, 1 + 2 * D))
+        ll = np.zeros(S)
+        rc = self.ctx.lib.gh_em_accumulate_multi(
+            self.ctx.h, self.h, S, _ptr(seg_off, _c_i64p), None if act is None else act.ctypes.data_as(C.POINTER(C.c_uint8)),
+            k, _ptr(mean, _c_f64p), _ptr(var, _c_f64p), _ptr(weight, _c_f64p), _ptr(stats, _c_f64p), _ptr(ll, _c_f64p),
+            stats_dev)
+        if rc == -1 and b"singular" in self.ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(self.ctx.lib, rc)
+        return stats, ll
 
     def bw_accumulate(self, gmm, occ_floor=0.0, stats_dev=None, fetch=True):
         """Baum-Welch statistics [S, M, 1+2D] of the whole batch from the resident occupancies

@@ -22,6 +22,7 @@ from . import _pack
 from .kmeans import kmeans
 from .hmm_state import GMM, NES, mahalanobis
 from .hmm import HMM
+from .lockstep import LockstepFitter
 
 __all__ = ["build_state_sequences", "build_loop_grammar", "continuous_train"]
 
@@ -242,22 +243,18 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             print("=" * 25)
 
             print('Doing HMM training...')
-            for sid, segs in gmm_data.items():
-                state: GMM = new_models[sid // n].gmm_states[sid % n]
-                seg = np.vstack(segs)
-                n_splits = int(np.log(n_gaussians))
-                assert n_splits > 0
-                centroids = np.mean(seg, axis=0).reshape((1, -1))
-                weights = np.full(n_gaussians, 1 / n_segments)
-                for i in range(n_splits):
-                    k = 2 ** (i + 1)
-                    centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=0)
-                    clusters, centroids, variance = kmeans(seg, k, centroids, dist_fun=mahalanobis)
-                    ids, counts = np.unique(clusters, return_counts=True)
-                    for c in ids:
-                        weights[c] = counts[c] / n_segments  # (:135-137)
-                    state.update_models(centroids, variance, weights[:k])
-                    state.em(seg, k)
+            # every visited state refit in lock-step (one launch per k-means / EM iteration for all of them); the
+            # states are taken in first-visit order, the order in which the reference consumes numpy's global RNG
+            keys = list(gmm_data.keys())
+            segs = [np.vstack(gmm_data[sid]) for sid in keys]
+            fitter = LockstepFitter(segs, ctx=frames.ctx)
+            try:
+                fitter.split_and_fit([new_models[sid // n].gmm_states[sid % n] for sid in keys],
+                                     start_centroids=[np.mean(seg, axis=0) for seg in segs],
+                                     weight_divisor=[n_segments] * len(keys),          # (:127, :135-137)
+                                     n_gaussians=n_gaussians, use_em=True)
+            finally:
+                fitter.close()
 
             print('Updating other model parameters...')
             for mi in range(n_models):

@@ -1,110 +1,107 @@
 # -*- coding: utf-8 -*-
-"""Word model: a left-to-right chain of mixture states (mirror of the reference's
-`sr/recognition/hmm.py`; attribute names kept so pickled models keep their layout:
-gmm_states, mu, n_segments, segments, sigma, transitions, use_em, use_gmm)."""
+"""Word model of the recogniser: `n_segments` left-to-right states with a cost matrix between them.
+
+API and pickled layout are the reference's (`sr/recognition/hmm.py:8-135`: the instance dictionary holds exactly
+gmm_states, mu, n_segments, segments, sigma, transitions, use_em, use_gmm, so models trained by either side load in
+the other), the training path is not: after the segmental k-means of `skmeans` ALL states of the word are refit
+together -- `lockstep.LockstepFitter` gathers their frames into one resident batch and advances every state's
+split-k-means / EM with one launch per iteration -- where the reference fits state after state (hmm.py:97-124).
+"""
 import numpy as np
 
-from .decode import dtw, decode_hmm_states
-from .kmeans import kmeans, skmeans, align_gmm_states
+from . import decode as _decode
+from . import kmeans as _km
 from .hmm_state import GMM, mahalanobis
+from .lockstep import LockstepFitter
 
 __all__ = ["HMM"]
+
+# what `reset` forgets: everything learnt from data (n_segments and the two switches stay)
+_LEARNT = {"mu": None, "sigma": None, "transitions": None, "segments": list, "gmm_states": None}
 
 
 class HMM:
     """
-    Attributes
-    ----------
-    mu, sigma: per-state mean / variance [n_segments, D] (single-Gaussian model)
-    transitions: cost matrix [n_segments, n_segments], [i, j] = cost of j -> i
-    segments: training frames of every state (list of [N_s, D])
-    gmm_states: list of GMM states when `use_gmm`
+    n_segments   number of states
+    mu, sigma    [n_segments, D] state means / variances of the single-Gaussian model (also the seeds of the mixtures)
+    transitions  [n_segments, n_segments] costs, entry [i, j] = cost of moving j -> i, +inf = no arc
+    segments     per state, the training frames aligned to it (list of [N_s, D])
+    gmm_states   list of `GMM` states when `use_gmm`
+    use_gmm / use_em   what `fit` was asked to train
     """
 
     def __init__(self, n_segments):
         self.n_segments = n_segments
-        self.mu = None
-        self.sigma = None
-        self.transitions = None
-        self.segments = []
-        self.gmm_states = None
-        self.use_gmm = True
-        self.use_em = True
-
-    def __eq__(self, other):
-        """Convergence test of continuous training (hmm.py:30-41): mixtures allclose;
-        transitions are not compared."""
-        if not self.use_gmm:
-            return np.allclose(self.mu, other.mu) and np.allclose(self.sigma, other.sigma)
-        if not other.use_gmm or self.n_segments != other.n_segments:
-            return False
-        return all(not (a != b) for a, b in zip(self.gmm_states[:self.n_segments], other.gmm_states))
+        self.reset()
+        self.use_gmm = self.use_em = True
 
     def reset(self):
-        self.mu = None
-        self.sigma = None
-        self.transitions = None
-        self.segments = []
-        self.gmm_states = None
+        for name, blank in _LEARNT.items():
+            setattr(self, name, blank() if callable(blank) else blank)
+
+    # ---- comparison / access ------------------------------------------------------------------------------
+    def __eq__(self, other):
+        """hmm.py:30-41 -- what `continuous_train` calls convergence: every state's mixture allclose to the other
+        model's; the transition costs play no part."""
+        if not self.use_gmm:
+            return bool(np.allclose(self.mu, other.mu) and np.allclose(self.sigma, other.sigma))
+        if not (other.use_gmm and self.n_segments == other.n_segments):
+            return False
+        mine, theirs = self.gmm_states, other.gmm_states
+        return not any(mine[i] != theirs[i] for i in range(self.n_segments))
 
     def __getitem__(self, item):
-        assert self.use_gmm == True
-        if type(item) is int or type(item) is slice:
-            return self.gmm_states[item]
-        raise TypeError('The type of index is not supported')
+        assert self.use_gmm == True  # noqa: E712 (the reference's own comparison: a non-bool truthy flag fails it too)
+        if type(item) not in (int, slice):
+            raise TypeError('The type of index is not supported')
+        return self.gmm_states[item]
 
+    # ---- training -----------------------------------------------------------------------------------------
     def fit(self, ys, n_gaussians, use_gmm=True, use_em=True):
-        """Train on a list of [T_u, D] templates (hmm.py:57-76).
-
-        use_gmm: mixture per state (segmental k-means, then split-k-means [+ EM] per state,
-        then re-alignment); otherwise one Gaussian per state from segmental k-means alone.
-        n_gaussians: size of every mixture; int(ln(n_gaussians)) binary splits are trained
-        (hmm.py:104), the remaining components keep the state's initial Gaussian."""
-        self.use_em = use_em
-        self.use_gmm = use_gmm
+        """Train on the templates `ys` (list of [T_u, D]; hmm.py:57-76).  use_gmm=False stops after the segmental
+        k-means (one Gaussian per state, scored by `dtw`); otherwise every state gets a mixture of `n_gaussians`
+        components of which int(ln n_gaussians) binary splits are trained (hmm.py:104) -- by k-means alone or, with
+        use_em, k-means followed by EM."""
+        self.use_gmm, self.use_em = use_gmm, use_em
         if use_gmm:
             self.fit_GMM(ys, n_gaussians)
         else:
-            self.mu, self.sigma, self.transitions, self.segments = skmeans(ys, self.n_segments,
-                                                                           return_segmented_data=True)
+            self._segmental_kmeans(ys)
         return self
 
-    def _init_gmm(self, n_gaussians):
-        self.gmm_states = [GMM(self.mu[i, :], self.sigma[i, :], n_gaussians) for i in range(self.n_segments)]
+    def _segmental_kmeans(self, ys):
+        self.mu, self.sigma, self.transitions, self.segments = _km.skmeans(ys, self.n_segments, return_segmented_data=True)
 
     def fit_GMM(self, ys, n_gaussians):
+        """Segmental k-means, then the mixtures of all states (hmm.py:81-95), then a re-alignment of the templates
+        against the trained mixtures."""
         print('Doing segmental k-means')
-        self.mu, self.sigma, self.transitions, self.segments = skmeans(ys, self.n_segments,
-                                                                       return_segmented_data=True)
-        self._init_gmm(n_gaussians)
-        for i, seg in enumerate(self.segments):
-            self._fit_GMM(seg, n_gaussians, i)
-        self.segments = align_gmm_states(ys, self.gmm_states, self.transitions, self.n_segments)
+        self._segmental_kmeans(ys)
+        self.gmm_states = [GMM(m, s, n_gaussians) for m, s in zip(self.mu, self.sigma)]
+        fitter = LockstepFitter(self.segments)
+        try:
+            fitter.split_and_fit(self.gmm_states, start_centroids=self.mu,
+                                 weight_divisor=[len(seg) for seg in self.segments],     # hmm.py:108,118
+                                 n_gaussians=n_gaussians, use_em=self.use_em)
+        finally:
+            fitter.close()
+        self.segments = _km.align_gmm_states(ys, self.gmm_states, self.transitions, self.n_segments)
 
     def _fit_GMM(self, data, n_gaussians, seg_i):
-        """Binary-split k-means (+ EM) of one state (hmm.py:97-124)."""
-        n_splits = int(np.log(n_gaussians))
-        assert n_splits > 0
-        state = self.gmm_states[seg_i]
-        n = data.shape[0]
-        centroids = np.array([self.mu[seg_i, :]])
-        weights = np.full(n_gaussians, 1 / n)
-        for i in range(n_splits):
-            k = 2 ** (i + 1)
-            centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=0)
-            clusters, centroids, variance = kmeans(data, k, centroids, dist_fun=mahalanobis)
-            ids, counts = np.unique(clusters, return_counts=True)
-            for c in ids:
-                weights[c] = counts[c] / n  # counts looked up by cluster ID, as in hmm.py:116-118
-            state.update_models(centroids, variance, weights[:k])
-            if self.use_em:
-                state.em(data, k)
+        """The refit of ONE state on `data` (hmm.py:97-124) -- the lock-step fitter with a single segment."""
+        assert int(np.log(n_gaussians)) > 0
+        fitter = LockstepFitter([data])
+        try:
+            fitter.split_and_fit([self.gmm_states[seg_i]], start_centroids=[self.mu[seg_i]], weight_divisor=[len(data)],
+                                 n_gaussians=n_gaussians, use_em=self.use_em)
+        finally:
+            fitter.close()
 
+    # ---- scoring ------------------------------------------------------------------------------------------
     def evaluate(self, x):
-        """Cost of the best alignment of `x` ending in the last state at the last frame
-        (hmm.py:126-135)."""
+        """Cost of the cheapest alignment of `x` that ends in the last state on the last frame (hmm.py:126-135)."""
         if self.use_gmm:
-            costs, _ = decode_hmm_states(x, self.gmm_states, self.transitions)
+            costs = _decode.decode_hmm_states(x, self.gmm_states, self.transitions)[0]
         else:
-            costs, _ = dtw(x, self.mu, mahalanobis, self.transitions, self.sigma)
+            costs = _decode.dtw(x, self.mu, mahalanobis, self.transitions, self.sigma)[0]
         return costs[-1, -1]

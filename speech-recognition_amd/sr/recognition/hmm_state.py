@@ -162,38 +162,48 @@ class GMM(HMMState):
             return -np.log(np.exp(self.component_log_density(X)).sum(axis=1))
 
     # ---- training ----------------------------------------------------------
+    def em_update(self, stats, n, k, it):
+        """M-step + convergence test of one EM iteration (hmm_state.py:134-159) from the E-step statistics
+        `stats` [k, 1+2D] of `gh_em_accumulate` (occupancy, first and second moments around the CURRENT means) over
+        the state's `n` frames.  Returns True when the reference's loop would `break` (parameters allclose to the
+        previous iteration's); like there, the new parameters are installed before the test."""
+        dim = (stats.shape[1] - 1) // 2
+        means = np.array([np.asarray(d.mean, dtype=np.float64) for d in self.dists[:k]])
+        occ = stats[:, 0].copy()
+        weights = occ / n                      # p.mean(axis=0)            (:148)
+        occ[occ == 0] = 10 ** (-5)             # avoid divide by 0        (:134-136)
+        # statistics are centred on the current means m0:  S1 = sum r (x - m0), S2 = sum r (x - m0)^2
+        mu = (means * stats[:, 0][:, None] + stats[:, 1:1 + dim]) / occ[:, None]   # sum r x / N
+        # sum r (x - mu)^2 / N around the NEW mean (:141-143), from the centred sums
+        delta = mu - means
+        sigma = (stats[:, 1 + dim:] - delta * (2.0 * stats[:, 1:1 + dim] - delta * stats[:, 0][:, None])) / occ[:, None]
+        self.update_models(mu, sigma, weights)
+        if np.allclose(mu, self.mu_old[:k, :]) and np.allclose(sigma, self.sigma_old[:k, :]) \
+                and np.allclose(weights, self.w_old[:k]):
+            print("EM converged at iteration:", it)
+            return True
+        print("EM iteration:", str(it), end="\r", flush=True)
+        self.mu_old[:k, :] = mu
+        self.sigma_old[:k, :] = sigma
+        self.w_old[:k] = weights
+        return False
+
     def em(self, data, n_gaussians, max_iteration=10000):
         """EM on the first `n_gaussians` components over frames hard-assigned to this
         state (hmm_state.py:122-159).  E-step statistics come from the HIP kernel
         (`gh_em_accumulate`: N_c and the first / second moments around the current means, one pass
-        over the resident frames);
-        the M-step, `update_models` and the allclose convergence test stay on the host."""
+        over the resident frames); the M-step, `update_models` and the allclose convergence test stay
+        on the host (`em_update`).  `lockstep.LockstepFitter` runs the same iteration for many states per launch."""
         data = np.ascontiguousarray(data, dtype=np.float64)
         k = n_gaussians
-        n, dim = data.shape
+        n = data.shape[0]
         frames = _hip.Batch(_ctx(), feats=data, offsets=[0, n])
         try:
             for it in range(max_iteration):
                 means, vars_, w = _pack.gmm_arrays(self)
                 stats, _ = frames.em_accumulate(means[:k], vars_[:k], w[:k])
-                occ = stats[:, 0].copy()
-                weights = occ / n                      # p.mean(axis=0)            (:148)
-                occ[occ == 0] = 10 ** (-5)             # avoid divide by 0        (:134-136)
-                # statistics are centred on the current means m0:  S1 = sum r (x - m0), S2 = sum r (x - m0)^2
-                mu = (means[:k] * stats[:, 0][:, None] + stats[:, 1:1 + dim]) / occ[:, None]   # sum r x / N
-                # sum r (x - mu)^2 / N around the NEW mean (:141-143), from the centred sums
-                delta = mu - means[:k]
-                sigma = (stats[:, 1 + dim:] - delta * (2.0 * stats[:, 1:1 + dim] - delta * stats[:, 0][:, None])) \
-                    / occ[:, None]
-                self.update_models(mu, sigma, weights)
-                if np.allclose(mu, self.mu_old[:k, :]) and np.allclose(sigma, self.sigma_old[:k, :]) \
-                        and np.allclose(weights, self.w_old[:k]):
-                    print("EM converged at iteration:", it)
+                if self.em_update(stats, n, k, it):
                     break
-                print("EM iteration:", str(it), end="\r", flush=True)
-                self.mu_old[:k, :] = mu
-                self.sigma_old[:k, :] = sigma
-                self.w_old[:k] = weights
         finally:
             frames.close()
 

@@ -1,0 +1,166 @@
+# -*- coding: utf-8 -*-
+"""Every state's mixture refit advanced in LOCK-STEP on the GPU.
+
+The reference trains one state after the other -- binary-split k-means, then mixture EM, on the frames the alignment
+gave that state (hmm.py:97-124 inside `HMM.fit`, continuous_speech.py:114-142 inside `continuous_train`) -- thousands
+of short passes over small arrays.  `LockstepFitter` gathers the frames of ALL states into one resident batch and
+advances every state that has not converged yet with ONE launch per iteration (`gh_kmeans_assign_multi`,
+`gh_em_accumulate_multi`); states drop out through a converged mask, exactly where the reference's per-state loops
+would `break`.  The results are the reference's: the random partitions behind the k-means variances are drawn from
+numpy's global generator in the order the sequential algorithm consumes it (they only depend on the frame counts), the
+centroid means are numpy's, the M-step / convergence test is `GMM.em_update`.
+
+Sharded over ranks (`reducer` = `parallel.StatsAllReducer` of a process group with more than one rank) every rank holds
+part of each state's frames; cluster sums / counts and the EM statistics are all-reduced -- ONE collective per
+lock-step iteration.  Summation order then differs from the single-process run, and the random
+partitions are per rank: parity is statistical there, as the survey says.
+"""
+import numpy as np
+
+from . import _hip
+from .hmm_state import GMM
+
+__all__ = ["LockstepFitter"]
+
+
+def _variance_rows(x):
+    """calc_variance(x.T) of kmeans.py:6-12: np.cov(...).diagonal() -- ddof = 1, per dimension."""
+    return np.cov(x.T).diagonal()
+
+
+class LockstepFitter:
+    """segments: list of [N_s, D] arrays, one per state, in the order the reference would train them."""
+
+    def __init__(self, segments, ctx=None, reducer=None):
+        self.ctx = ctx if ctx is not None else _hip.default_context()
+        self.segs = [np.ascontiguousarray(s, dtype=np.float64) for s in segments]
+        self.S = len(self.segs)
+        self.D = self.segs[0].shape[1] if self.S else 0
+        self.seg_off = np.zeros(self.S + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in self.segs], out=self.seg_off[1:])
+        self.batch = _hip.Batch(self.ctx, feats=np.concatenate(self.segs) if self.S else np.zeros((0, 1)),
+                                offsets=[0, int(self.seg_off[-1])]) if self.S else None
+        self.reducer = reducer
+        self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
+        self.collectives = 0
+        # frames per state over all ranks (weights are counts / n)
+        self.n_global = self._reduce(np.diff(self.seg_off).astype(np.float64)) if self.sharded else np.diff(self.seg_off)
+
+    def _reduce(self, a):
+        self.collectives += 1
+        return self.reducer(np.ascontiguousarray(a, dtype=np.float64))
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+            self.batch = None
+
+    # ------------------------------------------------------------------ k-means (kmeans.py:167-193), all states
+    def kmeans(self, k, centroids, max_iteration=1000, partitions=None):
+        """centroids [S, k, D] -> (clusters: list of int64 [N_s], centroids [S, k, D], cov [S, k, D]).
+        partitions: the random partition of every state's frames (kmeans.py:171), drawn by the caller when the order
+        of draws matters; default: drawn here, state after state."""
+        S, D, off = self.S, self.D, self.seg_off
+        cov = np.empty((S, k, D))
+        part_stats = np.zeros((S, 2 * D + 1))
+        for s, x in enumerate(self.segs):
+            part = np.random.randint(0, k, x.shape[0]) if partitions is None else partitions[s]
+            if self.sharded:      # variance of cluster 0 from sums over all ranks (ddof = 1), the only row that is used
+                x0 = x[part == 0]
+                part_stats[s, 0] = len(x0)
+                part_stats[s, 1:1 + D] = x0.sum(axis=0)
+                part_stats[s, 1 + D:] = (x0 * x0).sum(axis=0)
+            else:
+                with np.errstate(all="ignore"):
+                    cov[s] = np.array([_variance_rows(x[part == c]) for c in range(k)])
+        if self.sharded:
+            ps = self._reduce(part_stats)
+            n0 = ps[:, [0]]
+            with np.errstate(all="ignore"):
+                v0 = (ps[:, 1 + D:] - ps[:, 1:1 + D] ** 2 / n0) / (n0 - 1.0)
+            cov[:] = v0[:, None, :]
+        centroids = np.array(centroids, dtype=np.float64)
+        clusters = np.full(int(off[-1]), -1, dtype=np.int32)
+        active = np.ones(S, dtype=np.uint8)
+        for _ in range(max(max_iteration, 1)):
+            clusters, changed, sums = self.batch.kmeans_assign_multi(off, centroids, var=cov[:, 0, :], clusters=clusters,
+                                                                    active=active, want_sums=self.sharded)
+            if self.sharded:
+                red = self._reduce(np.concatenate([sums.reshape(S, -1), changed.reshape(S, 1).astype(np.float64)], axis=1))
+                sums, changed = red[:, :-1].reshape(S, k, D + 1), red[:, -1]
+                with np.errstate(all="ignore"):
+                    new = sums[:, :, :D] / sums[:, :, [D]]
+                for s in np.nonzero(active)[0]:
+                    if changed[s] == 0:
+                        active[s] = 0                 # assignments stable on every rank: centroids are stable
+                    centroids[s] = new[s]
+            else:
+                for s in np.nonzero(active)[0]:
+                    cl = clusters[off[s]:off[s + 1]]
+                    new = np.empty((k, D))
+                    with np.errstate(all="ignore"):
+                        for c in range(k):
+                            np.mean(self.segs[s][cl == c, :], axis=0, out=new[c])   # cluster_centroids, kmeans.py:158-164
+                    if np.array_equal(new, centroids[s]):
+                        active[s] = 0                 # kmeans.py:190-191
+                    else:
+                        centroids[s] = new
+            if not active.any():
+                break
+        return [clusters[off[s]:off[s + 1]].astype(np.int64) for s in range(S)], centroids, cov
+
+    # ------------------------------------------------------------------ mixture EM (hmm_state.py:122-159), all states
+    def em(self, states, k, max_iteration=10000):
+        """Run GMM.em(data_s, k) for every state object in `states` (one per segment), in lock-step."""
+        S, off = self.S, self.seg_off
+        active = np.ones(S, dtype=np.uint8)
+        for it in range(max_iteration):
+            means = np.array([[np.asarray(d.mean, dtype=np.float64) for d in g.dists[:k]] for g in states])
+            vars_ = np.array([[np.asarray(d.cov, dtype=np.float64) for d in g.dists[:k]] for g in states])
+            w = np.array([np.asarray(g.w[:k], dtype=np.float64) for g in states])
+            stats, _ = self.batch.em_accumulate_multi(off, means, vars_, w, active=active)
+            if self.sharded:
+                stats = self._reduce(stats)
+            for s in np.nonzero(active)[0]:
+                if states[s].em_update(stats[s], self.n_global[s], k, it):
+                    active[s] = 0
+            if not active.any():
+                break
+
+    # ------------------------------------------------------------------ the whole refit of hmm.py:97-124
+    def split_and_fit(self, states, start_centroids, n_gaussians, weight_divisor, use_em=True):
+        """Binary-split k-means + EM of every state: for i in range(int(ln n_gaussians)): centroids x 0.9 / x 1.1,
+        k-means under the mahalanobis distance, weights = cluster counts / weight_divisor[s] (looked up by cluster id,
+        hmm.py:116-118), update_models, EM on the first 2^(i+1) components.
+        start_centroids [S, D]; weight_divisor [S] (the state's frame count in HMM.fit, `n_segments` in
+        continuous_train, continuous_speech.py:127,137)."""
+        n_splits = int(np.log(n_gaussians))
+        assert n_splits > 0
+        S = self.S
+        centroids = np.asarray(start_centroids, dtype=np.float64).reshape(S, 1, self.D)
+        div = np.asarray(weight_divisor, dtype=np.float64)
+        weights = np.repeat((1.0 / div)[:, None], n_gaussians, axis=1)
+        # numpy's global generator is consumed the way the sequential algorithm consumes it: state after state, and
+        # inside a state split after split (one draw of N_s cluster ids per kmeans call, kmeans.py:171; nothing else
+        # in the refit draws) -- the draws only depend on the frame counts, so they can all be made up front
+        parts = [[np.random.randint(0, 2 ** (i + 1), x.shape[0]) for i in range(n_splits)] for x in self.segs]
+        for i in range(n_splits):
+            k = 2 ** (i + 1)
+            centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=1)
+            clusters, centroids, cov = self.kmeans(k, centroids, partitions=[p[i] for p in parts])
+            if self.sharded:
+                counts = np.zeros((S, k))
+                for s in range(S):
+                    counts[s] = np.bincount(clusters[s], minlength=k)[:k]
+                counts = self._reduce(counts)
+            for s in range(S):
+                if self.sharded:
+                    for c in np.nonzero(counts[s])[0]:
+                        weights[s, c] = counts[s, c] / div[s]
+                else:
+                    ids, cnt = np.unique(clusters[s], return_counts=True)
+                    for c in ids:
+                        weights[s, c] = cnt[c] / div[s]       # counts looked up by cluster ID, as in hmm.py:116-118
+                states[s].update_models(centroids[s], cov[s], weights[s, :k])
+            if use_em:
+                self.em(states, k)

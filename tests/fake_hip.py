@@ -139,6 +139,38 @@ class Batch:
             ll = float(np.log(rs[rs > 0]).sum())
         return stats, ll
 
+    def kmeans_assign_multi(self, seg_off, centroids, var=None, clusters=None, active=None, want_sums=False):
+        centroids = np.asarray(centroids, dtype=np.float64)
+        S, k, D = centroids.shape
+        if clusters is None:
+            clusters = np.full(self.N, -1, dtype=np.int32)
+        changed = np.zeros(S, dtype=np.int32)
+        sums = np.zeros((S, k, D + 1)) if want_sums else None
+        for s in range(S):
+            if active is not None and not active[s]:
+                continue
+            a, b = int(seg_off[s]), int(seg_off[s + 1])
+            new = self.kmeans_assign(centroids[s], None if var is None else np.asarray(var)[s], first=a, count=b - a).astype(np.int32)
+            changed[s] = int(np.sum(new != clusters[a:b]))
+            clusters[a:b] = new
+            if want_sums:
+                for c in range(k):
+                    x = self.feats[a:b][new == c]
+                    sums[s, c, :D] = x.sum(axis=0)
+                    sums[s, c, D] = len(x)
+        return clusters, changed, sums
+
+    def em_accumulate_multi(self, seg_off, mean, var, weight, active=None, stats_dev=None):
+        mean = np.asarray(mean, dtype=np.float64)
+        S, k, D = mean.shape
+        stats, ll = np.zeros((S, k, 1 + 2 * D)), np.zeros(S)
+        for s in range(S):
+            if active is not None and not active[s]:
+                continue
+            a, b = int(seg_off[s]), int(seg_off[s + 1])
+            stats[s], ll[s] = self.em_accumulate(mean[s], np.asarray(var)[s], np.asarray(weight)[s], first=a, count=b - a)
+        return stats, ll
+
     def close(self):
         pass
 
@@ -218,7 +250,7 @@ class Lattices:
         out["end_cost_flat"] = np.concatenate(out["end_cost"]) if out["end_cost"] else np.zeros(0)
         return out
 
-    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None):
+    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True):
         if isinstance(row_label, np.ndarray) and row_label.ndim == 1 and self.L == 1:
             row_label = [row_label]
         r = self.viterbi(batch, utt_lattice=utt_lattice, want_path=True)
