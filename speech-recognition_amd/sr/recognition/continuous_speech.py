@@ -208,14 +208,23 @@ def cut_segments(path, row_state):
 def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List[List[int]], output_path: AnyStr,
                      n_gaussians: int = 4,
                      n_segments: int = 5,
-                     max_iteration: int = 1000):
+                     max_iteration: int = 1000,
+                     reducer=None):
     """Embedded Viterbi training (continuous_speech.py:56-179).
 
     Per outer iteration: forced alignment of every utterance, frames regrouped per visited
     state, every visited state refit (binary-split k-means + EM, in first-visit order --
     numpy's global RNG is consumed in that order), transition costs re-estimated from the
     segment counts, every model pickled to `output_path/<index>.pkl`; stops when all models
-    compare equal (mixtures allclose) to the previous iteration's."""
+    compare equal (mixtures allclose) to the previous iteration's.
+
+    reducer (extension; the reference is single-process): a `parallel.StatsAllReducer` of a process group with more
+    than one rank shards the training by utterance -- `data` / `label_seqs` are THIS rank's utterances, alignment and
+    regrouping stay local, the refit runs in lock-step over the ranks (one collective per k-means / EM iteration,
+    `lockstep.LockstepFitter`), segment / frame counts for the transition costs are all-reduced, and every rank ends
+    each iteration with the same models (states are then visited in ascending order; parity with the single-process
+    run is statistical)."""
+    sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
     old_models = models
     new_models = copy.deepcopy(models)
     n_models = len(new_models)
@@ -247,10 +256,24 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             # states are taken in first-visit order, the order in which the reference consumes numpy's global RNG
             keys = list(gmm_data.keys())
             segs = [np.vstack(gmm_data[sid]) for sid in keys]
-            fitter = LockstepFitter(segs, ctx=frames.ctx)
+            starts = [np.mean(seg, axis=0) for seg in segs]
+            seg_counts = {sid: (len(v), sum(s.shape[0] for s in v)) for sid, v in gmm_data.items()}
+            if sharded:
+                # which states were visited anywhere, their frame sums (start centroids) and segment / frame counts
+                dim = data[0].shape[1] if len(data) else frames.D
+                loc = np.zeros((n_models * n, dim + 2))
+                for sid, v in gmm_data.items():
+                    x = np.vstack(v)
+                    loc[sid, :dim], loc[sid, dim], loc[sid, dim + 1] = x.sum(axis=0), x.shape[0], len(v)
+                glob = reducer(loc)
+                keys = [sid for sid in range(n_models * n) if glob[sid, dim] > 0]
+                segs = [np.vstack(gmm_data[sid]) if sid in gmm_data else np.zeros((0, dim)) for sid in keys]
+                starts = [glob[sid, :dim] / glob[sid, dim] for sid in keys]
+                seg_counts = {sid: (glob[sid, dim + 1], glob[sid, dim]) for sid in keys}
+            fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None)
             try:
                 fitter.split_and_fit([new_models[sid // n].gmm_states[sid % n] for sid in keys],
-                                     start_centroids=[np.mean(seg, axis=0) for seg in segs],
+                                     start_centroids=starts,
                                      weight_divisor=[n_segments] * len(keys),          # (:127, :135-137)
                                      n_gaussians=n_gaussians, use_em=True)
             finally:
@@ -259,14 +282,14 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             print('Updating other model parameters...')
             for mi in range(n_models):
                 for si in range(n):
-                    segs = gmm_data.get(mi * n + si)
+                    cnt = seg_counts.get(mi * n + si)
                     current = new_models[mi].gmm_states[si]
-                    if segs is not None and current is not first_copy[mi][si] and not (current == first_copy[mi][si]):
-                        segs = None
-                    if segs is None:
+                    if cnt is not None and current is not first_copy[mi][si] and not (current == first_copy[mi][si]):
+                        cnt = None
+                    if cnt is None:
                         warnings.warn("No MFCC data for state", UserWarning)
                         continue
-                    p_jump = len(segs) / sum(s.shape[0] for s in segs)
+                    p_jump = cnt[0] / cnt[1]
                     if si < n - 1:
                         new_models[mi].transitions[si + 1, si] = -np.log(p_jump)
                     new_models[mi].transitions[si, si] = -np.log(1 - p_jump)
