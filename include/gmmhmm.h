@@ -276,11 +276,15 @@ int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, const int64_t*
  *              log alpha, log beta, and the posterior of passing through the cell
  *   want_occ   != 0: keep occ[n, s] = sum of gamma over the rows scored by state s, for every
  *              frame, resident in the batch (input of the Baum-Welch statistics);
- *              out_occ (may be NULL) receives a copy [N, S]. */
+ *              out_occ (may be NULL) receives a copy [N, S].
+ *   out_self_xi (may be NULL) [S]: expected number of SELF transitions per state, sum over utterances and frames of
+ *              xi_t(r -> r) over the emitting rows r scored by the state -- with the occupancies this re-estimates
+ *              the transition costs the way continuous_speech.py:146-164 does from hard counts:
+ *              p_stay = self transitions / frames in the state, p_jump = 1 - p_stay. */
 int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b,
                         const int32_t* utt_lattice /*[U] or NULL*/, int want_occ,
                         double* out_logp, double* out_alpha, double* out_beta, double* out_gamma,
-                        const int64_t* mat_off /*[U+1]*/, double* out_occ);
+                        const int64_t* mat_off /*[U+1]*/, double* out_occ, double* out_self_xi /*[S] or NULL*/);
 
 /* ------------------------------------ Baum-Welch (soft) sufficient statistics
  * After gh_forward_backward(want_occ = 1): for every frame n and state s,

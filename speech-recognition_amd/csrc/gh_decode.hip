@@ -425,7 +425,7 @@ extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, co
 // --------------------------------------------------------- forward-backward
 extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b, const int32_t* utt_lattice,
                                    int want_occ, double* out_logp, double* out_alpha, double* out_beta,
-                                   double* out_gamma, const int64_t* mat_off, double* out_occ) {
+                                   double* out_gamma, const int64_t* mat_off, double* out_occ, double* out_self_xi) {
     GH_REQUIRE(ctx && lat && b, "gh_forward_backward: NULL argument");
     GH_REQUIRE(b->nll || b->N == 0, "gh_forward_backward: gh_loglik has not been run on this batch");
     GH_REQUIRE(!(out_alpha || out_beta || out_gamma) || mat_off, "gh_forward_backward: matrices need mat_off");
@@ -478,7 +478,9 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             int32_t* d_ul = nullptr;
             double *d_al, *d_lp;
             Carver cc;
+            double* d_xi = nullptr;
             cc.add(&d_coff, U); cc.add(&d_lp, U); cc.add(&d_al, cacc);
+            if (out_self_xi) cc.add(&d_xi, (size_t)U * GH_FBCHAIN_MAX);
             if (utt_lattice) cc.add(&d_ul, U);
             int rc2 = cc.commit(ctx);
             if (rc2) return rc2;
@@ -500,11 +502,24 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             ca.chains = lat->d_fbchain; ca.nll = b->nll; ca.S = S; ca.utt_off = b->d_offsets; ca.utt_lat = d_ul;
             ca.perm = b->d_perm; ca.U = U; ca.alpha_scratch = d_al; ca.scratch_off = d_coff; ca.logp = d_lp;
             ca.occ = want_occ ? b->occ : nullptr;
+            ca.self_xi_utt = d_xi;
             rc2 = gh_launch_fb_chain(ctx, ca, b->dtype == GH_F64);
             if (rc2) return rc2;
             if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_lp, U * 8, hipMemcpyDeviceToHost, s2));
             if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, s2));
+            std::vector<double> xi_utt;
+            if (out_self_xi) {
+                xi_utt.resize((size_t)U * GH_FBCHAIN_MAX);
+                GH_HIP(hipMemcpyAsync(xi_utt.data(), d_xi, xi_utt.size() * 8, hipMemcpyDeviceToHost, s2));
+            }
             GH_HIP(hipStreamSynchronize(s2));
+            if (out_self_xi) {   // per state, summed in utterance order (deterministic)
+                for (int s = 0; s < S; ++s) out_self_xi[s] = 0.0;
+                for (int64_t u = 0; u < U; ++u) {
+                    const gh_fbchain& fc = lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0];
+                    for (int j = 0; j < fc.n; ++j) out_self_xi[fc.state[j]] += xi_utt[(size_t)u * GH_FBCHAIN_MAX + j];
+                }
+            }
             return GH_OK;
         }
     }
@@ -512,7 +527,9 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     int32_t* d_uttlat = nullptr;
     double *d_scratch, *d_logp, *d_alpha = nullptr, *d_beta = nullptr, *d_gamma = nullptr;
     Carver cv;
+    double* d_selfxi = nullptr;
     cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
+    if (out_self_xi) cv.add(&d_selfxi, S);
     if (utt_lattice) cv.add(&d_uttlat, U);
     if (mats) cv.add(&d_matoff, U + 1);
     if (out_alpha) cv.add(&d_alpha, n_mat);
@@ -535,6 +552,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     a.alpha_scratch = d_scratch; a.scratch_off = d_soff; a.logp = d_logp;
     a.out_alpha = d_alpha; a.out_beta = d_beta; a.out_gamma = d_gamma; a.mat_off = d_matoff;
     a.occ = want_occ ? b->occ : nullptr;
+    a.self_xi = d_selfxi;
+    if (d_selfxi) GH_HIP(hipMemsetAsync(d_selfxi, 0, (size_t)S * 8, st));
     if (want_occ && b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }   // any state may be occupied
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
@@ -544,7 +563,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     for (auto& lh : lat->lat) fb_max_arcs = std::max(fb_max_arcs, lh.A);
     a.arc_cap = (fb_max_arcs + 2) & ~1;
     a.lev_cap = lat->max_nlev + 1;
-    const size_t lds = ((size_t)2 * a.r_pad + 4 * (size_t)S + 2 * (size_t)a.arc_cap) * sizeof(double) +
+    const size_t lds = ((size_t)2 * a.r_pad + 5 * (size_t)S + 2 * (size_t)a.arc_cap) * sizeof(double) +
                        ((size_t)2 * a.arc_cap + 2 * (size_t)(a.r_pad + 2) + 3 * (size_t)a.r_pad + a.lev_cap + 4) * sizeof(int32_t);
     if (lds > 150 * 1024) {
         gh_set_error("gh_forward_backward: %d rows + %d states need %zu B of LDS", lat->max_R, S, lds);
@@ -560,6 +579,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     if (out_beta) GH_HIP(hipMemcpyAsync(out_beta, d_beta, n_mat * 8, hipMemcpyDeviceToHost, st));
     if (out_gamma) GH_HIP(hipMemcpyAsync(out_gamma, d_gamma, n_mat * 8, hipMemcpyDeviceToHost, st));
     if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, st));
+    if (out_self_xi) GH_HIP(hipMemcpyAsync(out_self_xi, d_selfxi, (size_t)S * 8, hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
     return GH_OK;
 }

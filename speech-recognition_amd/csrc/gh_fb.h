@@ -32,6 +32,7 @@ struct gh_fb_args {
     double* out_gamma;
     const int64_t* mat_off;      // [U+1]
     double* occ;                 // optional [N,S] frame x state occupancies
+    double* self_xi;             // optional [S]: expected number of self transitions per state (double atomics)
 };
 
 int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, size_t lds_bytes, bool f64);
@@ -49,5 +50,6 @@ struct gh_fbchain_args {
     const int64_t* scratch_off;  // [slots]
     double* logp;                // [U]
     double* occ;                 // optional [N,S], zeroed by the caller
+    double* self_xi_utt;         // optional [U, GH_FBCHAIN_MAX]: expected self transitions of every chain row of every utterance
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);

@@ -55,7 +55,8 @@ __global__ void fb_kernel(gh_fb_args a) {
     double* emB = emA + S;
     double* emC = emB + S;
     double* occ = emC + S;               // [S] occupancy of the current column
-    double* g_pcost = occ + S;           // [arc_cap]
+    double* xis = occ + S;               // [S] expected self transitions of this utterance
+    double* g_pcost = xis + S;           // [arc_cap]
     double* g_scost = g_pcost + a.arc_cap;
     int32_t* g_prow = reinterpret_cast<int32_t*>(g_scost + a.arc_cap);   // [arc_cap]
     int32_t* g_srow = g_prow + a.arc_cap;
@@ -169,7 +170,7 @@ __global__ void fb_kernel(gh_fb_args a) {
     em0 = emA; emn = emB;
     em_prefetch(T - 1);
     em_park(em0, T - 1);
-    for (int s = tid; s < S; s += bd) em1[s] = 0.0;
+    for (int s = tid; s < S; s += bd) { em1[s] = 0.0; xis[s] = 0.0; }
     // alpha column of every row this lane owns (rows i = tid, tid + bd, ... of the level order), one column ahead
     constexpr int FB_AL = 4;
     const bool al_regs = R <= FB_AL * bd;
@@ -204,7 +205,12 @@ __global__ void fb_kernel(gh_fb_args a) {
                 if (w & GH_ARC_SAME) {
                     lse_add(cur[s2] - g_scost[p] - (st2 >= 0 ? em0[st2] : 0.0), m, sm);
                 } else if (t + 1 < T) {
-                    lse_add(nxt[s2] - g_scost[p] - (st2 >= 0 ? em1[st2] : 0.0), m, sm);
+                    const double term = nxt[s2] - g_scost[p] - (st2 >= 0 ? em1[st2] : 0.0);
+                    lse_add(term, m, sm);
+                    if (a.self_xi && s2 == r && st2 >= 0) {      // xi_t(r -> r): alpha_t(r) a_rr b_r(x_{t+1}) beta_{t+1}(r) / P
+                        const double x = exp(av + term - logp);
+                        if (x == x && x != 0.0) atomicAdd(&xis[st2], x);
+                    }
                 }
             }
             const double bv = lse_val(m, sm);
@@ -238,6 +244,10 @@ __global__ void fb_kernel(gh_fb_args a) {
         { double* t_ = em1; em1 = em0; em0 = emn; emn = t_; }   // window slides down: (t, t+1) -> (t-1, t)
         fb_lds_barrier();
         for (int r = tid; r < R; r += bd) cur[r] = NEG;  // same-column reads see only rows of this column
+    }
+    if (a.self_xi) {
+        __syncthreads();
+        for (int s = tid; s < S; s += bd) if (xis[s] != 0.0) atomicAdd(a.self_xi + s, xis[s]);
     }
 }
 
@@ -318,10 +328,12 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     }
     const double logp = __shfl(al_last, (n > 0 ? n - 1 : 0), NMAX);
     if (has_utt && j == 0 && T > 0 && a.logp) a.logp[u] = logp;
-    if (!a.occ) return;
+    if (!a.occ && !a.self_xi_utt) return;
     // ---- backward: beta in a register, gamma straight into the occupancy rows (e holds column T-1) ----
     auto load_a = [&](int t) -> double { return (act && t >= 0 && t < T) ? alpha[(int64_t)t * n + j] : NEG; };
     double be = (act && j == n - 1) ? 0.0 : NEG;
+    double xi_acc = 0.0;                      // expected self transitions of this row (when asked for)
+    const bool want_xi = a.self_xi_utt != nullptr;
     double ap = load_a(T - 1);
     double aring[PD];
 #pragma unroll
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
             const int tw = t0 - k;              // column index of the wave's longest utterance
             if (tw < 0) break;
             const int t = tw - (Tmax - T);      // this utterance's column (negative: it has not started yet)
-            if (act && t >= 0) {
+            if (a.occ && act && t >= 0) {
                 double g = exp(ap + be - logp);
                 if (!(g == g)) g = 0.0;
                 a.occ[(f0 + t) * a.S + st] = g;
@@ -345,10 +357,15 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
             const double b1 = (j + 1 < n) ? d1 - c_out1 : NEG;
             const double b2 = (j + 2 < n) ? d2 - c_out2 : NEG;
             const double nb = skip ? lse3(b0, b1, b2) : lse2(b0, b1);
+            if (want_xi && act && t > 0) {       // xi_t(j -> j) = alpha_{t-1}(j) a_jj b_j(x_t) beta_t(j) / P
+                const double x = exp(aring[k] + b0 - logp);
+                if (x == x) xi_acc += x;
+            }
             if (act && t > 0) { be = nb; ap = aring[k]; e = (double)ering[k]; }
             if (t >= 0) { aring[k] = load_a(t - 1 - PD); ering[k] = load_e(t - 1 - PD); }
         }
     }
+    if (want_xi && has_utt) a.self_xi_utt[u * NMAX + j] = act ? xi_acc : 0.0;
 }
 
 }  // namespace

@@ -77,7 +77,7 @@ SIGNATURES = {
     "gh_em_accumulate_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.POINTER(C.c_uint8), C.c_int, _c_f64p,
                                          _c_f64p, _c_f64p, _c_f64p, _c_f64p, C.c_void_p]),
     "gh_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, C.c_int, _c_f64p, _c_f64p, _c_f64p,
-                                      _c_f64p, _c_i64p, _c_f64p]),
+                                      _c_f64p, _c_i64p, _c_f64p, _c_f64p]),
     "gh_bw_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _c_f64p, C.c_void_p]),
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
@@ -591,7 +591,7 @@ class Lattices:
             out["labels"] = [labels[label_off[u]:label_off[u] + n_labels[u]] for u in range(U)]
         return out
 
-    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True):
+    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True, want_self_xi=False):
         """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].
         want_occ keeps the frame x state occupancies resident in the batch (input of bw_accumulate);
         fetch_occ=False skips the [N,S] device-to-host copy."""
@@ -607,10 +607,13 @@ class Lattices:
             al, be, ga = (np.empty(int(off[-1])) for _ in range(3))
         if want_occ and fetch_occ:
             occ = np.empty((batch.N, batch.S))
+        xi = np.zeros(batch.S) if want_self_xi else None
         _check(lib, lib.gh_forward_backward(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), int(want_occ),
                                             _ptr(logp, _c_f64p), _ptr(al, _c_f64p), _ptr(be, _c_f64p),
-                                            _ptr(ga, _c_f64p), _ptr(off, _c_i64p), _ptr(occ, _c_f64p)))
+                                            _ptr(ga, _c_f64p), _ptr(off, _c_i64p), _ptr(occ, _c_f64p), _ptr(xi, _c_f64p)))
         out = dict(logp=logp)
+        if xi is not None:
+            out["self_xi"] = xi   # expected number of self transitions per state
         if want_matrices:
             cut = lambda m: [m[off[u]:off[u + 1]].reshape(int(self.R[lidx[u]]), int(T[u])) for u in range(U)]
             out.update(alpha=cut(al), beta=cut(be), gamma=cut(ga))

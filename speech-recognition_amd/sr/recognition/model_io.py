@@ -16,7 +16,7 @@ import numpy as np
 from .hmm import HMM
 from .hmm_state import GMM
 
-__all__ = ["save_models_pickle", "load_models_pickle", "save_models_npz", "load_models_npz"]
+__all__ = ["save_models_pickle", "load_models_pickle", "save_models_npz", "load_models_npz", "models_from_arrays"]
 
 
 def save_models_pickle(path, models, protocol=2):
@@ -49,24 +49,33 @@ def save_models_npz(path, models):
                         use_em=np.array([bool(m.use_em) for m in models]), **extra)
 
 
-def load_models_npz(path):
-    """Inverse of `save_models_npz`: list of HMM objects (fresh state ids)."""
-    z = np.load(path, allow_pickle=False)
-    assert str(z["format"]) == "gmmhmm-npz-1", "not a gmmhmm npz model file"
-    means, vars_, w, trans = z["means"], z["vars"], z["weights"], z["transitions"]
+def models_from_arrays(means, vars_, weights, transitions, mu=None, sigma=None, use_em=True):
+    """HMM objects (fresh state ids) from packed arrays: means / vars_ [W, n, M, D], weights [W, n, M],
+    transitions [W, n, n] (or a list of W matrices)."""
+    means, vars_, weights = (np.asarray(a, dtype=np.float64) for a in (means, vars_, weights))
     W, n, M, D = means.shape
     out = []
     for i in range(W):
         h = HMM(n)
         h.use_gmm = True
-        h.use_em = bool(z["use_em"][i])
+        h.use_em = bool(use_em if np.isscalar(use_em) else use_em[i])
         h.gmm_states = []
         for s in range(n):
             g = GMM(means[i, s, 0].copy(), vars_[i, s, 0].copy(), M)
-            g.update_models(means[i, s].copy(), vars_[i, s].copy(), w[i, s].copy())
+            g.update_models(means[i, s].copy(), vars_[i, s].copy(), weights[i, s].copy())
+            g.parent = h
             h.gmm_states.append(g)
-        h.transitions = trans[i].copy()
-        if "mu" in z.files:
-            h.mu, h.sigma = z["mu"][i].copy(), z["sigma"][i].copy()
+        h.transitions = np.array(transitions[i], dtype=np.float64)
+        if mu is not None and sigma is not None:
+            h.mu, h.sigma = np.array(mu[i], dtype=np.float64), np.array(sigma[i], dtype=np.float64)
         out.append(h)
     return out
+
+
+def load_models_npz(path):
+    """Inverse of `save_models_npz`: list of HMM objects (fresh state ids)."""
+    z = np.load(path, allow_pickle=False)
+    assert str(z["format"]) == "gmmhmm-npz-1", "not a gmmhmm npz model file"
+    has_mu = "mu" in z.files
+    return models_from_arrays(z["means"], z["vars"], z["weights"], z["transitions"], z["mu"] if has_mu else None,
+                              z["sigma"] if has_mu else None, use_em=z["use_em"])

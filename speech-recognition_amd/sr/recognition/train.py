@@ -9,11 +9,15 @@ GPUs of a node.  This module is that loop; it is NEW functionality (SURVEY.md A1
 from the same graphs (`packed_lattice`) and the same centred-statistics layout as `GMM.em`.
 
 One EM iteration, per rank (utterances are sharded, models replicated):
-    gh_loglik            frame x state likelihoods of the rank's frames        (HIP, MFMA)
-    gh_forward_backward  log P(u), per-frame state occupancies                 (HIP)
-    gh_bw_accumulate     [S, M, 1+2D] centred statistics of the rank           (HIP)
-    all-reduce           ONE packed fp64 buffer (stats + counts + log P)       (RCCL / gloo)
-    m_step               new means / variances / weights                       (host, tiny)
+    gh_loglik_subset     likelihoods of every utterance's own states                            (HIP, MFMA)
+    gh_forward_backward  log P(u), per-frame state occupancies, expected self transitions       (HIP)
+    gh_bw_accumulate     [S, M, 1+2D] centred statistics of the rank                            (HIP)
+    all-reduce           ONE packed fp64 buffer (statistics + self transitions + log P + count) (RCCL / gloo)
+    m_step               new means / variances / weights, new transition costs                  (host, tiny)
+The loop around it is the reference's training loop in its soft form (continuous_speech.py:144-179): transition
+costs re-estimated every iteration (-log p_jump / -log(1 - p_jump), :146-164, with expected instead of counted
+segments), one pickle per word model and iteration (:167-170), stop when every mixture is `allclose` to the previous
+iteration's (:172-179; transitions are not compared there either).
 """
 import numpy as np
 
@@ -28,57 +32,75 @@ class BaumWelchTrainer:
     """Soft EM over word-level transcriptions.
 
     means / vars_ / weights: [W, n, M, D] / [W, n, M, D] / [W, n, M] word-state mixtures;
-    transitions: list of W [n, n] cost matrices (kept fixed);
+    transitions: list of W [n, n] cost matrices (re-estimated every iteration unless update_transitions=False);
     data: list of [T_u, D] utterances of THIS rank; label_seqs: word indices per utterance.
     var_floor: lower bound of the re-estimated variances; None (default) = 1e-6 x the mean variance of the
     initial model -- the centred single-pass variance can cancel to 0 (or slightly below) for a component
-    that holds on to a single frame, and a non-positive variance is a LinAlgError in the next E-step."""
+    that holds on to a single frame, and a non-positive variance is a LinAlgError in the next E-step.
+    output_path: directory that receives `<word index>.pkl` (reference-compatible HMM pickles) after every iteration,
+    written by rank 0 only."""
 
     def __init__(self, means, vars_, weights, transitions, data, label_seqs, device=None, reducer=None,
-                 var_floor=None, occ_floor=0.0, min_occupancy=1e-8):
+                 var_floor=None, occ_floor=0.0, min_occupancy=1e-8, update_transitions=True, output_path=None):
         self.ctx = _hip.default_context(device)
         self.W, self.n, self.M, self.D = means.shape
         self.S = self.W * self.n
         self.means = np.array(means, dtype=np.float64).reshape(self.S, self.M, self.D)
         self.vars = np.array(vars_, dtype=np.float64).reshape(self.S, self.M, self.D)
         self.weights = np.array(weights, dtype=np.float64).reshape(self.S, self.M)
+        self.transitions = [np.array(t, dtype=np.float64) for t in transitions]
+        self.update_transitions = bool(update_transitions)
+        self.output_path = output_path
         self.var_floor = 1e-6 * float(np.mean(self.vars)) if var_floor is None else float(var_floor)
         self.occ_floor, self.min_occupancy = occ_floor, float(min_occupancy)
         self.reducer = reducer if reducer is not None else StatsAllReducer(gpu_index=self.ctx.device)
         self.batch = _hip.Batch(self.ctx, data)
-        keys, graphs = {}, []
+        keys = {}
+        self.graph_labels = []
         self.utt_graph = np.empty(len(label_seqs), dtype=np.int32)
         for u, labels in enumerate(label_seqs):
             key = tuple(int(l) for l in labels)
             if key not in keys:
-                keys[key] = len(graphs)
-                graphs.append(packed_lattice(transitions, self.n, [[l] for l in key])[0])
+                keys[key] = len(self.graph_labels)
+                self.graph_labels.append(key)
             self.utt_graph[u] = keys[key]
-        self.lat = _hip.Lattices(self.ctx, graphs) if graphs else None
+        self.lat = None
+        self._build_lattices()
         # an utterance's alignment only involves the states of its own words: likelihoods for that range only
         lo = np.array([min(int(l) for l in labels) * self.n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
         hi = np.array([(max(int(l) for l in labels) + 1) * self.n if len(labels) else self.S for labels in label_seqs],
                       dtype=np.int32)
         self.state_ranges = (lo, hi)
         self.history = []
+        self.converged = False
         self.n_stats = self.S * self.M * (1 + 2 * self.D)
         self.last_timing = {}
 
-    # layout of the ONE buffer that crosses ranks: [statistics S*M*(1+2D) | total log-likelihood | utterances]
+    def _build_lattices(self):
+        """One forced-alignment graph per distinct label sequence, from the current transition costs."""
+        if self.lat is not None:
+            self.lat.close()
+        graphs = [packed_lattice(self.transitions, self.n, [[l] for l in key])[0] for key in self.graph_labels]
+        self.lat = _hip.Lattices(self.ctx, graphs) if graphs else None
+
+    # layout of the ONE buffer that crosses ranks:
+    #   [statistics S*M*(1+2D) | expected self transitions S | total log-likelihood | utterances]
     def _packed_len(self):
-        return self.n_stats + 2
+        return self.n_stats + self.S + 2
 
     def e_step(self, stats_dev=None):
-        """Returns (stats [S,M,1+2D] or None when they were left in `stats_dev`, total log-likelihood) of this rank."""
+        """Returns (stats [S,M,1+2D] or None when they were left in `stats_dev`, expected self transitions [S],
+        total log-likelihood) of this rank."""
         gmm = _hip.PackedGMM(self.ctx, self.means, self.vars, self.weights)
         try:
             if self.batch.U == 0:
-                return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), 0.0
+                return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), np.zeros(self.S), 0.0
             self.batch.loglik(gmm, fetch=False, state_ranges=self.state_ranges)
-            r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False)
+            r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False,
+                                          want_self_xi=True)
             stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor, stats_dev=stats_dev, fetch=stats_dev is None)
             logp = r["logp"]
-            return stats, float(np.sum(logp[np.isfinite(logp)]))
+            return stats, r["self_xi"], float(np.sum(logp[np.isfinite(logp)]))
         finally:
             gmm.close()
 
@@ -92,18 +114,20 @@ class BaumWelchTrainer:
             buf, ptr = red.device_buffer(self._packed_len())
             if self.batch.U == 0:
                 buf.zero_()
-            _, ll = self.e_step(stats_dev=ptr)
-            buf[self.n_stats:] = red.torch.tensor([ll, float(self.batch.U)], dtype=red.torch.float64)
+            _, xi, ll = self.e_step(stats_dev=ptr)
+            buf[self.n_stats:] = red.torch.from_numpy(np.concatenate([xi, [ll, float(self.batch.U)]]))
             t1 = time.perf_counter()
             packed = red.reduce_device()                     # the ONE collective of the iteration
         else:
-            stats, ll = self.e_step()
-            packed = np.concatenate([stats.reshape(-1), [ll, float(self.batch.U)]])
+            stats, xi, ll = self.e_step()
+            packed = np.concatenate([stats.reshape(-1), xi, [ll, float(self.batch.U)]])
             t1 = time.perf_counter()
             packed = red(packed)                            # the ONE collective of the iteration (gloo / single rank)
         t2 = time.perf_counter()
         stats = packed[:self.n_stats].reshape(self.S, self.M, 1 + 2 * self.D)
-        ll = float(packed[self.n_stats])
+        xi = packed[self.n_stats:self.n_stats + self.S]
+        ll = float(packed[self.n_stats + self.S])
+        old = (self.means.copy(), self.vars.copy(), self.weights.copy())
         counts = stats[:, :, 0].sum(axis=1)                  # responsibilities of a state add up to its occupancy
         seen = counts > 0
         mu, sigma, w = m_step(stats[seen], counts[seen], self.means[seen])
@@ -112,16 +136,68 @@ class BaumWelchTrainer:
         self.means[seen] = np.where(ok[:, :, None], mu, self.means[seen])
         self.vars[seen] = np.where(ok[:, :, None], sigma, self.vars[seen])
         self.weights[seen] = np.where(ok, w, self.weights[seen])
+        if self.update_transitions:
+            self._update_transitions(counts, xi)
         self.history.append(ll)
+        # the reference's stop rule (continuous_speech.py:172-179 -> GMM.__eq__): every mixture allclose to the last one's
+        self.converged = bool(np.allclose(self.weights, old[2]) and np.allclose(self.means, old[0]) and
+                              np.allclose(self.vars, old[1]))
+        if self.output_path is not None and self._is_writer():
+            self.save(self.output_path)
         self.last_timing = dict(e_step_s=t1 - t0, allreduce_s=t2 - t1, m_step_s=time.perf_counter() - t2)
         return ll
 
-    def fit(self, n_iterations=5):
+    def _update_transitions(self, counts, self_xi):
+        """continuous_speech.py:146-164 with expected counts: p_jump = segments / frames of the state, where the
+        expected number of segments (visits) is frames - self transitions; cost(s -> s+1) = -log p_jump (not for
+        the last state), cost(s -> s) = -log(1 - p_jump).  States without frames keep their costs (:149-153)."""
+        changed = False
+        for wi in range(self.W):
+            t = self.transitions[wi]
+            for si in range(self.n):
+                s = wi * self.n + si
+                if not counts[s] > 0:
+                    continue
+                p_stay = min(max(self_xi[s] / counts[s], 0.0), 1.0)
+                with np.errstate(divide="ignore"):
+                    if si < self.n - 1:
+                        t[si + 1, si] = -np.log(1.0 - p_stay)
+                    t[si, si] = -np.log(p_stay)
+                changed = True
+        if changed:
+            self._build_lattices()
+
+    def _is_writer(self):
+        red = self.reducer
+        return not (red.enabled and red.dist.get_rank() != 0)
+
+    def models(self):
+        """The current parameters as reference-compatible HMM objects (one per word)."""
+        from .model_io import models_from_arrays
+        shp = (self.W, self.n, self.M, self.D)
+        return models_from_arrays(self.means.reshape(shp), self.vars.reshape(shp), self.weights.reshape(shp[:3]),
+                                  self.transitions, mu=self.means.reshape(shp)[:, :, 0], sigma=self.vars.reshape(shp)[:, :, 0])
+
+    def save(self, output_path):
+        """`<word index>.pkl` per model, like continuous_speech.py:167-170."""
+        import os
+        import pickle
+        os.makedirs(output_path, exist_ok=True)
+        for i, m in enumerate(self.models()):
+            with open(os.path.join(output_path, str(i) + '.pkl'), 'wb') as f:
+                pickle.dump(m, f)
+
+    def fit(self, n_iterations=5, until_converged=False):
+        """n_iterations EM iterations; with until_converged the loop ends early once an iteration leaves every mixture
+        allclose to the previous one (continuous_speech.py:172-179), the reference's max_iteration otherwise."""
         for _ in range(n_iterations):
             self.iteration()
+            if until_converged and self.converged:
+                break
         return self.history
 
     def close(self):
         self.batch.close()
         if self.lat is not None:
             self.lat.close()
+            self.lat = None

@@ -129,7 +129,8 @@ def test_c3_em_statistics_of_sampled_states_vs_numpy():
     from sr.recognition import _hip
     means, vars_, w, trans, data, labels = c3_problem()
     tr = BaumWelchTrainer(means, vars_, w, trans, data, labels)
-    stats, ll = tr.e_step()
+    stats, xi, ll = tr.e_step()
+    assert xi.shape == (tr.S,) and np.all(xi >= 0) and np.all(xi <= stats[:, :, 0].sum(axis=1) + 1e-6)
     assert np.isfinite(ll) and ll < 0
     gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
     tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)
@@ -160,7 +161,7 @@ def test_c3_em_statistics_of_sampled_states_vs_numpy():
 def test_c3_em_likelihood_is_monotone_and_recovers_the_model():
     from sr.recognition.train import BaumWelchTrainer
     means, vars_, w, trans, data, labels = c3_problem()
-    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels)
+    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, update_transitions=False)   # (fixed transitions: the EM guarantee)
     hist = tr.fit(5)
     assert all(b >= a - 1e-9 * abs(a) for a, b in zip(hist, hist[1:])), hist
     assert hist[-1] > hist[0]
@@ -246,3 +247,67 @@ def test_fp32_loglik_on_unstandardised_features(offset):
     b32.close()
     b64.close()
     gmm.close()
+
+
+def test_c3_training_loop_transitions_convergence_and_pickles(tmp_path):
+    """The soft form of the reference's training loop (continuous_speech.py:144-179) at the configs[2] shape:
+    transition costs re-estimated from expected counts, one pickle per word model and iteration, the reference's stop
+    rule -- and the emitted pickles are HMM objects that score like the trainer's own parameters."""
+    import pickle
+    from sr.recognition.train import BaumWelchTrainer
+    from sr.recognition import _hip
+    import sr.recognition as R
+    means, vars_, w, trans, data, labels = c3_problem(800)
+    out = str(tmp_path / "models")
+    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, output_path=out)
+    t0 = [t.copy() for t in tr.transitions]
+    stats, xi, _ = tr.e_step()
+    counts = stats[:, :, 0].sum(axis=1)
+    # expected self transitions of a few states from the forward / backward matrices of the generic kernel
+    gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
+    tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)
+    nll = tr.batch.loglik(gmm, fetch=True)
+    r = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_matrices=True, want_self_xi=True)
+    np.testing.assert_allclose(r["self_xi"], xi, rtol=1e-9, atol=1e-9)       # generic kernel (atomics) == chain kernel
+    ref = np.zeros(tr.S)
+    n = tr.n
+    for u in range(0, tr.batch.U, 40):
+        wd = labels[u][0]
+        al, be, lp = r["alpha"][u], r["beta"][u], r["logp"][u]
+        E = nll[tr.batch.offsets[u]:tr.batch.offsets[u + 1], wd * n:(wd + 1) * n].T      # [n, T]
+        rows = [k for k in range(al.shape[0]) if al.shape[0] == n or 1 <= k <= n]          # (chain may be NES-wrapped)
+        for j, k in enumerate(rows[:n]):
+            c_self = t0[wd][j, j]
+            ref[wd * n + j] += np.exp(al[k, :-1] - c_self - E[j, 1:] + be[k, 1:] - lp).sum()
+    got = np.zeros(tr.S)
+    sub = _hip.Batch(tr.ctx, [data[u] for u in range(0, tr.batch.U, 40)])
+    lo = np.array([labels[u][0] * n for u in range(0, tr.batch.U, 40)], dtype=np.int32)
+    sub.loglik(gmm, fetch=False, state_ranges=(lo, lo + n))
+    got = tr.lat.forward_backward(sub, utt_lattice=tr.utt_graph[::40], want_self_xi=True)["self_xi"]
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10)
+    sub.close()
+    gmm.close()
+    hist = tr.fit(30, until_converged=True)
+    assert tr.converged and len(hist) < 30, len(hist)
+    assert hist[-1] > hist[0]
+    for wi in range(tr.W):
+        t = tr.transitions[wi]
+        assert np.all(np.isfinite(np.diag(t))) and not np.allclose(np.diag(t), np.diag(t0[wi]))
+        for si in range(n - 1):       # a proper pair of probabilities on every non-final state
+            np.testing.assert_allclose(np.exp(-t[si, si]) + np.exp(-t[si + 1, si]), 1.0, rtol=1e-9)
+        assert np.all(np.isinf(t[np.triu_indices(n, 1)]))
+    files = sorted(os.listdir(out))
+    assert files == sorted("%d.pkl" % i for i in range(tr.W))
+    models = [pickle.load(open(os.path.join(out, "%d.pkl" % i), "rb")) for i in range(tr.W)]
+    assert all(type(m) is R.HMM and sorted(m.__dict__) == ["gmm_states", "mu", "n_segments", "segments", "sigma",
+                                                           "transitions", "use_em", "use_gmm"] for m in models)
+    for wi in (0, 7):
+        np.testing.assert_array_equal(models[wi].transitions, tr.transitions[wi])
+        np.testing.assert_array_equal(np.array([[d.mean for d in g.dists] for g in models[wi].gmm_states]),
+                                      tr.means.reshape(tr.W, n, tr.M, tr.D)[wi])
+    # the pickled models recognise their own training words
+    from sr.recognition.batch import IsolatedWordRecognizer
+    rec = IsolatedWordRecognizer(models)
+    words, _ = rec.recognize(data[:200])
+    assert np.mean(words == np.array([l[0] for l in labels[:200]])) == 1.0
+    tr.close()
