@@ -1,0 +1,408 @@
+// Baum-Welch sufficient statistics on the matrix cores end to end, for batches whose forward-backward ran on one-word
+// chain graphs (gh_fbchain: isolated-word EM, BASELINE configs[2]).  NOT in the reference (it trains by Viterbi
+// alignment); the statistics are those of gh_bw_accumulate (include/gmmhmm.h):
+//     r_nsm = gamma_ns * w_sm pdf_sm(x_n) / sum_m' w_sm' pdf_sm'(x_n)
+//     stats[s, m] = [ sum r | sum r (x - mean_sm) | sum r (x - mean_sm)^2 ].
+//
+// What the first version (bw_stats_kernel, gh_train.hip) paid for: component densities on the VALU (lane = (frame,
+// component), 39 x 3 flops each), a frame x state occupancy matrix [N, S] that is cleared and 90 % zeros, and a
+// read-modify-write of the workgroup's 253 KB slab per (utterance, state).  Here
+//   * gamma comes straight from fb_chain_kernel as a compact [N, 8] matrix (one column per chain row);
+//   * the component log-densities are a GEMM, D[frame, comp] = C[comp] + Z'[frame, :] . P[comp, :] with
+//     Z' = [x^2 | x] -- v_mfma_f64_16x16x4 with the FRAMES on the rows, so the result registers (lane = component,
+//     registers = 4 frames) are directly the B operand of the accumulation GEMM: nothing is transposed, nothing
+//     goes through LDS between the two GEMMs;
+//   * the log-sum-exp over a state's 8 components runs across 8 lanes (two quad_perm steps + row_half_mirror), in the
+//     scaled log domain of the likelihood kernel (exp2 by table + degree-4 polynomial, gh_loglik_mfma.hip);
+//   * accumulation G^T[Zcol, comp] += Z[frame, Zcol] * r[frame, comp] with Z = [x - c, 1 | (x - c)^2] (c = a centre
+//     shared by the two states a wave owns; the component-centred sums follow algebraically at the very end; the two
+//     halves are padded to whole 16-column tiles so that a tile is either linear or squared for every lane, and the
+//     ones column is the first padding column of the linear half: x = 0 there, "centre" -1),
+//     accumulators PERSISTENT in registers over all utterances of the workgroup: utterances are grouped by graph
+//     (= word), a wave owns a PAIR of states (16 = 2 x 8 component columns), a workgroup = the pairs of one word;
+//   * one raw [80, 16] tile per wave leaves the workgroup; a small kernel sums the tiles of a pair over its
+//     workgroups in a fixed order and converts them (deterministic, no float atomics).
+#include "gh_internal.h"
+#include "gh_host.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct bwf_wg { int32_t graph, u_begin, u_end, pad; };           // utterances ulist[u_begin, u_end) of one graph
+struct bwf_pair { int32_t sa, sb, wg_begin, wg_end, p, pad; };    // state pair p of a graph, its workgroups
+
+__device__ __forceinline__ double bwf_vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ double bwf_dpp(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 8 lanes {8g .. 8g+7}: xor 1 (quad_perm 1,0,3,2), xor 2 (quad_perm 2,3,0,1), then the mirror image
+// inside the half row (lane i <-> 7 - i): every lane of one quad meets a lane of the other
+__device__ __forceinline__ double max8(double v) {
+    v = bwf_vmax(v, bwf_dpp<0xB1>(v));
+    v = bwf_vmax(v, bwf_dpp<0x4E>(v));
+    v = bwf_vmax(v, bwf_dpp<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ double sum8(double v) {
+    v += bwf_dpp<0xB1>(v);
+    v += bwf_dpp<0x4E>(v);
+    v += bwf_dpp<0x141>(v);
+    return v;
+}
+// 2^(y/128) for finite y <= 0 (or NaN): table + degree-4 polynomial (see gh_loglik_mfma.hip, exp2s)
+__device__ __forceinline__ double bwf_exp2s(double y, const double* __restrict__ tab) {
+    const double n = __builtin_rint(y);
+    const double r = y - n;
+    const int ni = (int)n;
+    const double t = tab[ni & 127];
+    double p = fma(r, 3.583032305400251285e-11, 2.6466421444330968834e-08);
+    p = fma(p, r, 1.4662262387640424337e-05);
+    p = fma(p, r, 5.4152123481245727298e-03);
+    p = p * r;
+    return __builtin_ldexp(fma(t, p, t), ni >> 7);
+}
+
+// KS = k-steps of the density GEMM (K = 4 KS = 2 KP), LT = 16-column tiles of each half of Z (D + 1 <= 16 LT)
+template <int KS, int LT>
+__global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
+                                                       const double* __restrict__ mean, const double* __restrict__ ivar,
+                                                       const double* __restrict__ logc, const double* __restrict__ gam,
+                                                       double occ_floor, const int64_t* __restrict__ utt_off,
+                                                       const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
+                                                       const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
+                                                       double* __restrict__ partial) {
+    constexpr int KP = 2 * KS;            // padded feature length
+    constexpr int TF = 32;                // frames staged per tile
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int DP = KP | 1;                // odd LDS row stride >= KP: columns D .. KP-1 stay zero, so the operand reads
+                                          // below need no bounds test (a conditional ds_read costs an exec-mask branch and
+                                          // its own s_waitcnt: 25 serialised LDS round trips per 16-frame block)
+    double* xt = sm;                      // [TF][DP]
+    double* gt = xt + TF * DP;            // [TF][8]  gamma of the tile's frames
+    double* tab = gt + TF * 8;            // [128]    2^(j/128)
+    const int tid = threadIdx.x, lane = tid & 63, p = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const bwf_wg wg = wgs[blockIdx.x];
+    const gh_fbchain* ch = chains + wg.graph;
+    const int n = ch->n;
+    for (int i = tid; i < 128; i += blockDim.x) tab[i] = tables[i];
+    for (int i = tid; i < TF * DP; i += blockDim.x) xt[i] = 0.0;
+    // ---- this wave's pair of states: operands that stay in registers for the whole workgroup ----
+    const bool wave_on = 2 * p < n;
+    const int sa = wave_on ? ch->state[2 * p] : 0;
+    const int sb = (2 * p + 1 < n) ? ch->state[2 * p + 1] : -1;
+    const int s_j = (j < 8) ? sa : sb;
+    const int m_j = j & 7;
+    const bool valid = wave_on && s_j >= 0 && m_j < M;
+    const int64_t g_j = valid ? (int64_t)s_j * M + m_j : 0;
+    const int grow = 2 * p + (j >> 3);    // chain row (gamma column) of this lane's state
+    double P[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + q;
+        const int d = (k < KP) ? k : k - KP;
+        double v = 0.0;
+        if (valid && d < D) {
+            const double iv = ivar[g_j * D + d];
+            v = (k < KP) ? -0.5 * iv : mean[g_j * D + d] * iv;
+        }
+        P[ks] = v * GH_LSE_SCALE64;
+    }
+    double Cj = GH_LSE_OFF64;
+    if (valid) {
+        double sm2 = 0;
+        for (int d = 0; d < D; ++d) { const double mu = mean[g_j * D + d]; sm2 = fma(mu * ivar[g_j * D + d], mu, sm2); }
+        const double c = logc[g_j] - 0.5 * sm2;
+        Cj = (c == -INFINITY) ? GH_LSE_OFF64 : bwf_vmax(c * GH_LSE_SCALE64, GH_LSE_OFF64);
+    }
+    // accumulation operand A = Z^T: this lane feeds Z column 16 ct + j of every tile
+    // accumulation operand A = Z^T: this lane feeds column 16 t + j of the linear tiles (x[d] - c[d]; d = D: the ones
+    // column, read from the zero padding with "centre" -1) and of the squared tiles
+    constexpr int NCT = 2 * LT;
+    int dd[LT];
+    double cs[LT];
+    v4d acc[NCT];
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+        const int d = t * 16 + j;
+        dd[t] = (d <= D && d < DP) ? d : D;                     // columns behind the ones column read the zero padding too
+        cs[t] = (d < D) ? (wave_on ? mean[(int64_t)sa * M * D + d] : 0.0) : (d == D ? -1.0 : 0.0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (v4d){0, 0, 0, 0};
+    __syncthreads();
+
+    // The (utterance, 32-frame tile) sequence of the workgroup is walked with the NEXT tile's frames and gammas already
+    // travelling from HBM into registers while the current tile is computed: staging a tile used to park all waves of
+    // the workgroup for a full memory round trip (SQ_WAIT_ANY was 42 % of the wave cycles).  256 threads always (the
+    // waves without a state pair only help to stage): 5 frame elements + 1 gamma per thread cover a 32 x 40 tile.
+    constexpr int PX = (TF * KP + 255) / 256;
+    int ui = wg.u_begin, t0 = 0, T = 0;
+    int64_t f0 = 0;
+    auto open_utt = [&]() {
+        while (ui < wg.u_end) {
+            const int64_t u = ulist[ui];
+            f0 = utt_off[u];
+            T = (int)(utt_off[u + 1] - f0);
+            t0 = 0;
+            if (T > 0) return true;
+            ++ui;
+        }
+        return false;
+    };
+    double pre_x[PX], pre_g;
+    auto prefetch = [&]() {   // tile (f0 + t0, min(TF, T - t0) frames) -> registers
+        const int nf_ = (T - t0 < TF) ? T - t0 : TF;
+        const double* src = X + (f0 + t0) * D;
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int i = tid + 256 * e;
+            pre_x[e] = (i < nf_ * D) ? src[i] : 0.0;
+        }
+        pre_g = (tid < nf_ * 8) ? gam[(f0 + t0) * 8 + tid] : 0.0;
+    };
+    bool have = open_utt();
+    if (have) prefetch();
+    while (have) {
+        const int nf = (T - t0 < TF) ? T - t0 : TF;
+        __syncthreads();                      // every wave is done with the previous tile
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int i = tid + 256 * e;
+            if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = pre_x[e]; }   // rows >= nf arrive as zeros
+        }
+        gt[tid] = pre_g;
+        // the tile after this one
+        t0 += TF;
+        if (t0 >= T) { ++ui; have = open_utt(); }
+        if (have) prefetch();
+        __syncthreads();
+        {
+            if (wave_on)
+            for (int bf = 0; bf < nf; bf += 16) {
+                // ---- component log-densities of 16 frames x 16 components (scaled log domain) ----
+                v4d da = (v4d){Cj, Cj, Cj, Cj};
+                const double* xr = xt + (bf + j) * DP + q;       // A operand: row = frame bf + j, columns q, q + 4, ...
+                double xa[KS / 2];
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks) xa[ks] = xr[4 * ks];             // (KS is even: k < KP <=> ks < KS / 2)
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks] * xa[ks], P[ks], da, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], P[KS / 2 + ks], da, 0, 0, 0);
+                // ---- responsibilities: lane = component j, register r = frame bf + q + 4 r ----
+                double R[4];
+#ifdef BWF_NOEPI     // diagnostic build: no responsibilities (MFMAs and operand traffic only)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[r] = da[r];
+#else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fr = bf + q + 4 * r;
+                    const double y = da[r];
+                    const double mx = max8(y);
+                    const double e = bwf_exp2s(y - mx, tab);
+                    const double s8 = sum8(e);
+                    const double g = gt[fr * 8 + grow];
+                    const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
+                    double inv = __builtin_amdgcn_rcp(s8);
+                    inv = fma(fma(-s8, inv, 1.0), inv, inv);      // two Newton steps: full double accuracy
+                    inv = fma(fma(-s8, inv, 1.0), inv, inv);
+                    const double rv = e * (wgt * inv);
+                    R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? rv : 0.0;   // (every component off: s8 = 8, e = 1 -- killed by `valid`)
+                }
+#endif
+                // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames bf + {0..3} + 4 r ----
+                double zx[4][LT];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < LT; ++t) zx[r][t] = xt[(bf + q + 4 * r) * DP + dd[t]];   // all reads in flight
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < LT; ++t) {
+                        const double xv = zx[r][t] - cs[t];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, R[r], acc[t], 0, 0, 0);
+                        // (the ones column squares to 1 as well: row D of the squared half holds sum r, unused)
+                        acc[LT + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv * xv, R[r], acc[LT + t], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- one raw tile per wave: partial[wg][p][Zcol = 16 ct + q + 4 reg][comp j] ----
+    double* out = partial + ((int64_t)blockIdx.x * (blockDim.x >> 6) + p) * (NCT * 16 * 16);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(ct * 16 + q + 4 * r) * 16 + j] = acc[ct][r];
+}
+
+// sum a pair's raw tiles over its workgroups (in order), re-centre on the component means, write [S, M, 1 + 2D]
+__global__ __launch_bounds__(256) void bw_fused_reduce_kernel(const double* __restrict__ partial, const bwf_pair* __restrict__ pairs,
+                                                              int waves_per_wg, int lt, int D, int M,
+                                                              const double* __restrict__ mean, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double G[];      // [2*lt*16][16]: rows d < D linear, row D the occupancy, rows 16 lt + d squared
+    const bwf_pair pr = pairs[blockIdx.x];
+    const int len = 2 * lt * 16 * 16;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        double a = 0;
+        for (int w = pr.wg_begin; w < pr.wg_end; ++w) a += partial[((int64_t)w * waves_per_wg + pr.p) * len + i];
+        G[i] = a;
+    }
+    __syncthreads();
+    const int W = 1 + 2 * D;
+    for (int i = threadIdx.x; i < 2 * M * (D + 1); i += blockDim.x) {
+        const int h = i / (M * (D + 1)), rem = i - h * M * (D + 1);
+        const int m = rem / (D + 1), d = rem - m * (D + 1);
+        const int s = h ? pr.sb : pr.sa;
+        if (s < 0) continue;
+        const int jj = 8 * h + m;
+        const double s0 = G[D * 16 + jj];
+        double* o = out + ((int64_t)s * M + m) * W;
+        if (d == D) {
+            o[0] = s0;
+        } else {
+            const double dl = mean[((int64_t)s * M + m) * D + d] - mean[(int64_t)pr.sa * M * D + d];
+            const double g1 = G[d * 16 + jj], g2 = G[(16 * lt + d) * 16 + jj];
+            o[1 + d] = g1 - dl * s0;
+            o[1 + D + d] = g2 - dl * (2.0 * g1 - dl * s0);
+        }
+    }
+}
+
+// compact gamma -> the [N, S] occupancy matrix of the generic statistics kernel (pre-cleared by the caller)
+__global__ void expand_gam_kernel(const double* __restrict__ gam, const int64_t* __restrict__ utt_off, const int32_t* __restrict__ utt_graph,
+                                  const gh_fbchain* __restrict__ chains, int S, double* __restrict__ occ, int32_t* __restrict__ occ_states) {
+    const int64_t u = blockIdx.x;
+    const gh_fbchain* ch = chains + (utt_graph ? utt_graph[u] : 0);
+    const int n = ch->n;
+    if (threadIdx.x < GH_FBCHAIN_MAX) occ_states[u * GH_FBCHAIN_MAX + threadIdx.x] = threadIdx.x < n ? ch->state[threadIdx.x] : -1;
+    const int64_t f0 = utt_off[u], f1 = utt_off[u + 1];
+    for (int64_t i = f0 * GH_FBCHAIN_MAX + threadIdx.x; i < f1 * GH_FBCHAIN_MAX; i += blockDim.x) {
+        const int64_t f = i / GH_FBCHAIN_MAX;
+        const int jx = (int)(i - f * GH_FBCHAIN_MAX);
+        if (jx < n) occ[f * S + ch->state[jx]] = gam[i];
+    }
+}
+
+}  // namespace
+
+// shapes the fused kernel does not cover: the compact gamma becomes the full occupancy matrix for the generic kernel
+int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S) {
+    hipStream_t st = ctx->stream;
+    if (b->occ && b->occ_S != S) { GH_HIP(hipStreamSynchronize(st)); GH_HIP(hipFree(b->occ)); b->occ = nullptr; }
+    if (!b->occ) { GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8)); b->occ_S = S; }
+    if (!b->d_occ_states) GH_HIP(hipMalloc((void**)&b->d_occ_states, (size_t)b->U * GH_FBCHAIN_MAX * 4));
+    GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, st));
+    void* base;
+    const size_t L = b->gam_chains.size();
+    int rc = gh_scratch(ctx, L * sizeof(gh_fbchain) + 256 + (size_t)b->U * 4, &base);
+    if (rc) return rc;
+    gh_fbchain* d_chains = (gh_fbchain*)base;
+    int32_t* d_ug = (int32_t*)((char*)base + ((L * sizeof(gh_fbchain) + 255) & ~size_t(255)));
+    GH_HIP(hipMemcpyAsync(d_chains, b->gam_chains.data(), L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
+    if (!b->gam_utt_graph.empty()) GH_HIP(hipMemcpyAsync(d_ug, b->gam_utt_graph.data(), (size_t)b->U * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(expand_gam_kernel, dim3((unsigned)b->U), dim3(256), 0, st, b->gam, b->d_offsets,
+                       b->gam_utt_graph.empty() ? nullptr : d_ug, d_chains, S, b->occ, b->d_occ_states);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipStreamSynchronize(st));
+    b->occ_valid = true;
+    return GH_OK;
+}
+
+// returns 1 when the fused path does not cover the shapes (the caller uses the generic kernels), < 0 on error
+int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result) {
+    const int S = g->S, M = g->M, D = g->D, KS = g->KP / 2;
+    const int lt = (D + 1 + 15) / 16;     // 16-column tiles of each half of Z = [x - c, 1 | (x - c)^2]
+    if (!b->gam || b->gam_chains.empty() || M > 8 || lt > 3) return 1;
+    if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
+    const int L = (int)b->gam_chains.size();
+    // a state may only sit in one place of one graph (the re-centring kernel writes every state once)
+    std::vector<int> owner(S, -1);
+    int max_pairs = 1;
+    for (int l = 0; l < L; ++l) {
+        const gh_fbchain& fc = b->gam_chains[l];
+        for (int jx = 0; jx < fc.n; ++jx) {
+            if (fc.state[jx] < 0 || fc.state[jx] >= S || owner[fc.state[jx]] >= 0) return 1;
+            owner[fc.state[jx]] = l;
+        }
+        max_pairs = std::max(max_pairs, (fc.n + 1) / 2);
+    }
+    // utterances grouped by graph, longest first inside a graph; ~16 utterances per workgroup
+    const int64_t U = b->U;
+    std::vector<std::vector<int32_t>> by_graph(L);
+    for (int64_t k = 0; k < U; ++k) {
+        const int64_t u = b->perm[k];
+        if (b->offsets[u + 1] > b->offsets[u]) by_graph[b->gam_utt_graph.empty() ? 0 : b->gam_utt_graph[u]].push_back((int32_t)u);
+    }
+    // workgroups of 3 waves (5 states = 3 pairs): FOUR per CU put exactly three waves on every SIMD (with three per CU
+    // one SIMD carries three waves, the others two: the kernel ran at the pace of the fullest one)
+    const int target_wgs = (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 4) * ctx->n_cu;
+    const int per_wg = (int)std::max<int64_t>(4, (U + target_wgs - 1) / target_wgs);
+    std::vector<int32_t> ulist;
+    std::vector<bwf_wg> wgs;
+    std::vector<bwf_pair> pairs;
+    for (int l = 0; l < L; ++l) {
+        const int wg_begin = (int)wgs.size();
+        const auto& v = by_graph[l];
+        // deal the (length sorted) utterances round-robin so that every workgroup of the graph gets the same mix
+        const int nw = (int)((v.size() + per_wg - 1) / per_wg);
+        for (int w = 0; w < nw; ++w) {
+            bwf_wg x{l, (int32_t)ulist.size(), 0, 0};
+            for (size_t i = w; i < v.size(); i += nw) ulist.push_back(v[i]);
+            x.u_end = (int32_t)ulist.size();
+            wgs.push_back(x);
+        }
+        const gh_fbchain& fc = b->gam_chains[l];
+        for (int p = 0; 2 * p < fc.n; ++p)
+            pairs.push_back(bwf_pair{fc.state[2 * p], 2 * p + 1 < fc.n ? fc.state[2 * p + 1] : -1, wg_begin, (int32_t)wgs.size(), p, 0});
+    }
+    hipStream_t st = ctx->stream;
+    const int W = 1 + 2 * D;
+    const int tile_len = 2 * lt * 16 * 16;
+    int32_t* d_ulist; bwf_wg* d_wgs; bwf_pair* d_pairs; gh_fbchain* d_chains; double *d_part, *d_own;
+    Carver cv;
+    cv.add(&d_own, (size_t)S * M * W);
+    cv.add(&d_ulist, std::max<size_t>(1, ulist.size())); cv.add(&d_wgs, std::max<size_t>(1, wgs.size()));
+    cv.add(&d_pairs, std::max<size_t>(1, pairs.size())); cv.add(&d_chains, (size_t)L);
+    cv.add(&d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len);
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    double* d_out = stats_dev ? stats_dev : d_own;
+    *d_result = d_out;
+    GH_HIP(hipMemsetAsync(d_out, 0, (size_t)S * M * W * 8, st));
+    if (wgs.empty()) return GH_OK;
+    GH_HIP(hipMemcpyAsync(d_ulist, ulist.data(), ulist.size() * 4, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_wgs, wgs.data(), wgs.size() * sizeof(bwf_wg), hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(bwf_pair), hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_chains, b->gam_chains.data(), (size_t)L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
+    const size_t lds = ((size_t)32 * ((2 * KS) | 1) + 32 * 8 + 128) * 8;
+    const dim3 grid((unsigned)wgs.size()), blk(256);   // 256 threads always: see the staging loop of the kernel
+#define GH_BWF(ks, nc)                                                                                                   \
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, (const double*)b->feats, D, M, g->dMean, g->dIvar,  \
+                       g->dLogc, b->gam, occ_floor, b->d_offsets, d_ulist, d_wgs, d_chains, ctx->d_fp64_tables, d_part)
+#define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
+    switch (KS) {
+        case 2: GH_BWF_N(2) break;
+        case 4: GH_BWF_N(4) break;
+        case 8: GH_BWF_N(8) break;
+        case 12: GH_BWF_N(12) break;
+        default: GH_BWF_N(20) break;
+    }
+#undef GH_BWF_N
+#undef GH_BWF
+    GH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pairs.size()), dim3(256), (size_t)tile_len * 8, st, d_part, d_pairs,
+                       4, lt, D, M, g->dMean, d_out);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipStreamSynchronize(st));   // ulist / wgs / pairs are host vectors of this call
+    return GH_OK;
+}

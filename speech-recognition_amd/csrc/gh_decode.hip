@@ -441,7 +441,25 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         for (int64_t u = 0; u < U; ++u)
             GH_REQUIRE(utt_lattice[u] >= 0 && utt_lattice[u] < lat->L, "gh_forward_backward: utt_lattice[%lld] out of range",
                        (long long)u);
-    if (want_occ && b->N > 0 && (!b->occ || b->occ_S != S)) {   // sized for the model in use, not for the first one seen
+    // chain graphs and nobody wants the [N, S] matrix on the host: gamma stays compact ([N, 8]) for the fused statistics
+    // kernel (GMMHMM_BW=generic keeps the full occupancy matrix and the generic statistics kernel)
+    bool compact_gam = false;
+    {
+        const char* e = getenv("GMMHMM_FB");
+        const char* e2 = getenv("GMMHMM_BW");
+        const bool mats_ = out_alpha || out_beta || out_gamma;
+        compact_gam = want_occ && !out_occ && lat->fbchain_ok && !mats_ && !(e && !strcmp(e, "generic")) && !(e2 && !strcmp(e2, "generic")) &&
+                      b->dtype == GH_F64;
+    }
+    if (compact_gam) {
+        if (!b->gam && b->N > 0) GH_HIP(hipMalloc((void**)&b->gam, (size_t)b->N * GH_FBCHAIN_MAX * 8));
+        b->gam_chains = lat->h_fbchain;
+        b->gam_utt_graph.assign(utt_lattice ? utt_lattice : nullptr, utt_lattice ? utt_lattice + U : nullptr);
+        b->occ_valid = false;
+    } else if (want_occ) {
+        b->gam_chains.clear();
+    }
+    if (want_occ && !compact_gam && b->N > 0 && (!b->occ || b->occ_S != S)) {   // sized for the model in use, not for the first one seen
         if (b->occ) { GH_HIP(hipStreamSynchronize(ctx->stream)); GH_HIP(hipFree(b->occ)); b->occ = nullptr; }
         if (b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }
         GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
@@ -487,8 +505,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             hipStream_t s2 = ctx->stream;
             GH_HIP(hipMemcpyAsync(d_coff, coff.data(), U * 8, hipMemcpyHostToDevice, s2));
             if (utt_lattice) GH_HIP(hipMemcpyAsync(d_ul, utt_lattice, U * 4, hipMemcpyHostToDevice, s2));
-            if (want_occ && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, s2));
-            if (want_occ) {   // the only states that can carry occupancy: each utterance's chain
+            if (want_occ && !compact_gam && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, s2));
+            if (want_occ && !compact_gam) {   // the only states that can carry occupancy: each utterance's chain
                 std::vector<int32_t> st((size_t)U * GH_FBCHAIN_MAX, -1);
                 for (int64_t u = 0; u < U; ++u) {
                     const gh_fbchain& fc = lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0];
@@ -501,7 +519,9 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             memset(&ca, 0, sizeof ca);
             ca.chains = lat->d_fbchain; ca.nll = b->nll; ca.S = S; ca.utt_off = b->d_offsets; ca.utt_lat = d_ul;
             ca.perm = b->d_perm; ca.U = U; ca.alpha_scratch = d_al; ca.scratch_off = d_coff; ca.logp = d_lp;
-            ca.occ = want_occ ? b->occ : nullptr;
+            ca.occ = (want_occ && !compact_gam) ? b->occ : nullptr;
+            ca.gam = compact_gam ? b->gam : nullptr;
+            if (want_occ && !compact_gam) b->occ_valid = true;
             ca.self_xi_utt = d_xi;
             rc2 = gh_launch_fb_chain(ctx, ca, b->dtype == GH_F64);
             if (rc2) return rc2;
@@ -552,6 +572,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     a.alpha_scratch = d_scratch; a.scratch_off = d_soff; a.logp = d_logp;
     a.out_alpha = d_alpha; a.out_beta = d_beta; a.out_gamma = d_gamma; a.mat_off = d_matoff;
     a.occ = want_occ ? b->occ : nullptr;
+    if (want_occ) b->occ_valid = true;
     a.self_xi = d_selfxi;
     if (d_selfxi) GH_HIP(hipMemsetAsync(d_selfxi, 0, (size_t)S * 8, st));
     if (want_occ && b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }   // any state may be occupied

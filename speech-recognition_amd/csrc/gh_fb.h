@@ -50,6 +50,7 @@ struct gh_fbchain_args {
     const int64_t* scratch_off;  // [slots]
     double* logp;                // [U]
     double* occ;                 // optional [N,S], zeroed by the caller
+    double* gam;                 // optional [N, GH_FBCHAIN_MAX]: gamma compact, column = chain row (instead of occ)
     double* self_xi_utt;         // optional [U, GH_FBCHAIN_MAX]: expected self transitions of every chain row of every utterance
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);

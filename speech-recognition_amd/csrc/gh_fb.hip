@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     }
     const double logp = __shfl(al_last, (n > 0 ? n - 1 : 0), NMAX);
     if (has_utt && j == 0 && T > 0 && a.logp) a.logp[u] = logp;
-    if (!a.occ && !a.self_xi_utt) return;
+    if (!a.occ && !a.gam && !a.self_xi_utt) return;
     // ---- backward: beta in a register, gamma straight into the occupancy rows (e holds column T-1) ----
     auto load_a = [&](int t) -> double { return (act && t >= 0 && t < T) ? alpha[(int64_t)t * n + j] : NEG; };
     double be = (act && j == n - 1) ? 0.0 : NEG;
@@ -345,10 +345,11 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
             const int tw = t0 - k;              // column index of the wave's longest utterance
             if (tw < 0) break;
             const int t = tw - (Tmax - T);      // this utterance's column (negative: it has not started yet)
-            if (a.occ && act && t >= 0) {
-                double g = exp(ap + be - logp);
+            if ((a.occ || a.gam) && has_utt && t >= 0) {
+                double g = act ? exp(ap + be - logp) : 0.0;
                 if (!(g == g)) g = 0.0;
-                a.occ[(f0 + t) * a.S + st] = g;
+                if (a.gam) a.gam[(f0 + t) * NMAX + j] = g;            // all 8 columns (rows >= n: 0): one 64-byte line per frame
+                else if (act) a.occ[(f0 + t) * a.S + st] = g;
             }
             // beta_{t-1}(j) = lse over successors j, j+1, j+2 of (beta_t(s) - cost(j -> s) - e_t(s))
             const double w = act ? be - e : NEG;

@@ -61,6 +61,7 @@ int gh_pinned(gh_ctx* ctx, size_t bytes, void** out);
 // g = s*M + m.  KP = D rounded up to a multiple of 4 (zero padded).
 struct gh_gmm {
     gh_ctx* ctx;
+    void* d_arena;   // the one device allocation all the d* pointers below point into
     int S, M, D, KP;
     std::vector<double> hA, hB, hC;  // host fp64 master copies [G,KP], [G,KP], [G]
     double *dA64, *dB64, *dC64;      // device fp64
@@ -77,6 +78,18 @@ struct gh_gmm {
     int M_pad, n_tiles;
     double *dApk64, *dCpk64;
     float *dApk32, *dCpk32;
+};
+
+// A graph that is ONE left-to-right chain of <= 8 emitting rows with distinct states (arcs from r, r-1, r-2 in the
+// previous column), started at its first row (directly, or through a non-emitting start row: cost c0) and ended
+// at its last row -- what a one-word forced-alignment lattice is.  gh_forward_backward runs these with one LANE
+// per utterance (fb_chain_kernel): the whole recursion lives in registers.
+#define GH_FBCHAIN_MAX 8
+struct gh_fbchain {
+    int32_t n, pad;                       // pad = 1 when the chain has r-2 -> r (skip) arcs
+    int32_t state[GH_FBCHAIN_MAX];
+    double c0;
+    double self_c[GH_FBCHAIN_MAX], next_c[GH_FBCHAIN_MAX], skip_c[GH_FBCHAIN_MAX];   // +inf = no such arc
 };
 
 struct gh_batch {
@@ -96,6 +109,13 @@ struct gh_batch {
     // after a chain-form forward-backward: the states that can carry occupancy in each utterance ([U][8], -1 padded),
     // so that gh_bw_accumulate need not scan the occupancy matrix for them; null otherwise
     int32_t* d_occ_states;
+    // after a chain-form forward-backward that nobody asked the full matrix of: gamma compact, one column per chain
+    // row ([N, GH_FBCHAIN_MAX]), the chains it belongs to and every utterance's chain -- what the fused Baum-Welch
+    // statistics kernel consumes (gh_bw_fused.hip); `occ` is then stale (occ_valid false)
+    double* gam;
+    bool occ_valid;
+    std::vector<gh_fbchain> gam_chains;
+    std::vector<int32_t> gam_utt_graph;
     // launch order of the DP kernels: utterances sorted longest first (computed once)
     std::vector<int64_t> perm;
     int64_t* d_perm;
@@ -112,17 +132,6 @@ struct gh_lattice_host {
     int max_state;
 };
 
-// A graph that is ONE left-to-right chain of <= 8 emitting rows with distinct states (arcs from r, r-1, r-2 in the
-// previous column), started at its first row (directly, or through a non-emitting start row: cost c0) and ended
-// at its last row -- what a one-word forced-alignment lattice is.  gh_forward_backward runs these with one LANE
-// per utterance (fb_chain_kernel): the whole recursion lives in registers.
-#define GH_FBCHAIN_MAX 8
-struct gh_fbchain {
-    int32_t n, pad;                       // pad = 1 when the chain has r-2 -> r (skip) arcs
-    int32_t state[GH_FBCHAIN_MAX];
-    double c0;
-    double self_c[GH_FBCHAIN_MAX], next_c[GH_FBCHAIN_MAX], skip_c[GH_FBCHAIN_MAX];   // +inf = no such arc
-};
 
 // Layer form of a word lattice (build_state_sequences, continuous_speech.py:13-53, with the SAME W words in each of
 // its K layers -- the decode lattice of main.py:35): row 0 = non-emitting start; layer k = rows
@@ -151,6 +160,7 @@ struct gh_layerform {
 
 struct gh_lattices {
     gh_ctx* ctx;
+    void* d_arena;   // the one device allocation all the d_* pointers below point into
     int L;
     std::vector<gh_lattice_host> lat;
     // concatenated device arrays
@@ -196,5 +206,8 @@ struct gh_lattices {
 // kernels (gh_loglik.hip / gh_viterbi.hip)
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
 // 1 = shape not covered; st_lo / st_hi (per utterance, or null): only the states [lo, hi) of every utterance are needed
+// gh_bw_fused.hip: 1 = shapes not covered
+int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result);
+int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
                           const int32_t* st_hi = nullptr);

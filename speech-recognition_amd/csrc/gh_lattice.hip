@@ -22,7 +22,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     std::vector<double> h_pcost(Atot), h_scost(Atot);
     std::vector<int32_t> h_sptr;
     gh_lattices* lt = new gh_lattices();
-    lt->ctx = ctx; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
+    lt->ctx = ctx; lt->d_arena = nullptr; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
     for (int64_t k = 0; k < Atot; ++k) lt->has_nan_arc = lt->has_nan_arc || std::isnan(arc_cost[k]);
     lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
     lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
@@ -397,29 +397,21 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             lt->layers_ok = true;
         }
     }
-    int rc = GH_OK;
-    if (lt->layers_ok) {
-        std::vector<gh_layerform> one(1, lt->h_layers);
-        if ((rc = upload(&lt->d_layers, one)) || (rc = upload(&lt->d_lf_end_slot, lf_slot))) {
-            gh_lattices_destroy(lt);
-            return rc;
-        }
+    UploadArena ar;
+    std::vector<gh_layerform> one(1, lt->h_layers);
+    if (lt->layers_ok) { ar.add(&lt->d_layers, one); ar.add(&lt->d_lf_end_slot, lf_slot); }
+    if (lt->chain_ok) {
+        ar.add(&lt->d_ch_cost0, ch0); ar.add(&lt->d_ch_cost1, ch1); ar.add(&lt->d_ch_cost2, ch2);
+        ar.add(&lt->d_ch_info, chinfo); ar.add(&lt->d_ch_end_slot, chslot); ar.add(&lt->d_ch_group_row0, chgroups);
     }
-    if (lt->chain_ok &&
-        ((rc = upload(&lt->d_ch_cost0, ch0)) || (rc = upload(&lt->d_ch_cost1, ch1)) || (rc = upload(&lt->d_ch_cost2, ch2)) ||
-         (rc = upload(&lt->d_ch_info, chinfo)) || (rc = upload(&lt->d_ch_end_slot, chslot)) ||
-         (rc = upload(&lt->d_ch_group_row0, chgroups)))) {
-        gh_lattices_destroy(lt);
-        return rc;
-    }
-    if ((rc = upload(&lt->d_row_state, h_state)) || (rc = upload(&lt->d_row_start, h_start)) ||
-        (rc = upload(&lt->d_pred_ptr, h_ptr)) || (rc = upload(&lt->d_pred_row, h_prow)) ||
-        (rc = upload(&lt->d_pred_cost, h_pcost)) || (rc = upload(&lt->d_order, h_order)) ||
-        (rc = upload(&lt->d_succ_ptr, h_sptr)) || (rc = upload(&lt->d_succ_row, h_srow)) ||
-        (rc = upload(&lt->d_succ_cost, h_scost)) ||
-        (rc = upload(&lt->d_level_ptr, h_lev)) || (rc = upload(&lt->d_level_narrow, h_narrow)) ||
-        (rc = upload(&lt->d_end_rows, h_end)) ||
-        (rc = upload(&lt->d_desc, lt->h_desc)) || (lt->fbchain_ok && (rc = upload(&lt->d_fbchain, lt->h_fbchain)))) {
+    ar.add(&lt->d_row_state, h_state); ar.add(&lt->d_row_start, h_start);
+    ar.add(&lt->d_pred_ptr, h_ptr); ar.add(&lt->d_pred_row, h_prow); ar.add(&lt->d_pred_cost, h_pcost); ar.add(&lt->d_order, h_order);
+    ar.add(&lt->d_succ_ptr, h_sptr); ar.add(&lt->d_succ_row, h_srow); ar.add(&lt->d_succ_cost, h_scost);
+    ar.add(&lt->d_level_ptr, h_lev); ar.add(&lt->d_level_narrow, h_narrow); ar.add(&lt->d_end_rows, h_end);
+    ar.add(&lt->d_desc, lt->h_desc);
+    if (lt->fbchain_ok) ar.add(&lt->d_fbchain, lt->h_fbchain);
+    const int rc = ar.commit(&lt->d_arena);
+    if (rc) {
         gh_lattices_destroy(lt);
         return rc;
     }
@@ -430,15 +422,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
 extern "C" void gh_lattices_destroy(gh_lattices* l) {
     if (!l) return;
     hipSetDevice(l->ctx->device);
-    hipFree(l->d_row_state); hipFree(l->d_row_start); hipFree(l->d_pred_ptr); hipFree(l->d_pred_row);
-    hipFree(l->d_pred_cost); hipFree(l->d_order); hipFree(l->d_level_ptr); hipFree(l->d_end_rows);
-    hipFree(l->d_level_narrow);
-    hipFree(l->d_ch_cost0); hipFree(l->d_ch_cost1); hipFree(l->d_ch_cost2); hipFree(l->d_ch_info);
-    hipFree(l->d_ch_end_slot); hipFree(l->d_ch_group_row0);
-    hipFree(l->d_succ_ptr); hipFree(l->d_succ_row); hipFree(l->d_succ_cost);
-    hipFree(l->d_desc);
-    hipFree(l->d_fbchain);
-    hipFree(l->d_layers); hipFree(l->d_lf_end_slot);
+    hipFree(l->d_arena);
     delete l;
 }
 

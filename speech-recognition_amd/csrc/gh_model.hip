@@ -13,6 +13,7 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     const int KP = (D + 3) & ~3;
     gh_gmm* g = new gh_gmm();
     g->ctx = ctx;
+    g->d_arena = nullptr;
     g->S = S; g->M = M; g->D = D; g->KP = KP;
     g->hA.assign((size_t)G * KP, 0.0);
     g->hB.assign((size_t)G * KP, 0.0);
@@ -95,12 +96,13 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
                 }
         }
     std::vector<double> vmean(mean, mean + (size_t)G * D);
-    int rc = GH_OK;
-    if ((rc = upload(&g->dA64, g->hA)) || (rc = upload(&g->dB64, g->hB)) || (rc = upload(&g->dC64, g->hC)) ||
-        (rc = upload(&g->dA32, fA)) || (rc = upload(&g->dB32, fB)) || (rc = upload(&g->dC32, fC)) || (rc = upload(&g->dCen32, cen32)) ||
-        (rc = upload(&g->dMean, vmean)) || (rc = upload(&g->dIvar, ivar)) || (rc = upload(&g->dLogc, logc)) ||
-        (rc = upload(&g->dApk64, apk64)) || (rc = upload(&g->dCpk64, cpk64)) ||
-        (rc = upload(&g->dApk32, apk32)) || (rc = upload(&g->dCpk32, cpk32))) {
+    UploadArena ar;
+    ar.add(&g->dA64, g->hA); ar.add(&g->dB64, g->hB); ar.add(&g->dC64, g->hC);
+    ar.add(&g->dA32, fA); ar.add(&g->dB32, fB); ar.add(&g->dC32, fC); ar.add(&g->dCen32, cen32);
+    ar.add(&g->dMean, vmean); ar.add(&g->dIvar, ivar); ar.add(&g->dLogc, logc);
+    ar.add(&g->dApk64, apk64); ar.add(&g->dCpk64, cpk64); ar.add(&g->dApk32, apk32); ar.add(&g->dCpk32, cpk32);
+    const int rc = ar.commit(&g->d_arena);
+    if (rc) {
         gh_gmm_destroy(g);
         return rc;
     }
@@ -111,10 +113,7 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
 extern "C" void gh_gmm_destroy(gh_gmm* g) {
     if (!g) return;
     hipSetDevice(g->ctx->device);
-    hipFree(g->dA64); hipFree(g->dB64); hipFree(g->dC64);
-    hipFree(g->dA32); hipFree(g->dB32); hipFree(g->dC32); hipFree(g->dCen32);
-    hipFree(g->dMean); hipFree(g->dIvar); hipFree(g->dLogc);
-    hipFree(g->dApk64); hipFree(g->dCpk64); hipFree(g->dApk32); hipFree(g->dCpk32);
+    hipFree(g->d_arena);
     delete g;
 }
 
@@ -133,6 +132,8 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     b->feats = nullptr; b->owns_feats = false; b->nll = nullptr; b->nll_S = 0; b->d_offsets = nullptr;
     b->occ = nullptr;
     b->occ_S = 0;
+    b->gam = nullptr;
+    b->occ_valid = false;
     b->d_occ_states = nullptr;
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;
@@ -187,6 +188,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
     if (b->owns_feats && b->feats) hipFree(b->feats);
     if (b->nll) hipFree(b->nll);
     if (b->occ) hipFree(b->occ);
+    if (b->gam) hipFree(b->gam);
     if (b->d_occ_states) hipFree(b->d_occ_states);
     if (b->d_offsets) hipFree(b->d_offsets);
     if (b->d_perm) hipFree(b->d_perm);

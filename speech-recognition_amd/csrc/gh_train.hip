@@ -562,14 +562,27 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
                                 double* out_stats, double* stats_dev) {
     GH_REQUIRE(ctx && g && b && (out_stats || stats_dev), "gh_bw_accumulate: NULL argument");
     GH_REQUIRE(b->dtype == GH_F64, "gh_bw_accumulate: needs an fp64 batch");
-    GH_REQUIRE(b->occ || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
-    GH_REQUIRE(b->N == 0 || b->occ_S == g->S, "gh_bw_accumulate: occupancies were computed for %d states, the model has %d", b->occ_S, g->S);
     GH_REQUIRE(g->D == b->D && g->S == b->nll_S, "gh_bw_accumulate: model / batch mismatch");
-    GH_REQUIRE(g->M * (g->D + 1) <= BW_MAXP * 256, "gh_bw_accumulate: M=%d x D=%d unsupported", g->M, g->D);
     GH_HIP(hipSetDevice(ctx->device));
     const int S = g->S, M = g->M, D = g->D, W = 1 + 2 * D;
     const int64_t len = (int64_t)S * M * W;
     hipStream_t st = ctx->stream;
+    if (!b->gam_chains.empty() && !b->occ_valid && b->N > 0) {
+        // the forward-backward left a compact gamma (chain graphs): densities + accumulation fused on the matrix cores
+        double* d_res = nullptr;
+        int rc0 = gh_bw_accumulate_fused(ctx, g, b, occ_floor, stats_dev, &d_res);
+        if (rc0 < 0) return rc0;
+        if (rc0 == 0) {
+            if (out_stats) GH_HIP(hipMemcpyAsync(out_stats, d_res, (size_t)len * 8, hipMemcpyDeviceToHost, st));
+            GH_HIP(hipStreamSynchronize(st));
+            return GH_OK;
+        }
+        rc0 = gh_bw_expand_gamma(ctx, const_cast<gh_batch*>(b), S);   // shapes it does not cover: generic kernel below
+        if (rc0) return rc0;
+    }
+    GH_REQUIRE((b->occ && b->occ_valid) || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
+    GH_REQUIRE(b->N == 0 || b->occ_S == g->S, "gh_bw_accumulate: occupancies were computed for %d states, the model has %d", b->occ_S, g->S);
+    GH_REQUIRE(g->M * (g->D + 1) <= BW_MAXP * 256, "gh_bw_accumulate: M=%d x D=%d unsupported", g->M, g->D);
     // The kernel is latency bound per workgroup (global round trips between barriers), so workgroups per CU
     // decide: frame tiles are sized for as many resident workgroups as the 160 KB of LDS allow (a tile one
     // entry too large silently drops a CU from 3 to 2 workgroups: measured 4.4 -> 5.0 ms).

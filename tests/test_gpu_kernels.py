@@ -749,3 +749,54 @@ def test_loglik_extreme_parameter_ranges(hip, ctx):
     assert np.max(np.abs(got - ref) / scale) < 1e-12
     b.close()
     gmm.close()
+
+
+@pytest.mark.parametrize("W,n,M,D", [(10, 5, 8, 39), (4, 3, 4, 13), (3, 8, 8, 6), (5, 2, 1, 7), (3, 5, 16, 13), (2, 4, 5, 24)])
+def test_bw_statistics_fused_matrix_core_path_equals_generic(hip, ctx, W, n, M, D):
+    """One-word chain graphs: when nobody asks for the [N, S] occupancy matrix the forward-backward keeps gamma compact
+    and gh_bw_accumulate runs the fused kernel (densities and accumulation on the matrix cores, gh_bw_fused.hip);
+    asking for the matrix takes the generic pair of kernels.  Same statistics (1e-9), also for mixtures padded to 8
+    components, odd numbers of states, a zero-weight component, and -- M = 16 -- shapes the fused kernel hands back."""
+    rng = np.random.default_rng(W * 100 + n * 10 + M)
+    S = W * n
+    means = rng.normal(size=(S, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    if M > 1:
+        w[1, 0] = 0.0                                     # a switched-off component
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = 0.4 if i < n - 1 else 0.0
+        if i < n - 1:
+            trans[i + 1, i] = 1.1
+    xs, words = [], []
+    for u in range(70):
+        wd = int(rng.integers(0, W))
+        T = int(rng.integers(n + 1, 150))
+        st = np.minimum(np.arange(T) * n // T, n - 1)
+        xs.append(means[wd * n + st, rng.integers(0, M, T)] + rng.normal(size=(T, D)))
+        words.append(wd)
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    lat = hip.Lattices(ctx, [graph(np.arange(n) + i * n, trans, [0], [n - 1]) for i in range(W)])
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    r_full = lat.forward_backward(b, utt_lattice=words, want_occ=True, fetch_occ=True)
+    generic = b.bw_accumulate(gmm)
+    r_cmp = lat.forward_backward(b, utt_lattice=words, want_occ=True, fetch_occ=False)
+    fused = b.bw_accumulate(gmm)
+    np.testing.assert_array_equal(r_cmp["logp"], r_full["logp"])
+    scale = np.abs(generic).max(axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(fused - generic) / scale) < 1e-9
+    np.testing.assert_allclose(fused[:, :, 0].sum(), sum(len(x) for x in xs), rtol=1e-9)
+    visited = sorted(set(words))
+    assert np.all(fused[[s for s in range(S) if s // n not in visited]] == 0)
+    # the same again through a device-side destination (what the trainer hands to RCCL) and with an occupancy floor
+    floor = 1e-3
+    lat.forward_backward(b, utt_lattice=words, want_occ=True, fetch_occ=True)
+    g2 = b.bw_accumulate(gmm, occ_floor=floor)
+    lat.forward_backward(b, utt_lattice=words, want_occ=True, fetch_occ=False)
+    f2 = b.bw_accumulate(gmm, occ_floor=floor)
+    assert np.max(np.abs(f2 - g2) / scale) < 1e-9
+    b.close()
+    lat.close()
+    gmm.close()

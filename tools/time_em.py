@@ -17,7 +17,7 @@ labels = [[int(w)] for w in wl["words"]]
 rng = np.random.default_rng(0)
 means0 = wl["means"] + 0.3 * rng.normal(size=wl["means"].shape)   # perturbed start
 t0 = time.perf_counter()
-tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, var_floor=1e-3)
+tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels)
 print("setup s", time.perf_counter() - t0, flush=True)
 ctx = tr.ctx
 hist = []
@@ -36,6 +36,6 @@ def t(fn, reps=3):
 print(json.dumps(dict(utts=U, frames=int(tr.batch.N),
                       loglik_full_ms=t(lambda: tr.batch.loglik(gmm, fetch=False)),
                       loglik_own_states_ms=t(lambda: tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)),
-                      fwdbwd_ms=t(lambda: tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True, fetch_occ=False)),
+                      fwdbwd_ms=t(lambda: tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True, fetch_occ=False, want_self_xi=True)),
                       bw_stats_ms=t(lambda: tr.batch.bw_accumulate(gmm)),
                       monotone=bool(all(b >= a - 1e-7 * abs(a) for a, b in zip(hist, hist[1:]))))))
