@@ -171,6 +171,13 @@ int gh_lattices_create(gh_ctx* ctx, int L,
                        const int64_t* end_off /*[L+1]*/, const int32_t* end_rows,
                        gh_lattices** out);
 void gh_lattices_destroy(gh_lattices* l);
+/* Rank beam for gh_viterbi / gh_viterbi_labels on these graphs (decode_hmm_states itself has no
+ * pruning -- this is the beam of dtw, decode.py:62-68, carried over to lattices).  After every column but the last, the
+ * cells of the finished column are ranked in ascending (cost, row) order and every finite cell ranked >= beam reads +inf
+ * when the next column takes it as an origin (and shows as +inf in out_costs); reads inside the column -- arcs touching
+ * a non-emitting row -- are not affected.  beam <= 0 switches pruning off (the default; results are then bit-identical
+ * to the unpruned kernels).  A pruned decode runs on the generic kernel. */
+int gh_lattices_set_beam(gh_lattices* l, int beam);
 
 /* --------------------------------------------------- A6: decode_hmm_states
  * Viterbi over graph utt_lattice[u] (NULL: graph 0) for every utterance of the

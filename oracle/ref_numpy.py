@@ -191,8 +191,15 @@ def emission_matrix(x, states, dense=False):
 _NOPTR = np.iinfo(np.int64).min  # what np.full(.., np.inf, dtype=int) yields (decode.py:95)
 
 
-def decode_fill(E, is_nes, trans):
-    """The forward sweep of decode_hmm_states (decode.py:94-124): cost matrix + back-pointers."""
+def decode_fill(E, is_nes, trans, beam=None):
+    """The forward sweep of decode_hmm_states (decode.py:94-124): cost matrix + back-pointers.
+
+    beam (SURVEY.md 8(f) N4 -- NOT in the reference's decode_hmm_states, which has no pruning): the rank beam of
+    `dtw` (decode.py:62-68) carried over to lattices.  After every column but the last, the cells of the finished
+    column are ranked in ascending (cost, row) order (np.argsort of the column, ties by row) and every finite cell
+    ranked >= beam is pruned: it reads +inf when the next column takes it as an origin, and the returned matrix shows
+    it as +inf (what dtw's matrix shows for every pruned cell but those of its last column).  Reads inside the column
+    (arcs touching a non-emitting row) happen before the pruning and are unaffected."""
     R, T = E.shape
     costs = np.full((R, T), np.inf)
     bp = np.full((R, T, 2), _NOPTR, dtype=np.int64)
@@ -215,10 +222,15 @@ def decode_fill(E, is_nes, trans):
                 raise NameError("FUCKED")  # decode.py:120-121 (self-pointing cell)
             bp[r, c] = best_pt
             costs[r, c] = min(costs[r, c], best_v + E[r, c])
+        if beam is not None and not isinf(beam) and c < T - 1:
+            order = np.argsort(costs[:, c], kind="stable")          # (cost, row) order
+            for r in order[int(beam):]:
+                if not isinf(costs[r, c]):
+                    costs[r, c] = np.inf
     return costs, bp
 
 
-def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
+def decode_states(E, is_nes, trans, end_points=None, return_bp=False, beam=None):
     """decode_hmm_states (decode.py:80-146) on an emission matrix.
 
     Columns outer / rows inner (decode.py:97-98); (0,0) is the only start cell
@@ -230,7 +242,7 @@ def decode_states(E, is_nes, trans, end_points=None, return_bp=False):
     (:143-145).
     """
     R, T = E.shape
-    costs, bp = decode_fill(E, is_nes, trans)
+    costs, bp = decode_fill(E, is_nes, trans, beam=beam)
     if end_points is None:
         end_points = [[R - 1, T - 1]]
     best = np.inf

@@ -62,7 +62,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     const bool uniform = utt_lattice == nullptr;
     // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
     // the reference's wrap-around semantics, which only the lean / generic kernels implement)
-    bool use_chain = lat->chain_ok && uniform;
+    bool use_chain = lat->chain_ok && uniform && lat->beam <= 0;   // (a beam needs the generic kernel)
     {
         static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
         if (no_chain) use_chain = false;
@@ -71,7 +71,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     }
     // layer-form kernels: one K-layer word lattice / word-loop grammar for the whole batch (GMMHMM_VITERBI=lean /
     // generic force the others)
-    bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs;
+    bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs && lat->beam <= 0;
     {
         static const bool no_layers = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
         if (no_layers) use_layers = false;
@@ -239,7 +239,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         const int lb = std::max(64, (lean_lanes + 63) & ~63);
         bool same_nlev = true;
         for (auto& d : lat->h_desc) same_nlev = same_nlev && d.nlev == lat->max_nlev;
-        if (!no_lean && !(out_costs && !want_path) && !lat->has_nan_arc && !lat->has_self_arc && same_nlev && lat->max_nlev <= 3 && lb <= 1024 &&
+        if (!no_lean && lat->beam <= 0 && !(out_costs && !want_path) && !lat->has_nan_arc && !lat->has_self_arc && same_nlev && lat->max_nlev <= 3 && lb <= 1024 &&
             S <= 8 * lb && max_arcs <= 4096) {
             lean_levels = lat->max_nlev;
             block = lb;
@@ -277,7 +277,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         for (auto& d : lat->h_desc) max_level_rows2 = std::max(max_level_rows2, d.pad);
         block = std::min(512, std::max(64, (max_level_rows2 + 63) & ~63));
         a.em_chunk = 1;
-        lds = ((size_t)2 * a.r_pad + S) * sizeof(double);
+        a.beam = lat->beam;
+        lds = ((size_t)2 * a.r_pad + S) * sizeof(double) + (lat->beam > 0 ? (size_t)a.r_pad * 4 : 0);
     }
     if (!use_chain && !use_layers && lds > 160 * 1024) {
         gh_set_error("gh_viterbi: %d rows + %d states need %zu B of LDS (> 160 KiB)", lat->max_R, S, lds);

@@ -199,6 +199,7 @@ struct gh_lattices {
     gh_layerform h_layers;
     gh_layerform* d_layers;
     int32_t* d_lf_end_slot;          // [R] position of a row in the end list or -1
+    int beam;           // rank beam per column of gh_viterbi (0 = off): gh_lattices_set_beam; generic kernel only
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };

@@ -22,7 +22,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     std::vector<double> h_pcost(Atot), h_scost(Atot);
     std::vector<int32_t> h_sptr;
     gh_lattices* lt = new gh_lattices();
-    lt->ctx = ctx; lt->d_arena = nullptr; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
+    lt->ctx = ctx; lt->d_arena = nullptr; lt->beam = 0; lt->L = L; lt->max_R = 0; lt->max_nlev = 0; lt->has_nan_arc = false; lt->has_self_arc = false;
     for (int64_t k = 0; k < Atot; ++k) lt->has_nan_arc = lt->has_nan_arc || std::isnan(arc_cost[k]);
     lt->d_row_state = nullptr; lt->d_row_start = nullptr; lt->d_pred_ptr = nullptr; lt->d_pred_row = nullptr;
     lt->d_pred_cost = nullptr; lt->d_order = nullptr; lt->d_succ_ptr = nullptr; lt->d_succ_row = nullptr;
@@ -424,6 +424,12 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     hipSetDevice(l->ctx->device);
     hipFree(l->d_arena);
     delete l;
+}
+
+extern "C" int gh_lattices_set_beam(gh_lattices* l, int beam) {
+    GH_REQUIRE(l, "gh_lattices_set_beam: NULL argument");
+    l->beam = beam > 0 ? beam : 0;
+    return GH_OK;
 }
 
 extern "C" int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T) {

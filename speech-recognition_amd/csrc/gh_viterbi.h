@@ -20,6 +20,7 @@ struct gh_vit_args {
     int arc_cap;              // lean kernel: LDS slots for a graph's arc list
     int lds_bytes;            // lean kernel: dynamic LDS of the launch (the back-trace re-uses all of it)
     int bpc_off;              // lean kernel: LDS byte offset of the 8-column back-pointer staging block
+    int beam;                 // generic kernel: rank beam per column (0 = off), gh_lattices_set_beam
     const int64_t* utt_off;   // [U+1] frame offsets
     const int32_t* utt_lat;   // [U] graph of each utterance, or null (graph 0)
     const int64_t* perm;      // launch slot -> utterance (longest first), or null

@@ -135,6 +135,31 @@ __global__ void viterbi_kernel(gh_vit_args a) {
                 }
                 __syncthreads();
             }
+            if (a.beam > 0 && t < T - 1) {
+                // Rank beam (the one of dtw, decode.py:62-68, carried over to lattices; gh_lattices_set_beam): cells of the
+                // FINISHED column ranked >= beam in ascending (cost, row) order are pruned -- they read +inf as origins of
+                // the next column.  Counting pairs is O(R^2) per column; a pruned decode of a few hundred rows is a
+                // feature for parity and experiments, not a speed-up (see profiles/: the active-row histogram of C5).
+                int* prn = reinterpret_cast<int*>(em + S);
+                for (int r = tid; r < R; r += bd) {
+                    const double c = cur[r];
+                    int rank = 0;
+                    if (c < INF) {
+                        for (int o = 0; o < R; ++o) {
+                            const double v = cur[o];
+                            rank += (v < c) || (v == c && o < r);
+                        }
+                    }
+                    prn[r] = (c < INF) && rank >= a.beam;
+                }
+                __syncthreads();
+                for (int r = tid; r < R; r += bd)
+                    if (prn[r]) {
+                        cur[r] = INF;
+                        if (costs) costs[(int64_t)r * T + t] = INF;
+                    }
+                __syncthreads();
+            }
             double* t_ = prev; prev = cur; cur = t_;
         }
     }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "gh_lattices_create": (C.c_int, [C.c_void_p, C.c_int, _c_i64p, _c_i32p, _c_i64p, _c_i32p, _c_i32p,
                                      _c_f64p, _c_i64p, _c_i32p, _c_i64p, _c_i32p, C.POINTER(C.c_void_p)]),
     "gh_lattices_destroy": (None, [C.c_void_p]),
+    "gh_lattices_set_beam": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
                              _c_i32p, _c_f64p, _c_i64p]),
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
@@ -518,6 +519,12 @@ class Lattices:
             _ptr(end_rows, _c_i32p), C.byref(h)))
         self.h = h
         self.L = L
+
+    def set_beam(self, beam):
+        """Rank beam per column for viterbi / viterbi_labels (None, 0 or inf: no pruning); see gh_lattices_set_beam."""
+        k = 0 if beam is None or beam != beam or beam == float("inf") or beam <= 0 else int(beam)
+        _check(self.ctx.lib, self.ctx.lib.gh_lattices_set_beam(self.h, k))
+        self.beam = k
 
     def path_cap(self, l, T):
         return int(self.ctx.lib.gh_viterbi_path_cap(self.h, int(l), int(T)))

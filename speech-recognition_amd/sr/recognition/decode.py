@@ -25,17 +25,23 @@ def _ctx():
 
 
 # ------------------------------------------------------------------------- A6
-def decode_batch(xs, states, transitions, end_rows=None, want_costs=False, dtype=np.float64):
+def decode_batch(xs, states, transitions, end_rows=None, want_costs=False, dtype=np.float64, beam=np.inf):
     """Viterbi of every utterance in `xs` through one state list.
 
     end_rows: candidate final rows in the last column (default: the last row).
+    beam: rank beam per column (see `decode_hmm_states`).
     Returns the dict of `_hip.Lattices.viterbi` (paths, best_end, end_cost[, costs])."""
     ctx = _ctx()
     row_state, uniq = _pack.pack_states(states)
     R = len(states)
     if end_rows is None:
         end_rows = [R - 1]
-    lat = _pack.device_lattices(ctx, [_pack.graph_from_dense(row_state, transitions, [0], end_rows)])
+    graph = _pack.graph_from_dense(row_state, transitions, [0], end_rows)
+    pruned = not (beam is None or isinf(beam) or beam <= 0)
+    # (a pruned decode gets a graph handle of its own: the beam is a property of the handle, and cached handles are shared)
+    lat = _hip.Lattices(ctx, [graph]) if pruned else _pack.device_lattices(ctx, [graph])
+    if pruned:
+        lat.set_beam(beam)
     batch = _hip.Batch(ctx, xs, dtype=dtype)
     try:
         if uniq:
@@ -49,15 +55,20 @@ def decode_batch(xs, states, transitions, end_rows=None, want_costs=False, dtype
         return lat.viterbi(batch, want_path=True, want_costs=want_costs)
     finally:
         batch.close()
+        if pruned:
+            lat.close()
 
 
-def decode_hmm_states(x, states, transitions, end_points=None):
+def decode_hmm_states(x, states, transitions, end_points=None, beam=np.inf):
     """
     :param x: an input, array [T, D].
     :param states: a list of hmm states (GMM / NES objects).
     :param transitions: transition matrix, `transitions[i,j]` = cost of going from the jth to the ith state
         (+inf = no arc).
     :param end_points: a list of cells `[r, c]` that may end the state sequence (default: last row, last column).
+    :param beam: EXTENSION (the reference's decode_hmm_states has no pruning; its `dtw` has, decode.py:62-68): after
+        every column but the last, all but the `beam` cheapest cells of the column -- ranked by (cost, row) -- read
+        +inf as origins of the next column and show as +inf in `costs`.  The default (inf) is the reference's decode.
     :return: costs: cost matrix [R, T].
             path: reversed path (from end to start) `[[r_n, c_n], ..., [r_1, c_1]]`, end cell excluded.
     """
@@ -70,7 +81,7 @@ def decode_hmm_states(x, states, transitions, end_points=None):
     last = T - 1
     norm = [(r, c + T if c < 0 else c) for r, c in end_points]
     last_rows = [r for r, c in norm if c == last]
-    full = decode_batch([x], states, transitions, end_rows=last_rows or [R - 1], want_costs=True)
+    full = decode_batch([x], states, transitions, end_rows=last_rows or [R - 1], want_costs=True, beam=beam)
     costs = full["costs"][0]
     # choose the end cell like decode.py:129-134 ('>=': the last minimum wins)
     best_cost, best = np.inf, None
@@ -85,7 +96,7 @@ def decode_hmm_states(x, states, transitions, end_points=None):
     if bc == last and last_rows and last_rows[full["best_end"][0]] == br:
         path = full["paths"][0]
     else:  # an inner column (or a tie resolved across columns): back-trace that prefix on its own
-        path = decode_batch([x[:bc + 1]], states, transitions, end_rows=[br])["paths"][0]
+        path = decode_batch([x[:bc + 1]], states, transitions, end_rows=[br], beam=beam)["paths"][0]
     if len(path) == 0:
         return costs, np.array([])
     return costs, path

@@ -182,6 +182,10 @@ class Lattices:
         self.L = len(graphs)
         self.R = [len(g["row_state"]) for g in graphs]
         self.n_end = [len(g["end_rows"]) for g in graphs]
+        self.beam = None
+
+    def set_beam(self, beam):
+        self.beam = None if (beam is None or beam <= 0 or beam == float("inf")) else int(beam)
 
     def _dense(self, g):
         R = len(g["row_state"])
@@ -225,7 +229,7 @@ class Lattices:
                 s1 = ss[k + 1] if k + 1 < len(ss) else R
                 lo = 0 if k == 0 else s0
                 sl = slice(lo, s1)
-                cs, bps = O.decode_fill(E[sl], nes[sl], trans[sl, sl])
+                cs, bps = O.decode_fill(E[sl], nes[sl], trans[sl, sl], beam=self.beam)
                 costs[sl] = cs
                 bps = bps.copy()
                 bps[:, :, 0] = np.where(bps[:, :, 0] == O._NOPTR, O._NOPTR, bps[:, :, 0] + lo)

@@ -800,3 +800,103 @@ def test_bw_statistics_fused_matrix_core_path_equals_generic(hip, ctx, W, n, M, 
     b.close()
     lat.close()
     gmm.close()
+
+
+def test_viterbi_lattice_beam(hip, ctx):
+    """N4, second half: rank beam per column in gh_viterbi (gh_lattices_set_beam).  (i) On a chain graph it reproduces the
+    reference's own dtw beam results (G5: surviving cells, costs, path); (ii) on K-layer word lattices and a loop
+    grammar it equals the oracle's lattice beam cell for cell, paths bit-exact; (iii) beam >= rows == no beam
+    (bit-identical to the unpruned kernels), pruned cost >= unpruned cost, labels follow."""
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    g = load_golden("G5_dtw")
+    x, y, var, trans = g["x"], g["y"], g["var"], g["trans"]
+    n, D = y.shape
+    gmm = hip.PackedGMM(ctx, y[:, None, :], var[:, None, :], np.ones((n, 1)))
+    b = hip.Batch(ctx, [x])
+    b.loglik(gmm, fetch=False)
+    lat = hip.Lattices(ctx, [graph(np.arange(n), trans, [0], [n - 1])])
+    lat.set_beam(3)
+    r = lat.viterbi(b, want_path=True, want_costs=True)
+    ref = g["costs_beam3"]                                        # mahalanobis distance == -log N(x; y_i, var_i)
+    alive = np.isfinite(ref) & (ref != -1)
+    np.testing.assert_array_equal(np.isfinite(r["costs"][0][:, :-1]), alive[:, :-1])
+    np.testing.assert_allclose(r["costs"][0][:, :-1][alive[:, :-1]], ref[:, :-1][alive[:, :-1]], rtol=1e-10)
+    np.testing.assert_array_equal(r["paths"][0], g["path_beam3"])
+    lat.close(); b.close(); gmm.close()
+    # ---- lattices against the oracle
+    rng = np.random.default_rng(41)
+    W, ns, M, D = 6, 3, 2, 5
+    means = rng.normal(size=(W, ns, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, ns, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, ns))
+    tr = np.full((ns, ns), np.inf)
+    for i in range(ns):
+        tr[i, i] = 0.3 if i < ns - 1 else 0.0
+        if i < ns - 1:
+            tr[i + 1, i] = 1.3
+    gmm = hip.PackedGMM(ctx, means.reshape(W * ns, M, D), vars_.reshape(W * ns, M, D), w.reshape(W * ns, M))
+    xs = []
+    for u in range(12):
+        segs = []
+        for wd in rng.integers(0, W, size=3):
+            Tw = int(rng.integers(ns + 1, 12))
+            st = np.minimum(np.arange(Tw) * ns // Tw, ns - 1)
+            segs.append(means[wd, st, rng.integers(0, M, Tw)] + rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+    b = hip.Batch(ctx, xs)
+    nll = b.loglik(gmm, fetch=True)
+    import warnings as _w
+    for gr in (packed_lattice([tr] * W, ns, [list(range(W))] * 3)[0], packed_loop_lattice([tr] * W, ns, 0.5)[0]):
+        R = len(gr["row_state"])
+        dense = np.full((R, R), np.inf)
+        dense[gr["arc_to"], gr["arc_from"]] = gr["arc_cost"]
+        is_nes = gr["row_state"] < 0
+        lat = hip.Lattices(ctx, [gr])
+        base = lat.viterbi(b, want_path=True)
+        row_word = np.where(gr["row_state"] >= 0, gr["row_state"] // ns, -1).astype(np.int32)
+        for beam in (4, 9, R):
+            lat.set_beam(beam)
+            r = lat.viterbi(b, want_path=True, want_costs=True)
+            rl = lat.viterbi_labels(b, row_word)
+            for u in range(b.U):
+                E = np.zeros((R, len(xs[u])))
+                E[~is_nes] = nll[b.offsets[u]:b.offsets[u + 1]][:, gr["row_state"][~is_nes]].T
+                with _w.catch_warnings():
+                    _w.simplefilter("ignore")
+                    try:
+                        costs, path = O.decode_states(E, is_nes, dense, end_points=[[int(e), -1] for e in gr["end_rows"]], beam=beam)
+                    except RuntimeError:
+                        continue                                  # every end pruned away: the reference-style walk does not terminate
+                np.testing.assert_array_equal(np.isfinite(r["costs"][u]), np.isfinite(costs))
+                fin = np.isfinite(costs)
+                np.testing.assert_allclose(r["costs"][u][fin], costs[fin], rtol=1e-12)
+                if np.isfinite(costs[np.asarray(gr["end_rows"]), -1]).any():
+                    np.testing.assert_array_equal(r["paths"][u], path)
+                    from sr.recognition.batch import path_to_words
+                    assert [int(v) for v in rl["labels"][u]] == path_to_words(path, gr["row_state"], ns)
+                assert np.min(r["end_cost"][u]) >= np.min(base["end_cost"][u])
+            if beam == R:
+                np.testing.assert_array_equal(r["end_cost_flat"], base["end_cost_flat"])
+                for u in range(b.U):
+                    np.testing.assert_array_equal(r["paths"][u], base["paths"][u])
+        lat.set_beam(None)
+        again = lat.viterbi(b, want_path=True)
+        np.testing.assert_array_equal(again["end_cost_flat"], base["end_cost_flat"])
+        lat.close()
+    b.close()
+    gmm.close()
+
+
+def test_decode_hmm_states_beam_kwarg(hip, ctx):
+    """The mirror API's extension kwarg: decode_hmm_states(..., beam=k); the default is the reference's decode."""
+    import sr.recognition as R
+    g = load_golden("G5_dtw")
+    x, y, var, trans = g["x"], g["y"], g["var"], g["trans"]
+    states = [R.GMM(y[i], var[i], 1) for i in range(len(y))]
+    c0, p0 = R.decode_hmm_states(x, states, trans)
+    c3, p3 = R.decode_hmm_states(x, states, trans, beam=3)
+    np.testing.assert_array_equal(p3, g["path_beam3"])
+    assert np.isinf(c3[:, :-1]).sum() > np.isinf(c0[:, :-1]).sum() and c3[-1, -1] >= c0[-1, -1]
+    cb, pb = R.decode_hmm_states(x, states, trans, beam=np.inf)
+    np.testing.assert_array_equal(cb, c0)
+    np.testing.assert_array_equal(pb, p0)

@@ -210,6 +210,29 @@ def test_G5_dtw():
     close(O.calc_transition_costs(2, g["seg_lens_skip"]), g["trans_skip"], rtol=0)
 
 
+def test_lattice_beam_reproduces_the_reference_dtw_beam_on_chains():
+    """N4: decode_hmm_states has no pruning in the reference; the oracle's lattice beam is dtw's rank beam
+    (decode.py:62-68) carried over.  On a left-to-right chain, where dtw and decode_hmm_states are the same DP, it
+    reproduces the reference's own beam results (G5): the same cells survive, same costs, same path."""
+    g = load_golden("G5_dtw")
+    x, y, var, trans = g["x"], g["y"], g["var"], g["trans"]
+    n = len(y)
+    for tag, E, beam in (("beam3", O.distance_matrix(x, y, "mahalanobis", var), 3), ("beam2", O.distance_matrix(x, y, "euclid"), 2)):
+        ref = g["costs_" + tag]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c, p = O.decode_states(E, np.zeros(n, dtype=bool), trans, beam=beam)
+            c_inf, p_inf = O.decode_states(E, np.zeros(n, dtype=bool), trans, beam=np.inf)
+            c_big, p_big = O.decode_states(E, np.zeros(n, dtype=bool), trans, beam=n)
+        alive = np.isfinite(ref) & (ref != -1)                    # (dtw leaves -1 marks in its last column only)
+        np.testing.assert_array_equal(np.isfinite(c[:, :-1]), alive[:, :-1])
+        close(c[:, :-1][alive[:, :-1]], ref[:, :-1][alive[:, :-1]])
+        np.testing.assert_array_equal(p, g["path_" + tag])
+        np.testing.assert_array_equal(c_big, c_inf)              # a beam as wide as the column prunes nothing
+        np.testing.assert_array_equal(p_big, p_inf)
+        assert c[-1, -1] >= c_inf[-1, -1]                        # pruning can only cost
+
+
 # ---------------------------------------------------------------------------- A7
 @pytest.mark.parametrize("k", [2, 3])
 @pytest.mark.parametrize("tag,iters", [("it1", 1), ("conv", 10000)])
