@@ -345,7 +345,7 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
     N = int(off[-1])
     b = _hip.Batch(ctx, feats_dev=xt.data_ptr(), dim=D, offsets=off, dtype=npdt)
     gmm = _hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), wl["w"].reshape(S, M))
-    t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()), reps=2, ramp=0.0)
+    t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()), reps=3, ramp=0.2)
     esz = np.dtype(npdt).itemsize
     out = {}
     truth = [list(w) for w in words]
@@ -356,7 +356,7 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
         R = len(graph["row_state"])
         row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
         ml = max_labels if max_labels is not None else b.lengths // (n - 1) + 2
-        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False), reps=2, ramp=0.0)
+        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False), reps=5, ramp=0.25)   # (the first calls grow the scratch arenas)
         lf, lo, ln = r["labels_flat"], r["label_off"], r["n_labels"]
         acc = float(np.mean([[int(v) for v in lf[lo[u]:lo[u] + ln[u]]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
         bytes_dp = float((esz * S + 4) * N)     # un-fused Viterbi over materialised likelihoods

@@ -213,6 +213,14 @@ int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
                       double* out_end_cost, int32_t* out_best_end,
                       int32_t* out_labels, const int64_t* label_off /*[U+1]*/, int32_t* out_n_labels);
 
+/* The same with a PACKED result: every utterance may produce up to `max_labels` labels (device-side slots), but only
+ * the labels that exist come back: out_labels holds utterance 0's labels, then utterance 1's, ... (utterance u at
+ * sum of out_n_labels[0..u-1]); out_capacity = entries out_labels can take (U * max_labels always suffices). */
+int gh_viterbi_labels_packed(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
+                             const int32_t* utt_lattice /*[U] or NULL*/, const int32_t* row_label, int max_labels,
+                             double* out_end_cost, int32_t* out_best_end,
+                             int32_t* out_labels, int64_t out_capacity, int32_t* out_n_labels);
+
 /* ------------------------------------------------------------------ A5: dtw
  * Template DP of every utterance of an fp64 batch against the n template rows y
  * (decode.py:7-77): every origin of the previous column is a candidate (+inf arcs

@@ -43,13 +43,25 @@ __global__ __launch_bounds__(64) void path_labels_kernel(const int32_t* __restri
     if (lane == 0) n_labels[u] = count;
 }
 
+// label mode, packed result: utterance u's labels move from its slot (label_off[u], capacity) to packed[pack_off[u] ...]
+__global__ void pack_labels_kernel(const int32_t* __restrict__ labels, const int64_t* __restrict__ label_off,
+                                   const int32_t* __restrict__ n_labels, const int64_t* __restrict__ pack_off,
+                                   int32_t* __restrict__ packed, int64_t U) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int32_t* src = labels + label_off[u];
+    int32_t* dst = packed + pack_off[u];
+    const int n = n_labels[u];
+    for (int i = 0; i < n; ++i) dst[i] = src[i];
+}
+
 }  // namespace
 
 static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
                         double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
                         const int64_t* path_off, int32_t* out_path_len, double* out_costs,
                         const int64_t* costs_off, const int32_t* row_label, int32_t* out_labels,
-                        const int64_t* label_off, int32_t* out_n_labels) {
+                        const int64_t* label_off, int32_t* out_n_labels, int64_t packed_cap = -1) {
     GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
     GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
@@ -162,12 +174,14 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (want_bp) cv.add(&d_bp, bp_max);
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
-    int64_t* d_labeloff = nullptr;
+    int64_t *d_labeloff = nullptr, *d_poff = nullptr;
+    int32_t* d_packed = nullptr;
     int64_t n_rows_total = 0;
     for (auto& lh : lat->lat) n_rows_total = std::max<int64_t>(n_rows_total, lh.row_base + lh.R);
     if (want_labels) {
         cv.add(&d_rowlabel, n_rows_total); cv.add(&d_labeloff, U + 1);
         cv.add(&d_nlabels, U); cv.add(&d_labels, label_off[U]);   // [n_labels | labels] back to back: one copy
+        if (packed_cap >= 0) { cv.add(&d_poff, U + 1); cv.add(&d_packed, label_off[U]); }
     }
     int rc = cv.commit(ctx);
     if (rc) return rc;
@@ -301,7 +315,20 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             GH_HIP(hipGetLastError());
         }
         GH_HIP(hipMemcpyAsync(out_n_labels, d_nlabels, U * 4, hipMemcpyDeviceToHost, st));
-        if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
+        if (packed_cap >= 0) {
+            // packed result: only the labels that exist cross the bus (a slot per utterance is sized for the longest
+            // word string the grammar allows -- 40 MB of slots against 3.5 MB of labels for 125 000 loop-grammar decodes)
+            GH_HIP(hipStreamSynchronize(st));
+            std::vector<int64_t> poff(U + 1, 0);
+            for (int64_t u = 0; u < U; ++u) poff[u + 1] = poff[u] + std::max(0, out_n_labels[u]);
+            GH_REQUIRE(poff[U] <= packed_cap, "gh_viterbi_labels_packed: %lld labels, capacity %lld", (long long)poff[U], (long long)packed_cap);
+            GH_HIP(hipMemcpyAsync(d_poff, poff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(pack_labels_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_labels, d_labeloff, d_nlabels,
+                               d_poff, d_packed, U);
+            GH_HIP(hipGetLastError());
+            if (poff[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_packed, (size_t)poff[U] * 4, hipMemcpyDeviceToHost, st));
+            GH_HIP(hipStreamSynchronize(st));   // (poff is a host vector of this scope)
+        } else if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
     }
     GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
     if (out_path) {
@@ -606,3 +633,14 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     return GH_OK;
 }
 
+
+extern "C" int gh_viterbi_labels_packed(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                                        const int32_t* row_label, int max_labels, double* out_end_cost, int32_t* out_best_end,
+                                        int32_t* out_labels, int64_t out_capacity, int32_t* out_n_labels) {
+    GH_REQUIRE(ctx && lat && b && row_label && out_labels && out_n_labels, "gh_viterbi_labels_packed: NULL argument");
+    GH_REQUIRE(max_labels > 0 && out_capacity >= 0, "gh_viterbi_labels_packed: max_labels=%d", max_labels);
+    std::vector<int64_t> off((size_t)b->U + 1);
+    for (int64_t u = 0; u <= b->U; ++u) off[u] = u * (int64_t)max_labels;
+    return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        row_label, out_labels, off.data(), out_n_labels, out_capacity);
+}

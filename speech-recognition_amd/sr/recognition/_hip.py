@@ -69,6 +69,8 @@ SIGNATURES = {
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
     "gh_viterbi_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, _c_f64p, _c_i32p, _c_i32p,
                                     _c_i64p, _c_i32p]),
+    "gh_viterbi_labels_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, C.c_int, _c_f64p, _c_i32p,
+                                           _c_i32p, C.c_int64, _c_i32p]),
     "gh_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f64p,
                          _c_f64p, _c_i32p, _c_i32p]),
     "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
@@ -586,9 +588,19 @@ class Lattices:
         cap = np.where(T > 1, T * nlev // 2 + 1, 0)
         if max_labels is not None:   # the caller knows a tighter bound (e.g. K + 1 for a K-layer lattice): smaller copy-back
             cap = np.minimum(cap, np.asarray(max_labels, dtype=np.int64))
+        n_labels = np.empty(U, dtype=np.int32)
+        if not as_lists and U > 0:
+            # packed: one device slot of the largest capacity per utterance, only the labels that exist come back
+            mx = int(max(1, np.max(cap)))
+            labels = np.empty(U * mx, dtype=np.int32)
+            _check(lib, lib.gh_viterbi_labels_packed(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(rl, _c_i32p), mx,
+                                                     _ptr(end_cost, _c_f64p), _ptr(best_end, _c_i32p), _ptr(labels, _c_i32p),
+                                                     labels.size, _ptr(n_labels, _c_i32p)))
+            label_off = np.concatenate([[0], np.cumsum(n_labels)]).astype(np.int64)
+            return dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost, labels_flat=labels[:label_off[-1]],
+                        label_off=label_off[:-1], n_labels=n_labels)
         label_off = np.concatenate([[0], np.cumsum(cap)]).astype(np.int64)
         labels = np.empty(int(label_off[-1]), dtype=np.int32)
-        n_labels = np.empty(U, dtype=np.int32)
         _check(lib, lib.gh_viterbi_labels(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(rl, _c_i32p),
                                           _ptr(end_cost, _c_f64p), _ptr(best_end, _c_i32p), _ptr(labels, _c_i32p),
                                           _ptr(label_off, _c_i64p), _ptr(n_labels, _c_i32p)))

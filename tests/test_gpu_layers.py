@@ -254,8 +254,13 @@ def test_loop_kernel_equals_lean_kernel(hip, ctx, W, n, skip, penalty):
         row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
         la = lat.viterbi_labels(b, row_word)
         lb = lat.viterbi_labels(b, row_word, utt_lattice=np.zeros(U, dtype=np.int32))
+        lc = lat.viterbi_labels(b, row_word, as_lists=False)                    # packed result (gh_viterbi_labels_packed)
+        ld = lat.viterbi_labels(b, row_word, utt_lattice=np.zeros(U, dtype=np.int32), as_lists=False)
         for u in range(U):
             np.testing.assert_array_equal(la["labels"][u], lb["labels"][u])
+            for pk in (lc, ld):
+                np.testing.assert_array_equal(pk["labels_flat"][pk["label_off"][u]:pk["label_off"][u] + pk["n_labels"][u]], la["labels"][u])
+        assert len(lc["labels_flat"]) == sum(len(l) for l in la["labels"])
         b.close()
     lat.close()
     gmm.close()
