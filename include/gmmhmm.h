@@ -179,6 +179,13 @@ void gh_lattices_destroy(gh_lattices* l);
  * to the unpruned kernels).  A pruned decode runs on the generic kernel. */
 int gh_lattices_set_beam(gh_lattices* l, int beam);
 
+/* Which special forms the graphs were recognised in when they were created (the kernels behind gh_viterbi and
+ * gh_forward_backward are chosen by form; anything else runs on the row-per-lane kernels).  Bit 0: one left-to-right
+ * chain (hmm.py:126-135); bit 1: K layers of the same W words (build_state_sequences, continuous_speech.py:13-53);
+ * bit 2: word-loop grammar; bit 3: one word per layer, a graph per transcript (continuous_speech.py:80); bit 4:
+ * one-word chains for forward-backward.  < 0: NULL argument. */
+int gh_lattices_forms(const gh_lattices* l);
+
 /* --------------------------------------------------- A6: decode_hmm_states
  * Viterbi over graph utt_lattice[u] (NULL: graph 0) for every utterance of the
  * batch, using the resident likelihood matrix (gh_loglik must have run).

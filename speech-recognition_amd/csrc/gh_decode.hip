@@ -57,6 +57,13 @@ __global__ void pack_labels_kernel(const int32_t* __restrict__ labels, const int
 
 }  // namespace
 
+// GMMHMM_VITERBI=lean / generic (read at every call: the parity tests switch it) keeps the form-specific kernels out:
+// 1 = the row-per-lane lean kernel where it applies, 2 = the generic kernel
+static int forced_kernel() {
+    const char* e = getenv("GMMHMM_VITERBI");
+    return !e ? 0 : !strcmp(e, "lean") ? 1 : !strcmp(e, "generic") ? 2 : 0;
+}
+
 static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
                         double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
                         const int64_t* path_off, int32_t* out_path_len, double* out_costs,
@@ -76,7 +83,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     // the reference's wrap-around semantics, which only the lean / generic kernels implement)
     bool use_chain = lat->chain_ok && uniform && lat->beam <= 0;   // (a beam needs the generic kernel)
     {
-        static const bool no_chain = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        const bool no_chain = forced_kernel() != 0;
         if (no_chain) use_chain = false;
         for (int64_t u = 0; use_chain && u < U; ++u)
             if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
@@ -85,10 +92,18 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     // generic force the others)
     bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs && lat->beam <= 0;
     {
-        static const bool no_layers = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && (!strcmp(e, "generic") || !strcmp(e, "lean")); }();
+        const bool no_layers = forced_kernel() != 0;
         if (no_layers) use_layers = false;
         for (int64_t u = 0; use_layers && u < U; ++u)
             if (b->offsets[u + 1] - b->offsets[u] == 1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
+    }
+    // sequence form (forced-alignment graphs, one per distinct transcript; gh_seq.hip)
+    bool use_seq = !use_chain && !use_layers && lat->seq_ok && !out_costs && lat->beam <= 0;
+    {
+        const bool no_seq = forced_kernel() != 0;
+        if (no_seq) use_seq = false;
+        for (int64_t u = 0; use_seq && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) use_seq = false;
     }
     // layer-form kernels in label mode: the back-trace writes the label sequences itself, no path is materialised
     const bool labels_direct = use_layers && want_labels && !out_path;
@@ -142,6 +157,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             const int l = utt_lattice ? utt_lattice[u] : 0;
             // (blocks padded to 8 entries = 16 bytes: the lean kernel flushes back-pointers with 16-byte stores)
             const size_t need = use_layers ? gh_layers_bp_entries(lat->h_layers, b->offsets[u + 1] - b->offsets[u])
+                                : use_seq ? gh_seq_bp_entries(lat->seq_N, lat->seq_skip, b->offsets[u + 1] - b->offsets[u])
                                            : ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
             if (acc && (acc + need) * 2 > BP_BUDGET) {
                 chunk_begin.push_back(k);
@@ -239,6 +255,22 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             if (rc) return rc;
         }
     }
+    if (use_seq) {
+        gh_layers_args c;
+        memset(&c, 0, sizeof c);
+        c.seqgraphs = lat->d_seqgraphs; c.seqwords = lat->d_seqwords; c.utt_lat = d_uttlat; c.end_off = d_endoff;
+        c.end_slot = lat->d_seq_end_slot; c.end_rows = lat->d_end_rows; c.n_end = lat->lat[0].n_end; c.S = S;
+        c.nll = b->nll; c.utt_off = b->d_offsets; c.perm = b->d_perm; c.bp = d_bp; c.bp_off = d_bpoff;
+        c.end_cost = d_endcost; c.best_end = d_bestend; c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen;
+        c.flag = d_flag2;
+        for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
+            const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
+            rc = gh_launch_viterbi_seq(ctx, c, lat->seq_N, lat->seq_skip, u0, nu, b->dtype == GH_F64, want_path);
+            if (!rc && want_path) rc = gh_launch_seq_backtrace(ctx, c, lat->seq_N, lat->seq_skip, u0, nu);
+            if (rc) return rc;
+        }
+        use_layers = true;   // (from here on: "a lattice kernel has run", the row-per-lane kernels are skipped)
+    }
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));
@@ -247,7 +279,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     int lean_levels = 0, max_arcs = 0;
     for (auto& lh : lat->lat) max_arcs = std::max(max_arcs, lh.A);
     {
-        static const bool no_lean = [] { const char* e = getenv("GMMHMM_VITERBI"); return e && !strcmp(e, "generic"); }();
+        const bool no_lean = forced_kernel() == 2;
         int lean_lanes = 1;
         for (auto& d : lat->h_desc) lean_lanes = std::max(lean_lanes, d.lean_lanes);
         const int lb = std::max(64, (lean_lanes + 63) & ~63);
@@ -577,7 +609,10 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     Carver cv;
     double* d_selfxi = nullptr;
     cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
+    const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !mats && !(e && !strcmp(e, "generic")); }();
+    double* d_xiparts = nullptr;
     if (out_self_xi) cv.add(&d_selfxi, S);
+    if (out_self_xi && use_fbseq) cv.add(&d_xiparts, (size_t)GH_FBSEQ_XI_PARTS * S);
     if (utt_lattice) cv.add(&d_uttlat, U);
     if (mats) cv.add(&d_matoff, U + 1);
     if (out_alpha) cv.add(&d_alpha, n_mat);
@@ -604,6 +639,37 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     a.self_xi = d_selfxi;
     if (d_selfxi) GH_HIP(hipMemsetAsync(d_selfxi, 0, (size_t)S * 8, st));
     if (want_occ && b->d_occ_states) { GH_HIP(hipFree(b->d_occ_states)); b->d_occ_states = nullptr; }   // any state may be occupied
+    // forced-alignment graphs (one word per layer): four utterances per wave, lane = layer (GMMHMM_FB=generic forces the other)
+    {
+        if (use_fbseq) {
+            if (out_self_xi) GH_HIP(hipMemsetAsync(d_xiparts, 0, (size_t)GH_FBSEQ_XI_PARTS * S * 8, st));
+            if (want_occ && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, st));
+            gh_fbseq_args q;
+            memset(&q, 0, sizeof q);
+            q.graphs = lat->d_seqgraphs; q.words = lat->d_seqwords; q.end_slot = lat->d_seq_end_slot; q.nll = b->nll; q.S = S;
+            q.utt_off = b->d_offsets; q.utt_lat = d_uttlat; q.perm = b->d_perm; q.alpha_scratch = d_scratch; q.scratch_off = d_soff;
+            q.logp = d_logp; q.occ = want_occ ? b->occ : nullptr; q.self_xi_parts = d_xiparts;
+            for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
+                rc = gh_launch_fb_seq(ctx, q, lat->seq_N, lat->seq_skip, chunk_begin[c], chunk_begin[c + 1] - chunk_begin[c], b->dtype == GH_F64);
+                if (rc) return rc;
+            }
+            if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_logp, U * 8, hipMemcpyDeviceToHost, st));
+            if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, st));
+            std::vector<double> parts;
+            if (out_self_xi) {
+                parts.resize((size_t)GH_FBSEQ_XI_PARTS * S);
+                GH_HIP(hipMemcpyAsync(parts.data(), d_xiparts, parts.size() * 8, hipMemcpyDeviceToHost, st));
+            }
+            GH_HIP(hipStreamSynchronize(st));
+            if (out_self_xi)
+                for (int s = 0; s < S; ++s) {
+                    double acc2 = 0.0;
+                    for (int p = 0; p < GH_FBSEQ_XI_PARTS; ++p) acc2 += parts[(size_t)p * S + s];
+                    out_self_xi[s] = acc2;
+                }
+            return GH_OK;
+        }
+    }
     int max_level_rows = 1;
     for (auto& d : lat->h_desc) max_level_rows = std::max(max_level_rows, d.pad);
     const int block = std::min(512, std::max(64, (max_level_rows + 63) & ~63));

@@ -54,3 +54,23 @@ struct gh_fbchain_args {
     double* self_xi_utt;         // optional [U, GH_FBCHAIN_MAX]: expected self transitions of every chain row of every utterance
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);
+
+// forced-alignment graphs in sequence form (gh_seqgraph): four utterances per wave, lane = layer (fb_seq_kernel, gh_seq.hip)
+#define GH_FBSEQ_XI_PARTS 256
+struct gh_fbseq_args {
+    const gh_seqgraph* graphs;
+    const gh_seqword* words;
+    const int32_t* end_slot;     // [rows of all graphs] >= 0 on end rows
+    const void* nll;
+    int S;
+    const int64_t* utt_off;
+    const int32_t* utt_lat;      // or null (graph 0)
+    const int64_t* perm;
+    int64_t slot0;
+    double* alpha_scratch;       // [T, K, N] per launch slot
+    const int64_t* scratch_off;  // [slots]
+    double* logp;                // [U]
+    double* occ;                 // optional [N,S], zeroed by the caller (double atomics: a word may stand in several layers)
+    double* self_xi_parts;       // optional [GH_FBSEQ_XI_PARTS, S], zeroed by the caller; summed by the caller
+};
+int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64);

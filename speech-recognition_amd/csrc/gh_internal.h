@@ -158,6 +158,25 @@ struct gh_layerform {
     double cin0[GH_LAYERS_MAXW];                        // loop form: arc from the start row into state 0 (arcs bit4)
 };
 
+// SEQUENCE form: a forced-alignment lattice (continuous_speech.py:80: build_state_sequences(models, [[l] for l in labels])) --
+// K <= 16 layers with ONE word each (different words in different layers), rows as in the layer form with W = 1:
+// row 0 non-emitting start, layer k = rows k*(N+1)+1 .. k*(N+1)+N, non-emitting row (k+1)*(N+1) behind it.  Word
+// templates are shared between graphs (thousands of transcripts use the same few words).  gh_viterbi and
+// gh_forward_backward run such graphs with FOUR utterances per wave: DPP row = utterance, lane = layer, the N states
+// of the layer's word in registers, the non-emitting row handed to the next lane by row_shr:1 (gh_seq.hip).
+#define GH_SEQ_MAXK 16
+struct gh_seqword {
+    int32_t state[GH_LAYERS_MAXN];
+    uint8_t arcs[GH_LAYERS_MAXN];          // bit0 self, bit1 from s-1, bit2 from s-2, bit3 from the non-emitting row
+    double c0[GH_LAYERS_MAXN], c1[GH_LAYERS_MAXN], c2[GH_LAYERS_MAXN];
+    double cin, cout;
+};
+struct gh_seqgraph {
+    int32_t K, n_end;
+    int64_t row_base, end_base;
+    int32_t word[GH_SEQ_MAXK];             // template of every layer's word
+};
+
 struct gh_lattices {
     gh_ctx* ctx;
     void* d_arena;   // the one device allocation all the d_* pointers below point into
@@ -199,6 +218,13 @@ struct gh_lattices {
     gh_layerform h_layers;
     gh_layerform* d_layers;
     int32_t* d_lf_end_slot;          // [R] position of a row in the end list or -1
+    bool seq_ok;                     // every graph is in sequence form with the same N
+    int seq_N, seq_skip;
+    std::vector<gh_seqgraph> h_seqgraphs;
+    std::vector<gh_seqword> h_seqwords;
+    gh_seqgraph* d_seqgraphs;
+    gh_seqword* d_seqwords;
+    int32_t* d_seq_end_slot;         // [Rtot] position of a row in its graph's end list or -1
     int beam;           // rank beam per column of gh_viterbi (0 = off): gh_lattices_set_beam; generic kernel only
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only

@@ -33,6 +33,9 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     lt->d_desc = nullptr;
     lt->d_fbchain = nullptr; lt->fbchain_ok = true;
     lt->layers_ok = false; lt->d_layers = nullptr; lt->d_lf_end_slot = nullptr;
+    lt->seq_ok = true; lt->seq_N = 0; lt->seq_skip = 0; lt->d_seqgraphs = nullptr; lt->d_seqwords = nullptr; lt->d_seq_end_slot = nullptr;
+    std::vector<int32_t> seq_slot(Rtot, -1);
+    std::vector<std::string> seq_keys;   // content keys of the word templates collected so far
     h_end.assign(end_rows, end_rows + Etot);
     for (int l = 0; l < L; ++l) {
         const int64_t r0 = row_off[l], a0 = arc_off[l];
@@ -145,6 +148,77 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         lt->max_R = std::max(lt->max_R, R);
         lt->max_nlev = std::max(lt->max_nlev, nlev);
 
+        // ---- sequence form (gh_seqgraph): K layers of ONE word each, non-emitting rows between them ----
+        if (lt->seq_ok) {
+            bool ok = R >= 4 && h_state[r0] < 0 && ns == 1 && (h_start[r0] & 1) && !lt->has_nan_arc;
+            int N = 0;
+            if (ok) {
+                int r = 1;
+                while (r < R && h_state[r0 + r] >= 0) ++r;
+                N = r - 1;
+                ok = N >= 2 && N <= GH_LAYERS_MAXN && r < R && (R - 1) % (N + 1) == 0 && (lt->seq_N == 0 || lt->seq_N == N);
+            }
+            const int K = ok ? (R - 1) / (N + 1) : 0;
+            ok = ok && K >= 1 && K <= GH_SEQ_MAXK;
+            for (int r = 0; ok && r < R; ++r) if ((r % (N + 1) == 0) != (h_state[r0 + r] < 0)) ok = false;
+            std::vector<gh_seqword> wl(ok ? K : 0);
+            for (auto& wd : wl) {
+                memset(&wd, 0, sizeof wd);
+                wd.cin = wd.cout = INFINITY;
+                for (int sx = 0; sx < GH_LAYERS_MAXN; ++sx) { wd.c0[sx] = wd.c1[sx] = wd.c2[sx] = INFINITY; wd.state[sx] = -1; }
+            }
+            bool skip = false;
+            for (int r = 0; ok && r < R; ++r)
+                for (int p = ptr[r]; ok && p < ptr[r + 1]; ++p) {
+                    const int o = (int)(h_prow[a0 + p] & GH_ARC_ROW);
+                    const double c = h_pcost[a0 + p];
+                    const bool r_nes = r % (N + 1) == 0, o_nes = o % (N + 1) == 0;
+                    if (!r_nes && !o_nes) {
+                        const int k = (r - 1) / (N + 1), sx = (r - 1) % (N + 1), d = r - o;
+                        if ((o - 1) / (N + 1) != k || d < 0 || d > 2 || d > sx) { ok = false; break; }
+                        double& t = d == 0 ? wl[k].c0[sx] : d == 1 ? wl[k].c1[sx] : wl[k].c2[sx];
+                        if (!std::isinf(t)) { ok = false; break; }
+                        t = c;
+                        wl[k].arcs[sx] |= (uint8_t)(1 << d);
+                        if (d == 2) skip = true;
+                    } else if (o_nes && !r_nes) {              // non-emitting row k -> state 0 of layer k
+                        const int k = (r - 1) / (N + 1), sx = (r - 1) % (N + 1);
+                        if (o != k * (N + 1) || sx != 0 || !std::isinf(wl[k].cin)) { ok = false; break; }
+                        wl[k].cin = c;
+                        wl[k].arcs[0] |= 8;
+                    } else if (r_nes && !o_nes) {              // last state of layer k -> non-emitting row k + 1
+                        const int k = (o - 1) / (N + 1), sx = (o - 1) % (N + 1);
+                        if (r != (k + 1) * (N + 1) || sx != N - 1 || !std::isinf(wl[k].cout)) { ok = false; break; }
+                        wl[k].cout = c;
+                    } else { ok = false; break; }
+                }
+            for (int k = 0; ok && k < K; ++k) {
+                if (std::isinf(wl[k].cin)) ok = false;        // every layer is entered through its non-emitting row
+                for (int sx = 0; sx < N; ++sx) wl[k].state[sx] = h_state[r0 + k * (N + 1) + 1 + sx];
+            }
+            for (int k = 0; ok && k < ne; ++k) {
+                const int r = end_rows[end_off[l] + k];
+                if (r % (N + 1) == 0 || seq_slot[r0 + r] >= 0) ok = false;
+                else seq_slot[r0 + r] = k;
+            }
+            if (ok) {
+                gh_seqgraph sg;
+                memset(&sg, 0, sizeof sg);
+                sg.K = K; sg.n_end = ne; sg.row_base = r0; sg.end_base = end_off[l];
+                for (int k = 0; k < K; ++k) {
+                    const std::string key(reinterpret_cast<const char*>(&wl[k]), sizeof(gh_seqword));
+                    int id = -1;
+                    for (size_t i = 0; i < seq_keys.size(); ++i) if (seq_keys[i] == key) { id = (int)i; break; }
+                    if (id < 0) { id = (int)seq_keys.size(); seq_keys.push_back(key); lt->h_seqwords.push_back(wl[k]); }
+                    sg.word[k] = id;
+                }
+                lt->h_seqgraphs.push_back(sg);
+                lt->seq_N = N;
+                if (skip) lt->seq_skip = 1;
+            } else {
+                lt->seq_ok = false;
+            }
+        }
         // ---- one-word chain form for the forward-backward kernel (see gh_fbchain) ----
         if (lt->fbchain_ok) {
             gh_fbchain fc;
@@ -410,6 +484,8 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
     ar.add(&lt->d_level_ptr, h_lev); ar.add(&lt->d_level_narrow, h_narrow); ar.add(&lt->d_end_rows, h_end);
     ar.add(&lt->d_desc, lt->h_desc);
     if (lt->fbchain_ok) ar.add(&lt->d_fbchain, lt->h_fbchain);
+    if (lt->seq_ok) { ar.add(&lt->d_seqgraphs, lt->h_seqgraphs); ar.add(&lt->d_seqwords, lt->h_seqwords); ar.add(&lt->d_seq_end_slot, seq_slot); }
+    else { lt->h_seqgraphs.clear(); lt->h_seqwords.clear(); }
     const int rc = ar.commit(&lt->d_arena);
     if (rc) {
         gh_lattices_destroy(lt);
@@ -430,6 +506,12 @@ extern "C" int gh_lattices_set_beam(gh_lattices* l, int beam) {
     GH_REQUIRE(l, "gh_lattices_set_beam: NULL argument");
     l->beam = beam > 0 ? beam : 0;
     return GH_OK;
+}
+
+extern "C" int gh_lattices_forms(const gh_lattices* l) {
+    if (!l) return -1;
+    const bool loop = l->layers_ok && l->h_layers.loop;
+    return (l->chain_ok ? 1 : 0) | (l->layers_ok && !loop ? 2 : 0) | (loop ? 4 : 0) | (l->seq_ok ? 8 : 0) | (l->fbchain_ok ? 16 : 0);
 }
 
 extern "C" int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T) {

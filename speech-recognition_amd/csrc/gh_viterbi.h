@@ -93,6 +93,12 @@ struct gh_layers_args {
     int32_t* path;
     const int64_t* path_off;
     int32_t* path_len;
+    // sequence form (gh_seq.hip): per-utterance graphs made of shared word templates
+    const gh_seqgraph* seqgraphs;
+    const gh_seqword* seqwords;
+    const int32_t* utt_lat;    // [U] graph of every utterance, or null (graph 0)
+    const int64_t* end_off;    // [U] offset of the utterance's end costs, or null (u * n_end)
+    int seq_N;
     const int32_t* row_label;  // label mode (gh_viterbi_labels): label per row, < 0 on non-emitting rows
     int32_t* labels;           // utterance u at label_off[u]
     const int64_t* label_off;  // [U+1]
@@ -103,3 +109,8 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T);
 int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                              bool f64, bool want_path);
 int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);
+// sequence form (forced-alignment lattices, gh_seq.hip): forward sweep, four utterances per wave, and its back-trace
+size_t gh_seq_bp_entries(int N, int skip, int64_t T);
+int gh_launch_viterbi_seq(gh_ctx* ctx, const gh_layers_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64,
+                          bool want_path);
+int gh_launch_seq_backtrace(gh_ctx* ctx, const gh_layers_args& a, int N, int skip, int64_t u_begin, int64_t n_utts);

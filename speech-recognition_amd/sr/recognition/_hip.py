@@ -64,6 +64,7 @@ SIGNATURES = {
                                      _c_f64p, _c_i64p, _c_i32p, _c_i64p, _c_i32p, C.POINTER(C.c_void_p)]),
     "gh_lattices_destroy": (None, [C.c_void_p]),
     "gh_lattices_set_beam": (C.c_int, [C.c_void_p, C.c_int]),
+    "gh_lattices_forms": (C.c_int, [C.c_void_p]),
     "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
                              _c_i32p, _c_f64p, _c_i64p]),
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
@@ -527,6 +528,13 @@ class Lattices:
         k = 0 if beam is None or beam != beam or beam == float("inf") or beam <= 0 else int(beam)
         _check(self.ctx.lib, self.ctx.lib.gh_lattices_set_beam(self.h, k))
         self.beam = k
+
+    FORMS = ("chain", "layers", "loop", "sequence", "fb_chain")
+
+    def forms(self):
+        """Names of the special forms the graphs were recognised in (gh_lattices_forms): they select the kernels."""
+        bits = int(self.ctx.lib.gh_lattices_forms(self.h))
+        return {name for k, name in enumerate(self.FORMS) if bits >> k & 1}
 
     def path_cap(self, l, T):
         return int(self.ctx.lib.gh_viterbi_path_cap(self.h, int(l), int(T)))

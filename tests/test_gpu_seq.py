@@ -1,0 +1,219 @@
+# -*- coding: utf-8 -*-
+"""Forced-alignment lattices (continuous_speech.py:80-89: one word per layer, a graph per distinct transcript) through
+the sequence-form kernels (gh_seq.hip: four utterances per wave, lane = layer) against the row-per-lane lean kernel
+(GMMHMM_VITERBI=lean, read per call), the generic forward-backward and the oracle's reference-shaped DP."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as O
+from test_gpu_layers import word_trans
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sr.recognition import _hip
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    return hip.default_context()
+
+
+class forced:
+    """GMMHMM_VITERBI / GMMHMM_FB for the duration of a with block."""
+
+    def __init__(self, **env):
+        self.env = env
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def make_task(rng, W, n, skip, Kmax, U, M=2, D=6, short=8):
+    from sr.recognition.continuous_speech import packed_lattice
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    wt = [word_trans(rng, n, skip, last_self=rng.uniform(0.0, 0.3)) for _ in range(W)]
+    xs, labels = [], []
+    for u in range(U):
+        K = int(rng.integers(1, Kmax + 1))
+        words = [int(v) for v in rng.integers(0, W, size=K)]
+        if u < short:
+            T = int(rng.integers(2, max(3, K * (n - 1) + 1)))              # (mostly) too short for the transcript
+            xs.append(rng.normal(size=(T, D)) * 2.0)
+        else:
+            segs = []
+            for wd in words:
+                Tw = int(rng.integers(n, 3 * n + 4))
+                st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+                comp = rng.integers(0, M, size=Tw)
+                segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(Tw, D)))
+            xs.append(np.concatenate(segs))
+        labels.append(words)
+    keys, graphs, utt_graph = {}, [], np.empty(U, dtype=np.int32)
+    for u, l in enumerate(labels):
+        if tuple(l) not in keys:
+            keys[tuple(l)] = len(graphs)
+            graphs.append(packed_lattice(wt, n, [[x] for x in l])[0])
+        utt_graph[u] = keys[tuple(l)]
+    return means, vars_, w, wt, xs, labels, graphs, utt_graph
+
+
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (4, 2, False, 16), (6, 3, True, 9), (3, 8, True, 5),
+                                           (5, 4, False, 12), (2, 7, True, 3), (7, 6, False, 1)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sequence_kernel_equals_lean_kernel(hip, ctx, W, n, skip, Kmax, dtype):
+    """end costs BITWISE, chosen end and paths equal -- reachable and unreachable utterances, transcripts of 1..Kmax
+    words, ragged lengths in one launch; then the oracle on a few utterances."""
+    rng = np.random.default_rng(77 * W + 5 * n + Kmax)
+    U = 90
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U)
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, -1, means.shape[-1]), vars_.reshape(W * n, -1, means.shape[-1]),
+                        w.reshape(W * n, -1))
+    lat = hip.Lattices(ctx, graphs)
+    assert "sequence" in lat.forms()
+    b = hip.Batch(ctx, xs, dtype=dtype)
+    b.loglik(gmm, fetch=False)
+
+    def run(want_path):
+        try:
+            return lat.viterbi(b, utt_lattice=utt_graph, want_path=want_path), None
+        except hip.BackendError as e:
+            return None, str(e)
+
+    with forced(GMMHMM_VITERBI="lean"):
+        lean, lean_err = run(True)
+    fast, fast_err = run(True)
+    if lean is None:
+        # an unreachable utterance whose back-trace runs into the start row: both routes report the same thing
+        assert fast is None and "without predecessor" in lean_err and "without predecessor" in fast_err
+        keep = [u for u in range(U) if u >= 8]
+        b.close()
+        xs = [xs[u] for u in keep]
+        utt_graph = utt_graph[keep]
+        b = hip.Batch(ctx, xs, dtype=dtype)
+        b.loglik(gmm, fetch=False)
+        with forced(GMMHMM_VITERBI="lean"):
+            lean, lean_err = run(True)
+        fast, fast_err = run(True)
+        assert lean is not None and fast is not None, (lean_err, fast_err)
+    np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+    np.testing.assert_array_equal(fast["best_end"], lean["best_end"])
+    assert np.isfinite(lean["end_cost_flat"]).any()
+    for u in range(b.U):
+        np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+    nopath, _ = run(False)
+    np.testing.assert_array_equal(nopath["end_cost_flat"], lean["end_cost_flat"])
+    nll = b.loglik(gmm, fetch=True)
+    for u in (0, b.U // 2, b.U - 1):
+        graph = graphs[utt_graph[u]]
+        R = len(graph["row_state"])
+        dense = np.full((R, R), np.inf)
+        dense[graph["arc_to"], graph["arc_from"]] = graph["arc_cost"]
+        is_nes = graph["row_state"] < 0
+        E = np.zeros((R, len(xs[u])))
+        E[~is_nes] = nll[b.offsets[u]:b.offsets[u + 1]][:, graph["row_state"][~is_nes]].T
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            costs, path = O.decode_states(E, is_nes, dense, end_points=[[int(e), -1] for e in graph["end_rows"]])
+        ec = costs[np.asarray(graph["end_rows"]), -1]
+        if np.isfinite(ec).all():
+            np.testing.assert_allclose(fast["end_cost"][u], ec, rtol=1e-12 if dtype == np.float64 else 1e-5)
+            if dtype == np.float64:
+                np.testing.assert_array_equal(fast["paths"][u], path)
+    b.close()
+    lat.close()
+    gmm.close()
+
+
+def test_sequence_kernel_long_utterances_many_graphs(hip, ctx):
+    """Several hundred frames per utterance (many decision words), 300 utterances with ~300 distinct transcripts, the
+    shape of `continuous_train`'s alignment step (continuous_speech.py:80-106)."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(11)
+    W, n, M, D = 10, 5, 4, 13
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    wt = [word_trans(rng, n) for _ in range(W)]
+    xs, graphs = [], []
+    for u in range(300):
+        K = int(rng.integers(4, 8))
+        words = rng.integers(0, W, size=K)
+        segs = []
+        for wd in words:
+            Tw = int(rng.integers(6, 120 if u % 7 == 0 else 40))
+            st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+            comp = rng.integers(0, M, size=Tw)
+            segs.append(means[wd, st, comp] + np.sqrt(vars_[wd, st, comp]) * rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+        graphs.append(packed_lattice(wt, n, [[int(x)] for x in words])[0])
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    lat = hip.Lattices(ctx, graphs)
+    assert "sequence" in lat.forms()
+    ug = np.arange(300, dtype=np.int32)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    with forced(GMMHMM_VITERBI="lean"):
+        lean = lat.viterbi(b, utt_lattice=ug, want_path=True)
+    fast = lat.viterbi(b, utt_lattice=ug, want_path=True)
+    np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+    for u in range(b.U):
+        np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+    assert max(len(x) for x in xs) > 300
+    b.close()
+    lat.close()
+    gmm.close()
+
+
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (4, 2, False, 16), (6, 3, True, 9), (3, 8, True, 5), (7, 6, False, 1)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, Kmax, dtype):
+    """log P, frame x state occupancies and expected self transitions of the lane-per-layer kernel against the generic
+    row-per-lane forward-backward (GMMHMM_FB=generic) -- reachable and unreachable utterances, repeated words in one
+    transcript (the occupancies of their layers add up), single-frame utterances."""
+    rng = np.random.default_rng(31 * W + 7 * n + Kmax)
+    U = 70
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U)
+    xs[9] = xs[9][:1]                                                  # T == 1
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, -1, means.shape[-1]), vars_.reshape(W * n, -1, means.shape[-1]),
+                        w.reshape(W * n, -1))
+    lat = hip.Lattices(ctx, graphs)
+    assert "sequence" in lat.forms()
+    b = hip.Batch(ctx, xs, dtype=dtype)
+    b.loglik(gmm, fetch=False)
+    with forced(GMMHMM_FB="generic"):
+        ref = lat.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+    got = lat.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+    fin = np.isfinite(ref["logp"])
+    assert fin.any() and (Kmax < 3 or (~fin).any())
+    np.testing.assert_array_equal(np.isfinite(got["logp"]), fin)
+    np.testing.assert_allclose(got["logp"][fin], ref["logp"][fin], rtol=1e-12)
+    np.testing.assert_allclose(got["occ"], ref["occ"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got["self_xi"], ref["self_xi"], rtol=1e-9, atol=1e-12)
+    # every frame of a reachable utterance is in exactly one state of its transcript... or, on a word boundary, in two:
+    # the last state of a word and the first of the next share the boundary frame (decode.py:109-111)
+    rows = got["occ"].sum(axis=1)
+    for u in np.nonzero(fin)[0][:10]:
+        r = rows[b.offsets[u]:b.offsets[u + 1]]
+        assert (r > 1 - 1e-9).all() and (r < 2 + 1e-9).all()
+    only = lat.forward_backward(b, utt_lattice=utt_graph)            # log P alone: no backward sweep
+    np.testing.assert_array_equal(only["logp"], got["logp"])
+    b.close()
+    lat.close()
+    gmm.close()
