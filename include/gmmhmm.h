@@ -220,6 +220,19 @@ int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
                       double* out_end_cost, int32_t* out_best_end,
                       int32_t* out_labels, const int64_t* label_off /*[U+1]*/, int32_t* out_n_labels);
 
+/* A6 + the regrouping step of continuous_train in one call (continuous_speech.py:80-106): the same decode, the path
+ * stays on the device and what comes back is, per FRAME of the batch, the state whose training data the frame joins:
+ * walking an utterance's path start -> end, a run opens at the first cell of an emitting row seen while no run is open;
+ * a cell of a different row closes the open run as the frames [start, c) -- c = that cell's column -- provided
+ * start < c, and does not itself open a run (:96-106; so the frame on which a state is entered inside a word is
+ * dropped, a word-boundary frame goes to the next word only, the final state's last run is never closed).
+ * out_frame_state [N]: row_state of the run's row, | GH_SEGMENT_START on the first frame of a run (the number of runs
+ * of a state is the segment count of :158-160); -1 for frames in no run. */
+#define GH_SEGMENT_START (1 << 30)
+int gh_align_segments(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
+                      const int32_t* utt_lattice /*[U] or NULL*/,
+                      double* out_end_cost, int32_t* out_best_end, int32_t* out_frame_state /*[N]*/);
+
 /* The same with a PACKED result: every utterance may produce up to `max_labels` labels (device-side slots), but only
  * the labels that exist come back: out_labels holds utterance 0's labels, then utterance 1's, ... (utterance u at
  * sum of out_n_labels[0..u-1]); out_capacity = entries out_labels can take (U * max_labels always suffices). */

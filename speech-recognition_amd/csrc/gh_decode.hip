@@ -43,6 +43,35 @@ __global__ __launch_bounds__(64) void path_labels_kernel(const int32_t* __restri
     if (lane == 0) n_labels[u] = count;
 }
 
+// The regrouping step of continuous_train (continuous_speech.py:90-106) on the device-resident path, one lane per
+// utterance: walking the path start -> end, a run opens at the first cell of an emitting row seen while no run is open;
+// a cell of a DIFFERENT row closes the open run as the frames [start, c), c being that cell's column, provided
+// start < c, and does not itself open a run (so the frame on which a state is entered inside a word is dropped, the
+// frame on a word boundary goes to the next word only, and the final state's last run is never closed).
+// frame_state[f] = state of the run frame f belongs to, | GH_SEGMENT_START on the first frame of a run; -1 otherwise.
+__global__ void cut_segments_kernel(const int32_t* __restrict__ path, const int64_t* __restrict__ path_off,
+                                    const int32_t* __restrict__ path_len, const int32_t* __restrict__ utt_lat,
+                                    const gh_lattices::desc* __restrict__ descs, const int32_t* __restrict__ row_state,
+                                    const int64_t* __restrict__ utt_off, int64_t U, int32_t* __restrict__ frame_state) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int2* p = reinterpret_cast<const int2*>(path) + path_off[u];
+    const int32_t* rs = row_state + descs[utt_lat ? utt_lat[u] : 0].row_base;
+    int32_t* out = frame_state + utt_off[u];
+    int open_row = -1, open_at = -1;
+    for (int i = path_len[u] - 1; i >= 0; --i) {
+        const int2 cell = p[i];
+        if (open_at < 0 && rs[cell.x] >= 0) { open_row = cell.x; open_at = cell.y; }
+        if (cell.x != open_row && open_at >= 0 && open_at < cell.y) {
+            const int sid = rs[open_row];
+            out[open_at] = sid | GH_SEGMENT_START;
+            for (int f = open_at + 1; f < cell.y; ++f) out[f] = sid;
+            open_row = -1;
+            open_at = -1;
+        }
+    }
+}
+
 // label mode, packed result: utterance u's labels move from its slot (label_off[u], capacity) to packed[pack_off[u] ...]
 __global__ void pack_labels_kernel(const int32_t* __restrict__ labels, const int64_t* __restrict__ label_off,
                                    const int32_t* __restrict__ n_labels, const int64_t* __restrict__ pack_off,
@@ -68,7 +97,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
                         double* out_end_cost, int32_t* out_best_end, int32_t* out_path,
                         const int64_t* path_off, int32_t* out_path_len, double* out_costs,
                         const int64_t* costs_off, const int32_t* row_label, int32_t* out_labels,
-                        const int64_t* label_off, int32_t* out_n_labels, int64_t packed_cap = -1) {
+                        const int64_t* label_off, int32_t* out_n_labels, int64_t packed_cap = -1,
+                        int32_t* out_frame_state = nullptr) {
     GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
     GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
@@ -78,6 +108,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
     const bool want_labels = out_labels != nullptr;
+    const bool want_segments = out_frame_state != nullptr;
     const bool uniform = utt_lattice == nullptr;
     // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
     // the reference's wrap-around semantics, which only the lean / generic kernels implement)
@@ -108,7 +139,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     // layer-form kernels in label mode: the back-trace writes the label sequences itself, no path is materialised
     const bool labels_direct = use_layers && want_labels && !out_path;
     std::vector<int64_t> own_path_off;  // label mode: the path lives on the device only, capacities are ours
-    if (want_labels && !out_path && !labels_direct) {
+    if ((want_labels || want_segments) && !out_path && !labels_direct) {
         own_path_off.assign(U + 1, 0);
         for (int64_t u = 0; u < U; ++u) {
             const int l = utt_lattice ? utt_lattice[u] : 0;
@@ -118,7 +149,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         }
         path_off = own_path_off.data();
     }
-    const bool want_path = out_path != nullptr || want_labels;
+    const bool want_path = out_path != nullptr || want_labels || want_segments;
     for (int l = 0; l < lat->L; ++l)
         GH_REQUIRE(lat->lat[l].max_state < S, "gh_viterbi: graph %d uses state %d but the model has %d", l,
                    lat->lat[l].max_state, S);
@@ -189,6 +220,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     if (want_path && !labels_direct) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
     if (want_bp) cv.add(&d_bp, bp_max);
     if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+    int32_t* d_framestate = nullptr;
+    if (want_segments) cv.add(&d_framestate, b->N);
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
     int64_t *d_labeloff = nullptr, *d_poff = nullptr;
     int32_t* d_packed = nullptr;
@@ -362,6 +395,13 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             GH_HIP(hipStreamSynchronize(st));   // (poff is a host vector of this scope)
         } else if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
     }
+    if (want_segments && b->N > 0) {
+        GH_HIP(hipMemsetAsync(d_framestate, 0xFF, (size_t)b->N * 4, st));
+        hipLaunchKernelGGL(cut_segments_kernel, dim3((unsigned)((U + 63) / 64)), dim3(64), 0, st, d_path, d_pathoff, d_pathlen, d_uttlat,
+                           lat->d_desc, lat->d_row_state, b->d_offsets, U, d_framestate);
+        GH_HIP(hipGetLastError());
+        GH_HIP(hipMemcpyAsync(out_frame_state, d_framestate, (size_t)b->N * 4, hipMemcpyDeviceToHost, st));
+    }
     GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
     if (out_path) {
         GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
@@ -527,12 +567,17 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     }
     // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
     const size_t BUDGET = (size_t)4 << 30;
+    const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
     std::vector<int64_t> soff(U, 0), chunk_begin{0};
     size_t acc = 0, smax = 0;
     for (int64_t k = 0; k < U; ++k) {
         const int64_t u = b->perm[k];
         const int l = utt_lattice ? utt_lattice[u] : 0;
-        const size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+        size_t need = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R;
+        if (use_fbseq) {   // [T, K, N] mantissas (double) followed by as many exponents (int32)
+            const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->h_seqgraphs[l].K * lat->seq_N;
+            need = cells + (cells + 1) / 2;
+        }
         if (acc && (acc + need) * 8 > BUDGET) { chunk_begin.push_back(k); smax = std::max(smax, acc); acc = 0; }
         soff[k] = (int64_t)acc;
         acc += need;
@@ -609,7 +654,6 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     Carver cv;
     double* d_selfxi = nullptr;
     cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
-    const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !mats && !(e && !strcmp(e, "generic")); }();
     double* d_xiparts = nullptr;
     if (out_self_xi) cv.add(&d_selfxi, S);
     if (out_self_xi && use_fbseq) cv.add(&d_xiparts, (size_t)GH_FBSEQ_XI_PARTS * S);
@@ -643,9 +687,11 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     {
         if (use_fbseq) {
             if (out_self_xi) GH_HIP(hipMemsetAsync(d_xiparts, 0, (size_t)GH_FBSEQ_XI_PARTS * S * 8, st));
-            if (want_occ && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, st));
+            const bool occ_lds = S <= 256;   // (a word may stand in several layers of a transcript: their occupancies add up)
+            if (want_occ && !occ_lds && b->N > 0) GH_HIP(hipMemsetAsync(b->occ, 0, (size_t)b->N * S * 8, st));
             gh_fbseq_args q;
             memset(&q, 0, sizeof q);
+            q.occ_in_lds = occ_lds;
             q.graphs = lat->d_seqgraphs; q.words = lat->d_seqwords; q.end_slot = lat->d_seq_end_slot; q.nll = b->nll; q.S = S;
             q.utt_off = b->d_offsets; q.utt_lat = d_uttlat; q.perm = b->d_perm; q.alpha_scratch = d_scratch; q.scratch_off = d_soff;
             q.logp = d_logp; q.occ = want_occ ? b->occ : nullptr; q.self_xi_parts = d_xiparts;
@@ -699,6 +745,13 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     return GH_OK;
 }
 
+
+extern "C" int gh_align_segments(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                                 double* out_end_cost, int32_t* out_best_end, int32_t* out_frame_state) {
+    GH_REQUIRE(ctx && lat && b && out_frame_state, "gh_align_segments: NULL argument");
+    return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, -1, out_frame_state);
+}
 
 extern "C" int gh_viterbi_labels_packed(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
                                         const int32_t* row_label, int max_labels, double* out_end_cost, int32_t* out_best_end,

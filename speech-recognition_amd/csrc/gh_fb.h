@@ -70,7 +70,9 @@ struct gh_fbseq_args {
     double* alpha_scratch;       // [T, K, N] per launch slot
     const int64_t* scratch_off;  // [slots]
     double* logp;                // [U]
-    double* occ;                 // optional [N,S], zeroed by the caller (double atomics: a word may stand in several layers)
+    double* occ;                 // optional [N,S]
+    int occ_in_lds;              // 1: a frame's S occupancies are summed in LDS and stored as one row (every frame of every
+                                 //    utterance is written: no zeroing needed); 0: double atomics on occ, zeroed by the caller
     double* self_xi_parts;       // optional [GH_FBSEQ_XI_PARTS, S], zeroed by the caller; summed by the caller
 };
 int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64);

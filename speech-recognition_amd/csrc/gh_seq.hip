@@ -13,6 +13,7 @@
 #include "gh_internal.h"
 #include "gh_viterbi.h"
 #include "gh_fb.h"
+#include "gh_xnum.h"
 
 namespace {
 
@@ -224,26 +225,38 @@ __global__ __launch_bounds__(64) void seq_backtrace_kernel(gh_layers_args a, int
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Forward-backward over the same graphs (definition: fb_kernel, gh_fb.hip -- same arcs, same same-column rule, start row
-// in column 0, end rows in the last column, min -> -logsumexp).  Log domain, fp64; alpha columns go to HBM scratch
-// [T, K, N] and come back in the backward sweep, beta lives in registers.  Inside a column the backward order is:
-// states 0..N-2 of every layer (they only read the next column), the non-emitting rows (one row_shl:1), then the last
-// states.  gamma is added into occ[frame, state] with double atomics (a word may stand in several layers of one
-// transcript); the expected self transitions are kept per lane and added into one of GH_FBSEQ_XI_PARTS partial vectors.
-__device__ __forceinline__ double sq_lse2(double x, double y) {
-    const double m = fmax(x, y);
-    if (m == -INFINITY) return -INFINITY;
-    return m + log1p(exp(fmin(x, y) - m));
+// in column 0, end rows in the last column, min -> -logsumexp).  The recursion runs on probabilities with an extended
+// exponent (gh_xnum.h): a term is a multiply and an integer add, the one transcendental per state and column is the
+// split exponential of the emission cost.  (A first version in the log domain -- exp per term, log per sum -- spent
+// 3 700 instructions per column and lane and was issue bound at 6.7 ms for 12 500 seven-word transcripts.)
+// alpha columns go to HBM scratch ([T, K, N] mantissas, then [T, K, N] exponents) and come back in the backward sweep,
+// beta lives in registers.  Inside a column the backward order is: states 0..N-2 of every layer (they only read the
+// next column), the non-emitting rows (one row_shl:1), then the last states.  gamma is added into occ[frame, state]
+// with double atomics (a word may stand in several layers of one transcript); the expected self transitions are kept
+// per lane and added into one of GH_FBSEQ_XI_PARTS partial vectors.
+__device__ __forceinline__ xnum xn_row_shr1(xnum v, xnum fill) {
+    xnum o;
+    o.f = row_shr1(v.f, fill.f);
+    o.e = __builtin_amdgcn_update_dpp(fill.e, v.e, 0x111, 0xF, 0xF, false);
+    return o;
 }
-__device__ __forceinline__ double sq_lse3(double x, double y, double z) {
-    const double m = fmax(fmax(x, y), z);
-    if (m == -INFINITY) return -INFINITY;
-    return m + log(exp(x - m) + exp(y - m) + exp(z - m));
+__device__ __forceinline__ xnum xn_row_shl1(xnum v, xnum fill) {
+    xnum o;
+    o.f = row_shl1(v.f, fill.f);
+    o.e = __builtin_amdgcn_update_dpp(fill.e, v.e, 0x101, 0xF, 0xF, false);
+    return o;
 }
 
-template <typename ET, int N, bool SKIP>
+template <typename ET, int N, bool SKIP, bool OCC_LDS>
 __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slot_end) {
     constexpr int PF = 2;
+    extern __shared__ __attribute__((aligned(16))) double seq_lds[];   // OCC_LDS: [4 utterances][S] occupancies of a frame
     const int lane = threadIdx.x, kk = lane >> 4, k = lane & 15;
+    double* occ_row = seq_lds + (OCC_LDS ? kk * a.S : 0);
+    if (OCC_LDS) {
+        for (int s = k; s < a.S; s += 16) occ_row[s] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     const int64_t slot = a.slot0 + (int64_t)blockIdx.x * 4 + kk;
     const bool has_utt = slot < slot_end;
     const int64_t u = has_utt ? (a.perm ? a.perm[slot] : slot) : 0;
@@ -251,29 +264,30 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
     const int K = g->K;
     const int64_t f0 = has_utt ? a.utt_off[u] : 0;
     const int T = has_utt ? (int)(a.utt_off[u + 1] - f0) : 0;
-    const double INF = INFINITY, NEG = -INFINITY;
+    const double INF = INFINITY;
     int Tmax = T;
     Tmax = max(Tmax, __shfl_xor(Tmax, 16));
     Tmax = max(Tmax, __shfl_xor(Tmax, 32));
     const bool lact = has_utt && k < K;
     const gh_seqword* wd = a.words + (lact ? g->word[k] : 0);
-    double c0[N], c1[N], c2[N];
+    xnum p0[N], p1[N], p2[N];                                 // arc probabilities exp(-cost); absent arcs: 0
     int st[N];
     unsigned endm = 0;
 #pragma unroll
     for (int s = 0; s < N; ++s) {
-        c0[s] = lact ? wd->c0[s] : INF;
-        c1[s] = lact ? wd->c1[s] : INF;
-        c2[s] = (SKIP && lact) ? wd->c2[s] : INF;
+        p0[s] = xn_exp_neg(lact ? wd->c0[s] : INF);
+        p1[s] = xn_exp_neg(lact ? wd->c1[s] : INF);
+        p2[s] = xn_exp_neg((SKIP && lact) ? wd->c2[s] : INF);
         st[s] = lact ? wd->state[s] : 0;
         if (lact && a.end_slot[g->row_base + k * (N + 1) + 1 + s] >= 0) endm |= 1u << s;
     }
-    const double cin = lact ? wd->cin : INF, cout = lact ? wd->cout : INF;
+    const xnum pin = xn_exp_neg(lact ? wd->cin : INF), pout = xn_exp_neg(lact ? wd->cout : INF);
     const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
-    double* alpha = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0) + (int64_t)k * N;
     const int64_t astride = (int64_t)K * N;
+    double* alf = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0) + (int64_t)k * N;             // [T, K, N]
+    int* ale = reinterpret_cast<int*>(a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0) + (int64_t)T * astride) + k * N;
     if (T <= 0) {                                             // (a whole row: no shuffle below involves it)
-        if (has_utt && k == 0 && a.logp) a.logp[u] = NEG;
+        if (has_utt && k == 0 && a.logp) a.logp[u] = -INF;
     }
     // ---- forward ----
     ET ring[PF][N];
@@ -281,59 +295,69 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int s = 0; s < N; ++s) ring[p][s] = (lact && p < T) ? nll[(int64_t)p * a.S + st[s]] : ET(0);
-    double al[N];
+    xnum al[N];
 #pragma unroll
-    for (int s = 0; s < N; ++s) al[s] = NEG;
+    for (int s = 0; s < N; ++s) al[s] = xn_zero();
     for (int t0 = 0; t0 < Tmax; t0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int t = t0 + p;
             if (t >= Tmax) break;
             if (t < T) {
-                double e[N];
+                xnum b[N];
 #pragma unroll
-                for (int s = 0; s < N; ++s) e[s] = (double)ring[p][s];
+                for (int s = 0; s < N; ++s) b[s] = xn_exp_neg((double)ring[p][s]);
                 if (lact && t + PF < T) {
 #pragma unroll
                     for (int s = 0; s < N; ++s) ring[p][s] = nll[(int64_t)(t + PF) * a.S + st[s]];
                 }
-                const double self0 = al[0] - c0[0];
+                const xnum self0 = xn_mul(al[0], p0[0]);
 #pragma unroll
                 for (int s = N - 1; s >= 1; --s) {
-                    const double a0 = al[s] - c0[s], a1 = al[s - 1] - c1[s];
-                    if (SKIP && s >= 2) al[s] = sq_lse3(a0, a1, al[s - 2] - c2[s]) - e[s];
-                    else al[s] = sq_lse2(a0, a1) - e[s];
+                    const xnum a0 = xn_mul(al[s], p0[s]), a1 = xn_mul(al[s - 1], p1[s]);
+                    const xnum sum = (SKIP && s >= 2) ? xn_add3(a0, a1, xn_mul(al[s - 2], p2[s])) : xn_add(a0, a1);
+                    al[s] = xn_norm(xn_mul(sum, b[s]));
                 }
-                const double nin = row_shr1(al[N - 1] - cout, (t == 0) ? 0.0 : NEG);   // lane 0: the start row
-                al[0] = sq_lse2(self0, nin - cin) - e[0];
+                const xnum nin = xn_row_shr1(xn_mul(al[N - 1], pout), (t == 0) ? xn_one() : xn_zero());   // lane 0: the start row
+                al[0] = xn_norm(xn_mul(xn_add(self0, xn_mul(nin, pin)), b[0]));
                 if (lact) {
 #pragma unroll
-                    for (int s = 0; s < N; ++s) alpha[(int64_t)t * astride + s] = al[s];
+                    for (int s = 0; s < N; ++s) { alf[(int64_t)t * astride + s] = al[s].f; ale[(int64_t)t * astride + s] = al[s].e; }
                 }
             }
         }
     }
-    double lp = NEG;
+    xnum P = xn_zero();
 #pragma unroll
-    for (int s = 0; s < N; ++s) if (endm >> s & 1) lp = sq_lse2(lp, al[s]);
+    for (int s = 0; s < N; ++s) if (endm >> s & 1) P = xn_add(P, al[s]);
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) lp = sq_lse2(lp, __shfl_xor(lp, o));
-    const double logp = lp;
-    if (has_utt && k == 0 && T > 0 && a.logp) a.logp[u] = logp;
+    for (int o = 8; o >= 1; o >>= 1) {
+        xnum q;
+        q.f = __shfl_xor(P.f, o);
+        q.e = __shfl_xor(P.e, o);
+        P = xn_add(P, q);
+    }
+    P = xn_norm(P);
+    if (has_utt && k == 0 && T > 0 && a.logp) a.logp[u] = xn_log(P);
     if (!a.occ && !a.self_xi_parts) return;
+    const bool reach = P.f > 0.0;                             // log P = -inf: every gamma is 0 (the generic kernel's NaN -> 0)
+    const double inv_pf = 1.0 / P.f;
     // ---- backward (column t = T - 1 - i of this row's utterance) ----
-    double be[N], en[N], xi[N];
+    xnum be[N], bn[N];                                        // beta and emission probability of column t + 1
+    double xi[N];
 #pragma unroll
-    for (int s = 0; s < N; ++s) { be[s] = NEG; en[s] = 0.0; xi[s] = 0.0; }
+    for (int s = 0; s < N; ++s) { be[s] = xn_zero(); bn[s] = xn_one(); xi[s] = 0.0; }
     ET ering[PF][N];
-    double aring[PF][N];
+    double arf[PF][N];
+    int are[PF][N];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int s = 0; s < N; ++s) {
             const int t = T - 1 - p;
             ering[p][s] = (lact && t >= 0) ? nll[(int64_t)t * a.S + st[s]] : ET(0);
-            aring[p][s] = (lact && t >= 0) ? alpha[(int64_t)t * astride + s] : NEG;
+            arf[p][s] = (lact && t >= 0) ? alf[(int64_t)t * astride + s] : 0.0;
+            are[p][s] = (lact && t >= 0) ? ale[(int64_t)t * astride + s] : XN_ZERO_E;
         }
     for (int i0 = 0; i0 < Tmax; i0 += PF) {
 #pragma unroll
@@ -342,45 +366,60 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
             if (i >= Tmax) break;
             if (i < T) {
                 const int t = T - 1 - i;
-                double e[N], av[N];
+                xnum b[N], av[N];
 #pragma unroll
-                for (int s = 0; s < N; ++s) { e[s] = (double)ering[p][s]; av[s] = aring[p][s]; }
+                for (int s = 0; s < N; ++s) { b[s] = xn_exp_neg((double)ering[p][s]); av[s] = xnum{arf[p][s], are[p][s]}; }
                 if (lact && t - PF >= 0) {
 #pragma unroll
                     for (int s = 0; s < N; ++s) {
                         ering[p][s] = nll[(int64_t)(t - PF) * a.S + st[s]];
-                        aring[p][s] = alpha[(int64_t)(t - PF) * astride + s];
+                        arf[p][s] = alf[(int64_t)(t - PF) * astride + s];
+                        are[p][s] = ale[(int64_t)(t - PF) * astride + s];
                     }
                 }
-                double w[N], nb[N];
+                xnum w[N], ws[N], nb[N];
 #pragma unroll
-                for (int s = 0; s < N; ++s) w[s] = be[s] - en[s];      // column t + 1 seen from column t, before the arc cost
+                for (int s = 0; s < N; ++s) {
+                    w[s] = xn_mul(be[s], bn[s]);                  // column t + 1 seen from column t, before the arc
+                    ws[s] = xn_mul(w[s], p0[s]);                  // ... through the self arc
+                }
+                const xnum end1 = (i == 0) ? xn_one() : xn_zero();
 #pragma unroll
                 for (int s = 0; s < N - 1; ++s) {
-                    const double b0 = w[s] - c0[s], b1 = w[s + 1] - c1[s + 1];
-                    if (SKIP && s + 2 < N) nb[s] = sq_lse3(b0, b1, w[s + 2] - c2[s + 2]);
-                    else nb[s] = sq_lse2(b0, b1);
-                    if (i == 0 && (endm >> s & 1)) nb[s] = sq_lse2(nb[s], 0.0);
+                    const xnum b1 = xn_mul(w[s + 1], p1[s + 1]);
+                    xnum sum = (SKIP && s + 2 < N) ? xn_add3(ws[s], b1, xn_mul(w[s + 2], p2[s + 2])) : xn_add(ws[s], b1);
+                    if (endm >> s & 1) sum = xn_add(sum, end1);
+                    nb[s] = xn_norm(sum);
                 }
                 // the non-emitting row in front of layer k + 1 (its only successor: that layer's first state, same column)
-                const double nesb = row_shl1(nb[0] - cin - e[0], NEG);
-                nb[N - 1] = sq_lse2(w[N - 1] - c0[N - 1], nesb - cout);
-                if (i == 0 && (endm >> (N - 1) & 1)) nb[N - 1] = sq_lse2(nb[N - 1], 0.0);
-                if (lact) {
+                const xnum nesb = xn_row_shl1(xn_mul(xn_mul(nb[0], pin), b[0]), xn_zero());
+                {
+                    xnum sum = xn_add(ws[N - 1], xn_mul(nesb, pout));
+                    if (endm >> (N - 1) & 1) sum = xn_add(sum, end1);
+                    nb[N - 1] = xn_norm(sum);
+                }
+                if (lact && reach) {
 #pragma unroll
                     for (int s = 0; s < N; ++s) {
-                        if (a.self_xi_parts && i > 0) {             // xi_t(s -> s) = alpha_t(s) a_ss b_s(x_{t+1}) beta_{t+1}(s) / P
-                            const double x = exp(av[s] + (w[s] - c0[s]) - logp);
-                            if (x == x) xi[s] += x;
-                        }
+                        if (a.self_xi_parts && i > 0)               // xi_t(s -> s) = alpha_t(s) a_ss b_s(x_{t+1}) beta_{t+1}(s) / P
+                            xi[s] += xn_ratio(av[s], ws[s], inv_pf, P.e);
                         if (a.occ) {
-                            double gm = exp(av[s] + nb[s] - logp);
-                            if (gm == gm && gm != 0.0) unsafeAtomicAdd(a.occ + (f0 + t) * a.S + st[s], gm);
+                            const double gm = xn_ratio(av[s], nb[s], inv_pf, P.e);
+                            if (OCC_LDS) { if (gm != 0.0) atomicAdd(occ_row + st[s], gm); }   // ds_add_f64
+                            else if (gm != 0.0) unsafeAtomicAdd(a.occ + (f0 + t) * a.S + st[s], gm);
                         }
                     }
                 }
+                if (OCC_LDS && a.occ) {
+                    // the row of S occupancies of this frame: out of LDS as one contiguous store, and back to zero
+                    // (LDS executes a wave's instructions in order; the fences only keep the compiler from reordering)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    double* orow = a.occ + (f0 + t) * a.S;
+                    for (int s = k; s < a.S; s += 16) { orow[s] = occ_row[s]; occ_row[s] = 0.0; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
 #pragma unroll
-                for (int s = 0; s < N; ++s) { be[s] = nb[s]; en[s] = e[s]; }
+                for (int s = 0; s < N; ++s) { be[s] = nb[s]; bn[s] = b[s]; }
             }
         }
     }
@@ -457,7 +496,12 @@ int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64
     b.slot0 = u_begin;
     const dim3 grid((unsigned)((n_utts + 3) / 4)), blk(64);
     const int64_t slot_end = u_begin + n_utts;
-#define GH_FS(ET, NN, SK) hipLaunchKernelGGL((fb_seq_kernel<ET, NN, SK>), grid, blk, 0, ctx->stream, b, slot_end)
+    const bool occ_lds = a.occ && a.occ_in_lds;
+#define GH_FS(ET, NN, SK)                                                                                                       \
+    do {                                                                                                                        \
+        if (occ_lds) hipLaunchKernelGGL((fb_seq_kernel<ET, NN, SK, true>), grid, blk, (size_t)4 * a.S * 8, ctx->stream, b, slot_end); \
+        else hipLaunchKernelGGL((fb_seq_kernel<ET, NN, SK, false>), grid, blk, 0, ctx->stream, b, slot_end);                    \
+    } while (0)
 #define GH_FS_N(ET)                                                                          \
     switch (N) {                                                                             \
         case 2: GH_FS(ET, 2, false); break;                                                  \

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
     "gh_viterbi_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, _c_f64p, _c_i32p, _c_i32p,
                                     _c_i64p, _c_i32p]),
+    "gh_align_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p]),
     "gh_viterbi_labels_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, C.c_int, _c_f64p, _c_i32p,
                                            _c_i32p, C.c_int64, _c_i32p]),
     "gh_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f64p,
@@ -617,6 +618,25 @@ class Lattices:
         if as_lists:
             out["labels"] = [labels[label_off[u]:label_off[u] + n_labels[u]] for u in range(U)]
         return out
+
+    SEGMENT_START = 1 << 30
+
+    def align_segments(self, batch, utt_lattice=None):
+        """Alignment + regrouping of continuous_train (continuous_speech.py:80-106) in one call, see gh_align_segments.
+        Returns dict(frame_state int32 [N] (-1: the frame joins no state's data), segment_start bool [N], end_cost,
+        best_end)."""
+        lib, U = self.ctx.lib, batch.U
+        lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
+        lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
+        n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
+        end_cost = np.empty(int(n_end.sum()))
+        best_end = np.empty(U, dtype=np.int32)
+        fs = np.empty(batch.N, dtype=np.int32)
+        _check(lib, lib.gh_align_segments(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(end_cost, _c_f64p),
+                                          _ptr(best_end, _c_i32p), _ptr(fs, _c_i32p)))
+        start = (fs >= 0) & ((fs & self.SEGMENT_START) != 0)
+        fs[start] &= ~self.SEGMENT_START
+        return dict(frame_state=fs, segment_start=start, end_cost_flat=end_cost, best_end=best_end)
 
     def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True, want_self_xi=False):
         """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].

@@ -24,7 +24,8 @@ from .hmm_state import GMM, NES, mahalanobis
 from .hmm import HMM
 from .lockstep import LockstepFitter
 
-__all__ = ["build_state_sequences", "build_loop_grammar", "continuous_train"]
+__all__ = ["build_state_sequences", "build_loop_grammar", "continuous_train", "forced_alignments", "aligned_frame_states",
+           "cut_segments"]
 
 
 def _layout(n_per_word, label_matrix):
@@ -158,11 +159,9 @@ def packed_loop_lattice(word_transitions, n_per_word, word_penalty=0.0, state_ba
                 end_rows=np.asarray(ends, dtype=np.int32)), [0, loop_row]
 
 
-def forced_alignments(frames, models, label_seqs):
-    """Viterbi alignment of every utterance through its own one-word-per-layer lattice
-    (continuous_speech.py:80-89), all utterances in one launch.
-    Returns (paths, row_state per utterance) with row_state[r] = -1 on non-emitting rows,
-    else word * n + state."""
+def _alignment_lattices(frames, models, label_seqs):
+    """Likelihoods of every utterance against the states of its own words, and its one-word-per-layer lattice
+    (continuous_speech.py:80-82): (device lattices, graph dicts, graph index per utterance)."""
     ctx = frames.ctx
     n = len(models[0].gmm_states)
     gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
@@ -178,12 +177,32 @@ def forced_alignments(frames, models, label_seqs):
             keys[key] = len(graphs)
             graphs.append(packed_lattice(wt, n, [[l] for l in labels])[0])
         utt_graph[u] = keys[key]
-    lat = _hip.Lattices(ctx, graphs)
+    return _hip.Lattices(ctx, graphs), graphs, utt_graph
+
+
+def forced_alignments(frames, models, label_seqs):
+    """Viterbi alignment of every utterance through its own one-word-per-layer lattice
+    (continuous_speech.py:80-89), all utterances in one launch.
+    Returns (paths, row_state per utterance) with row_state[r] = -1 on non-emitting rows,
+    else word * n + state."""
+    lat, graphs, utt_graph = _alignment_lattices(frames, models, label_seqs)
     try:
         res = lat.viterbi(frames, utt_lattice=utt_graph, want_path=True)
     finally:
         lat.close()
     return res["paths"], [graphs[g]["row_state"] for g in utt_graph]
+
+
+def aligned_frame_states(frames, models, label_seqs):
+    """Alignment AND regrouping (continuous_speech.py:80-106) in one launch sequence, nothing but one int per frame
+    coming back: (frame_state [N]: word * n + state of the training data the frame joins, -1 for none;
+    segment_start bool [N]: first frame of a segment).  Equals `cut_segments` applied to `forced_alignments`."""
+    lat, _, utt_graph = _alignment_lattices(frames, models, label_seqs)
+    try:
+        res = lat.align_segments(frames, utt_lattice=utt_graph)
+    finally:
+        lat.close()
+    return res["frame_state"], res["segment_start"]
 
 
 def cut_segments(path, row_state):
@@ -237,37 +256,42 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     n = len(new_models[0].gmm_states)
 
     frames = _hip.Batch(_hip.default_context(), data)
+    all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, 1))
     try:
         for it in range(max_iteration):
             print('=' * 25)
             print('Continuous training iteration:', it)
             print('Building state sequences')
             print('Rearranging data, this may take a while...')
-            paths, row_states = forced_alignments(frames, new_models, label_seqs)
-            gmm_data = {}
-            for x, path, rs in zip(data, paths, row_states):
-                for sid, a, b in cut_segments(path, rs):
-                    gmm_data.setdefault(sid, []).append(x[a:b])
+            # alignment + regrouping on the device; per state, its frames in utterance / time order -- what the
+            # reference's vstack of the segments holds (:90-113) -- and the states in first-visit order
+            frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs)
+            used = np.flatnonzero(frame_state >= 0)
+            sid_of = frame_state[used]
+            by_state = np.argsort(sid_of, kind="stable")
+            uniq, first, n_frames = np.unique(sid_of, return_index=True, return_counts=True)
+            cuts = np.concatenate([[0], np.cumsum(n_frames)])
+            n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
+            seg_of = {int(sid): all_frames[used[by_state[cuts[i]:cuts[i + 1]]]] for i, sid in enumerate(uniq)}
             print('Complete data rearrangement')
             print("=" * 25)
 
             print('Doing HMM training...')
             # every visited state refit in lock-step (one launch per k-means / EM iteration for all of them); the
             # states are taken in first-visit order, the order in which the reference consumes numpy's global RNG
-            keys = list(gmm_data.keys())
-            segs = [np.vstack(gmm_data[sid]) for sid in keys]
+            keys = [int(sid) for sid in uniq[np.argsort(first, kind="stable")]]
+            segs = [seg_of[sid] for sid in keys]
             starts = [np.mean(seg, axis=0) for seg in segs]
-            seg_counts = {sid: (len(v), sum(s.shape[0] for s in v)) for sid, v in gmm_data.items()}
+            seg_counts = {sid: (int(n_runs[sid]), len(seg_of[sid])) for sid in keys}
             if sharded:
                 # which states were visited anywhere, their frame sums (start centroids) and segment / frame counts
                 dim = data[0].shape[1] if len(data) else frames.D
                 loc = np.zeros((n_models * n, dim + 2))
-                for sid, v in gmm_data.items():
-                    x = np.vstack(v)
-                    loc[sid, :dim], loc[sid, dim], loc[sid, dim + 1] = x.sum(axis=0), x.shape[0], len(v)
+                for sid, x in seg_of.items():
+                    loc[sid, :dim], loc[sid, dim], loc[sid, dim + 1] = x.sum(axis=0), x.shape[0], n_runs[sid]
                 glob = reducer(loc)
                 keys = [sid for sid in range(n_models * n) if glob[sid, dim] > 0]
-                segs = [np.vstack(gmm_data[sid]) if sid in gmm_data else np.zeros((0, dim)) for sid in keys]
+                segs = [seg_of[sid] if sid in seg_of else np.zeros((0, dim)) for sid in keys]
                 starts = [glob[sid, :dim] / glob[sid, dim] for sid in keys]
                 seg_counts = {sid: (glob[sid, dim + 1], glob[sid, dim]) for sid in keys}
             fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None)

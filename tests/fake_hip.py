@@ -265,6 +265,25 @@ class Lattices:
             labels.append(np.array(O.path_to_words(p, rl < 0, rl), dtype=np.int32) if len(p) else np.zeros(0, dtype=np.int32))
         return dict(labels=labels, best_end=r["best_end"], end_cost_flat=r["end_cost_flat"])
 
+    def align_segments(self, batch, utt_lattice=None):
+        """gh_align_segments: the reference's own regrouping loop (continuous_speech.py:90-106) over the oracle's paths."""
+        r = self.viterbi(batch, utt_lattice=utt_lattice, want_path=True)
+        lidx = np.zeros(batch.U, dtype=int) if utt_lattice is None else np.asarray(utt_lattice, dtype=int)
+        fs = np.full(batch.N, -1, dtype=np.int32)
+        start = np.zeros(batch.N, dtype=bool)
+        for u, path in enumerate(r["paths"]):
+            rs = np.asarray(self.graphs[lidx[u]]["row_state"])
+            f0 = int(batch.offsets[u])
+            open_row, open_at = None, None
+            for row, c in path[::-1]:
+                if open_at is None and rs[row] >= 0:
+                    open_row, open_at = row, c
+                if row != open_row and open_at is not None and open_at < c:
+                    fs[f0 + open_at:f0 + c] = rs[open_row]
+                    start[f0 + open_at] = True
+                    open_row, open_at = None, None
+        return dict(frame_state=fs, segment_start=start, end_cost_flat=r["end_cost_flat"], best_end=r["best_end"])
+
     def close(self):
         pass
 

@@ -217,3 +217,44 @@ def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, K
     b.close()
     lat.close()
     gmm.close()
+
+
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (4, 2, False, 16)])
+def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, Kmax):
+    """gh_align_segments (alignment + the regrouping loop of continuous_speech.py:90-106 on the device, one int per
+    frame back) against the reference-shaped Python loop `cut_segments` over the paths of gh_viterbi -- per frame the
+    same state, per state the same number of segments."""
+    from sr.recognition.continuous_speech import cut_segments
+    rng = np.random.default_rng(5 * W + n + Kmax)
+    U = 80
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U, short=0)
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, -1, means.shape[-1]), vars_.reshape(W * n, -1, means.shape[-1]),
+                        w.reshape(W * n, -1))
+    lat = hip.Lattices(ctx, graphs)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    paths = lat.viterbi(b, utt_lattice=utt_graph, want_path=True)
+    got = lat.align_segments(b, utt_lattice=utt_graph)
+    np.testing.assert_array_equal(got["end_cost_flat"], paths["end_cost_flat"])
+    want = np.full(b.N, -1, dtype=np.int32)
+    want_start = np.zeros(b.N, dtype=bool)
+    for u in range(U):
+        for sid, lo, hi in cut_segments(paths["paths"][u], graphs[utt_graph[u]]["row_state"]):
+            want[b.offsets[u] + lo:b.offsets[u] + hi] = sid
+            want_start[b.offsets[u] + lo] = True
+    np.testing.assert_array_equal(got["frame_state"], want)
+    np.testing.assert_array_equal(got["segment_start"], want_start)
+    assert (want >= 0).mean() > 0.5 and want_start.sum() >= U
+    # the same through the layer-form and the lean kernels (one graph for the whole batch)
+    one = hip.Lattices(ctx, [graphs[utt_graph[0]]])
+    p1 = one.viterbi(b, want_path=True)
+    g1 = one.align_segments(b)
+    w1 = np.full(b.N, -1, dtype=np.int32)
+    for u in range(U):
+        for sid, lo, hi in cut_segments(p1["paths"][u], graphs[utt_graph[0]]["row_state"]):
+            w1[b.offsets[u] + lo:b.offsets[u] + hi] = sid
+    np.testing.assert_array_equal(g1["frame_state"], w1)
+    one.close()
+    b.close()
+    lat.close()
+    gmm.close()

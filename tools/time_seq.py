@@ -51,3 +51,8 @@ for name, env in (("sequence form", {}), ("row-per-lane", {"GMMHMM_VITERBI": "le
     v = timed(lambda: lat.viterbi(b, utt_lattice=ug, want_path=True))
     f = timed(lambda: lat.forward_backward(b, utt_lattice=ug, want_occ=True, fetch_occ=False, want_self_xi=True))
     print("%-14s viterbi+paths %.2f ms   forward-backward (occ, xi) %.2f ms" % (name, v, f))
+os.environ.pop("GMMHMM_VITERBI", None); os.environ.pop("GMMHMM_FB", None)
+print("sequence-form forward-backward, parts: forward only %.2f ms | + backward with xi %.2f ms | + occupancies %.2f ms" % (
+    timed(lambda: lat.forward_backward(b, utt_lattice=ug)),
+    timed(lambda: lat.forward_backward(b, utt_lattice=ug, want_self_xi=True)),
+    timed(lambda: lat.forward_backward(b, utt_lattice=ug, want_occ=True, fetch_occ=False, want_self_xi=True))))
