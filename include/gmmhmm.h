@@ -170,6 +170,16 @@ int gh_lattices_create(gh_ctx* ctx, int L,
                        const int64_t* start_off /*[L+1]*/, const int32_t* start_rows,
                        const int64_t* end_off /*[L+1]*/, const int32_t* end_rows,
                        gh_lattices** out);
+/* The forced-alignment graphs of continuous_train (continuous_speech.py:80-82: build_state_sequences(models,
+ * [[l] for l in labels]) -- one word per layer) straight from the transcripts: W word models of n states each,
+ * word_trans [W, n, n] with entry [i, j] = cost of j -> i and +inf = no arc (HMM.transitions, hmm.py:24), the first
+ * state index of every word (NULL: w * n), and L label strings (graph l = labels[label_off[l] .. label_off[l+1])).
+ * Graph l equals the one build_state_sequences makes -- row 0 non-emitting, then per word its n states and one
+ * non-emitting row; zero-cost arcs into a word's first and out of its last state; end row = last state of the last
+ * word -- and every call that takes a gh_lattices accepts the handle. */
+int gh_lattices_create_transcripts(gh_ctx* ctx, int W, int n, const double* word_trans /*[W,n,n]*/,
+                                   const int32_t* state_base /*[W] or NULL*/, int64_t L,
+                                   const int64_t* label_off /*[L+1]*/, const int32_t* labels, gh_lattices** out);
 void gh_lattices_destroy(gh_lattices* l);
 /* Rank beam for gh_viterbi / gh_viterbi_labels on these graphs (decode_hmm_states itself has no
  * pruning -- this is the beam of dtw, decode.py:62-68, carried over to lattices).  After every column but the last, the

@@ -107,6 +107,15 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
+    if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernels runs on its expanded twin
+        bool seq_fit = forced_kernel() == 0 && lat->beam <= 0 && !out_costs;
+        for (int64_t u = 0; seq_fit && u < U; ++u)
+            if (b->offsets[u + 1] - b->offsets[u] == 1) seq_fit = false;
+        if (!seq_fit) {
+            const int rc0 = gh_lattices_full(lat, &lat);
+            if (rc0) return rc0;
+        }
+    }
     const bool want_labels = out_labels != nullptr;
     const bool want_segments = out_frame_state != nullptr;
     const bool uniform = utt_lattice == nullptr;
@@ -534,6 +543,13 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
+    if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernel runs on its expanded twin
+        const char* e = getenv("GMMHMM_FB");
+        if (out_alpha || out_beta || out_gamma || (e && !strcmp(e, "generic"))) {
+            const int rc0 = gh_lattices_full(lat, &lat);
+            if (rc0) return rc0;
+        }
+    }
     for (int l = 0; l < lat->L; ++l)
         GH_REQUIRE(lat->lat[l].max_state < S, "gh_forward_backward: graph %d uses state %d but the model has %d", l,
                    lat->lat[l].max_state, S);

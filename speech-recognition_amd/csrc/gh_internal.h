@@ -177,8 +177,15 @@ struct gh_seqgraph {
     int32_t word[GH_SEQ_MAXK];             // template of every layer's word
 };
 
+struct gh_transcripts_src;   // gh_transcripts.hip: what a handle made by gh_lattices_create_transcripts was made from
+void gh_transcripts_src_free(gh_transcripts_src* s);
+
 struct gh_lattices {
     gh_ctx* ctx;
+    // gh_lattices_create_transcripts: only the sequence form (and the row / end tables) is filled in; the row-per-lane
+    // arrays live in `full`, an ordinary handle expanded from `deferred_src` the first time a fallback needs it
+    gh_transcripts_src* deferred_src = nullptr;
+    gh_lattices* full = nullptr;
     void* d_arena;   // the one device allocation all the d_* pointers below point into
     int L;
     std::vector<gh_lattice_host> lat;
@@ -229,6 +236,9 @@ struct gh_lattices {
     bool has_nan_arc;   // a NaN arc cost needs np.argmin's NaN-first rule: generic kernel only
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };
+
+// the handle whose row-per-lane arrays are valid: `l` itself, or the lazily expanded twin of a transcripts handle
+int gh_lattices_full(const gh_lattices* l, const gh_lattices** out);
 
 // kernels (gh_loglik.hip / gh_viterbi.hip)
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);

@@ -499,6 +499,8 @@ extern "C" void gh_lattices_destroy(gh_lattices* l) {
     if (!l) return;
     hipSetDevice(l->ctx->device);
     hipFree(l->d_arena);
+    if (l->full) gh_lattices_destroy(l->full);
+    if (l->deferred_src) gh_transcripts_src_free(l->deferred_src);
     delete l;
 }
 

@@ -62,6 +62,8 @@ SIGNATURES = {
                                      C.c_int, _c_f64p]),
     "gh_lattices_create": (C.c_int, [C.c_void_p, C.c_int, _c_i64p, _c_i32p, _c_i64p, _c_i32p, _c_i32p,
                                      _c_f64p, _c_i64p, _c_i32p, _c_i64p, _c_i32p, C.POINTER(C.c_void_p)]),
+    "gh_lattices_create_transcripts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_f64p, _c_i32p, C.c_int64, _c_i64p, _c_i32p,
+                                                 C.POINTER(C.c_void_p)]),
     "gh_lattices_destroy": (None, [C.c_void_p]),
     "gh_lattices_set_beam": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_lattices_forms": (C.c_int, [C.c_void_p]),
@@ -523,6 +525,30 @@ class Lattices:
             _ptr(end_rows, _c_i32p), C.byref(h)))
         self.h = h
         self.L = L
+
+    @classmethod
+    def from_transcripts(cls, ctx, word_transitions, n, label_seqs, state_base=None):
+        """The forced-alignment graph of every label string in `label_seqs` (continuous_speech.py:80-82: one word per
+        layer; the graphs `continuous_speech.packed_lattice(word_transitions, n, [[l] for l in labels])` describes),
+        built on the library's side from the W [n, n] cost matrices -- see gh_lattices_create_transcripts."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        wt = np.ascontiguousarray(np.asarray([np.asarray(t, dtype=np.float64) for t in word_transitions]), dtype=np.float64)
+        assert wt.ndim == 3 and wt.shape[1] == n and wt.shape[2] == n, "word_transitions: W matrices of n x n costs"
+        K = np.array([len(l) for l in label_seqs], dtype=np.int64)
+        self.L = len(label_seqs)
+        label_off = np.concatenate([[0], np.cumsum(K)]).astype(np.int64)
+        labels = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).ravel() for l in label_seqs])
+                                      if self.L else np.zeros(0), dtype=np.int32)
+        base = None if state_base is None else np.ascontiguousarray(state_base, dtype=np.int32)
+        self.R = list(K * (n + 1) + 1)
+        self.n_end = [1] * self.L
+        self.end_rows = [np.array([(k - 1) * (n + 1) + n], dtype=np.int64) for k in K]
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.gh_lattices_create_transcripts(ctx.h, wt.shape[0], int(n), _ptr(wt, _c_f64p), _ptr(base, _c_i32p),
+                                                               self.L, _ptr(label_off, _c_i64p), _ptr(labels, _c_i32p), C.byref(h)))
+        self.h = h
+        return self
 
     def set_beam(self, beam):
         """Rank beam per column for viterbi / viterbi_labels (None, 0 or inf: no pruning); see gh_lattices_set_beam."""

@@ -161,7 +161,7 @@ def packed_loop_lattice(word_transitions, n_per_word, word_penalty=0.0, state_ba
 
 def _alignment_lattices(frames, models, label_seqs):
     """Likelihoods of every utterance against the states of its own words, and its one-word-per-layer lattice
-    (continuous_speech.py:80-82): (device lattices, graph dicts, graph index per utterance)."""
+    (continuous_speech.py:80-82): (device lattices, distinct transcripts, transcript index per utterance)."""
     ctx = frames.ctx
     n = len(models[0].gmm_states)
     gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
@@ -169,15 +169,24 @@ def _alignment_lattices(frames, models, label_seqs):
     lo = np.array([min(labels) * n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
     hi = np.array([(max(labels) + 1) * n if len(labels) else len(models) * n for labels in label_seqs], dtype=np.int32)
     frames.loglik(gmm, fetch=False, state_ranges=(lo, hi))
-    keys, graphs, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
-    wt = [m.transitions for m in models]
+    keys, transcripts, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
     for u, labels in enumerate(label_seqs):
-        key = tuple(labels)
+        key = tuple(int(l) for l in labels)
         if key not in keys:
-            keys[key] = len(graphs)
-            graphs.append(packed_lattice(wt, n, [[l] for l in labels])[0])
+            keys[key] = len(transcripts)
+            transcripts.append(key)
         utt_graph[u] = keys[key]
-    return _hip.Lattices(ctx, graphs), graphs, utt_graph
+    lat = _hip.Lattices.from_transcripts(ctx, [m.transitions for m in models], n, transcripts)
+    return lat, transcripts, utt_graph
+
+
+def transcript_row_state(labels, n):
+    """row_state of the forced-alignment graph of `labels` (see `packed_lattice`): -1 on non-emitting rows, else
+    word * n + state."""
+    rs = np.full(len(labels) * (n + 1) + 1, -1, dtype=np.int32)
+    for k, l in enumerate(labels):
+        rs[k * (n + 1) + 1:k * (n + 1) + 1 + n] = l * n + np.arange(n)
+    return rs
 
 
 def forced_alignments(frames, models, label_seqs):
@@ -185,12 +194,14 @@ def forced_alignments(frames, models, label_seqs):
     (continuous_speech.py:80-89), all utterances in one launch.
     Returns (paths, row_state per utterance) with row_state[r] = -1 on non-emitting rows,
     else word * n + state."""
-    lat, graphs, utt_graph = _alignment_lattices(frames, models, label_seqs)
+    lat, transcripts, utt_graph = _alignment_lattices(frames, models, label_seqs)
     try:
         res = lat.viterbi(frames, utt_lattice=utt_graph, want_path=True)
     finally:
         lat.close()
-    return res["paths"], [graphs[g]["row_state"] for g in utt_graph]
+    n = len(models[0].gmm_states)
+    row_states = [transcript_row_state(t, n) for t in transcripts]
+    return res["paths"], [row_states[g] for g in utt_graph]
 
 
 def aligned_frame_states(frames, models, label_seqs):

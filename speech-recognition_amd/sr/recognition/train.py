@@ -22,7 +22,6 @@ iteration's (:172-179; transitions are not compared there either).
 import numpy as np
 
 from . import _hip
-from .continuous_speech import packed_lattice
 from .parallel import m_step, StatsAllReducer
 
 __all__ = ["BaumWelchTrainer"]
@@ -80,8 +79,8 @@ class BaumWelchTrainer:
         """One forced-alignment graph per distinct label sequence, from the current transition costs."""
         if self.lat is not None:
             self.lat.close()
-        graphs = [packed_lattice(self.transitions, self.n, [[l] for l in key])[0] for key in self.graph_labels]
-        self.lat = _hip.Lattices(self.ctx, graphs) if graphs else None
+        self.lat = (_hip.Lattices.from_transcripts(self.ctx, self.transitions, self.n, self.graph_labels)
+                    if self.graph_labels else None)
 
     # layout of the ONE buffer that crosses ranks:
     #   [statistics S*M*(1+2D) | expected self transitions S | total log-likelihood | utterances]

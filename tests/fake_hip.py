@@ -184,6 +184,12 @@ class Lattices:
         self.n_end = [len(g["end_rows"]) for g in graphs]
         self.beam = None
 
+    @classmethod
+    def from_transcripts(cls, ctx, word_transitions, n, label_seqs, state_base=None):
+        from sr.recognition.continuous_speech import packed_lattice
+        return cls(ctx, [packed_lattice(word_transitions, n, [[int(l)] for l in labels], state_base=state_base)[0]
+                         for labels in label_seqs])
+
     def set_beam(self, beam):
         self.beam = None if (beam is None or beam <= 0 or beam == float("inf")) else int(beam)
 

@@ -258,3 +258,105 @@ def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, K
     b.close()
     lat.close()
     gmm.close()
+
+
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (3, 8, True, 5)])
+def test_transcripts_handle_equals_arc_list_handle(hip, ctx, W, n, skip, Kmax):
+    """gh_lattices_create_transcripts (graphs from W word models + label strings, sequence form written directly, the
+    row-per-lane arrays expanded lazily) against gh_lattices_create on the arc lists of `packed_lattice`: Viterbi
+    (costs, ends, paths), segments, forward-backward (log P, occupancies, xi) identical; and every fallback -- a
+    single-frame utterance, GMMHMM_VITERBI=lean, alpha / beta / gamma matrices, a beam -- lands on the same numbers."""
+    rng = np.random.default_rng(3 * W + n + 100 * Kmax)
+    U = 60
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U, short=0)
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, -1, means.shape[-1]), vars_.reshape(W * n, -1, means.shape[-1]),
+                        w.reshape(W * n, -1))
+    transcripts = [None] * len(graphs)
+    for u, l in enumerate(labels):
+        transcripts[utt_graph[u]] = l
+    a = hip.Lattices(ctx, graphs)
+    t = hip.Lattices.from_transcripts(ctx, wt, n, transcripts)
+    assert t.forms() == {"sequence"} and "sequence" in a.forms()
+    assert list(t.R) == list(a.R) and t.n_end == a.n_end
+
+    def same(b, beam=None, paths=True):
+        a.set_beam(beam), t.set_beam(beam)
+        ra = a.viterbi(b, utt_lattice=utt_graph, want_path=paths)
+        rt = t.viterbi(b, utt_lattice=utt_graph, want_path=paths)
+        np.testing.assert_array_equal(rt["end_cost_flat"], ra["end_cost_flat"])
+        np.testing.assert_array_equal(rt["best_end"], ra["best_end"])
+        for u in range(b.U if paths else 0):
+            np.testing.assert_array_equal(rt["paths"][u], ra["paths"][u])
+        a.set_beam(None), t.set_beam(None)
+
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    same(b)
+    np.testing.assert_array_equal(t.align_segments(b, utt_lattice=utt_graph)["frame_state"],
+                                  a.align_segments(b, utt_lattice=utt_graph)["frame_state"])
+    fa = a.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+    ft = t.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+    np.testing.assert_array_equal(ft["logp"], fa["logp"])
+    np.testing.assert_array_equal(ft["occ"], fa["occ"])
+    np.testing.assert_allclose(ft["self_xi"], fa["self_xi"], rtol=1e-12)     # (atomics: summation order)
+    with forced(GMMHMM_VITERBI="lean"):
+        same(b)
+    same(b, beam=6)
+    ma = a.forward_backward(b, utt_lattice=utt_graph, want_matrices=True)
+    mt = t.forward_backward(b, utt_lattice=utt_graph, want_matrices=True)
+    for u in (0, U - 1):
+        np.testing.assert_array_equal(mt["gamma"][u], ma["gamma"][u])
+    b.close()
+    xs1 = list(xs)
+    xs1[5] = xs1[5][:1]                                                # a single-frame utterance: the reference's column wrap
+    utt1 = utt_graph.copy()
+    k1 = [g for g in range(len(transcripts)) if len(transcripts[g]) == 1]
+    if k1:
+        utt1[5] = k1[0]
+    b = hip.Batch(ctx, xs1)
+    b.loglik(gmm, fetch=False)
+    ra = a.viterbi(b, utt_lattice=utt1, want_path=False)
+    rt = t.viterbi(b, utt_lattice=utt1, want_path=False)
+    np.testing.assert_array_equal(rt["end_cost_flat"], ra["end_cost_flat"])
+    b.close()
+    a.close()
+    t.close()
+    gmm.close()
+
+
+def test_transcripts_handle_isolated_words_and_odd_models(hip, ctx):
+    """Transcripts of one word each take the ordinary handle (one-word chain forms); word models with an arc the
+    sequence form cannot hold (a backward arc) are expanded eagerly -- same results as the arc-list handle."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(2)
+    W, n, M, D = 4, 3, 2, 5
+    means = rng.normal(size=(W, n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
+    w = rng.dirichlet(np.ones(M), size=(W, n))
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    wt = [word_trans(rng, n) for _ in range(W)]
+    xs = [rng.normal(size=(int(rng.integers(4, 30)), D)) for _ in range(12)]
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    single = hip.Lattices.from_transcripts(ctx, wt, n, [[i] for i in range(W)])
+    assert "fb_chain" in single.forms()
+    ug = (np.arange(12) % W).astype(np.int32)
+    ref = hip.Lattices(ctx, [packed_lattice(wt, n, [[i]])[0] for i in range(W)])
+    np.testing.assert_array_equal(single.viterbi(b, utt_lattice=ug)["end_cost_flat"], ref.viterbi(b, utt_lattice=ug)["end_cost_flat"])
+    np.testing.assert_array_equal(single.forward_backward(b, utt_lattice=ug)["logp"], ref.forward_backward(b, utt_lattice=ug)["logp"])
+    odd = [m.copy() for m in wt]
+    odd[1][0, 2] = 1.7                                                 # state 2 -> state 0: not left-to-right
+    seqs = [[0, 1], [1, 2, 3], [2, 1]]
+    o = hip.Lattices.from_transcripts(ctx, odd, n, seqs)
+    r = hip.Lattices(ctx, [packed_lattice(odd, n, [[l] for l in s])[0] for s in seqs])
+    ug = (np.arange(12) % 3).astype(np.int32)
+    ro, rr = o.viterbi(b, utt_lattice=ug), r.viterbi(b, utt_lattice=ug)
+    np.testing.assert_array_equal(ro["end_cost_flat"], rr["end_cost_flat"])
+    for u in range(12):
+        np.testing.assert_array_equal(ro["paths"][u], rr["paths"][u])
+    with pytest.raises(hip.BackendError):
+        hip.Lattices.from_transcripts(ctx, wt, n, [[0], []])
+    for h in (single, ref, o, r):
+        h.close()
+    b.close()
+    gmm.close()

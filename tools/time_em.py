@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time one soft-EM iteration (configs[2] shape: C2 model, isolated words, per-rank shard) on one GPU."""
+"""Time one soft-EM iteration (configs[2] shape: C2 model, per-rank shard) on one GPU.
+usage: time_em.py [utterances] [words per transcript, default 1 = isolated words]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
@@ -12,8 +13,13 @@ from sr.recognition import _hip
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
 wl = bench.synth_workload(1003, U)
 W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
 labels = [[int(w)] for w in wl["words"]]
+if K > 1:   # transcripts of K words: K isolated-word utterances back to back
+    data = [np.concatenate(data[i:i + K]) for i in range(0, U - K + 1, K)]
+    labels = [[l[0] for l in labels[i:i + K]] for i in range(0, U - K + 1, K)]
+    U = len(data)
 rng = np.random.default_rng(0)
 means0 = wl["means"] + 0.3 * rng.normal(size=wl["means"].shape)   # perturbed start
 t0 = time.perf_counter()
