@@ -90,6 +90,11 @@ int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
 /* same, features already in HBM (e.g. a torch tensor's data_ptr); not copied, not freed */
 int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
                   void* feats_dev, const int64_t* utt_offsets, gh_batch** out);
+/* Rows idx[0..n) of a resident batch as a new resident batch of U utterances (utt_offsets as in gh_batch_create), copied
+ * on the device: continuous_train's regrouping of the frames per state (continuous_speech.py:107-113, np.vstack of the
+ * segments) without a trip through the host. */
+int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* idx /*[n]*/, int64_t n, int64_t U,
+                    const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
 void gh_batch_destroy(gh_batch* b);
 /* N3 front-end: cepstra [N, C] (fp64, ragged by utt_offsets) -> [cepstra | delta | delta-delta]
  * (delta_feature, sr/core.py:13-22) -> per-utterance (x - mean) / std (standardize,
@@ -299,10 +304,15 @@ int gh_em_accumulate(gh_ctx* ctx, const gh_batch* b, int64_t first, int64_t coun
  *   variance cov[0] of kmeans.py:183, mahalanobis; NULL: Euclidean) for every frame of every active state; frames of
  *   inactive states keep their entry.  out_changed[s] (may be NULL) = number of frames of s whose entry changed;
  *   out_sums (may be NULL) [S,k,D+1] = per cluster the sum of its frames and, in column D, their number (the centroid
- *   update of kmeans.py:158-164 as sufficient statistics).
+ *   update of kmeans.py:158-164 as sufficient statistics), accumulated in FRAME ORDER -- the order in which
+ *   np.mean(data[clusters == c], axis=0) adds the rows of a C-contiguous array -- so that sums / count is bitwise the
+ *   reference's centroid for D >= 2 (with D = 1 numpy sums pairwise).
+ *   clusters_io NULL: the assignments live in the batch, on the device, from one call to the next (initially -1);
+ *   gh_kmeans_resident_clusters resets them to -1 (reset != 0) and / or copies them out (out != NULL, [N]).
  * gh_em_accumulate_multi: gh_em_accumulate for every active state in one launch: the first k components of state s are
  *   mean/var/weight[s, 0..k-1]; out_stats [S,k,1+2D] (centred on the means given), out_loglik [S] (either may be NULL);
  *   stats_dev (may be NULL): device buffer [S,k,1+2D] that receives the statistics, e.g. a tensor RCCL all-reduces. */
+int gh_kmeans_resident_clusters(gh_ctx* ctx, gh_batch* b, int reset, int32_t* out /*[N] or NULL*/);
 int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off /*[S+1]*/,
                            const uint8_t* active /*[S] or NULL*/, int k, const double* centroids /*[S,k,D]*/,
                            const double* var /*[S,D] or NULL*/, int32_t* clusters_io /*[N]*/, int32_t* out_changed /*[S]*/,

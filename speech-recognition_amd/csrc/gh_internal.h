@@ -119,6 +119,9 @@ struct gh_batch {
     // launch order of the DP kernels: utterances sorted longest first (computed once)
     std::vector<int64_t> perm;
     int64_t* d_perm;
+    // k-means assignments that stay on the device between lock-step iterations (gh_kmeans_assign_multi with
+    // clusters_io == NULL; gh_kmeans_resident_clusters resets / fetches them)
+    int32_t* d_clusters = nullptr;
 };
 
 // arc flag bits stored in pred_row

@@ -5,7 +5,8 @@
 // [seg_off[s], seg_off[s+1])) and one launch advances every state that has not converged yet:
 //   * gh_kmeans_assign_multi  -- the N x k distance / arg-min sweep of kmeans.py:180-186 for every active state,
 //     optionally with the per-(state, cluster) sums and counts of the centroid update (cluster_centroids,
-//     kmeans.py:158-164) and the number of assignments that changed (the sharded trainer all-reduces those);
+//     kmeans.py:158-164; kmeans_rowsum_kernel, in numpy's summation order) and the number of assignments that changed
+//     (the sharded trainer all-reduces those);
 //   * gh_em_accumulate_multi  -- the E-step statistics of hmm_state.py:127-143 for every active state
 //     (same centred layout as gh_em_accumulate).
 // One WAVE per tile of <= 64 frames of one state (tiles never straddle states): the frames are staged through LDS
@@ -38,6 +39,98 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ X, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------ k-means
+// Cluster sums in FRAME ORDER: numpy reduces a C-contiguous [n, D] array over axis 0 row after row (pairwise summation
+// only applies along the contiguous axis), so cluster_centroids' np.mean(data[clusters == c], axis=0)
+// (kmeans.py:158-164) is the sequential sum of the cluster's frames divided by their number; sums / count is then
+// BITWISE the reference's centroid (for D >= 2).  A sequential sum is a serial chain per (state, cluster, dimension),
+// so everything that is NOT the chain is taken out of it:
+//   * the frames of every cluster are first listed in order (stable compaction: per-tile cluster counts from the
+//     assignment kernel -> exclusive scan over the state's tiles -> every tile scatters its frame numbers), so a
+//     chain walks only its own cluster's frames -- n / k steps instead of n compare-and-select steps;
+//   * one wave per (state, cluster), lane = dimension: the frame numbers of 64 list entries are ONE coalesced load
+//     (lane j holds entry j's) handed out by v_readlane; a ring of RS_B registers keeps RS_B row loads in flight and
+//     refills a slot right after it is summed.
+// (History: a thread per (state, cluster, dimension) reading global memory in the chain, 8 loads in flight: 150
+// cycles per frame, 1.9 ms per k-means iteration for 50 states of 28 000 frames; staging through LDS made the state's
+// waves queue for their CU's LDS; a 64-deep register ring with select: 0.89 ms; compacted lists: see profiles.)
+constexpr int RS_B = 64;
+
+// exclusive scan of the per-tile cluster counts over the tiles of every state (in tile = frame order); also the
+// number of frames of every (state, cluster) and where its list starts inside the state's segment
+__global__ void kmeans_scan_kernel(const int32_t* __restrict__ tile_ptr /*[S+1]*/, int k, int32_t* __restrict__ tilecnt /*[tiles][k] -> offsets*/,
+                                   int32_t* __restrict__ counts /*[S,k]*/, int32_t* __restrict__ cbase /*[S,k]*/) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    __shared__ int tot[64];
+    int run = 0;
+    if (c < k)
+        for (int t = tile_ptr[s]; t < tile_ptr[s + 1]; ++t) {
+            const int v = tilecnt[(int64_t)t * k + c];
+            tilecnt[(int64_t)t * k + c] = run;
+            run += v;
+        }
+    tot[c] = c < k ? run : 0;
+    __syncthreads();
+    if (c < k) {
+        int base = 0;
+        for (int j = 0; j < c; ++j) base += tot[j];
+        counts[s * k + c] = run;
+        cbase[s * k + c] = base;
+    }
+}
+
+// every tile writes the (segment-local) numbers of its frames into their clusters' lists, keeping frame order
+__global__ __launch_bounds__(64) void kmeans_scatter_kernel(const ls_tile* __restrict__ tiles, int k, const int32_t* __restrict__ clusters,
+                                                            const int64_t* __restrict__ seg_off, const int32_t* __restrict__ tileoff,
+                                                            const int32_t* __restrict__ cbase, int32_t* __restrict__ lists /*[N]*/) {
+    const ls_tile tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x;
+    const bool act = lane < tl.count;
+    const int id = act ? clusters[tl.first + lane] : -1;
+    const int64_t seg0 = seg_off[tl.state];
+    for (int c = 0; c < k; ++c) {
+        const unsigned long long m = __ballot(act && id == c);
+        if (act && id == c) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            lists[seg0 + cbase[tl.state * k + c] + tileoff[(int64_t)blockIdx.x * k + c] + rank] = (int32_t)(tl.first + lane - seg0);
+        }
+    }
+}
+
+// grid (S, k), block = D rounded up to waves: the chain of (state, cluster, dimension = thread)
+__global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restrict__ X, int D, int k,
+                                                           const int64_t* __restrict__ seg_off, const uint8_t* __restrict__ active,
+                                                           const int32_t* __restrict__ lists, const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ cbase, double* __restrict__ sums) {
+    const int s = blockIdx.x, c = blockIdx.y;
+    if (active && !active[s]) return;
+    const int d = blockIdx.z * 64 + threadIdx.x, lane = threadIdx.x;
+    const bool live = d < D;
+    const int64_t f0 = seg_off[s];
+    const int n = counts[s * k + c];
+    if (d == 0) sums[((int64_t)s * k + c) * (D + 1) + D] = (double)n;
+    if (n <= 0) return;
+    const double* col = X + f0 * D + (live ? d : 0);
+    const int32_t* li = lists + f0 + cbase[s * k + c];
+    int id = li[min(lane, n - 1)];
+    double x[RS_B];
+#pragma unroll
+    for (int j = 0; j < RS_B; ++j) x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
+    double acc = 0.0;
+    int b = 0;
+    for (; b + RS_B <= n; b += RS_B) {                        // full rounds: the chain is one add per frame
+        id = li[min(b + RS_B + lane, n - 1)];                 // the next 64 entries (clamped: re-reads the last frame, never summed)
+#pragma unroll
+        for (int j = 0; j < RS_B; ++j) {
+            acc += x[j];
+            x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
+        }
+    }
+    const int left = n - b;                                   // the last, partial round
+#pragma unroll
+    for (int j = 0; j < RS_B; ++j) acc += (j < left) ? x[j] : 0.0;
+    if (live) sums[((int64_t)s * k + c) * (D + 1) + d] = acc;
+}
+
 template <int DR>
 __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
                                                           const double* __restrict__ cent /*[S,k,D]*/,
@@ -45,7 +138,7 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
                                                           const double* __restrict__ logdet /*[S]*/,
                                                           int32_t* __restrict__ clusters /*[N] in/out*/,
                                                           int32_t* __restrict__ changed /*[S] or null*/,
-                                                          double* __restrict__ partial /*[tiles][k][D+1] or null*/) {
+                                                          int32_t* __restrict__ counts /*[tiles][k] or null*/) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sc = sm;                  // [k][D]
     double* sv = sc + k * D;          // [D]
@@ -79,19 +172,11 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
         if (changed && *slot != bi) atomicAdd(changed + tl.state, 1);
         *slot = bi;
     }
-    if (partial) {   // per-cluster sums of the tile: lane = (cluster, dimension); "dimension" D counts the frames
-        int* sci = reinterpret_cast<int*>(tile + 64 * (D + 1));   // cluster of every frame (tile[] still holds the frames)
-        sci[lane] = act ? bi : -1;
-        __syncthreads();
-        double* out = partial + (int64_t)blockIdx.x * k * (D + 1);
-        for (int p = lane; p < k * (D + 1); p += 64) {
-            const int c = p / (D + 1), d = p - c * (D + 1);
-            double acc = 0;
-            for (int f = 0; f < tl.count; ++f)
-                if (sci[f] == c) acc += (d == D) ? 1.0 : tile[f * (D + 1) + d];
-            out[p] = acc;
+    if (counts)                                               // frames of this tile per cluster (scanned by kmeans_scan_kernel)
+        for (int c = 0; c < k; ++c) {
+            const int nc = __popcll(__ballot(act && bi == c));
+            if (lane == 0) counts[(int64_t)blockIdx.x * k + c] = nc;
         }
-    }
 }
 
 // partial[tile][len] summed over the tiles of each state (contiguous, in order) -> out[state][len]
@@ -203,10 +288,29 @@ int check_segments(const gh_batch* b, int S, const int64_t* seg_off, const char*
 
 }  // namespace
 
+static int resident_clusters(gh_ctx* ctx, gh_batch* b, bool reset) {
+    if (!b->d_clusters && b->N > 0) {
+        GH_HIP(hipMalloc((void**)&b->d_clusters, (size_t)b->N * 4));
+        reset = true;
+    }
+    if (reset && b->N > 0) GH_HIP(hipMemsetAsync(b->d_clusters, 0xFF, (size_t)b->N * 4, ctx->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_kmeans_resident_clusters(gh_ctx* ctx, gh_batch* b, int reset, int32_t* out) {
+    GH_REQUIRE(ctx && b, "gh_kmeans_resident_clusters: NULL argument");
+    GH_HIP(hipSetDevice(ctx->device));
+    const int rc = resident_clusters(ctx, b, reset != 0);
+    if (rc) return rc;
+    if (out && b->N > 0) GH_HIP(hipMemcpyAsync(out, b->d_clusters, (size_t)b->N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+}
+
 extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off, const uint8_t* active,
                                       int k, const double* centroids, const double* var, int32_t* clusters_io,
                                       int32_t* out_changed, double* out_sums) {
-    GH_REQUIRE(ctx && b && centroids && clusters_io, "gh_kmeans_assign_multi: NULL argument");
+    GH_REQUIRE(ctx && b && centroids, "gh_kmeans_assign_multi: NULL argument");
     GH_REQUIRE(k > 0 && k <= 64, "gh_kmeans_assign_multi: k=%d (1..64)", k);
     int rc = check_segments(b, S, seg_off, "gh_kmeans_assign_multi");
     if (rc) return rc;
@@ -230,35 +334,54 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     ls_tile* d_tiles; double *d_cent, *d_var = nullptr, *d_ld, *d_part = nullptr, *d_sums = nullptr;
     int32_t *d_cl, *d_changed, *d_tptr;
     Carver cv;
-    cv.add(&d_tiles, tiles.size()); cv.add(&d_cent, (size_t)S * k * D); cv.add(&d_ld, S); cv.add(&d_cl, N);
+    cv.add(&d_tiles, tiles.size()); cv.add(&d_cent, (size_t)S * k * D); cv.add(&d_ld, S);
+    if (clusters_io) cv.add(&d_cl, N);
     cv.add(&d_changed, S); cv.add(&d_tptr, S + 1);
     if (var) cv.add(&d_var, (size_t)S * D);
-    if (out_sums) { cv.add(&d_part, tiles.size() * (size_t)plen); cv.add(&d_sums, (size_t)S * plen); }
+    int64_t* d_segoff = nullptr;
+    uint8_t* d_active = nullptr;
+    int32_t *d_counts = nullptr, *d_tilecnt = nullptr, *d_cbase = nullptr, *d_lists = nullptr;
+    if (out_sums) {
+        cv.add(&d_sums, (size_t)S * plen); cv.add(&d_segoff, S + 1); cv.add(&d_counts, (size_t)S * k); cv.add(&d_cbase, (size_t)S * k);
+        cv.add(&d_tilecnt, tiles.size() * (size_t)k); cv.add(&d_lists, N);
+        if (active) cv.add(&d_active, S);
+    }
     rc = cv.commit(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     GH_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(ls_tile), hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_cent, centroids, (size_t)S * k * D * 8, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_ld, logdet.data(), (size_t)S * 8, hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_cl, clusters_io, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    if (clusters_io) GH_HIP(hipMemcpyAsync(d_cl, clusters_io, (size_t)N * 4, hipMemcpyHostToDevice, st));
+    else {   // assignments resident in the batch
+        rc = resident_clusters(ctx, const_cast<gh_batch*>(b), false);
+        if (rc) return rc;
+        d_cl = b->d_clusters;
+    }
     GH_HIP(hipMemsetAsync(d_changed, 0, (size_t)S * 4, st));
+    if (d_counts) { GH_HIP(hipMemsetAsync(d_counts, 0, (size_t)S * k * 4, st)); GH_HIP(hipMemsetAsync(d_cbase, 0, (size_t)S * k * 4, st)); }
     if (var) GH_HIP(hipMemcpyAsync(d_var, var, (size_t)S * D * 8, hipMemcpyHostToDevice, st));
     const size_t lds = ((size_t)k * D + D + 64 * (size_t)(D + 1)) * 8 + 64 * 4 + 16;
     GH_REQUIRE(lds <= 150 * 1024, "gh_kmeans_assign_multi: k=%d x D=%d does not fit LDS", k, D);
     const dim3 grid((unsigned)tiles.size()), blk(64);
 #define GH_KM(DR) hipLaunchKernelGGL((kmeans_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_cent, \
-                                     d_var, d_ld, d_cl, out_changed ? d_changed : nullptr, d_part)
+                                     d_var, d_ld, d_cl, out_changed ? d_changed : nullptr, d_tilecnt)
     if (D <= 16) GH_KM(16); else if (D <= 40) GH_KM(40); else GH_KM(64);
 #undef GH_KM
     GH_HIP(hipGetLastError());
     if (out_sums) {
+        GH_HIP(hipMemcpyAsync(d_segoff, seg_off, (size_t)(S + 1) * 8, hipMemcpyHostToDevice, st));
+        if (active) GH_HIP(hipMemcpyAsync(d_active, active, (size_t)S, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemsetAsync(d_sums, 0, (size_t)S * plen * 8, st));
         GH_HIP(hipMemcpyAsync(d_tptr, tile_ptr.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, d_part,
-                           d_tptr, plen, d_sums);
+        hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(64), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase);
+        hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists);
+        hipLaunchKernelGGL(kmeans_rowsum_kernel, dim3((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64)), dim3(64), 0, st,
+                           (const double*)b->feats, D, k, d_segoff, d_active, d_lists, d_counts, d_cbase, d_sums);
         GH_HIP(hipGetLastError());
         GH_HIP(hipMemcpyAsync(out_sums, d_sums, (size_t)S * plen * 8, hipMemcpyDeviceToHost, st));
     }
-    GH_HIP(hipMemcpyAsync(clusters_io, d_cl, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    if (clusters_io) GH_HIP(hipMemcpyAsync(clusters_io, d_cl, (size_t)N * 4, hipMemcpyDeviceToHost, st));
     if (out_changed) GH_HIP(hipMemcpyAsync(out_changed, d_changed, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
     return GH_OK;

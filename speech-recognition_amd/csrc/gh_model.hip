@@ -181,6 +181,49 @@ extern "C" int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int6
     return GH_OK;
 }
 
+// rows `idx` of a resident batch as a new resident batch (no host round trip): what the regrouping of continuous_train
+// (continuous_speech.py:107-113: np.vstack of every state's segments) is on the device
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int D, T* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int64_t r = i / D;
+    dst[i] = src[idx[r] * D + (i - r * D)];
+}
+
+extern "C" int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* idx, int64_t n, int64_t U, const int64_t* off,
+                               gh_batch** out) {
+    GH_REQUIRE(ctx && src && out && (idx || n == 0), "gh_batch_gather: NULL argument");
+    for (int64_t i = 0; i < n; ++i) GH_REQUIRE(idx[i] >= 0 && idx[i] < src->N, "gh_batch_gather: row %lld out of range", (long long)idx[i]);
+    int rc = batch_common(ctx, src->dtype, src->D, n, U, off, out);
+    if (rc) return rc;
+    gh_batch* b = *out;
+    const size_t es = src->dtype == GH_F64 ? 8 : 4;
+    b->owns_feats = true;
+    if (n > 0) {
+        int64_t* d_idx = nullptr;
+        hipError_t e = hipMalloc(&b->feats, (size_t)n * src->D * es);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_idx, (size_t)n * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const int64_t total = n * src->D;
+            const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+            if (src->dtype == GH_F64) hipLaunchKernelGGL(gather_rows_kernel<double>, grid, blk, 0, ctx->stream, (const double*)src->feats, d_idx, n, src->D, (double*)b->feats);
+            else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, blk, 0, ctx->stream, (const float*)src->feats, d_idx, n, src->D, (float*)b->feats);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_idx) hipFree(d_idx);
+        if (e != hipSuccess) {
+            gh_set_error("gh_batch_gather: %s", hipGetErrorString(e));
+            gh_batch_destroy(b);
+            *out = nullptr;
+            return e == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+        }
+    }
+    return GH_OK;
+}
+
 extern "C" void gh_batch_destroy(gh_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
@@ -192,6 +235,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
     if (b->d_occ_states) hipFree(b->d_occ_states);
     if (b->d_offsets) hipFree(b->d_offsets);
     if (b->d_perm) hipFree(b->d_perm);
+    if (b->d_clusters) hipFree(b->d_clusters);
     delete b;
 }
 

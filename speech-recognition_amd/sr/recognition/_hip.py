@@ -41,6 +41,7 @@ SIGNATURES = {
     "gh_gmm_destroy": (None, [C.c_void_p]),
     "gh_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                   C.POINTER(C.c_void_p)]),
+    "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
     "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_batch_destroy": (None, [C.c_void_p]),
@@ -79,6 +80,7 @@ SIGNATURES = {
                          _c_f64p, _c_i32p, _c_i32p]),
     "gh_kmeans_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_i32p]),
+    "gh_kmeans_resident_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i32p]),
     "gh_kmeans_assign_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.POINTER(C.c_uint8), C.c_int, _c_f64p,
                                          _c_f64p, _c_i32p, _c_i32p, _c_f64p]),
     "gh_em_accumulate_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.POINTER(C.c_uint8), C.c_int, _c_f64p,
@@ -89,6 +91,9 @@ SIGNATURES = {
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
 }
+
+
+RESIDENT = object()   # kmeans_assign_multi(clusters=RESIDENT): assignments stay on the device between calls
 
 
 class BackendError(RuntimeError):
@@ -423,7 +428,9 @@ class Batch:
         assert len(seg_off) == S + 1 and D == self.D
         if clusters is None:
             clusters = np.full(self.N, -1, dtype=np.int32)
-        assert clusters.dtype == np.int32 and clusters.flags.c_contiguous and len(clusters) == self.N
+        elif clusters is RESIDENT:
+            clusters = None         # the assignments stay in the batch, on the device (see resident_clusters)
+        assert clusters is None or (clusters.dtype == np.int32 and clusters.flags.c_contiguous and len(clusters) == self.N)
         v = None if var is None else _f64(var).reshape(S, D)
         act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
         changed = np.zeros(S, dtype=np.int32)
@@ -433,6 +440,27 @@ class Batch:
             k, _ptr(centroids, _c_f64p), _ptr(v, _c_f64p), _ptr(clusters, _c_i32p), _ptr(changed, _c_i32p),
             _ptr(sums, _c_f64p)))
         return clusters, changed, sums
+
+    def gather(self, rows, offsets=None):
+        """Rows `rows` of this batch as a new resident batch (gh_batch_gather: copied on the device); offsets: utterance
+        boundaries of the new batch (default: one utterance)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        off = np.ascontiguousarray([0, len(rows)] if offsets is None else offsets, dtype=np.int64)
+        new = Batch.__new__(Batch)
+        new.ctx, new.np_dtype = self.ctx, self.np_dtype
+        new.offsets, new.N, new.D, new.U, new.S = off, len(rows), self.D, len(off) - 1, None
+        h = C.c_void_p()
+        _check(self.ctx.lib, self.ctx.lib.gh_batch_gather(self.ctx.h, self.h, _ptr(rows, _c_i64p), len(rows), new.U,
+                                                          _ptr(off, _c_i64p), C.byref(h)))
+        new.h = h
+        return new
+
+    def resident_clusters(self, reset=False, fetch=True):
+        """The k-means assignments kept on the device by kmeans_assign_multi(clusters=RESIDENT): reset to -1 and / or
+        fetch them (int32 [N])."""
+        out = np.empty(self.N, dtype=np.int32) if fetch else None
+        _check(self.ctx.lib, self.ctx.lib.gh_kmeans_resident_clusters(self.ctx.h, self.h, int(bool(reset)), _ptr(out, _c_i32p)))
+        return out
 
     def em_accumulate_multi(self, seg_off, mean, var, weight, active=None, stats_dev=None):
         """A7 E-step statistics of every (active) state in one launch: mean / var [S,k,D], weight [S,k].

@@ -305,7 +305,9 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                 segs = [seg_of[sid] if sid in seg_of else np.zeros((0, dim)) for sid in keys]
                 starts = [glob[sid, :dim] / glob[sid, dim] for sid in keys]
                 seg_counts = {sid: (glob[sid, dim + 1], glob[sid, dim]) for sid in keys}
-            fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None)
+            rows_of = {int(sid): used[by_state[cuts[i]:cuts[i + 1]]] for i, sid in enumerate(uniq)}
+            rows = np.concatenate([rows_of.get(sid, np.zeros(0, dtype=np.int64)) for sid in keys]) if keys else np.zeros(0, np.int64)
+            fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None, source=(frames, rows))
             try:
                 fitter.split_and_fit([new_models[sid // n].gmm_states[sid % n] for sid in keys],
                                      start_centroids=starts,

@@ -29,17 +29,23 @@ def _variance_rows(x):
 
 
 class LockstepFitter:
-    """segments: list of [N_s, D] arrays, one per state, in the order the reference would train them."""
+    """segments: list of [N_s, D] arrays, one per state, in the order the reference would train them.
+    source: (resident batch, row indices) -- the rows of an fp64 batch that, in this order, ARE the concatenated
+    segments; the fitter's batch is then gathered on the device instead of uploaded again."""
 
-    def __init__(self, segments, ctx=None, reducer=None):
+    def __init__(self, segments, ctx=None, reducer=None, source=None):
         self.ctx = ctx if ctx is not None else _hip.default_context()
         self.segs = [np.ascontiguousarray(s, dtype=np.float64) for s in segments]
         self.S = len(self.segs)
         self.D = self.segs[0].shape[1] if self.S else 0
         self.seg_off = np.zeros(self.S + 1, dtype=np.int64)
         np.cumsum([len(s) for s in self.segs], out=self.seg_off[1:])
-        self.batch = _hip.Batch(self.ctx, feats=np.concatenate(self.segs) if self.S else np.zeros((0, 1)),
-                                offsets=[0, int(self.seg_off[-1])]) if self.S else None
+        if self.S and source is not None and hasattr(source[0], "gather") and source[0].np_dtype == np.float64:
+            assert len(source[1]) == int(self.seg_off[-1])
+            self.batch = source[0].gather(source[1])
+        else:
+            self.batch = _hip.Batch(self.ctx, feats=np.concatenate(self.segs) if self.S else np.zeros((0, 1)),
+                                    offsets=[0, int(self.seg_off[-1])]) if self.S else None
         self.reducer = reducer
         self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
         self.collectives = 0
@@ -80,11 +86,21 @@ class LockstepFitter:
                 v0 = (ps[:, 1 + D:] - ps[:, 1:1 + D] ** 2 / n0) / (n0 - 1.0)
             cov[:] = v0[:, None, :]
         centroids = np.array(centroids, dtype=np.float64)
-        clusters = np.full(int(off[-1]), -1, dtype=np.int32)
+        # the assignments stay on the device between iterations when nothing on the host needs them (D >= 2)
+        resident = D >= 2 and hasattr(self.batch, "resident_clusters")
+        if resident:
+            self.batch.resident_clusters(reset=True, fetch=False)
+        clusters = _hip.RESIDENT if resident else np.full(int(off[-1]), -1, dtype=np.int32)
         active = np.ones(S, dtype=np.uint8)
+        # cluster sums come back accumulated in frame order -- the order np.mean(x[cl == c], axis=0) adds the rows of a
+        # C-contiguous array -- so sums / count IS cluster_centroids' mean, bit for bit (kmeans.py:158-164); with one
+        # feature dimension numpy sums pairwise instead, and the means are taken on the host
+        dev_means = D >= 2
         for _ in range(max(max_iteration, 1)):
-            clusters, changed, sums = self.batch.kmeans_assign_multi(off, centroids, var=cov[:, 0, :], clusters=clusters,
-                                                                    active=active, want_sums=self.sharded)
+            got, changed, sums = self.batch.kmeans_assign_multi(off, centroids, var=cov[:, 0, :], clusters=clusters,
+                                                               active=active, want_sums=self.sharded or dev_means)
+            if not resident:
+                clusters = got
             if self.sharded:
                 red = self._reduce(np.concatenate([sums.reshape(S, -1), changed.reshape(S, 1).astype(np.float64)], axis=1))
                 sums, changed = red[:, :-1].reshape(S, k, D + 1), red[:, -1]
@@ -95,18 +111,26 @@ class LockstepFitter:
                         active[s] = 0                 # assignments stable on every rank: centroids are stable
                     centroids[s] = new[s]
             else:
-                for s in np.nonzero(active)[0]:
-                    cl = clusters[off[s]:off[s + 1]]
-                    new = np.empty((k, D))
+                if dev_means:
                     with np.errstate(all="ignore"):
-                        for c in range(k):
-                            np.mean(self.segs[s][cl == c, :], axis=0, out=new[c])   # cluster_centroids, kmeans.py:158-164
+                        means = sums[:, :, :D] / sums[:, :, [D]]       # an empty cluster: 0 / 0 = nan, like np.mean of nothing
+                for s in np.nonzero(active)[0]:
+                    if dev_means:
+                        new = means[s]
+                    else:
+                        cl = clusters[off[s]:off[s + 1]]
+                        new = np.empty((k, D))
+                        with np.errstate(all="ignore"):
+                            for c in range(k):
+                                np.mean(self.segs[s][cl == c, :], axis=0, out=new[c])   # cluster_centroids, kmeans.py:158-164
                     if np.array_equal(new, centroids[s]):
                         active[s] = 0                 # kmeans.py:190-191
                     else:
                         centroids[s] = new
             if not active.any():
                 break
+        if resident:
+            clusters = self.batch.resident_clusters()
         return [clusters[off[s]:off[s + 1]].astype(np.int64) for s in range(S)], centroids, cov
 
     # ------------------------------------------------------------------ mixture EM (hmm_state.py:122-159), all states

@@ -142,6 +142,12 @@ class Batch:
     def kmeans_assign_multi(self, seg_off, centroids, var=None, clusters=None, active=None, want_sums=False):
         centroids = np.asarray(centroids, dtype=np.float64)
         S, k, D = centroids.shape
+        from sr.recognition import _hip as real
+        resident = clusters is real.RESIDENT
+        if resident:
+            if getattr(self, "_clusters", None) is None:
+                self._clusters = np.full(self.N, -1, dtype=np.int32)
+            clusters = self._clusters
         if clusters is None:
             clusters = np.full(self.N, -1, dtype=np.int32)
         changed = np.zeros(S, dtype=np.int32)
@@ -158,7 +164,16 @@ class Batch:
                     x = self.feats[a:b][new == c]
                     sums[s, c, :D] = x.sum(axis=0)
                     sums[s, c, D] = len(x)
-        return clusters, changed, sums
+        return (None if resident else clusters), changed, sums
+
+    def gather(self, rows, offsets=None):
+        rows = np.asarray(rows, dtype=np.int64)
+        return Batch(self.ctx, feats=self.feats[rows], offsets=[0, len(rows)] if offsets is None else offsets)
+
+    def resident_clusters(self, reset=False, fetch=True):
+        if reset or getattr(self, "_clusters", None) is None:
+            self._clusters = np.full(self.N, -1, dtype=np.int32)
+        return self._clusters.copy() if fetch else None
 
     def em_accumulate_multi(self, seg_off, mean, var, weight, active=None, stats_dev=None):
         mean = np.asarray(mean, dtype=np.float64)

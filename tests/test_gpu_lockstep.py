@@ -275,3 +275,44 @@ def test_continuous_train_sharded_over_two_ranks(tmp_path):
         seq, trans, ends = R.build_state_sequences(models, [[l] for l in lab])
         costs, path = R.decode_hmm_states(x, seq, trans, end_points=[[e, -1] for e in ends])
         assert np.isfinite(costs[ends[-1], -1]) and len(path) > 0
+
+
+def test_batch_gather_and_resident_clusters():
+    """gh_batch_gather: rows of a resident batch regrouped on the device equal the host's fancy index, fp64 and fp32;
+    gh_kmeans_assign_multi with the assignments resident in the batch walks through the same assignments as with a
+    host array, and its frame-order sums divided by the counts are np.mean of the clusters bit for bit."""
+    from sr.recognition import _hip
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(3)
+    xs = [rng.normal(size=(int(rng.integers(1, 40)), 7)) for _ in range(30)]
+    X = np.concatenate(xs)
+    rows = rng.permutation(len(X))[:500]
+    for dt in (np.float64, np.float32):
+        b = _hip.Batch(ctx, xs, dtype=dt)
+        g = b.gather(rows, offsets=[0, 100, 100, 500])
+        got = g.features()
+        assert [len(u) for u in got] == [100, 0, 400]
+        np.testing.assert_array_equal(np.concatenate(got), X.astype(dt)[rows])
+        g.close()
+        b.close()
+    b = _hip.Batch(ctx, feats=X, offsets=[0, len(X)])
+    off = np.array([0, 200, 200, len(X)], dtype=np.int64)
+    cent = rng.normal(size=(3, 4, 7))
+    var = rng.uniform(0.5, 2.0, size=(3, 7))
+    host = np.full(len(X), -1, dtype=np.int32)
+    b.resident_clusters(reset=True, fetch=False)
+    for it in range(3):
+        host, ch_h, sums_h = b.kmeans_assign_multi(off, cent, var=var, clusters=host, want_sums=True)
+        none, ch_r, sums_r = b.kmeans_assign_multi(off, cent, var=var, clusters=_hip.RESIDENT, want_sums=True)
+        assert none is None
+        np.testing.assert_array_equal(ch_r, ch_h)
+        np.testing.assert_array_equal(sums_r, sums_h)
+        np.testing.assert_array_equal(b.resident_clusters(), host)
+        for s in (0, 2):
+            seg, cl = X[off[s]:off[s + 1]], host[off[s]:off[s + 1]]
+            for c in range(4):
+                if (cl == c).any():
+                    np.testing.assert_array_equal(sums_h[s, c, :7] / sums_h[s, c, 7], np.mean(seg[cl == c, :], axis=0))
+                    cent[s, c] = sums_h[s, c, :7] / sums_h[s, c, 7]
+    assert (b.resident_clusters(reset=True) == -1).all()
+    b.close()
