@@ -268,7 +268,7 @@ int gh_viterbi_labels_packed(gh_ctx* ctx, const gh_lattices* lat, const gh_batch
  *              by the caller), utterance u = [n, T_u] block at n*utt_offsets[u]; then y/var unused
  *   out_costs  same layout as dist_host (marked cells: -1 in the last column, +inf elsewhere)
  *   out_path   [N, 2] (row, col) pairs, utterance u at utt_offsets[u]; out_path_len [U]
- * n <= 64. */
+ * n <= 1024 (one workgroup per utterance, thread = template row). */
 int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, const double* var,
            const double* trans, int beam, const double* dist_host,
            double* out_costs, int32_t* out_path, int32_t* out_path_len);

@@ -462,7 +462,7 @@ extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, co
                       int32_t* out_path, int32_t* out_path_len) {
     GH_REQUIRE(ctx && b && trans, "gh_dtw: NULL argument");
     GH_REQUIRE(dist_host || y, "gh_dtw: need template rows or a distance matrix");
-    GH_REQUIRE(n > 1 && n <= 64, "gh_dtw: n=%d (2..64 supported; decode.py:22 asserts n > 1)", n);
+    GH_REQUIRE(n > 1 && n <= 1024, "gh_dtw: n=%d (2..1024 supported; decode.py:22 asserts n > 1)", n);
     GH_REQUIRE(b->dtype == GH_F64 || dist_host, "gh_dtw: built-in distances need an fp64 batch");
     GH_REQUIRE(!out_path || out_path_len, "gh_dtw: out_path needs out_path_len");
     GH_HIP(hipSetDevice(ctx->device));
@@ -486,7 +486,7 @@ extern "C" int gh_dtw(gh_ctx* ctx, const gh_batch* b, int n, const double* y, co
     uint8_t* d_bp;
     int32_t *d_path = nullptr, *d_plen = nullptr;
     Carver cv;
-    cv.add(&d_tr, (size_t)n * n); cv.add(&d_moff, U + 1); cv.add(&d_bp, (size_t)n * N);
+    cv.add(&d_tr, (size_t)n * n); cv.add(&d_moff, U + 1); cv.add(&d_bp, (size_t)n * N * (n <= 255 ? 1 : 2));
     if (!dist_host) { cv.add(&d_y, (size_t)n * D); if (var) { cv.add(&d_var, (size_t)n * D); cv.add(&d_ld, n); } }
     if (dist_host) cv.add(&d_E, (size_t)n * N);
     if (out_costs) cv.add(&d_costs, (size_t)n * N);

@@ -12,7 +12,7 @@ struct gh_dtw_args {
     const double* var;       // [n,D] per-row variance or null (Euclidean)
     const double* logdet;    // [n] 0.5*log((2pi)^D prod var)
     const double* trans;     // [n,n] dense, +inf = no arc
-    uint8_t* bp;             // scratch
+    uint8_t* bp;             // scratch: origin row per cell, bytes for n <= 255, uint16 above
     const int64_t* bp_off;   // [U]
     double* costs;           // optional [n,T] per utterance
     const int64_t* costs_off;

@@ -1,7 +1,8 @@
 // Template-matching dynamic program with optional beam (reference: dtw,
 // sr/recognition/decode.py:7-77).
 //
-// One utterance per wave: lane i owns template row i (n <= 64).  Per column the
+// One utterance per workgroup: thread i owns template row i (one wave for n <= 64 -- the reference's 5-state word
+// templates -- up to 16 waves for n <= 1024; back-pointers are bytes up to 255 rows, 16-bit above).  Per column the
 // lanes compute their distance to the frame (Euclidean norm or the diagonal-
 // Gaussian negative log-likelihood `mahalanobis`, hmm_state.py:48-58) -- or read
 // a caller-supplied distance matrix -- then minimise over ALL origins of the
@@ -18,9 +19,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
-    __shared__ double col[2][64];
-    __shared__ unsigned char mark[2][64];
+template <typename BPT>
+__global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
+    extern __shared__ __attribute__((aligned(16))) double dtw_lds[];
+    const int np = blockDim.x;                                // n rounded up to whole waves
+    double* col0 = dtw_lds;                                   // [2][np] columns, then [2][np] beam marks
+    unsigned char* mark0 = reinterpret_cast<unsigned char*>(dtw_lds + 2 * np);
+    auto col = [&](int b) { return col0 + b * np; };
+    auto mark = [&](int b) { return mark0 + b * np; };
     const int i = threadIdx.x;
     const int64_t u = blockIdx.x;
     const int n = a.n, D = a.D;
@@ -28,7 +34,7 @@ __global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
     const int T = (int)(a.utt_off[u + 1] - f0);
     const double INF = INFINITY;
     double* costs = a.costs ? a.costs + a.costs_off[u] : nullptr;
-    uint8_t* bp = a.bp + a.bp_off[u];
+    BPT* bp = reinterpret_cast<BPT*>(a.bp) + a.bp_off[u];
     const bool act = i < n;
     if (T <= 0) {
         if (i == 0 && a.path_len) a.path_len[u] = 0;
@@ -39,8 +45,8 @@ __global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
     const double* vrow = a.var ? a.var + (int64_t)(act ? i : 0) * D : nullptr;
     double logdet = 0;
     if (a.var && act) logdet = a.logdet[i];
-    col[0][i] = INF; col[1][i] = INF;
-    mark[0][i] = 0; mark[1][i] = 0;
+    col(0)[i] = INF; col(1)[i] = INF;
+    mark(0)[i] = 0; mark(1)[i] = 0;
     __syncthreads();
     int pb = 0;  // buffer holding column j-1
     for (int j = 0; j < T; ++j) {
@@ -65,32 +71,32 @@ __global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
         if (act) {
             if (i == 0 && j == 0) {
                 c = dist;  // decode.py:34-40
-                bp[0] = 0xFF;
+                bp[0] = (BPT)~BPT(0);
             } else {
                 double best = 0;
                 int bo = -1;
                 for (int o = 0; o < n; ++o) {
-                    const bool pruned = mark[pb][o] != 0;
+                    const bool pruned = mark(pb)[o] != 0;
                     if (pruned && i == 0) continue;  // first reader drops the marked cell
-                    const double v = a.trans[i * n + o] + (pruned ? INF : col[pb][o]);
+                    const double v = a.trans[i * n + o] + (pruned ? INF : col(pb)[o]);
                     // np.argmin: the first NaN wins over everything, else the first minimum
                     if (bo < 0 || v < best || (v != v && best == best)) { best = v; bo = o; }
                 }
                 c = best + dist;
                 if (c != c) c = INF;  // min(inf, nan) keeps inf (decode.py:60)
                 if (bo < 0) { atomicOr(a.flag, 8); bo = 0; c = INF; }  // np.argmin([]) -> ValueError
-                bp[(int64_t)j * n + i] = (uint8_t)bo;
+                bp[(int64_t)j * n + i] = (BPT)bo;
             }
         }
-        col[cb][i] = c;
-        mark[cb][i] = 0;
+        col(cb)[i] = c;
+        mark(cb)[i] = 0;
         __syncthreads();
         unsigned char mk = 0;
         if (a.beam > 0 && act) {
             // rank in ascending (value, row) order == position in np.argsort of the column
             int rank = 0;
             for (int o = 0; o < n; ++o) {
-                const double v = col[cb][o];
+                const double v = col(cb)[o];
                 rank += (v < c) || (v == c && o < i);
             }
             if (rank >= a.beam && !isinf(c)) mk = 1;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
             costs[(int64_t)i * T + j] = mk ? ((j == T - 1) ? -1.0 : INF) : c;
         }
         __syncthreads();
-        mark[cb][i] = mk;
+        mark(cb)[i] = mk;
         __syncthreads();
         pb = cb;
     }
@@ -125,7 +131,10 @@ __global__ __launch_bounds__(64) void dtw_kernel(gh_dtw_args a) {
 
 int gh_launch_dtw(gh_ctx* ctx, const gh_dtw_args& a, int64_t U) {
     if (U <= 0) return GH_OK;
-    hipLaunchKernelGGL(dtw_kernel, dim3((unsigned)U), dim3(64), 0, ctx->stream, a);
+    const int np = (a.n + 63) & ~63;
+    const size_t lds = (size_t)2 * np * 8 + (size_t)2 * np;
+    if (a.n <= 255) hipLaunchKernelGGL(dtw_kernel<uint8_t>, dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(dtw_kernel<uint16_t>, dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

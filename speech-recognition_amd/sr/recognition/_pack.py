@@ -105,6 +105,7 @@ class _LRU(OrderedDict):
 
 
 _gmm_cache = _LRU(8)
+_normal_cache = _LRU(1024)   # single Gaussians behind MultivariateNormal.pdf (a few hundred bytes of HBM each)
 _lat_cache = _LRU(16)
 
 
@@ -113,6 +114,15 @@ def device_gmm(ctx, gmms):
     means, vars_, w = stack_gmms(gmms)
     key = (id(ctx), _digest(means, vars_, w))
     return _gmm_cache.lookup(key, lambda: _hip.PackedGMM(ctx, means, vars_, w))
+
+
+def device_normal(ctx, mean, var):
+    """PackedGMM of ONE diagonal Gaussian (cached on parameter content): what `MultivariateNormal.pdf` evaluates -- the
+    reference calls it frame by frame (hmm_state.py:36-45), so the handle outlives the call."""
+    mean = np.asarray(mean, dtype=np.float64)
+    var = np.asarray(var, dtype=np.float64)
+    key = (id(ctx), _digest(mean, var))
+    return _normal_cache.lookup(key, lambda: _hip.PackedGMM(ctx, mean[None, None, :], var[None, None, :], np.ones((1, 1))))
 
 
 def graph_from_dense(row_state, transitions, start_rows, end_rows):
@@ -133,7 +143,7 @@ def device_lattices(ctx, graphs):
 
 
 def clear_caches():
-    for c in (_gmm_cache, _lat_cache):
+    for c in (_gmm_cache, _normal_cache, _lat_cache):
         while c:
             _, v = c.popitem()
             v.close()

@@ -176,4 +176,5 @@ class InFlight:
         for c in self.ctxs:
             _pack._gmm_cache.purge(c)     # handles are bound to the context they were created with
             _pack._lat_cache.purge(c)
+            _pack._normal_cache.purge(c)
             c.close()

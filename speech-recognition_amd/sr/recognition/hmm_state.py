@@ -62,7 +62,7 @@ class MultivariateNormal:
         mean = np.asarray(self.mean, dtype=np.float64)
         if x.shape[0] != mean.shape[0]:
             raise NameError("The dimensions of the input don't match")
-        model = _hip.PackedGMM(_ctx(), mean[None, None, :], self._diag()[None, None, :], np.ones((1, 1)))
+        model = _pack.device_normal(_ctx(), mean, self._diag())      # cached on (mean, variance): pdf is called per frame
         return np.exp(model.component_loglik(0, x[None, :])[0, 0])
 
 

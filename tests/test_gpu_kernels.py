@@ -900,3 +900,32 @@ def test_decode_hmm_states_beam_kwarg(hip, ctx):
     cb, pb = R.decode_hmm_states(x, states, trans, beam=np.inf)
     np.testing.assert_array_equal(cb, c0)
     np.testing.assert_array_equal(pb, p0)
+
+
+@pytest.mark.parametrize("n,beam", [(65, 0), (100, 12), (300, 0), (300, 40)])
+def test_dtw_long_templates(n, beam):
+    """gh_dtw beyond one wave: templates of 65..300 rows (several waves per utterance, 16-bit back-pointers above 255
+    rows) against the oracle's reference-shaped DP -- costs (with the beam's -1 / +inf marks), paths."""
+    from sr.recognition import _hip
+    from oracle import ref_numpy as O
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(n + beam)
+    D = 5
+    y = rng.normal(size=(n, D))
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = rng.uniform(0.1, 0.5)
+        if i + 1 < n:
+            trans[i + 1, i] = rng.uniform(0.3, 1.0)
+        if i + 2 < n:
+            trans[i + 2, i] = rng.uniform(0.8, 2.0)
+    xs = [y[np.minimum(np.arange(T) * n // T, n - 1)] + 0.3 * rng.normal(size=(T, D)) for T in (n // 2 + 3, n + 7)]
+    b = _hip.Batch(ctx, xs)
+    costs, paths = b.dtw(trans, y=y, beam=beam)
+    for u, x in enumerate(xs):
+        E = np.array([[O.euclid(x[j], y[i]) for j in range(len(x))] for i in range(n)])
+        with np.errstate(invalid="ignore"):
+            rc, rp = O.dtw(E, trans, beam=beam if beam else np.inf)
+        np.testing.assert_allclose(costs[u], rc, rtol=1e-12)
+        np.testing.assert_array_equal(paths[u], np.asarray(rp).reshape(-1, 2))
+    b.close()
