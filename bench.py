@@ -377,6 +377,49 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
     return out
 
 
+def _training_config(ctx, U, K=7):
+    """configs[2]'s model on K-word transcripts (the reference's own training data are digit strings,
+    continuous_speech.py:56-179): (a) the alignment + regrouping step of continuous_train -- own-state likelihoods,
+    forced-alignment Viterbi through one graph per distinct transcript, frames regrouped per state
+    (gh_lattices_create_transcripts + gh_loglik_subset + gh_align_segments); (b) one soft-EM iteration on the same
+    transcripts (forward-backward in sequence form + statistics + host M-step, graphs rebuilt from the new costs)."""
+    from sr.recognition import _hip
+    from sr.recognition.train import BaumWelchTrainer
+    wl = synth_workload(1003, U * K)
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    off = wl["off"][::K]
+    labels = [[int(w) for w in wl["words"][i * K:(i + 1) * K]] for i in range(U)]
+    data = [wl["X"][off[u]:off[u + 1]] for u in range(U)]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)
+    gmm = _hip.PackedGMM(ctx, means0.reshape(W * n, M, D), wl["vars"].reshape(W * n, M, D), wl["w"].reshape(W * n, M))
+    b = _hip.Batch(ctx, feats=wl["X"], offsets=off)
+    keys, utt_graph = {}, np.empty(U, dtype=np.int32)
+    for u, l in enumerate(labels):
+        utt_graph[u] = keys.setdefault(tuple(l), len(keys))
+    lo = np.array([min(l) * n for l in labels], dtype=np.int32)
+    hi = np.array([(max(l) + 1) * n for l in labels], dtype=np.int32)
+
+    def align():
+        lat = _hip.Lattices.from_transcripts(ctx, [wl["trans"]] * W, n, list(keys))
+        b.loglik(gmm, fetch=False, state_ranges=(lo, hi))
+        r = lat.align_segments(b, utt_lattice=utt_graph)
+        lat.close()
+        return r
+    t_align, r = _timeit(align)
+    fs = r["frame_state"]
+    b.close(); gmm.close()
+    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device)
+    hist = [tr.iteration()]
+    t_em, _ = _timeit(lambda: hist.append(tr.iteration()), reps=3)
+    tr.close()
+    N = int(off[-1])
+    return {"workload": "configs[2] model, %d utterances of %d words (%d frames, %d distinct transcripts)" % (U, K, N, len(keys)),
+            "align_and_regroup": {"ms_per_call": t_align * 1e3, "utterances_per_s": U / t_align, "frames_per_s": N / t_align,
+                                  "frames_assigned_to_a_state": float(np.mean(fs >= 0))},
+            "soft_em_iteration": {"ms_per_iteration": t_em * 1e3, "utterances_per_s": U / t_em,
+                                  "loglik_monotone": bool(all(y >= x - 1e-7 * abs(x) for x, y in zip(hist, hist[1:])))}}
+
+
 def extra_configs(args, dev, npdt, peak_flops):
     from sr.recognition import _hip
     ctx = _hip.Context(dev)
@@ -386,6 +429,7 @@ def extra_configs(args, dev, npdt, peak_flops):
                                                  1001, 100000, 10, 5, 1, 13, npdt, peak_flops)),
             ("C4", lambda: _isolated_config(ctx, "configs[3] (reduced utterance count): 64 HMMs x 16 states x 32 mixtures, 39-dim",
                                             1004, args.c4_utts, 64, 16, 32, 39, npdt, peak_flops)),
+            ("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)),
             ("C5", lambda: _continuous_config(ctx, args.c5_utts, min(args.c5_utts, 5000), npdt))):
         t0 = time.perf_counter()
         try:
@@ -452,6 +496,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip C1 x1000 / C4 / C5 / PCIe legs (single-GPU runs only)")
     ap.add_argument("--c4-utts", type=int, default=10000, help="utterances of the C4 leg (~1 M frames)")
     ap.add_argument("--c5-utts", type=int, default=125000, help="utterances of the C5 legs (1 M / 8 GPUs)")
+    ap.add_argument("--c3-utts", type=int, default=2000, help="7-word utterances of the training-step leg (C3_word_strings)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

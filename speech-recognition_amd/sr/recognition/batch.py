@@ -13,7 +13,7 @@ from . import _hip
 from . import _pack
 from .continuous_speech import packed_lattice, packed_loop_lattice
 
-__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_words"]
+__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_words", "sequence_report"]
 
 
 def _stack_models(ctx, models):
@@ -62,6 +62,48 @@ class IsolatedWordRecognizer:
         finally:
             batch.close()
         return np.argmin(c, axis=1), c
+
+    def accuracy(self, xs, words, verbose=False):
+        """The report of `sr/core.py:test` (core.py:63-94) as a call: fraction of utterances whose cheapest model is
+        the labelled word.  The reference keeps the FIRST of equal minima (`if cost < c`), which is np.argmin's rule.
+        Returns (n_passed / n_tests, recognised words [U])."""
+        got, _ = self.recognize(xs)
+        words = np.asarray(words)
+        if verbose:
+            for w in words[got != words]:
+                print("Digit:", int(w), "is wrong")                       # core.py:93
+        return float(np.sum(got == words)) / len(words), got
+
+
+def sequence_report(decoded, labels, verbose=False):
+    """The tally at the end of the reference's `main.py` (:69-84): an utterance is correct when its decoded word
+    string equals the label string; for a wrong one the number of differing positions (np.count_nonzero(matched - l),
+    strings of equal length -- the K-layer lattice always decodes exactly K words) counts against the digit accuracy.
+    Returns dict(sequence_accuracy, digit_accuracy, n_correct, n_digits, n_digit_errors)."""
+    correct = n_digits = n_diff = 0
+    for got, want in zip(decoded, labels):
+        got, want = [int(v) for v in got], [int(v) for v in want]
+        n_digits += len(want)
+        if got == want:
+            correct += 1
+            if verbose:
+                print('Correct:', got)
+            continue
+        if verbose:
+            print('Incorrect:', got, want)
+        if len(got) != len(want):
+            # main.py:79 subtracts the two arrays, which numpy refuses for different lengths (the loop grammar can
+            # produce them): every position beyond the shorter string counts as a difference here
+            k = min(len(got), len(want))
+            d = int(np.count_nonzero(np.asarray(got[:k]) - np.asarray(want[:k]))) + max(len(got), len(want)) - k
+        else:
+            d = int(np.count_nonzero(np.asarray(got) - np.asarray(want)))
+        if verbose:
+            print('Diff:', d)
+        n_diff += d
+    n = max(len(labels), 1)
+    return dict(sequence_accuracy=correct / n, digit_accuracy=(n_digits - n_diff) / max(n_digits, 1), n_correct=correct,
+                n_digits=n_digits, n_digit_errors=n_diff)
 
 
 def path_to_words(path, row_state, n_per_word):
@@ -125,6 +167,10 @@ class ContinuousDecoder:
             return self.decode_batch(batch)[0]
         finally:
             batch.close()
+
+    def accuracy(self, xs, labels, verbose=False):
+        """Decode `xs` and tally against the label strings like main.py:54-84 -- see `sequence_report`."""
+        return sequence_report(self.decode(xs), labels, verbose=verbose)
 
 
 class InFlight:

@@ -101,6 +101,11 @@ def test_decode_hmm_states_isolated(R, tag):
     words, costs = IsolatedWordRecognizer(hmms).recognize(xs)
     np.testing.assert_array_equal(words, g["words"])
     np.testing.assert_allclose(costs, [g["evaluate_%d" % u] for u in range(len(xs))], rtol=1e-10)
+    # core.py:63-94 as a call: the labels are the reference's own decisions here, so everything passes
+    acc, got = IsolatedWordRecognizer(hmms).accuracy(xs, g["words"])
+    assert acc == 1.0 and list(got) == list(g["words"])
+    wrong = (np.asarray(g["words"]) + 1) % W
+    assert IsolatedWordRecognizer(hmms).accuracy(xs, wrong)[0] == 0.0
 
 
 def test_build_state_sequences_and_lattice_decode(R):
@@ -124,6 +129,8 @@ def test_build_state_sequences_and_lattice_decode(R):
         dec = ContinuousDecoder(hmms, n_layers=K)
         assert dec.decode([g[p + "x"]])[0] == list(g[p + "digits"])
         assert path_to_words(path, dec.row_state, n) == list(g[p + "digits"])
+        rep = dec.accuracy([g[p + "x"]] * 2, [list(g[p + "digits"]), [(d + 1) % W for d in g[p + "digits"]]])   # main.py:69-84
+        assert rep["sequence_accuracy"] == 0.5 and rep["n_digit_errors"] == K and rep["digit_accuracy"] == 0.5
     labels = list(g["forced_labels"])
     seq, trans, ends = R.build_state_sequences(hmms, [[l] for l in labels])
     costs, path = R.decode_hmm_states(g["forced_x"], seq, trans, end_points=[[e, -1] for e in ends])

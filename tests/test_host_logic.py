@@ -110,6 +110,29 @@ def test_path_postprocessing_matches_reference_main(R):
     assert path_to_words(np.array([]), [0], n) == []
 
 
+def test_sequence_report_is_the_tally_of_reference_main(R):
+    """main.py:54-84: sequence accuracy = exact string matches / utterances; digit accuracy = 1 - differing positions of
+    the WRONG strings / all label digits."""
+    from sr.recognition.batch import sequence_report
+    labels = [[1, 2, 3], [4, 5, 6], [7, 8, 9], [0, 0, 0]]
+    decoded = [[1, 2, 3], [4, 9, 6], [9, 8, 7], [0, 0, 0]]
+    r = sequence_report(decoded, labels)
+    # the reference's own arithmetic
+    correct = digit_ndiff = n_digits = 0
+    for m, l in zip(decoded, labels):
+        n_digits += len(l)
+        if m == l:
+            correct += 1
+        else:
+            digit_ndiff += np.count_nonzero(np.asarray(m) - np.asarray(l))
+    assert r["sequence_accuracy"] == correct / len(labels) == 0.5
+    assert r["digit_accuracy"] == (n_digits - digit_ndiff) / n_digits == 9 / 12
+    assert r["n_digit_errors"] == 3 and r["n_digits"] == 12 and r["n_correct"] == 2
+    # strings of different length (only the loop grammar can produce them): the surplus positions count as errors
+    assert sequence_report([[1, 2]], [[1, 2, 3]])["n_digit_errors"] == 1
+    assert sequence_report([], [])["sequence_accuracy"] == 0
+
+
 def test_cut_segments_matches_reference_rule(R):
     """The frame ranges cut from the reference's own alignment path, against the oracle's
     restatement of continuous_speech.py:90-106."""
