@@ -19,7 +19,13 @@
 
 namespace {
 
-template <typename BPT>
+// workgroup barrier that orders LDS traffic only: the frame prefetch and the back-pointer / cost stores stay in flight
+// (a full __syncthreads waits for their round trips: three per column)
+__device__ __forceinline__ void dtw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// STAGED: template rows, variances, arc costs and the current frame are read from LDS (address space known at compile
+// time: with one pointer that may be LDS or global the compiler falls back to flat loads and spills the selects)
+template <typename BPT, bool STAGED>
 __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
     extern __shared__ __attribute__((aligned(16))) double dtw_lds[];
     const int np = blockDim.x;                                // n rounded up to whole waves
@@ -40,29 +46,72 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
         if (i == 0 && a.path_len) a.path_len[u] = 0;
         return;
     }
-    // per-lane template row kept in registers when it fits, else re-read from memory
-    const double* yrow = a.y ? a.y + (int64_t)(act ? i : 0) * D : nullptr;
-    const double* vrow = a.var ? a.var + (int64_t)(act ? i : 0) * D : nullptr;
+    // built-in distances: the template rows (and their variances) are staged in LDS once when they fit, and the frame
+    // of column j + 1 travels from HBM into registers while column j is computed -- the distance loop itself only
+    // reads LDS.  (Reading template row and frame element by element from global memory inside the loop cost one
+    // memory round trip per dimension: 16 k cycles per column for D = 39.)
+    double* xs0 = reinterpret_cast<double*>(mark0 + 2 * np + ((8 - (2 * np) % 8) % 8));   // [2][D] frames, 8-byte aligned
+    double* ys = xs0 + 2 * D;                                 // [n][D] template rows (a.tpl_lds)
+    double* vs = ys + (STAGED ? n * D : 0);                   // [n][D] variances
+    double* ts = vs + ((STAGED && a.var) ? n * D : 0);        // [n][n] arc costs
+    const bool own_dist = a.E == nullptr;
+    if (STAGED) {
+        for (int k = i; k < n * n; k += np) ts[k] = a.trans[k];
+        if (own_dist) for (int k = i; k < n * D; k += np) { ys[k] = a.y[k]; if (a.var) vs[k] = a.var[k]; }
+    }
+    const double* g_trow = a.trans + (int64_t)(act ? i : 0) * n;
+    const double* g_yrow = own_dist ? a.y + (int64_t)(act ? i : 0) * D : nullptr;
+    const double* g_vrow = (own_dist && a.var) ? a.var + (int64_t)(act ? i : 0) * D : nullptr;
+    const double* l_trow = ts + (act ? i : 0) * n;
+    const double* l_yrow = ys + (act ? i : 0) * D;
+    const double* l_vrow = vs + (act ? i : 0) * D;
     double logdet = 0;
     if (a.var && act) logdet = a.logdet[i];
     col(0)[i] = INF; col(1)[i] = INF;
     mark(0)[i] = 0; mark(1)[i] = 0;
+    constexpr int XR = 4;                                     // frame elements per thread (D <= 4 * threads; else global reads)
+    const bool x_lds = STAGED && own_dist;                    // (the host only picks STAGED when D <= XR * threads)
+    double xn[XR];
+    auto x_fetch = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < XR; ++q) {
+            const int d = i + q * np;
+            xn[q] = (x_lds && j < T && d < D) ? a.x[(f0 + j) * D + d] : 0.0;
+        }
+    };
+    auto x_park = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < XR; ++q) {
+            const int d = i + q * np;
+            if (x_lds && d < D) xs0[buf * D + d] = xn[q];
+        }
+    };
+    x_fetch(0);
+    x_park(0);
     __syncthreads();
     int pb = 0;  // buffer holding column j-1
     for (int j = 0; j < T; ++j) {
         const int cb = pb ^ 1;
+        x_fetch(j + 1);                                       // in flight during this column
         double dist = 0;
         if (act) {
             if (a.E) {
                 dist = a.E[a.e_off[u] + (int64_t)i * T + j];
             } else {
-                const double* x = a.x + (f0 + j) * D;
+                const double* xl = xs0 + (j & 1) * D;
+                const double* xg = a.x + (f0 + j) * D;
                 double q = 0;
+                // (unrolled: the reads of 8 dimensions are in flight together; the sum keeps its order)
                 if (a.var) {
-                    for (int d = 0; d < D; ++d) { const double t = x[d] - yrow[d]; q += t / vrow[d] * t; }
+#pragma unroll 8
+                    for (int d = 0; d < D; ++d) {
+                        const double t = STAGED ? xl[d] - l_yrow[d] : xg[d] - g_yrow[d];
+                        q += t / (STAGED ? l_vrow[d] : g_vrow[d]) * t;
+                    }
                     dist = logdet + 0.5 * q;
                 } else {
-                    for (int d = 0; d < D; ++d) { const double t = x[d] - yrow[d]; q = fma(t, t, q); }
+#pragma unroll 8
+                    for (int d = 0; d < D; ++d) { const double t = STAGED ? xl[d] - l_yrow[d] : xg[d] - g_yrow[d]; q = fma(t, t, q); }
                     dist = sqrt(q);
                 }
             }
@@ -78,7 +127,7 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
                 for (int o = 0; o < n; ++o) {
                     const bool pruned = mark(pb)[o] != 0;
                     if (pruned && i == 0) continue;  // first reader drops the marked cell
-                    const double v = a.trans[i * n + o] + (pruned ? INF : col(pb)[o]);
+                    const double v = (STAGED ? l_trow[o] : g_trow[o]) + (pruned ? INF : col(pb)[o]);
                     // np.argmin: the first NaN wins over everything, else the first minimum
                     if (bo < 0 || v < best || (v != v && best == best)) { best = v; bo = o; }
                 }
@@ -90,7 +139,7 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
         }
         col(cb)[i] = c;
         mark(cb)[i] = 0;
-        __syncthreads();
+        dtw_lds_barrier();
         unsigned char mk = 0;
         if (a.beam > 0 && act) {
             // rank in ascending (value, row) order == position in np.argsort of the column
@@ -106,24 +155,48 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
             // and +inf elsewhere (reset by the next column's row 0)
             costs[(int64_t)i * T + j] = mk ? ((j == T - 1) ? -1.0 : INF) : c;
         }
-        __syncthreads();
+        dtw_lds_barrier();
         mark(cb)[i] = mk;
-        __syncthreads();
+        x_park((j + 1) & 1);
+        dtw_lds_barrier();
         pb = cb;
     }
-    if (i == 0 && a.path) {
+    __syncthreads();   // (full barrier: the back-pointers written above are read back below)
+    if (a.path) {
+        // the walk is a chain of dependent reads (one per column): blocks of back-pointer columns are staged into LDS
+        // by all threads (coalesced) and thread 0 walks them there
+        BPT* win = reinterpret_cast<BPT*>(dtw_lds);            // the column buffers are free now
+        const int cap_cols = (int)(((size_t)2 * np * 8 + (size_t)2 * np) / sizeof(BPT) / n);   // columns that fit (>= 8)
+        __shared__ int s_state[3];                            // r, j, done
         int32_t* path = a.path + 2 * a.path_off[u];
         const int64_t cap = a.path_off[u + 1] - a.path_off[u];
-        int r = n - 1, j = T - 1, len = 0;
-        while (r != 0 || j != 0) {  // decode.py:74
-            if (j <= 0 || len >= cap) { atomicOr(a.flag, 2); break; }  // would wrap to column -1
-            r = bp[(int64_t)j * n + r];
-            --j;
-            path[2 * len] = r;
-            path[2 * len + 1] = j;
-            ++len;
+        int len = 0;
+        if (i == 0) { s_state[0] = n - 1; s_state[1] = T - 1; s_state[2] = 0; }
+        __syncthreads();
+        while (!s_state[2]) {
+            const int jhi = s_state[1];                        // highest column still to be read
+            const int jlo = max(0, jhi - cap_cols + 1);
+            __syncthreads();
+            for (int k = i; k < (jhi - jlo + 1) * n; k += np) win[k] = bp[(int64_t)jlo * n + k];
+            __syncthreads();
+            if (i == 0) {
+                int r = s_state[0], j = jhi;
+                bool done = false;
+                while (true) {
+                    if (r == 0 && j == 0) { done = true; break; }                      // decode.py:74
+                    if (j <= 0 || len >= cap) { atomicOr(a.flag, 2); done = true; break; }  // would wrap to column -1
+                    if (j < jlo) break;                                                // next block
+                    r = win[(j - jlo) * n + r];
+                    --j;
+                    path[2 * len] = r;
+                    path[2 * len + 1] = j;
+                    ++len;
+                }
+                s_state[0] = r; s_state[1] = j; s_state[2] = done ? 1 : 0;
+            }
+            __syncthreads();
         }
-        a.path_len[u] = len;
+        if (i == 0) a.path_len[u] = len;
     }
 }
 
@@ -132,9 +205,17 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
 int gh_launch_dtw(gh_ctx* ctx, const gh_dtw_args& a, int64_t U) {
     if (U <= 0) return GH_OK;
     const int np = (a.n + 63) & ~63;
-    const size_t lds = (size_t)2 * np * 8 + (size_t)2 * np;
-    if (a.n <= 255) hipLaunchKernelGGL(dtw_kernel<uint8_t>, dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(dtw_kernel<uint16_t>, dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+    const size_t base = (size_t)2 * np * 8 + (size_t)2 * np + 8 + (size_t)2 * a.D * 8;
+    const size_t extra = (size_t)a.n * a.n * 8 + (a.E ? 0 : (size_t)a.n * a.D * 8 * (a.var ? 2 : 1));
+    const bool staged = extra <= 96 * 1024 && a.D <= 4 * np;      // templates, variances and arc costs fit LDS
+    const size_t lds = base + (staged ? extra : 0);
+    if (a.n <= 255) {
+        if (staged) hipLaunchKernelGGL((dtw_kernel<uint8_t, true>), dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((dtw_kernel<uint8_t, false>), dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+    } else {
+        if (staged) hipLaunchKernelGGL((dtw_kernel<uint16_t, true>), dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((dtw_kernel<uint16_t, false>), dim3((unsigned)U), dim3((unsigned)np), lds, ctx->stream, a);
+    }
     GH_HIP(hipGetLastError());
     return GH_OK;
 }
