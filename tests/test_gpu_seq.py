@@ -360,3 +360,26 @@ def test_transcripts_handle_isolated_words_and_odd_models(hip, ctx):
         h.close()
     b.close()
     gmm.close()
+
+
+def test_sequence_forward_backward_fp32_likelihoods(hip, ctx):
+    """fp32 resident likelihoods (the recursion itself is fp64 either way): log P AND the occupancies / expected self
+    transitions against the fp64 batch within the north star's fp32 tolerance (1e-3)."""
+    rng = np.random.default_rng(8)
+    W, n, U = 8, 5, 60
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, False, 6, U, short=0)
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, -1, means.shape[-1]), vars_.reshape(W * n, -1, means.shape[-1]),
+                        w.reshape(W * n, -1))
+    lat = hip.Lattices(ctx, graphs)
+    out = {}
+    for dt in (np.float64, np.float32):
+        b = hip.Batch(ctx, xs, dtype=dt)
+        b.loglik(gmm, fetch=False)
+        out[dt] = lat.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+        b.close()
+    a, f = out[np.float64], out[np.float32]
+    np.testing.assert_allclose(f["logp"], a["logp"], rtol=1e-3)
+    np.testing.assert_allclose(f["occ"], a["occ"], atol=1e-3)
+    np.testing.assert_allclose(f["self_xi"], a["self_xi"], rtol=1e-3, atol=1e-3)
+    lat.close()
+    gmm.close()
