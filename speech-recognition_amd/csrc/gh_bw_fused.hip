@@ -74,7 +74,8 @@ template <int KS, int LT>
 __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ gam,
-                                                       double occ_floor, const int64_t* __restrict__ utt_off,
+                                                       double occ_floor, int gam_stride, int gam_by_state, const int64_t* __restrict__ seg_first,
+                                                       const int32_t* __restrict__ seg_len,
                                                        const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
                                                        const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
                                                        double* __restrict__ partial) {
@@ -146,11 +147,14 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
     constexpr int PX = (TF * KP + 255) / 256;
     int ui = wg.u_begin, t0 = 0, T = 0;
     int64_t f0 = 0;
+    // gamma of the tile: compact [N, 8] (column = chain row) or the frame x state occupancy matrix (gam_by_state:
+    // stride S, column = the chain row's state) -- sequence-form forward-backward, segments of (utterance, layer)
+    const int gcol = !gam_by_state ? (tid & 7) : ((tid & 7) < n ? ch->state[tid & 7] : -1);
     auto open_utt = [&]() {
         while (ui < wg.u_end) {
-            const int64_t u = ulist[ui];
-            f0 = utt_off[u];
-            T = (int)(utt_off[u + 1] - f0);
+            const int32_t u = ulist[ui];
+            f0 = seg_first[u];
+            T = seg_len[u];
             t0 = 0;
             if (T > 0) return true;
             ++ui;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
             const int i = tid + 256 * e;
             pre_x[e] = (i < nf_ * D) ? src[i] : 0.0;
         }
-        pre_g = (tid < nf_ * 8) ? gam[(f0 + t0) * 8 + tid] : 0.0;
+        pre_g = (tid < nf_ * 8 && gcol >= 0) ? gam[(f0 + t0 + (tid >> 3)) * gam_stride + gcol] : 0.0;
     };
     bool have = open_utt();
     if (have) prefetch();
@@ -318,42 +322,92 @@ int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S) {
     return GH_OK;
 }
 
-// returns 1 when the fused path does not cover the shapes (the caller uses the generic kernels), < 0 on error
-int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result) {
+// returns 1 when the fused path does not cover the shapes (the caller uses the generic kernels), < 0 on error.
+// Two sources of gamma: the compact [N, 8] matrix of a chain-form forward-backward (one "segment" per utterance), or --
+// seq = true -- the occupancy matrix of a sequence-form one, walked as (utterance, layer) segments grouped by word.
+int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result,
+                           bool seq) {
     const int S = g->S, M = g->M, D = g->D, KS = g->KP / 2;
     const int lt = (D + 1 + 15) / 16;     // 16-column tiles of each half of Z = [x - c, 1 | (x - c)^2]
-    if (!b->gam || b->gam_chains.empty() || M > 8 || lt > 3) return 1;
+    const std::vector<gh_fbchain>& chains = seq ? b->seq_word_chains : b->gam_chains;
+    if (seq ? !(b->seq_seg_valid && b->occ && b->occ_valid && b->occ_S == S) : !b->gam) return 1;
+    if (chains.empty() || M > 8 || lt > 3) return 1;
     if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
-    const int L = (int)b->gam_chains.size();
+    const int L = (int)chains.size();
     // a state may only sit in one place of one graph (the re-centring kernel writes every state once)
     std::vector<int> owner(S, -1);
     int max_pairs = 1;
     for (int l = 0; l < L; ++l) {
-        const gh_fbchain& fc = b->gam_chains[l];
+        const gh_fbchain& fc = chains[l];
+        if (fc.n > GH_FBCHAIN_MAX) return 1;
         for (int jx = 0; jx < fc.n; ++jx) {
             if (fc.state[jx] < 0 || fc.state[jx] >= S || owner[fc.state[jx]] >= 0) return 1;
             owner[fc.state[jx]] = l;
         }
         max_pairs = std::max(max_pairs, (fc.n + 1) / 2);
     }
-    // utterances grouped by graph, longest first inside a graph; ~16 utterances per workgroup
+    if (max_pairs > 4) return 1;
+    // segments: (first frame, length, graph); grouped by graph, longest first inside a graph
     const int64_t U = b->U;
+    std::vector<int64_t> seg_first;
+    std::vector<int32_t> seg_len;
     std::vector<std::vector<int32_t>> by_graph(L);
-    for (int64_t k = 0; k < U; ++k) {
-        const int64_t u = b->perm[k];
-        if (b->offsets[u + 1] > b->offsets[u]) by_graph[b->gam_utt_graph.empty() ? 0 : b->gam_utt_graph[u]].push_back((int32_t)u);
+    if (!seq) {
+        seg_first.resize(U); seg_len.resize(U);
+        for (int64_t u = 0; u < U; ++u) { seg_first[u] = b->offsets[u]; seg_len[u] = (int32_t)(b->offsets[u + 1] - b->offsets[u]); }
+        for (int64_t k = 0; k < U; ++k) {
+            const int64_t u = b->perm[k];
+            if (seg_len[u] > 0) by_graph[b->gam_utt_graph.empty() ? 0 : b->gam_utt_graph[u]].push_back((int32_t)u);
+        }
+    } else {
+        // the occupancy matrix is per STATE: a word that stands in several layers of a transcript has their occupancies
+        // added up in its columns, so its segments are the UNION of its layers' frame ranges (every frame once)
+        for (int64_t u = 0; u < U; ++u) {
+            struct iv { int w, lo, hi; };
+            iv v[GH_SEQ_MAXK];
+            int nv = 0;
+            for (int k = 0; k < b->seq_utt_K[u] && k < GH_SEQ_MAXK; ++k) {
+                const int lo = b->seq_seg_lo[(size_t)u * GH_SEQ_MAXK + k], hi = b->seq_seg_hi[(size_t)u * GH_SEQ_MAXK + k];
+                const int w = b->seq_utt_word[(size_t)u * GH_SEQ_MAXK + k];
+                if (hi < lo || w < 0 || w >= L) continue;
+                v[nv++] = iv{w, lo, hi};
+            }
+            std::sort(v, v + nv, [](const iv& x, const iv& y) { return x.w != y.w ? x.w < y.w : x.lo < y.lo; });
+            for (int i = 0; i < nv;) {
+                int hi = v[i].hi, j = i + 1;
+                while (j < nv && v[j].w == v[i].w && v[j].lo <= hi + 1) { hi = std::max(hi, v[j].hi); ++j; }
+                by_graph[v[i].w].push_back((int32_t)seg_first.size());
+                seg_first.push_back(b->offsets[u] + v[i].lo);
+                seg_len.push_back(hi - v[i].lo + 1);
+                i = j;
+            }
+        }
+        // longest first inside a graph: a counting sort over the lengths (stable; a comparison sort of ~10^5 segments
+        // cost more than the host's share of the whole call)
+        int max_len = 0;
+        for (int32_t l : seg_len) max_len = std::max(max_len, l);
+        std::vector<int32_t> cnt((size_t)max_len + 2), sorted;
+        for (auto& v : by_graph) {
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int32_t i : v) cnt[max_len - seg_len[i] + 1]++;
+            for (int k = 0; k <= max_len; ++k) cnt[k + 1] += cnt[k];
+            sorted.resize(v.size());
+            for (int32_t i : v) sorted[cnt[max_len - seg_len[i]]++] = i;
+            v.swap(sorted);
+        }
     }
+    const int64_t n_seg = (int64_t)seg_first.size();
     // workgroups of 3 waves (5 states = 3 pairs): FOUR per CU put exactly three waves on every SIMD (with three per CU
     // one SIMD carries three waves, the others two: the kernel ran at the pace of the fullest one)
     const int target_wgs = (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 4) * ctx->n_cu;
-    const int per_wg = (int)std::max<int64_t>(4, (U + target_wgs - 1) / target_wgs);
+    const int per_wg = (int)std::max<int64_t>(4, (n_seg + target_wgs - 1) / target_wgs);
     std::vector<int32_t> ulist;
     std::vector<bwf_wg> wgs;
     std::vector<bwf_pair> pairs;
     for (int l = 0; l < L; ++l) {
         const int wg_begin = (int)wgs.size();
         const auto& v = by_graph[l];
-        // deal the (length sorted) utterances round-robin so that every workgroup of the graph gets the same mix
+        // deal the (length sorted) segments round-robin so that every workgroup of the graph gets the same mix
         const int nw = (int)((v.size() + per_wg - 1) / per_wg);
         for (int w = 0; w < nw; ++w) {
             bwf_wg x{l, (int32_t)ulist.size(), 0, 0};
@@ -361,18 +415,19 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
             x.u_end = (int32_t)ulist.size();
             wgs.push_back(x);
         }
-        const gh_fbchain& fc = b->gam_chains[l];
+        const gh_fbchain& fc = chains[l];
         for (int p = 0; 2 * p < fc.n; ++p)
             pairs.push_back(bwf_pair{fc.state[2 * p], 2 * p + 1 < fc.n ? fc.state[2 * p + 1] : -1, wg_begin, (int32_t)wgs.size(), p, 0});
     }
     hipStream_t st = ctx->stream;
     const int W = 1 + 2 * D;
     const int tile_len = 2 * lt * 16 * 16;
-    int32_t* d_ulist; bwf_wg* d_wgs; bwf_pair* d_pairs; gh_fbchain* d_chains; double *d_part, *d_own;
+    int32_t *d_ulist, *d_seglen; int64_t* d_segfirst; bwf_wg* d_wgs; bwf_pair* d_pairs; gh_fbchain* d_chains; double *d_part, *d_own;
     Carver cv;
     cv.add(&d_own, (size_t)S * M * W);
     cv.add(&d_ulist, std::max<size_t>(1, ulist.size())); cv.add(&d_wgs, std::max<size_t>(1, wgs.size()));
     cv.add(&d_pairs, std::max<size_t>(1, pairs.size())); cv.add(&d_chains, (size_t)L);
+    cv.add(&d_segfirst, std::max<size_t>(1, seg_first.size())); cv.add(&d_seglen, std::max<size_t>(1, seg_len.size()));
     cv.add(&d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len);
     int rc = cv.commit(ctx);
     if (rc) return rc;
@@ -383,12 +438,17 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     GH_HIP(hipMemcpyAsync(d_ulist, ulist.data(), ulist.size() * 4, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_wgs, wgs.data(), wgs.size() * sizeof(bwf_wg), hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(bwf_pair), hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_chains, b->gam_chains.data(), (size_t)L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_chains, chains.data(), (size_t)L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_segfirst, seg_first.data(), seg_first.size() * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_seglen, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, st));
     const size_t lds = ((size_t)32 * ((2 * KS) | 1) + 32 * 8 + 128) * 8;
     const dim3 grid((unsigned)wgs.size()), blk(256);   // 256 threads always: see the staging loop of the kernel
+    const double* gam = seq ? b->occ : b->gam;
+    const int gam_stride = seq ? S : 8;
 #define GH_BWF(ks, nc)                                                                                                   \
     hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, (const double*)b->feats, D, M, g->dMean, g->dIvar,  \
-                       g->dLogc, b->gam, occ_floor, b->d_offsets, d_ulist, d_wgs, d_chains, ctx->d_fp64_tables, d_part)
+                       g->dLogc, gam, occ_floor, gam_stride, seq ? 1 : 0, d_segfirst, d_seglen, d_ulist, d_wgs, d_chains,             \
+                       ctx->d_fp64_tables, d_part)
 #define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;
@@ -403,6 +463,6 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pairs.size()), dim3(256), (size_t)tile_len * 8, st, d_part, d_pairs,
                        4, lt, D, M, g->dMean, d_out);
     GH_HIP(hipGetLastError());
-    GH_HIP(hipStreamSynchronize(st));   // ulist / wgs / pairs are host vectors of this call
+    GH_HIP(hipStreamSynchronize(st));   // the work lists are host vectors of this call
     return GH_OK;
 }

@@ -543,6 +543,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
+    if (want_occ) b->seq_seg_valid = false;
     if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernel runs on its expanded twin
         const char* e = getenv("GMMHMM_FB");
         if (out_alpha || out_beta || out_gamma || (e && !strcmp(e, "generic"))) {
@@ -671,6 +672,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     double* d_selfxi = nullptr;
     cv.add(&d_soff, U); cv.add(&d_logp, U); cv.add(&d_scratch, smax);
     double* d_xiparts = nullptr;
+    int32_t *d_seglo = nullptr, *d_seghi = nullptr;
+    if (use_fbseq && want_occ) { cv.add(&d_seglo, (size_t)U * GH_SEQ_MAXK); cv.add(&d_seghi, (size_t)U * GH_SEQ_MAXK); }
     if (out_self_xi) cv.add(&d_selfxi, S);
     if (out_self_xi && use_fbseq) cv.add(&d_xiparts, (size_t)GH_FBSEQ_XI_PARTS * S);
     if (utt_lattice) cv.add(&d_uttlat, U);
@@ -711,12 +714,32 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             q.graphs = lat->d_seqgraphs; q.words = lat->d_seqwords; q.end_slot = lat->d_seq_end_slot; q.nll = b->nll; q.S = S;
             q.utt_off = b->d_offsets; q.utt_lat = d_uttlat; q.perm = b->d_perm; q.alpha_scratch = d_scratch; q.scratch_off = d_soff;
             q.logp = d_logp; q.occ = want_occ ? b->occ : nullptr; q.self_xi_parts = d_xiparts;
+            q.seg_lo = d_seglo; q.seg_hi = d_seghi; q.occ_floor = 0.0;
             for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
                 rc = gh_launch_fb_seq(ctx, q, lat->seq_N, lat->seq_skip, chunk_begin[c], chunk_begin[c + 1] - chunk_begin[c], b->dtype == GH_F64);
                 if (rc) return rc;
             }
             if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_logp, U * 8, hipMemcpyDeviceToHost, st));
             if (out_occ) GH_HIP(hipMemcpyAsync(out_occ, b->occ, (size_t)b->N * S * 8, hipMemcpyDeviceToHost, st));
+            if (want_occ) {   // what the fused statistics kernel needs to walk (utterance, layer) segments grouped by word
+                b->seq_seg_lo.resize((size_t)U * GH_SEQ_MAXK); b->seq_seg_hi.resize((size_t)U * GH_SEQ_MAXK);
+                GH_HIP(hipMemcpyAsync(b->seq_seg_lo.data(), d_seglo, (size_t)U * GH_SEQ_MAXK * 4, hipMemcpyDeviceToHost, st));
+                GH_HIP(hipMemcpyAsync(b->seq_seg_hi.data(), d_seghi, (size_t)U * GH_SEQ_MAXK * 4, hipMemcpyDeviceToHost, st));
+                b->seq_utt_K.resize(U); b->seq_utt_word.assign((size_t)U * GH_SEQ_MAXK, -1);
+                for (int64_t u = 0; u < U; ++u) {
+                    const gh_seqgraph& sg = lat->h_seqgraphs[utt_lattice ? utt_lattice[u] : 0];
+                    b->seq_utt_K[u] = sg.K;
+                    for (int k = 0; k < sg.K; ++k) b->seq_utt_word[(size_t)u * GH_SEQ_MAXK + k] = sg.word[k];
+                }
+                b->seq_word_chains.resize(lat->h_seqwords.size());
+                for (size_t w = 0; w < lat->h_seqwords.size(); ++w) {
+                    gh_fbchain& fc = b->seq_word_chains[w];
+                    memset(&fc, 0, sizeof fc);
+                    fc.n = lat->seq_N;
+                    for (int j = 0; j < lat->seq_N; ++j) fc.state[j] = lat->h_seqwords[w].state[j];
+                }
+                b->seq_seg_valid = true;
+            }
             std::vector<double> parts;
             if (out_self_xi) {
                 parts.resize((size_t)GH_FBSEQ_XI_PARTS * S);

@@ -74,5 +74,8 @@ struct gh_fbseq_args {
     int occ_in_lds;              // 1: a frame's S occupancies are summed in LDS and stored as one row (every frame of every
                                  //    utterance is written: no zeroing needed); 0: double atomics on occ, zeroed by the caller
     double* self_xi_parts;       // optional [GH_FBSEQ_XI_PARTS, S], zeroed by the caller; summed by the caller
+    int32_t* seg_lo;             // optional [U, GH_SEQ_MAXK] (with occ): first / last frame of every layer whose occupancy
+    int32_t* seg_hi;             //   exceeds occ_floor (hi < lo: none) -- the segments of the fused statistics kernel
+    double occ_floor;
 };
 int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64);

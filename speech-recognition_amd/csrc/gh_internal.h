@@ -119,6 +119,13 @@ struct gh_batch {
     // launch order of the DP kernels: utterances sorted longest first (computed once)
     std::vector<int64_t> perm;
     int64_t* d_perm;
+    // after a sequence-form forward-backward with occupancies (gh_seq.hip): per (utterance, layer) the frame range that
+    // carries occupancy, the word of every layer and the word chains -- what lets the fused Baum-Welch statistics
+    // kernel walk (utterance, layer) segments grouped by word and read gamma from `occ` (gh_bw_fused.hip)
+    bool seq_seg_valid = false;
+    std::vector<int32_t> seq_seg_lo, seq_seg_hi;      // [U, GH_SEQ_MAXK] first / last frame (utterance-local), hi < lo: none
+    std::vector<int32_t> seq_utt_K, seq_utt_word;     // [U], [U, GH_SEQ_MAXK] word template of every layer
+    std::vector<gh_fbchain> seq_word_chains;          // per word template: its states as a chain (costs unused)
     // k-means assignments that stay on the device between lock-step iterations (gh_kmeans_assign_multi with
     // clusters_io == NULL; gh_kmeans_resident_clusters resets / fetches them)
     int32_t* d_clusters = nullptr;
@@ -247,7 +254,8 @@ int gh_lattices_full(const gh_lattices* l, const gh_lattices** out);
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
 // 1 = shape not covered; st_lo / st_hi (per utterance, or null): only the states [lo, hi) of every utterance are needed
 // gh_bw_fused.hip: 1 = shapes not covered
-int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result);
+int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result,
+                           bool seq = false);
 int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
                           const int32_t* st_hi = nullptr);

@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
     double xi[N];
 #pragma unroll
     for (int s = 0; s < N; ++s) { be[s] = xn_zero(); bn[s] = xn_one(); xi[s] = 0.0; }
+    int seg_first = 0x7fffffff, seg_last = -1;             // frames of this layer with occupancy above the floor
     ET ering[PF][N];
     double arf[PF][N];
     int are[PF][N];
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
                             const double gm = xn_ratio(av[s], nb[s], inv_pf, P.e);
                             if (OCC_LDS) { if (gm != 0.0) atomicAdd(occ_row + st[s], gm); }   // ds_add_f64
                             else if (gm != 0.0) unsafeAtomicAdd(a.occ + (f0 + t) * a.S + st[s], gm);
+                            if (gm > a.occ_floor || gm != gm) { seg_first = t; seg_last = max(seg_last, t); }   // (t descends)
                         }
                     }
                 }
@@ -422,6 +424,10 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
                 for (int s = 0; s < N; ++s) { be[s] = nb[s]; bn[s] = b[s]; }
             }
         }
+    }
+    if (a.seg_lo && has_utt && k < GH_SEQ_MAXK) {
+        a.seg_lo[u * GH_SEQ_MAXK + k] = lact ? seg_first : 0x7fffffff;
+        a.seg_hi[u * GH_SEQ_MAXK + k] = lact ? seg_last : -1;
     }
     if (a.self_xi_parts && lact) {
         double* part = a.self_xi_parts + (size_t)(blockIdx.x % GH_FBSEQ_XI_PARTS) * a.S;

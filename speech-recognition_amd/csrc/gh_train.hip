@@ -2,6 +2,7 @@
 //   * k-means assignment  (reference: inner N x k loop of kmeans, kmeans.py:180-186)
 //   * mixture-EM E-step sufficient statistics (reference: GMM.em, hmm_state.py:127-143)
 #include "gh_internal.h"
+#include <cstring>
 #include <cmath>
 
 namespace {
@@ -579,6 +580,21 @@ extern "C" int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b,
         }
         rc0 = gh_bw_expand_gamma(ctx, const_cast<gh_batch*>(b), S);   // shapes it does not cover: generic kernel below
         if (rc0) return rc0;
+    }
+    if (b->seq_seg_valid && b->occ && b->occ_valid && b->N > 0) {
+        // the forward-backward ran in sequence form (multi-word transcripts): the same fused kernel over (utterance,
+        // layer) segments grouped by word, gamma read from the occupancy matrix (GMMHMM_BW=generic: the generic kernel)
+        const char* e2 = getenv("GMMHMM_BW");
+        if (!(e2 && !strcmp(e2, "generic"))) {
+            double* d_res = nullptr;
+            const int rc0 = gh_bw_accumulate_fused(ctx, g, b, occ_floor, stats_dev, &d_res, true);
+            if (rc0 < 0) return rc0;
+            if (rc0 == 0) {
+                if (out_stats) GH_HIP(hipMemcpyAsync(out_stats, d_res, (size_t)len * 8, hipMemcpyDeviceToHost, st));
+                GH_HIP(hipStreamSynchronize(st));
+                return GH_OK;
+            }
+        }
     }
     GH_REQUIRE((b->occ && b->occ_valid) || b->N == 0, "gh_bw_accumulate: run gh_forward_backward(want_occ=1) first");
     GH_REQUIRE(b->N == 0 || b->occ_S == g->S, "gh_bw_accumulate: occupancies were computed for %d states, the model has %d", b->occ_S, g->S);

@@ -383,3 +383,39 @@ def test_sequence_forward_backward_fp32_likelihoods(hip, ctx):
     np.testing.assert_allclose(f["self_xi"], a["self_xi"], rtol=1e-3, atol=1e-3)
     lat.close()
     gmm.close()
+
+
+@pytest.mark.parametrize("W,n,M,D,Kmax", [(10, 5, 8, 39, 7), (4, 2, 4, 13, 12), (6, 3, 8, 5, 6), (3, 8, 2, 20, 4), (5, 4, 16, 13, 5)])
+def test_bw_statistics_over_sequence_segments_equal_generic(hip, ctx, W, n, M, D, Kmax):
+    """Multi-word transcripts: after the sequence-form forward-backward gh_bw_accumulate runs the fused matrix-core
+    kernel over (utterance, layer) segments grouped by word, gamma read from the occupancy matrix -- against the generic
+    statistics kernel on the same occupancies (GMMHMM_BW=generic).  Repeated words in a transcript, ragged lengths,
+    unreachable utterances, words that never occur; M = 16 is a shape the fused kernel hands back."""
+    rng = np.random.default_rng(W + 10 * n + M)
+    U = 50
+    means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, False, Kmax, U, M=M, D=D, short=4)
+    labels = [[l % (W - 1) for l in ls] for ls in labels] if W > 2 else labels      # the last word never occurs
+    transcripts, keys = [], {}
+    for u, l in enumerate(labels):
+        if tuple(l) not in keys:
+            keys[tuple(l)] = len(transcripts)
+            transcripts.append(l)
+        utt_graph[u] = keys[tuple(l)]
+    gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
+    lat = hip.Lattices.from_transcripts(ctx, wt, n, transcripts)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    r = lat.forward_backward(b, utt_lattice=utt_graph, want_occ=True, fetch_occ=True)
+    fused = b.bw_accumulate(gmm)
+    with forced(GMMHMM_BW="generic"):
+        generic = b.bw_accumulate(gmm)
+    scale = np.maximum(np.abs(generic).max(axis=(1, 2), keepdims=True), 1e-300)
+    assert np.max(np.abs(fused - generic) / scale) < 1e-9
+    reach = np.isfinite(r["logp"])
+    np.testing.assert_allclose(fused[:, :, 0].sum(), r["occ"].sum(), rtol=1e-9)
+    assert fused[:, :, 0].sum() >= sum(len(xs[u]) for u in range(U) if reach[u]) * (1 - 1e-9)
+    if W > 2:
+        assert np.all(fused[(W - 1) * n:] == 0)
+    b.close()
+    lat.close()
+    gmm.close()
