@@ -419,3 +419,51 @@ def test_bw_statistics_over_sequence_segments_equal_generic(hip, ctx, W, n, M, D
     b.close()
     lat.close()
     gmm.close()
+
+
+def test_sequence_forward_backward_many_states_and_state_base(hip, ctx):
+    """More than 256 states (the occupancy rows no longer fit the LDS row buffers: double atomics on the matrix) and a
+    transcripts handle with explicit first-state indices per word (`state_base`), against the generic kernels."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(21)
+    W, n, M, D, U = 60, 5, 1, 4, 24
+    base = (np.arange(W)[::-1] * n).astype(np.int32)                    # word w owns states base[w] .. base[w] + n - 1
+    means = rng.normal(size=(W * n, M, D)) * 2.0
+    vars_ = rng.uniform(0.5, 1.5, size=(W * n, M, D))
+    wgt = np.ones((W * n, M))
+    wt = [word_trans(rng, n) for _ in range(W)]
+    seqs = [[int(v) for v in rng.integers(0, W, size=int(rng.integers(1, 9)))] for _ in range(U)]
+    xs = []
+    for l in seqs:
+        segs = []
+        for wd in l:
+            Tw = int(rng.integers(n, 3 * n))
+            st = np.minimum(np.arange(Tw) * n // Tw, n - 1)
+            segs.append(means[base[wd] + st, 0] + rng.normal(size=(Tw, D)))
+        xs.append(np.concatenate(segs))
+    gmm = hip.PackedGMM(ctx, means, vars_, wgt)
+    t = hip.Lattices.from_transcripts(ctx, wt, n, seqs, state_base=base)
+    a = hip.Lattices(ctx, [packed_lattice(wt, n, [[l] for l in s], state_base=base)[0] for s in seqs])
+    assert t.forms() == {"sequence"}
+    ug = np.arange(U, dtype=np.int32)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    rt, ra = t.viterbi(b, utt_lattice=ug), a.viterbi(b, utt_lattice=ug)
+    np.testing.assert_array_equal(rt["end_cost_flat"], ra["end_cost_flat"])
+    for u in range(U):
+        np.testing.assert_array_equal(rt["paths"][u], ra["paths"][u])
+    with forced(GMMHMM_FB="generic"):
+        ref = a.forward_backward(b, utt_lattice=ug, want_occ=True, want_self_xi=True)
+    got = t.forward_backward(b, utt_lattice=ug, want_occ=True, want_self_xi=True)
+    np.testing.assert_allclose(got["logp"], ref["logp"], rtol=1e-12)
+    np.testing.assert_allclose(got["occ"], ref["occ"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(got["self_xi"], ref["self_xi"], rtol=1e-9, atol=1e-12)
+    fused = b.bw_accumulate(gmm)
+    with forced(GMMHMM_BW="generic"):
+        generic = b.bw_accumulate(gmm)
+    scale = np.maximum(np.abs(generic).max(axis=(1, 2), keepdims=True), 1e-300)
+    assert np.max(np.abs(fused - generic) / scale) < 1e-9
+    for h in (a, t):
+        h.close()
+    b.close()
+    gmm.close()
