@@ -112,3 +112,77 @@ def test_fullsize_fp32_against_fp64(full):
     assert np.mean(np.argmin(ec, axis=1) == wl["words"]) == 1.0
     b32.close()
     lat.close()
+
+
+def test_fullsize_forced_alignment_and_forward_backward_properties():
+    """configs[2]'s model on 2000 seven-word transcripts (1.4 M frames, one graph per transcript) -- the training shape of
+    `continuous_train` / the soft-EM trainer -- through the sequence-form kernels, checked by properties that need no
+    per-cell oracle:
+      * Viterbi: costs, ends and paths identical to the row-per-lane lean kernel on every utterance (bitwise);
+      * alignment + regrouping: per utterance the states appear in transcript order, every state's frames are one run
+        per visit, the frames a run drops are exactly the reference's (one per state entry inside a word, none at a word
+        boundary: continuous_speech.py:96-106);
+      * forward-backward: log P >= -(best path cost) (the sum over paths contains the best one), occupancies of a frame
+        add up to 1 (2 on a word boundary: decode.py:109-111), expected self transitions of a state < its occupancy;
+      * sampled utterances against the oracle's reference-shaped DP (costs 1e-12, paths exact)."""
+    import warnings
+    import bench
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice
+    ctx = _hip.default_context()
+    U, K = 2000, 7
+    wl = bench.synth_workload(1003, U * K)
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    off = wl["off"][::K]
+    labels = [[int(w) for w in wl["words"][i * K:(i + 1) * K]] for i in range(U)]
+    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(W * n, M, D), wl["vars"].reshape(W * n, M, D), wl["w"].reshape(W * n, M))
+    b = _hip.Batch(ctx, feats=wl["X"], offsets=off)
+    nll = b.loglik(gmm, fetch=True)
+    keys, ug = {}, np.empty(U, dtype=np.int32)
+    for u, l in enumerate(labels):
+        ug[u] = keys.setdefault(tuple(l), len(keys))
+    lat = _hip.Lattices.from_transcripts(ctx, [wl["trans"]] * W, n, list(keys))
+    assert lat.forms() == {"sequence"}
+    fast = lat.viterbi(b, utt_lattice=ug, want_path=True)
+    os.environ["GMMHMM_VITERBI"] = "lean"
+    try:
+        lean = lat.viterbi(b, utt_lattice=ug, want_path=True)
+    finally:
+        os.environ.pop("GMMHMM_VITERBI")
+    np.testing.assert_array_equal(fast["end_cost_flat"], lean["end_cost_flat"])
+    assert np.isfinite(fast["end_cost_flat"]).all()
+    for u in range(U):
+        np.testing.assert_array_equal(fast["paths"][u], lean["paths"][u])
+    seg = lat.align_segments(b, utt_lattice=ug)
+    fs, st = seg["frame_state"], seg["segment_start"]
+    for u in range(0, U, 7):
+        f = fs[off[u]:off[u + 1]]
+        used = f[f >= 0]
+        runs = used[np.insert(np.diff(used) != 0, 0, True)]                   # the states in the order they are visited
+        want = [l * n + s for l in labels[u] for s in range(n)]
+        # (the last state's run is never closed, and a state visited for a single frame inside a word leaves no frame)
+        it = iter(want)
+        assert all(any(r == w for w in it) for r in runs), (u, runs, want)
+        assert st[off[u]:off[u + 1]].sum() == len(runs)
+    fb = lat.forward_backward(b, utt_lattice=ug, want_occ=True, want_self_xi=True)
+    assert np.all(fb["logp"] >= -fast["end_cost_flat"] - 1e-9 * np.abs(fast["end_cost_flat"]))
+    rows = fb["occ"].sum(axis=1)
+    assert rows.min() > 1 - 1e-9 and rows.max() < 2 + 1e-9
+    assert np.all(fb["self_xi"] < fb["occ"].sum(axis=0) + 1e-9)
+    is_cache = {}
+    for u in (0, 777, U - 1):
+        g = packed_lattice([wl["trans"]] * W, n, [[l] for l in labels[u]])[0]
+        R = len(g["row_state"])
+        dense = np.full((R, R), np.inf)
+        dense[g["arc_to"], g["arc_from"]] = g["arc_cost"]
+        is_nes = g["row_state"] < 0
+        E = np.zeros((R, off[u + 1] - off[u]))
+        E[~is_nes] = nll[off[u]:off[u + 1]][:, g["row_state"][~is_nes]].T
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            costs, path = O.decode_states(E, is_nes, dense, end_points=[[int(e), -1] for e in g["end_rows"]])
+        np.testing.assert_allclose(fast["end_cost"][u], costs[np.asarray(g["end_rows"]), -1], rtol=1e-12)
+        np.testing.assert_array_equal(fast["paths"][u], path)
+    b.close()
+    lat.close()
+    gmm.close()
