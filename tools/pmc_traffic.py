@@ -27,12 +27,15 @@ kernels = {}
 for (name, grid) in f:
     short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if not (short.startswith("loglik") or short.startswith("viterbi") or short.startswith("lattice_backtrace")
-            or short.startswith("bw_fused") or short.startswith("fb_chain")):
+            or short.startswith("bw_fused") or short.startswith("fb_chain") or short.startswith("fb_seq")
+            or short.startswith("seq_backtrace") or short.startswith("fb_kernel") or short.startswith("cut_segments")):
         continue
     fv, wv = f[(name, grid)], w.get((name, grid), [0.0])
     fm, wm = sum(fv) / len(fv), sum(wv) / max(1, len(wv))
     if short.startswith("loglik"):
         alg = n_frames * esz * (D + S)               # features in once + likelihoods out once
+    elif short.startswith("viterbi_seq") or short.startswith("fb_seq"):
+        alg = None                                   # (only the states of the transcript are read: see the caller's note)
     elif short.startswith("viterbi"):
         alg = n_frames * (esz * S + 4)               # likelihoods in once + 4 B of path per frame
     else:
