@@ -103,15 +103,17 @@ def profiled_traffic(dtype, n_frames):
     same command, folded by tools/pmc_traffic.py); None when no profile matches this dtype / workload size."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % dtype)))
-    try:
-        d = json.load(open(paths[-1]))["kernels"]
-        k = next(v for name, v in d.items() if name.startswith("loglik"))
-        esz = 8 if dtype == "f64" else 4
-        if abs(k["algorithmic_bytes_per_launch"] - n_frames * esz * (39 + 50)) > 1e-3 * k["algorithmic_bytes_per_launch"]:
-            return None
-        return k["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    esz = 8 if dtype == "f64" else 4
+    for path in reversed(paths):      # newest first; profiles of other workloads (C5, forced alignment) do not match the size
+        try:
+            d = json.load(open(path))["kernels"]
+            k = next(v for name, v in d.items() if name.startswith("loglik"))
+            alg = k["algorithmic_bytes_per_launch"]
+            if alg and abs(alg - n_frames * esz * (39 + 50)) <= 1e-3 * alg:
+                return k["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(wl, n_utts=20):
