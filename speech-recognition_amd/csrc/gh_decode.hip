@@ -612,7 +612,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             for (int64_t k = 0; k < U; ++k) {
                 const int64_t u = b->perm[k];
                 coff[k] = (int64_t)cacc;
-                cacc += (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0].n;
+                const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0].n;
+                cacc += cells + (cells + 1) / 2;   // [T, n] mantissas (double) followed by as many exponents (int32)
             }
             int64_t* d_coff;
             int32_t* d_ul = nullptr;

@@ -12,6 +12,7 @@
 // (optionally) folded into per-frame state occupancies occ[n,s] with LDS fp64 atomics.
 #include "gh_internal.h"
 #include "gh_fb.h"
+#include "gh_xnum.h"
 
 namespace {
 
@@ -272,11 +273,23 @@ __device__ __forceinline__ double lse2(double x, double y) {
 // Lane layout: 8 lanes per utterance (lane j of the group = chain row j, idle when j >= n), 8 utterances per wave.
 // A first version with one lane per utterance and all rows in registers had U/64 waves of ~800 dependent
 // instructions per column (0.85 ms for 12 500 utterances); one row per lane gives 8x the waves and 1/5 of the
-// serial work per lane.  Neighbouring rows are one __shfl_up / __shfl_down (width 8) away.
+// serial work per lane.  Neighbouring rows are one DPP row shift away (the 8-lane groups sit inside 16-lane DPP rows;
+// what a shift drags in from the neighbouring group is masked by the j >= 1 / j >= 2 tests).
+// The recursion runs on probabilities with an extended exponent (gh_xnum.h), like fb_seq_kernel: a term is a multiply
+// and an integer add, the one transcendental per cell is the split exponential of the emission cost (the log-domain
+// version -- exp per term, log per sum -- took 0.34 ms per 12 500 utterances, compute bound at 8 % of HBM).
+template <int CTRL> __device__ __forceinline__ xnum fbc_dpp(xnum v) {
+    xnum o;
+    o.f = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v.f), CTRL, 0xF, 0xF, true),
+                           __builtin_amdgcn_update_dpp(0, __double2loint(v.f), CTRL, 0xF, 0xF, true));
+    o.e = __builtin_amdgcn_update_dpp(XN_ZERO_E, v.e, CTRL, 0xF, 0xF, false);
+    return o;
+}
+
 template <typename ET>
 __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     constexpr int NMAX = GH_FBCHAIN_MAX;   // == 8 == lanes per utterance
-    constexpr int PD = 4;                  // columns of loads in flight per lane
+    constexpr int PD = 4;                  // columns of loads in flight per lane (8: no change)
     const int j = threadIdx.x & (NMAX - 1);
     const int64_t slot = (int64_t)blockIdx.x * (64 / NMAX) + (threadIdx.x / NMAX);
     const bool has_utt = slot < a.U;
@@ -286,59 +299,71 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     const bool act = has_utt && j < n;     // this lane owns a row
     const bool skip = chp->pad != 0;
     const int st = act ? chp->state[j] : 0;
-    const double NEG = -INFINITY;
-    const double c_self = act ? chp->self_c[j] : INFINITY, c_next = act ? chp->next_c[j] : INFINITY,
-                 c_skip = act ? chp->skip_c[j] : INFINITY;
-    // costs of the arcs LEAVING this row towards j+1 / j+2 (stored at their destination)
-    const double c_out1 = (act && j + 1 < n) ? chp->next_c[(j + 1 < NMAX) ? j + 1 : j] : INFINITY;
-    const double c_out2 = (act && j + 2 < n) ? chp->skip_c[(j + 2 < NMAX) ? j + 2 : j] : INFINITY;
+    const double INF = INFINITY;
+    // arc probabilities exp(-cost): into this row from j, j-1, j-2, and out of it towards j+1 / j+2 (stored at their
+    // destination); absent arcs are 0
+    const xnum p_self = xn_exp_neg(act ? chp->self_c[j] : INF);
+    const xnum p_next = xn_exp_neg((act && j >= 1) ? chp->next_c[j] : INF);
+    const xnum p_skip = xn_exp_neg((act && j >= 2 && skip) ? chp->skip_c[j] : INF);
+    const xnum p_out1 = xn_exp_neg((act && j + 1 < n) ? chp->next_c[(j + 1 < NMAX) ? j + 1 : j] : INF);
+    const xnum p_out2 = xn_exp_neg((act && j + 2 < n && skip) ? chp->skip_c[(j + 2 < NMAX) ? j + 2 : j] : INF);
     const int64_t f0 = has_utt ? a.utt_off[u] : 0;
     const int T = has_utt ? (int)(a.utt_off[u + 1] - f0) : 0;
-    // every lane of the wave runs to the longest utterance of the wave (shuffles need converged lanes)
+    // every lane of the wave runs to the longest utterance of the wave (cross-lane operations need converged lanes)
     int Tmax = T;
 #pragma unroll
     for (int o = 32; o >= NMAX; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
-    if (has_utt && j == 0 && T <= 0 && a.logp) a.logp[u] = NEG;
+    if (has_utt && j == 0 && T <= 0 && a.logp) a.logp[u] = -INF;
     const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
-    double* alpha = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0);   // [T, n]
+    const int64_t cells = (int64_t)T * n;
+    double* alf = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0);   // [T, n] mantissas, then [T, n] exponents
+    int* ale = reinterpret_cast<int*>(alf + cells);
     auto load_e = [&](int t) -> ET { return (act && t >= 0 && t < T) ? nll[(int64_t)t * a.S + st] : ET(0); };
     ET ering[PD];
-    double e = (double)load_e(0);
 #pragma unroll
     for (int k = 0; k < PD; ++k) ering[k] = load_e(1 + k);
     // ---- forward ----
-    double al = (act && j == 0 && T > 0) ? -chp->c0 - e : NEG;
-    double al_last = NEG;   // alpha of this row in column T - 1
+    xnum al = (act && j == 0 && T > 0) ? xn_norm(xn_mul(xn_exp_neg(chp->c0), xn_exp_neg((double)load_e(0)))) : xn_zero();
+    xnum al_last = xn_zero();   // alpha of this row in column T - 1
     for (int t0 = 0; t0 < Tmax; t0 += PD) {
 #pragma unroll
         for (int k = 0; k < PD; ++k) {
             const int t = t0 + k;
             if (t >= Tmax) break;
-            if (act && t < T) alpha[(int64_t)t * n + j] = al;
+            if (act && t < T) { alf[(int64_t)t * n + j] = al.f; ale[(int64_t)t * n + j] = al.e; }
             if (t == T - 1) al_last = al;
-            const double up1 = __shfl_up(al, 1, NMAX), up2 = __shfl_up(al, 2, NMAX);
-            const double a0 = al - c_self;
-            const double a1 = (j >= 1) ? up1 - c_next : NEG;
-            const double a2 = (j >= 2) ? up2 - c_skip : NEG;
-            const double en = (double)ering[k];
-            const double nx = (skip ? lse3(a0, a1, a2) : lse2(a0, a1)) - en;
-            if (act && t + 1 < T) { al = nx; e = en; }
+            xnum up1 = fbc_dpp<0x111>(al), up2 = fbc_dpp<0x112>(al);            // rows j - 1, j - 2 (row_shr)
+            if (j < 1) up1 = xn_zero();                                          // (what came from the neighbouring group)
+            if (j < 2) up2 = xn_zero();
+            const xnum bn = xn_exp_neg((double)ering[k]);                        // emission probability of column t + 1
+            const xnum sum = skip ? xn_add3(xn_mul(al, p_self), xn_mul(up1, p_next), xn_mul(up2, p_skip))
+                                  : xn_add(xn_mul(al, p_self), xn_mul(up1, p_next));
+            const xnum nx = xn_norm(xn_mul(sum, bn));
+            if (act && t + 1 < T) al = nx;
             ering[k] = load_e(t + 1 + PD);   // slot k next serves column t + 1 + PD
         }
     }
-    const double logp = __shfl(al_last, (n > 0 ? n - 1 : 0), NMAX);
+    xnum P;
+    P.f = __shfl(al_last.f, (n > 0 ? n - 1 : 0), NMAX);
+    P.e = __shfl(al_last.e, (n > 0 ? n - 1 : 0), NMAX);
+    const double logp = xn_log(P);
     if (has_utt && j == 0 && T > 0 && a.logp) a.logp[u] = logp;
     if (!a.occ && !a.gam && !a.self_xi_utt) return;
-    // ---- backward: beta in a register, gamma straight into the occupancy rows (e holds column T-1) ----
-    auto load_a = [&](int t) -> double { return (act && t >= 0 && t < T) ? alpha[(int64_t)t * n + j] : NEG; };
-    double be = (act && j == n - 1) ? 0.0 : NEG;
+    const bool reach = P.f > 0.0;              // log P = -inf: every gamma is 0
+    const double inv_pf = 1.0 / P.f;
+    // ---- backward: beta in a register, gamma straight into the occupancy rows ----
+    auto load_af = [&](int t) -> double { return (act && t >= 0 && t < T) ? alf[(int64_t)t * n + j] : 0.0; };
+    auto load_ae = [&](int t) -> int { return (act && t >= 0 && t < T) ? ale[(int64_t)t * n + j] : XN_ZERO_E; };
+    xnum be = (act && j == n - 1) ? xn_one() : xn_zero();
     double xi_acc = 0.0;                      // expected self transitions of this row (when asked for)
     const bool want_xi = a.self_xi_utt != nullptr;
-    double ap = load_a(T - 1);
-    double aring[PD];
+    xnum ap = xnum{load_af(T - 1), load_ae(T - 1)};
+    double e = (double)load_e(T - 1);
+    double arf[PD];
+    int are[PD];
 #pragma unroll
-    for (int k = 0; k < PD; ++k) { aring[k] = load_a(T - 2 - k); ering[k] = load_e(T - 2 - k); }
-    // lanes of shorter utterances idle (be = -inf, no stores) until the wave's column index reaches their T - 1
+    for (int k = 0; k < PD; ++k) { arf[k] = load_af(T - 2 - k); are[k] = load_ae(T - 2 - k); ering[k] = load_e(T - 2 - k); }
+    // lanes of shorter utterances idle (be = 0, no stores) until the wave's column index reaches their T - 1
     for (int t0 = Tmax - 1; t0 >= 0; t0 -= PD) {
 #pragma unroll
         for (int k = 0; k < PD; ++k) {
@@ -346,24 +371,21 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
             if (tw < 0) break;
             const int t = tw - (Tmax - T);      // this utterance's column (negative: it has not started yet)
             if ((a.occ || a.gam) && has_utt && t >= 0) {
-                double g = act ? exp(ap + be - logp) : 0.0;
-                if (!(g == g)) g = 0.0;
+                const double g = (act && reach) ? xn_ratio(ap, be, inv_pf, P.e) : 0.0;
                 if (a.gam) a.gam[(f0 + t) * NMAX + j] = g;            // all 8 columns (rows >= n: 0): one 64-byte line per frame
                 else if (act) a.occ[(f0 + t) * a.S + st] = g;
             }
-            // beta_{t-1}(j) = lse over successors j, j+1, j+2 of (beta_t(s) - cost(j -> s) - e_t(s))
-            const double w = act ? be - e : NEG;
-            const double d1 = __shfl_down(w, 1, NMAX), d2 = __shfl_down(w, 2, NMAX);
-            const double b0 = w - c_self;
-            const double b1 = (j + 1 < n) ? d1 - c_out1 : NEG;
-            const double b2 = (j + 2 < n) ? d2 - c_out2 : NEG;
-            const double nb = skip ? lse3(b0, b1, b2) : lse2(b0, b1);
-            if (want_xi && act && t > 0) {       // xi_t(j -> j) = alpha_{t-1}(j) a_jj b_j(x_t) beta_t(j) / P
-                const double x = exp(aring[k] + b0 - logp);
-                if (x == x) xi_acc += x;
-            }
-            if (act && t > 0) { be = nb; ap = aring[k]; e = (double)ering[k]; }
-            if (t >= 0) { aring[k] = load_a(t - 1 - PD); ering[k] = load_e(t - 1 - PD); }
+            // beta_{t-1}(j) = sum over successors s = j, j+1, j+2 of beta_t(s) b_s(x_t) a_{j -> s}
+            const xnum w = (act && t >= 0) ? xn_mul(be, xn_exp_neg(e)) : xn_zero();
+            xnum d1 = fbc_dpp<0x101>(w), d2 = fbc_dpp<0x102>(w);                // rows j + 1, j + 2 (row_shl)
+            if (j + 1 >= n) d1 = xn_zero();
+            if (j + 2 >= n) d2 = xn_zero();
+            const xnum ws = xn_mul(w, p_self);
+            const xnum nb = xn_norm(skip ? xn_add3(ws, xn_mul(d1, p_out1), xn_mul(d2, p_out2)) : xn_add(ws, xn_mul(d1, p_out1)));
+            const xnum aprev = xnum{arf[k], are[k]};
+            if (want_xi && act && reach && t > 0) xi_acc += xn_ratio(aprev, ws, inv_pf, P.e);   // xi_t(j -> j) = alpha_{t-1}(j) a_jj b_j(x_t) beta_t(j) / P
+            if (act && t > 0) { be = nb; ap = aprev; e = (double)ering[k]; }
+            if (t >= 0) { arf[k] = load_af(t - 1 - PD); are[k] = load_ae(t - 1 - PD); ering[k] = load_e(t - 1 - PD); }
         }
     }
     if (want_xi && has_utt) a.self_xi_utt[u * NMAX + j] = act ? xi_acc : 0.0;
