@@ -145,6 +145,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         for (int64_t u = 0; use_seq && u < U; ++u)
             if (b->offsets[u + 1] - b->offsets[u] == 1) use_seq = false;
     }
+    GH_REQUIRE(!lat->deferred_src || use_seq, "gh_viterbi: internal: a transcripts handle left the sequence-form path unexpanded");
     // layer-form kernels in label mode: the back-trace writes the label sequences itself, no path is materialised
     const bool labels_direct = use_layers && want_labels && !out_path;
     std::vector<int64_t> own_path_off;  // label mode: the path lives on the device only, capacities are ours
@@ -585,6 +586,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
     const size_t BUDGET = (size_t)4 << 30;
     const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
+    GH_REQUIRE(!lat->deferred_src || use_fbseq, "gh_forward_backward: internal: a transcripts handle left the sequence-form path unexpanded");
     std::vector<int64_t> soff(U, 0), chunk_begin{0};
     size_t acc = 0, smax = 0;
     for (int64_t k = 0; k < U; ++k) {
