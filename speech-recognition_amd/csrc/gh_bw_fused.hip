@@ -25,6 +25,10 @@
 #include "gh_internal.h"
 #include "gh_host.h"
 
+#ifndef BWF_TF
+#define BWF_TF 32   // frames staged per tile (tuning knob: -DBWF_TF=64)
+#endif
+
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -80,7 +84,10 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
                                                        const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
                                                        double* __restrict__ partial) {
     constexpr int KP = 2 * KS;            // padded feature length
-    constexpr int TF = 32;                // frames staged per tile
+#ifndef BWF_TF
+#define BWF_TF 32
+#endif
+    constexpr int TF = BWF_TF;            // frames staged per tile
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int DP = KP | 1;                // odd LDS row stride >= KP: columns D .. KP-1 stay zero, so the operand reads
                                           // below need no bounds test (a conditional ds_read costs an exec-mask branch and
@@ -161,7 +168,8 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
         }
         return false;
     };
-    double pre_x[PX], pre_g;
+    constexpr int PG = TF * 8 / 256;       // gamma entries per thread
+    double pre_x[PX], pre_g[PG];
     auto prefetch = [&]() {   // tile (f0 + t0, min(TF, T - t0) frames) -> registers
         const int nf_ = (T - t0 < TF) ? T - t0 : TF;
         const double* src = X + (f0 + t0) * D;
@@ -170,7 +178,11 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
             const int i = tid + 256 * e;
             pre_x[e] = (i < nf_ * D) ? src[i] : 0.0;
         }
-        pre_g = (tid < nf_ * 8 && gcol >= 0) ? gam[(f0 + t0 + (tid >> 3)) * gam_stride + gcol] : 0.0;
+#pragma unroll
+        for (int e = 0; e < PG; ++e) {
+            const int i = tid + 256 * e;
+            pre_g[e] = (i < nf_ * 8 && gcol >= 0) ? gam[(f0 + t0 + (i >> 3)) * gam_stride + gcol] : 0.0;
+        }
     };
     bool have = open_utt();
     if (have) prefetch();
@@ -182,7 +194,8 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
             const int i = tid + 256 * e;
             if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = pre_x[e]; }   // rows >= nf arrive as zeros
         }
-        gt[tid] = pre_g;
+#pragma unroll
+        for (int e = 0; e < PG; ++e) gt[tid + 256 * e] = pre_g[e];
         // the tile after this one
         t0 += TF;
         if (t0 >= T) { ++ui; have = open_utt(); }
@@ -441,7 +454,7 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     GH_HIP(hipMemcpyAsync(d_chains, chains.data(), (size_t)L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_segfirst, seg_first.data(), seg_first.size() * 8, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemcpyAsync(d_seglen, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, st));
-    const size_t lds = ((size_t)32 * ((2 * KS) | 1) + 32 * 8 + 128) * 8;
+    const size_t lds = ((size_t)BWF_TF * ((2 * KS) | 1) + BWF_TF * 8 + 128) * 8;
     const dim3 grid((unsigned)wgs.size()), blk(256);   // 256 threads always: see the staging loop of the kernel
     const double* gam = seq ? b->occ : b->gam;
     const int gam_stride = seq ? S : 8;
