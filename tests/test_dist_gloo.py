@@ -103,3 +103,72 @@ def test_stats_allreduce_world2_matches_single_process(tmp_path):
         np.testing.assert_allclose(mu[s], st["means"][:k], rtol=1e-10)
         np.testing.assert_allclose(sigma[s], st["vars"][:k], rtol=1e-9)
         np.testing.assert_allclose(wn[s], st["w"][:k], rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own training algorithm (continuous_train, continuous_speech.py:56-179) sharded over two gloo ranks, on
+# the oracle-backed test double of the binding (tests/fake_hip.py): alignment + regrouping per rank, the refit of all
+# states in lock-step with ONE collective per k-means / EM iteration, segment / frame counts all-reduced.
+def _ct_worker(rank, world, port, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "speech-recognition_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import contextlib
+    import io
+    import warnings
+    import torch.distributed as dist
+    import fake_hip
+    from sr.recognition import _hip
+    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc"):
+        setattr(_hip, name, getattr(fake_hip, name))          # what fake_hip.install does through monkeypatch
+    import sr.recognition as R
+    from sr.recognition.parallel import StatsAllReducer, shard_utterances
+    from test_gpu_api import make_hmm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("G11_continuous_train")
+        W, U = int(g["n_words"]), int(g["n_utts"])
+        data = [g["x%d" % i] for i in range(U)]
+        labels = [[int(v) for v in g["labels%d" % i]] for i in range(U)]
+        models = [make_hmm(R, g["init%d_means" % wi], g["init%d_vars" % wi], g["init%d_w" % wi], g["init%d_transitions" % wi])
+                  for wi in range(W)]
+        mine = shard_utterances([len(x) for x in data], world)[rank] if world > 1 else list(range(U))
+        out = os.path.join(out_dir, "world%d_rank%d" % (world, rank))
+        os.makedirs(out, exist_ok=True)
+        np.random.seed(7 + rank)
+        red = StatsAllReducer()
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            R.continuous_train([data[i] for i in mine], models, [labels[i] for i in mine], out, n_gaussians=4,
+                               n_segments=5, max_iteration=2, reducer=red)
+        np.savez(os.path.join(out, "meta.npz"), calls=red.calls, mine=mine)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_continuous_train_sharded_world2_on_the_test_double(tmp_path, built_library):
+    """Both ranks write the SAME models after the last iteration (bit for bit: every rank applies the same all-reduced
+    statistics), the shards cover the utterances, and the number of collectives is that of the lock-step schedule (a
+    handful per outer iteration, not one per state)."""
+    import pickle
+    import torch.multiprocessing as mp
+    mp.spawn(_ct_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = load_golden("G11_continuous_train")
+    W, U = int(g["n_words"]), int(g["n_utts"])
+    m0, m1 = np.load(tmp_path / "world2_rank0" / "meta.npz"), np.load(tmp_path / "world2_rank1" / "meta.npz")
+    assert sorted(np.concatenate([m0["mine"], m1["mine"]]).tolist()) == list(range(U))
+    assert int(m0["calls"]) == int(m1["calls"]) and 4 <= int(m0["calls"]) < 400
+    for wi in range(W):
+        a = pickle.load(open(tmp_path / "world2_rank0" / ("%d.pkl" % wi), "rb"))
+        b = pickle.load(open(tmp_path / "world2_rank1" / ("%d.pkl" % wi), "rb"))
+        np.testing.assert_array_equal(a.transitions, b.transitions)
+        for sa, sb in zip(a.gmm_states, b.gmm_states):
+            np.testing.assert_array_equal(np.asarray(sa.w), np.asarray(sb.w))
+            for da, db in zip(sa.dists, sb.dists):
+                np.testing.assert_array_equal(np.asarray(da.mean), np.asarray(db.mean))
+                np.testing.assert_array_equal(np.asarray(da.cov), np.asarray(db.cov))
+                assert np.all(np.isfinite(np.asarray(da.mean))) and np.all(np.asarray(da.cov) > 0)
