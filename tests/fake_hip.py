@@ -166,6 +166,28 @@ class Batch:
                     sums[s, c, D] = len(x)
         return (None if resident else clusters), changed, sums
 
+    def bw_accumulate(self, gmm, occ_floor=0.0, stats_dev=None, fetch=True):
+        """gh_bw_accumulate: r_nsm = occ[n,s] w_sm pdf_sm(x_n) / sum_m' ...; [S, M, 1 + 2D] centred statistics."""
+        S, M, D = gmm.mean.shape
+        stats = np.zeros((S, M, 1 + 2 * D))
+        for s in range(S):
+            fr = np.flatnonzero(self.occ[:, s] > occ_floor)
+            if len(fr) == 0:
+                continue
+            x = self.feats[fr]
+            with np.errstate(all="ignore"):
+                ll = np.stack([np.log(gmm.w[s, m]) - 0.5 * (D * np.log(2 * np.pi) + np.log(gmm.var[s, m]).sum()
+                                                                + ((x - gmm.mean[s, m]) ** 2 / gmm.var[s, m]).sum(axis=1)) for m in range(M)], axis=1)
+                ll -= ll.max(axis=1, keepdims=True)
+                r = np.exp(ll)
+                r = r / r.sum(axis=1, keepdims=True) * self.occ[fr, s][:, None]
+            for m in range(M):
+                d = x - gmm.mean[s, m]
+                stats[s, m, 0] = r[:, m].sum()
+                stats[s, m, 1:1 + D] = (r[:, [m]] * d).sum(axis=0)
+                stats[s, m, 1 + D:] = (r[:, [m]] * d * d).sum(axis=0)
+        return stats
+
     def gather(self, rows, offsets=None):
         rows = np.asarray(rows, dtype=np.int64)
         return Batch(self.ctx, feats=self.feats[rows], offsets=[0, len(rows)] if offsets is None else offsets)
@@ -285,6 +307,45 @@ class Lattices:
             rl = np.asarray(row_label[lidx[u]])
             labels.append(np.array(O.path_to_words(p, rl < 0, rl), dtype=np.int32) if len(p) else np.zeros(0, dtype=np.int32))
         return dict(labels=labels, best_end=r["best_end"], end_cost_flat=r["end_cost_flat"])
+
+    def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True, want_self_xi=False):
+        """gh_forward_backward through the oracle (O.forward_backward): log P, occupancies [N,S], expected self
+        transitions xi_t(r -> r) = alpha_t(r) a_rr b_r(x_{t+1}) beta_{t+1}(r) / P summed per state."""
+        U = batch.U
+        lidx = np.zeros(U, dtype=int) if utt_lattice is None else np.asarray(utt_lattice, dtype=int)
+        S = batch.nll.shape[1]
+        logp = np.empty(U)
+        occ = np.zeros((batch.N, S))
+        xi = np.zeros(S)
+        mats = dict(alpha=[], beta=[], gamma=[])
+        for u in range(U):
+            g = self.graphs[lidx[u]]
+            E, nes = self._emissions(batch, u, g)
+            trans = self._dense(g)
+            rs = np.asarray(g["row_state"], dtype=int)
+            if E.shape[1] == 0:
+                logp[u] = -np.inf
+                continue
+            with np.errstate(all="ignore"):
+                la, lb, gamma, lp = O.forward_backward(E, nes, trans, [int(e) for e in g["end_rows"]])
+            logp[u] = lp
+            f0 = int(batch.offsets[u])
+            for r in np.flatnonzero(rs >= 0):
+                occ[f0:f0 + E.shape[1], rs[r]] += gamma[r]
+                if np.isfinite(trans[r, r]) and np.isfinite(lp):
+                    with np.errstate(all="ignore"):
+                        x = np.exp(la[r, :-1] - trans[r, r] - E[r, 1:] + lb[r, 1:] - lp)
+                    xi[rs[r]] += np.nansum(x)
+            mats["alpha"].append(la); mats["beta"].append(lb); mats["gamma"].append(gamma)
+        batch.occ = occ
+        out = dict(logp=logp)
+        if want_self_xi:
+            out["self_xi"] = xi
+        if want_matrices:
+            out.update(mats)
+        if want_occ and fetch_occ:
+            out["occ"] = occ
+        return out
 
     def align_segments(self, batch, utt_lattice=None):
         """gh_align_segments: the reference's own regrouping loop (continuous_speech.py:90-106) over the oracle's paths."""

@@ -172,3 +172,67 @@ def test_continuous_train_sharded_world2_on_the_test_double(tmp_path, built_libr
                 np.testing.assert_array_equal(np.asarray(da.mean), np.asarray(db.mean))
                 np.testing.assert_array_equal(np.asarray(da.cov), np.asarray(db.cov))
                 assert np.all(np.isfinite(np.asarray(da.mean))) and np.all(np.asarray(da.cov) > 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The soft-EM trainer (train.BaumWelchTrainer: forward-backward E-step, ONE all-reduce of the packed statistics buffer
+# per iteration, host M-step + transition re-estimation) over two gloo ranks on the test double, against one rank.
+def _bw_problem():
+    g = load_golden("G11_continuous_train")
+    W, U = int(g["n_words"]), int(g["n_utts"])
+    data = [g["x%d" % i] for i in range(U)]
+    labels = [[int(v) for v in g["labels%d" % i]] for i in range(U)]
+    means = np.stack([g["init%d_means" % wi] for wi in range(W)])
+    vars_ = np.stack([g["init%d_vars" % wi] for wi in range(W)])
+    w = np.stack([g["init%d_w" % wi] for wi in range(W)])
+    trans = [g["init%d_transitions" % wi] for wi in range(W)]
+    return data, labels, means, vars_, w, trans
+
+
+def _bw_worker(rank, world, port, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "speech-recognition_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import fake_hip
+    from sr.recognition import _hip
+    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc"):
+        setattr(_hip, name, getattr(fake_hip, name))
+    from sr.recognition.parallel import StatsAllReducer, shard_utterances
+    from sr.recognition.train import BaumWelchTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data, labels, means, vars_, w, trans = _bw_problem()
+        mine = shard_utterances([len(x) for x in data], world)[rank] if world > 1 else list(range(len(data)))
+        red = StatsAllReducer()
+        tr = BaumWelchTrainer(means, vars_, w, trans, [data[i] for i in mine], [labels[i] for i in mine], reducer=red,
+                              var_floor=1e-3)
+        hist = tr.fit(3)
+        np.savez(os.path.join(out_dir, "bw_world%d_rank%d.npz" % (world, rank)), means=tr.means, vars=tr.vars, w=tr.weights,
+                 trans=np.stack(tr.transitions), hist=hist, calls=red.calls)
+        tr.close()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_soft_em_trainer_world2_equals_world1_on_the_test_double(tmp_path, built_library):
+    """Three EM iterations with re-estimated transition costs: both ranks end with bit-identical parameters, they equal
+    the one-rank run within summation-order tolerance, the total log-likelihood is the same and monotone, and every
+    iteration used exactly one collective."""
+    import torch.multiprocessing as mp
+    mp.spawn(_bw_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _bw_worker(0, 1, 0, str(tmp_path))
+    r0, r1 = np.load(tmp_path / "bw_world2_rank0.npz"), np.load(tmp_path / "bw_world2_rank1.npz")
+    one = np.load(tmp_path / "bw_world1_rank0.npz")
+    for k in ("means", "vars", "w", "trans", "hist"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+        np.testing.assert_allclose(r0[k], one[k], rtol=1e-8, atol=1e-10)
+    assert int(r0["calls"]) == 3
+    h = one["hist"]
+    assert all(b >= a - 1e-9 * abs(a) for a, b in zip(h, h[1:]))
