@@ -262,19 +262,27 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
         for (int r = 0; r < 4; ++r) out[(ct * 16 + q + 4 * r) * 16 + j] = acc[ct][r];
 }
 
-// sum a pair's raw tiles over its workgroups (in order), re-centre on the component means, write [S, M, 1 + 2D]
-__global__ __launch_bounds__(256) void bw_fused_reduce_kernel(const double* __restrict__ partial, const bwf_pair* __restrict__ pairs,
-                                                              int waves_per_wg, int lt, int D, int M,
+// sum a pair's raw tiles over its workgroups (in order: deterministic) -- one thread per tile element, grid (pairs,
+// len / 256): with one block per pair every thread walked 6 elements x ~100 workgroups back to back (0.17 ms)
+__global__ __launch_bounds__(256) void bw_fused_sum_kernel(const double* __restrict__ partial, const bwf_pair* __restrict__ pairs,
+                                                           int waves_per_wg, int len, double* __restrict__ gsum /*[pairs][len]*/) {
+    const bwf_pair pr = pairs[blockIdx.x];
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const double* src = partial + (int64_t)pr.p * len + i;
+    double a = 0;
+#pragma unroll 8
+    for (int w = pr.wg_begin; w < pr.wg_end; ++w) a += src[(int64_t)w * waves_per_wg * len];
+    gsum[(int64_t)blockIdx.x * len + i] = a;
+}
+
+// re-centre a pair's summed tile on the component means, write [S, M, 1 + 2D]
+__global__ __launch_bounds__(256) void bw_fused_reduce_kernel(const double* __restrict__ gsum, const bwf_pair* __restrict__ pairs,
+                                                              int lt, int D, int M,
                                                               const double* __restrict__ mean, double* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double G[];      // [2*lt*16][16]: rows d < D linear, row D the occupancy, rows 16 lt + d squared
     const bwf_pair pr = pairs[blockIdx.x];
     const int len = 2 * lt * 16 * 16;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        double a = 0;
-        for (int w = pr.wg_begin; w < pr.wg_end; ++w) a += partial[((int64_t)w * waves_per_wg + pr.p) * len + i];
-        G[i] = a;
-    }
-    __syncthreads();
+    const double* G = gsum + (int64_t)blockIdx.x * len;   // [2*lt*16][16]: rows d < D linear, row D the occupancy, rows 16 lt + d squared
     const int W = 1 + 2 * D;
     for (int i = threadIdx.x; i < 2 * M * (D + 1); i += blockDim.x) {
         const int h = i / (M * (D + 1)), rem = i - h * M * (D + 1);
@@ -442,6 +450,8 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     cv.add(&d_pairs, std::max<size_t>(1, pairs.size())); cv.add(&d_chains, (size_t)L);
     cv.add(&d_segfirst, std::max<size_t>(1, seg_first.size())); cv.add(&d_seglen, std::max<size_t>(1, seg_len.size()));
     cv.add(&d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len);
+    double* d_gsum;
+    cv.add(&d_gsum, std::max<size_t>(1, pairs.size()) * (size_t)tile_len);
     int rc = cv.commit(ctx);
     if (rc) return rc;
     double* d_out = stats_dev ? stats_dev : d_own;
@@ -473,8 +483,9 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
 #undef GH_BWF_N
 #undef GH_BWF
     GH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pairs.size()), dim3(256), (size_t)tile_len * 8, st, d_part, d_pairs,
-                       4, lt, D, M, g->dMean, d_out);
+    hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pairs.size(), (unsigned)((tile_len + 255) / 256)), dim3(256), 0, st, d_part,
+                       d_pairs, 4, tile_len, d_gsum);
+    hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pairs.size()), dim3(256), 0, st, d_gsum, d_pairs, lt, D, M, g->dMean, d_out);
     GH_HIP(hipGetLastError());
     GH_HIP(hipStreamSynchronize(st));   // the work lists are host vectors of this call
     return GH_OK;
