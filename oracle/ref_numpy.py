@@ -687,6 +687,20 @@ def path_to_words(path, is_nes, row_word):
 
 
 # -------------------------------------------------------------------------- A11
+def cut_segments(path, is_nes):
+    """The regrouping loop of continuous_train (continuous_speech.py:90-106) on one alignment path (end -> start, as
+    decode_states returns it): walking it start -> end, a run opens at the first cell of an emitting row seen while no
+    run is open; a cell of a DIFFERENT row closes the open run as the frames [start, c), c = that cell's column,
+    provided start < c, and does not itself open a run.  Yields (row, start, stop)."""
+    start, cur = None, None
+    for r, c in reversed(np.asarray(path).tolist()):
+        if start is None and not is_nes[r]:
+            start, cur = c, r
+        if r != cur and start is not None and start < c:
+            yield int(cur), int(start), int(c)
+            start, cur = None, None
+
+
 def continuous_train(data, models, label_seqs, n_gaussians=4, n_segments=5, max_iteration=1000,
                      on_iteration=None):
     """continuous_train (continuous_speech.py:56-179) on packed models.
@@ -727,13 +741,8 @@ def continuous_train(data, models, label_seqs, n_gaussians=4, n_segments=5, max_
                     states[r] = uniq.setdefault((rw[r], rs[r]), states[r])
             _, path = decode_states(emission_matrix(x, states), nes, trans,
                                     end_points=[[e, -1] for e in ends])
-            start, cur = None, None
-            for r, c in reversed(path.tolist()):
-                if start is None and not nes[r]:
-                    start, cur = c, r
-                if r != cur and start is not None and start < c:
-                    gmm_data.setdefault((int(rw[cur]), int(rs[cur])), []).append(x[start:c])
-                    start, cur = None, None
+            for cur, start, c in cut_segments(path, nes):
+                gmm_data.setdefault((int(rw[cur]), int(rs[cur])), []).append(x[start:c])
         for (wi, si), segs in gmm_data.items():
             seg = np.vstack(segs)
             split_fit_gmm(seg, np.mean(seg, axis=0), new_models[wi]["gmm"][si], n_gaussians,

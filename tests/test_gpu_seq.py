@@ -222,9 +222,13 @@ def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, K
 @pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (4, 2, False, 16)])
 def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, Kmax):
     """gh_align_segments (alignment + the regrouping loop of continuous_speech.py:90-106 on the device, one int per
-    frame back) against the reference-shaped Python loop `cut_segments` over the paths of gh_viterbi -- per frame the
-    same state, per state the same number of segments."""
-    from sr.recognition.continuous_speech import cut_segments
+    frame back) against the ORACLE's restatement of that loop (O.cut_segments) over the paths of gh_viterbi -- per
+    frame the same state, per state the same number of segments."""
+
+    def cut_segments(path, row_state):
+        rs = np.asarray(row_state)
+        for row, lo, hi in O.cut_segments(path, rs < 0):
+            yield int(rs[row]), lo, hi
     rng = np.random.default_rng(5 * W + n + Kmax)
     U = 80
     means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U, short=0)

@@ -142,15 +142,9 @@ def test_cut_segments_matches_reference_rule(R):
     labels = list(g["forced_labels"])
     pk, _ = packed_lattice([g["word_trans"]] * W, n, [[l] for l in labels])
     got = list(cut_segments(g["forced_path"], pk["row_state"]))
-    # reference rule, straight from the oracle's loop
+    # reference rule: the oracle's restatement of the loop
     rw, rs, nes, _, _ = O.build_state_sequences(n, [g["word_trans"]] * W, [[l] for l in labels])
-    exp, start, cur = [], None, None
-    for r, c in reversed(g["forced_path"].tolist()):
-        if start is None and not nes[r]:
-            start, cur = c, r
-        if r != cur and start is not None and start < c:
-            exp.append((int(rw[cur]) * n + int(rs[cur]), start, c))
-            start, cur = None, None
+    exp = [(int(rw[cur]) * n + int(rs[cur]), start, c) for cur, start, c in O.cut_segments(g["forced_path"], nes)]
     assert got == exp and len(got) >= 2 * n
     # consequences the docstring promises: entering frame dropped inside a word, final run open
     assert all(b > a for _, a, b in got)
