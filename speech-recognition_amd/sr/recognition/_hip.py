@@ -554,8 +554,18 @@ class Lattices:
         self.h = h
         self.L = L
 
+    @staticmethod
+    def flatten_transcripts(label_seqs):
+        """(label_off int64 [L+1], labels int32 [sum K]) of a list of label strings -- what `from_transcripts` hands to
+        the library; a trainer that rebuilds its graphs every iteration flattens once and passes `flat=`."""
+        K = np.array([len(l) for l in label_seqs], dtype=np.int64)
+        label_off = np.concatenate([[0], np.cumsum(K)]).astype(np.int64)
+        labels = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).ravel() for l in label_seqs])
+                                      if len(label_seqs) else np.zeros(0), dtype=np.int32)
+        return label_off, labels
+
     @classmethod
-    def from_transcripts(cls, ctx, word_transitions, n, label_seqs, state_base=None):
+    def from_transcripts(cls, ctx, word_transitions, n, label_seqs=None, state_base=None, flat=None):
         """The forced-alignment graph of every label string in `label_seqs` (continuous_speech.py:80-82: one word per
         layer; the graphs `continuous_speech.packed_lattice(word_transitions, n, [[l] for l in labels])` describes),
         built on the library's side from the W [n, n] cost matrices -- see gh_lattices_create_transcripts."""
@@ -563,20 +573,30 @@ class Lattices:
         self.ctx = ctx
         wt = np.ascontiguousarray(np.asarray([np.asarray(t, dtype=np.float64) for t in word_transitions]), dtype=np.float64)
         assert wt.ndim == 3 and wt.shape[1] == n and wt.shape[2] == n, "word_transitions: W matrices of n x n costs"
-        K = np.array([len(l) for l in label_seqs], dtype=np.int64)
-        self.L = len(label_seqs)
-        label_off = np.concatenate([[0], np.cumsum(K)]).astype(np.int64)
-        labels = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).ravel() for l in label_seqs])
-                                      if self.L else np.zeros(0), dtype=np.int32)
+        label_off, labels = flat if flat is not None else cls.flatten_transcripts(label_seqs)
+        K = np.diff(label_off)
+        self.L = len(K)
         base = None if state_base is None else np.ascontiguousarray(state_base, dtype=np.int32)
-        self.R = list(K * (n + 1) + 1)
-        self.n_end = [1] * self.L
-        self.end_rows = [np.array([(k - 1) * (n + 1) + n], dtype=np.int64) for k in K]
+        self.R = K * (n + 1) + 1
+        self.n_end = np.ones(self.L, dtype=np.int64)
+        self._n_per_word = n
+        self._K = K
         h = C.c_void_p()
         _check(ctx.lib, ctx.lib.gh_lattices_create_transcripts(ctx.h, wt.shape[0], int(n), _ptr(wt, _c_f64p), _ptr(base, _c_i32p),
                                                                self.L, _ptr(label_off, _c_i64p), _ptr(labels, _c_i32p), C.byref(h)))
         self.h = h
         return self
+
+    @property
+    def end_rows(self):
+        if "_end_rows" not in self.__dict__:      # (transcripts handle: the end row is the last state of the last word)
+            n = self._n_per_word
+            self._end_rows = [np.array([(k - 1) * (n + 1) + n], dtype=np.int64) for k in self._K]
+        return self._end_rows
+
+    @end_rows.setter
+    def end_rows(self, value):
+        self._end_rows = value
 
     def set_beam(self, beam):
         """Rank beam per column for viterbi / viterbi_labels (None, 0 or inf: no pruning); see gh_lattices_set_beam."""

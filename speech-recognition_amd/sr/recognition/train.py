@@ -79,8 +79,12 @@ class BaumWelchTrainer:
         """One forced-alignment graph per distinct label sequence, from the current transition costs."""
         if self.lat is not None:
             self.lat.close()
-        self.lat = (_hip.Lattices.from_transcripts(self.ctx, self.transitions, self.n, self.graph_labels)
-                    if self.graph_labels else None)
+        if not self.graph_labels:
+            self.lat = None
+            return
+        if getattr(self, "_flat_labels", None) is None:      # the label strings never change: flattened once
+            self._flat_labels = _hip.Lattices.flatten_transcripts(self.graph_labels)
+        self.lat = _hip.Lattices.from_transcripts(self.ctx, self.transitions, self.n, self.graph_labels, flat=self._flat_labels)
 
     # layout of the ONE buffer that crosses ranks:
     #   [statistics S*M*(1+2D) | expected self transitions S | total log-likelihood | utterances]

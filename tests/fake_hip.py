@@ -221,8 +221,12 @@ class Lattices:
         self.n_end = [len(g["end_rows"]) for g in graphs]
         self.beam = None
 
+    @staticmethod
+    def flatten_transcripts(label_seqs):
+        return None
+
     @classmethod
-    def from_transcripts(cls, ctx, word_transitions, n, label_seqs, state_base=None):
+    def from_transcripts(cls, ctx, word_transitions, n, label_seqs=None, state_base=None, flat=None):
         from sr.recognition.continuous_speech import packed_lattice
         return cls(ctx, [packed_lattice(word_transitions, n, [[int(l)] for l in labels], state_base=state_base)[0]
                          for labels in label_seqs])

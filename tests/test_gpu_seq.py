@@ -281,7 +281,7 @@ def test_transcripts_handle_equals_arc_list_handle(hip, ctx, W, n, skip, Kmax):
     a = hip.Lattices(ctx, graphs)
     t = hip.Lattices.from_transcripts(ctx, wt, n, transcripts)
     assert t.forms() == {"sequence"} and "sequence" in a.forms()
-    assert list(t.R) == list(a.R) and t.n_end == a.n_end
+    assert list(t.R) == list(a.R) and list(t.n_end) == list(a.n_end)
 
     def same(b, beam=None, paths=True):
         a.set_beam(beam), t.set_beam(beam)
