@@ -560,8 +560,8 @@ class Lattices:
         the library; a trainer that rebuilds its graphs every iteration flattens once and passes `flat=`."""
         K = np.array([len(l) for l in label_seqs], dtype=np.int64)
         label_off = np.concatenate([[0], np.cumsum(K)]).astype(np.int64)
-        labels = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int32).ravel() for l in label_seqs])
-                                      if len(label_seqs) else np.zeros(0), dtype=np.int32)
+        import itertools
+        labels = np.fromiter(itertools.chain.from_iterable(label_seqs), dtype=np.int32, count=int(label_off[-1]))
         return label_off, labels
 
     @classmethod

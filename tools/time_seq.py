@@ -10,7 +10,6 @@ for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
 import numpy as np
 import bench
 from sr.recognition import _hip
-from sr.recognition.continuous_speech import packed_lattice
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 7
@@ -25,17 +24,13 @@ gmm = _hip.PackedGMM(ctx, wl["means"].reshape(W * n, M, D), wl["vars"].reshape(W
 b = _hip.Batch(ctx, feats=X, offsets=off)
 b.loglik(gmm, fetch=False)
 labels = rng.integers(0, W, size=(U, K))
-keys, graphs, ug = {}, [], np.empty(U, dtype=np.int32)
+keys, ug = {}, np.empty(U, dtype=np.int32)
 for u in range(U):
-    key = tuple(int(v) for v in labels[u])
-    if key not in keys:
-        keys[key] = len(graphs)
-        graphs.append(packed_lattice([wl["trans"]] * W, n, [[l] for l in key])[0])
-    ug[u] = keys[key]
+    ug[u] = keys.setdefault(tuple(int(v) for v in labels[u]), len(keys))
 t0 = time.perf_counter()
-lat = _hip.Lattices(ctx, graphs)
-print("%d utterances, %d frames, %d graphs (forms %s), Lattices() %.1f ms" % (U, off[-1], len(graphs), sorted(lat.forms()),
-                                                                           (time.perf_counter() - t0) * 1e3))
+lat = _hip.Lattices.from_transcripts(ctx, [wl["trans"]] * W, n, list(keys))   # (the row-per-lane arrays are expanded on demand)
+print("%d utterances, %d frames, %d graphs (forms %s), Lattices.from_transcripts() %.1f ms" % (U, off[-1], len(keys), sorted(lat.forms()),
+                                                                                             (time.perf_counter() - t0) * 1e3))
 
 
 def timed(fn, reps=3):
@@ -46,11 +41,16 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+ref = {}
 for name, env in (("sequence form", {}), ("row-per-lane", {"GMMHMM_VITERBI": "lean", "GMMHMM_FB": "generic"})):
     os.environ.update(env)
-    v = timed(lambda: lat.viterbi(b, utt_lattice=ug, want_path=True))
-    f = timed(lambda: lat.forward_backward(b, utt_lattice=ug, want_occ=True, fetch_occ=False, want_self_xi=True))
-    print("%-14s viterbi+paths %.2f ms   forward-backward (occ, xi) %.2f ms" % (name, v, f))
+    v = timed(lambda: lat.viterbi(b, utt_lattice=ug, want_path=False), reps=2)
+    f = timed(lambda: lat.forward_backward(b, utt_lattice=ug, want_occ=True, fetch_occ=False, want_self_xi=True), reps=2)
+    r = lat.viterbi(b, utt_lattice=ug, want_path=False)["end_cost_flat"]
+    lp = lat.forward_backward(b, utt_lattice=ug)["logp"]
+    ref.setdefault("v", r); ref.setdefault("lp", lp)
+    print("%-14s viterbi (costs) %.2f ms   forward-backward (occ, xi) %.2f ms   | costs identical: %s, max |dlogP|/|logP| %.1e" % (
+        name, v, f, np.array_equal(r, ref["v"]), np.max(np.abs(lp - ref["lp"]) / np.abs(ref["lp"]))))
 os.environ.pop("GMMHMM_VITERBI", None); os.environ.pop("GMMHMM_FB", None)
 print("sequence-form forward-backward, parts: forward only %.2f ms | + backward with xi %.2f ms | + occupancies %.2f ms" % (
     timed(lambda: lat.forward_backward(b, utt_lattice=ug)),
