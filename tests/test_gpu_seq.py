@@ -471,3 +471,59 @@ def test_sequence_forward_backward_many_states_and_state_base(hip, ctx):
         h.close()
     b.close()
     gmm.close()
+
+
+def test_new_entry_points_edge_cases(hip, ctx):
+    """Error paths and edge cases of the round-2 entry points: labels out of range, an empty label string, rows out of
+    range in gh_batch_gather, empty gathers, align_segments with single-frame and unreachable utterances (the expanded
+    twin takes over: same answers as the arc-list handle), forms() of an expanded handle."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(4)
+    W, n, M, D = 3, 3, 2, 4
+    wt = [word_trans(rng, n) for _ in range(W)]
+    with pytest.raises(hip.BackendError):
+        hip.Lattices.from_transcripts(ctx, wt, n, [[0, 3]])
+    with pytest.raises(hip.BackendError):
+        hip.Lattices.from_transcripts(ctx, wt, n, [[0, -1]])
+    with pytest.raises(hip.BackendError):
+        hip.Lattices.from_transcripts(ctx, wt, n, [[]])
+    means = rng.normal(size=(W * n, M, D))
+    gmm = hip.PackedGMM(ctx, means, np.ones_like(means), np.full((W * n, M), 0.5))
+    xs = [rng.normal(size=(T, D)) for T in (1, 2, 9, 30, 5)]
+    seqs = [[0], [1, 2], [2, 0], [0, 1, 2, 1], [1, 1, 1]]           # utterance 1 is too short for its two words (4 states)
+    b = hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    t = hip.Lattices.from_transcripts(ctx, wt, n, seqs)
+    a = hip.Lattices(ctx, [packed_lattice(wt, n, [[l] for l in s])[0] for s in seqs])
+    ug = np.arange(5, dtype=np.int32)
+    try:
+        ra = a.align_segments(b, utt_lattice=ug)
+    except hip.BackendError as e:          # an unreachable utterance: the back-trace runs into the start row
+        with pytest.raises(hip.BackendError):
+            t.align_segments(b, utt_lattice=ug)
+        assert "predecessor" in str(e)
+    else:
+        rt = t.align_segments(b, utt_lattice=ug)
+        np.testing.assert_array_equal(rt["frame_state"], ra["frame_state"])
+        np.testing.assert_array_equal(rt["segment_start"], ra["segment_start"])
+    keep = [0, 2, 3, 4]                                               # without the unreachable one: T == 1 is still in
+    b2 = b.gather(np.concatenate([np.arange(b.offsets[u], b.offsets[u + 1]) for u in keep]),
+                  offsets=np.concatenate([[0], np.cumsum([len(xs[u]) for u in keep])]))
+    b2.loglik(gmm, fetch=False)
+    ug2 = np.array(keep, dtype=np.int32)
+    rt, ra = t.align_segments(b2, utt_lattice=ug2), a.align_segments(b2, utt_lattice=ug2)
+    np.testing.assert_array_equal(rt["frame_state"], ra["frame_state"])
+    np.testing.assert_array_equal(rt["end_cost_flat"], ra["end_cost_flat"])
+    assert rt["frame_state"][0] == -1                                 # the single frame of a T == 1 utterance joins nothing
+    ft, fa = t.forward_backward(b2, utt_lattice=ug2, want_occ=True), a.forward_backward(b2, utt_lattice=ug2, want_occ=True)
+    np.testing.assert_array_equal(ft["logp"], fa["logp"])
+    np.testing.assert_array_equal(ft["occ"], fa["occ"])
+    with pytest.raises(hip.BackendError):
+        b.gather([0, b.N])
+    e = b.gather(np.zeros(0, dtype=np.int64))
+    assert e.N == 0 and e.U == 1
+    e.close()
+    for h in (t, a):
+        h.close()
+    b.close(); b2.close()
+    gmm.close()
