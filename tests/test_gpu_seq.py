@@ -298,6 +298,13 @@ def test_transcripts_handle_equals_arc_list_handle(hip, ctx, W, n, skip, Kmax):
     same(b)
     np.testing.assert_array_equal(t.align_segments(b, utt_lattice=utt_graph)["frame_state"],
                                   a.align_segments(b, utt_lattice=utt_graph)["frame_state"])
+    # label mode (main.py:59-67 on the device) through the sequence-form kernels: the transcript comes back
+    row_word = [np.where(g["row_state"] >= 0, g["row_state"] // n, -1).astype(np.int32) for g in graphs]
+    la = a.viterbi_labels(b, row_word, utt_lattice=utt_graph, max_labels=Kmax + 1)
+    lt = t.viterbi_labels(b, row_word, utt_lattice=utt_graph, max_labels=Kmax + 1)
+    for u in range(b.U):
+        np.testing.assert_array_equal(lt["labels"][u], la["labels"][u])
+        assert [int(v) for v in lt["labels"][u]] == list(transcripts[utt_graph[u]])
     fa = a.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
     ft = t.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
     np.testing.assert_array_equal(ft["logp"], fa["logp"])
