@@ -383,7 +383,7 @@ def _training_config(ctx, U, K=7):
     """configs[2]'s model on K-word transcripts (the reference's own training data are digit strings,
     continuous_speech.py:56-179): (a) the alignment + regrouping step of continuous_train -- own-state likelihoods,
     forced-alignment Viterbi through one graph per distinct transcript, frames regrouped per state
-    (gh_lattices_create_transcripts + gh_loglik_subset + gh_align_segments); (b) one soft-EM iteration on the same
+    (gh_lattices_create_transcripts + gh_loglik_sets + gh_align_segments); (b) one soft-EM iteration on the same
     transcripts (forward-backward in sequence form + statistics + host M-step, graphs rebuilt from the new costs)."""
     from sr.recognition import _hip
     from sr.recognition.train import BaumWelchTrainer
@@ -398,12 +398,12 @@ def _training_config(ctx, U, K=7):
     keys, utt_graph = {}, np.empty(U, dtype=np.int32)
     for u, l in enumerate(labels):
         utt_graph[u] = keys.setdefault(tuple(l), len(keys))
-    lo = np.array([min(l) * n for l in labels], dtype=np.int32)
-    hi = np.array([(max(l) + 1) * n for l in labels], dtype=np.int32)
+    from sr.recognition.continuous_speech import transcript_state_sets
+    sets = transcript_state_sets(labels, n, W)
 
     def align():
         lat = _hip.Lattices.from_transcripts(ctx, [wl["trans"]] * W, n, list(keys))
-        b.loglik(gmm, fetch=False, state_ranges=(lo, hi))
+        b.loglik(gmm, fetch=False, state_sets=sets)
         r = lat.align_segments(b, utt_lattice=utt_graph)
         lat.close()
         return r

@@ -138,6 +138,11 @@ int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host /*[N,S] 
  * models: a tenth of the work of gh_loglik. */
 int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo /*[U]*/,
                      const int32_t* state_hi /*[U]*/);
+/* The same with SEVERAL state ranges per utterance: utterance u needs [state_lo[r], state_hi[r]) for r in
+ * [range_off[u], range_off[u+1]) -- the states of the words of its transcript (continuous_speech.py:80: the lattice of an
+ * utterance holds its own words' states only), which for word strings is a set, not an interval. */
+int gh_loglik_sets(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int64_t* range_off /*[U+1]*/,
+                   const int32_t* state_lo, const int32_t* state_hi);
 void* gh_loglik_dev_ptr(gh_batch* b);
 /* copy of the resident [N,S] likelihood matrix (dtype of the batch) after gh_loglik / gh_loglik_subset */
 int gh_loglik_fetch(gh_ctx* ctx, const gh_batch* b, void* out_host /*[N,S]*/);

@@ -258,4 +258,4 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
                            bool seq = false);
 int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
-                          const int32_t* st_hi = nullptr);
+                          const int32_t* st_hi = nullptr, const int64_t* rng_off = nullptr);   // rng_off: several ranges per utterance

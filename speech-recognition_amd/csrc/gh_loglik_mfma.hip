@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
 
 template <typename T>
 int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk, const int32_t* st_lo,
-                  const int32_t* st_hi, const T* cen) {
+                  const int32_t* st_hi, const T* cen, const int64_t* rng_off) {
     const int64_t N = b->N;
     if (N == 0) return GH_OK;
     const int KS = g->KP / 2;
@@ -532,17 +532,36 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     if (st_lo) {
         std::vector<gh_loglik_blk> tabv;
         max_tiles = 1;
+        // rng_off == null: one state range per utterance; else utterance u owns the ranges [rng_off[u], rng_off[u + 1]) --
+        // the states of its transcript's words.  Ranges become runs of Gaussian tiles; runs that touch are merged (two
+        // words may share a tile), and every run gets its own table entries for the utterance's 32-frame blocks.
+        std::vector<std::pair<int, int>> runs;
         for (int64_t u = 0; u < b->U; ++u) {
-            const int lo = st_lo[u], hi = st_hi[u];
-            if (lo < 0 || hi > S || lo >= hi) { gh_set_error("gh_loglik_subset: utterance %lld has state range [%d, %d)", (long long)u, lo, hi); return GH_ERR_INVALID; }
-            int t0, t1;
-            if (M_pad <= 16) { const int spt = 16 / M_pad; t0 = lo / spt; t1 = (hi + spt - 1) / spt; }
-            else { const int tps = M_pad / 16; t0 = lo * tps; t1 = hi * tps; }
-            const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
-            if (span > SC) return 1;   // range wider than one LDS chunk: the caller computes the full matrix
-            max_tiles = std::max(max_tiles, t1 - t0);
-            for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
-                tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), t0, t1, 0});
+            runs.clear();
+            const int64_t r0 = rng_off ? rng_off[u] : u, r1 = rng_off ? rng_off[u + 1] : u + 1;
+            for (int64_t r = r0; r < r1; ++r) {
+                const int lo = st_lo[r], hi = st_hi[r];
+                if (lo < 0 || hi > S || lo >= hi) { gh_set_error("gh_loglik_subset: utterance %lld has state range [%d, %d)", (long long)u, lo, hi); return GH_ERR_INVALID; }
+                int t0, t1;
+                if (M_pad <= 16) { const int spt = 16 / M_pad; t0 = lo / spt; t1 = (hi + spt - 1) / spt; }
+                else { const int tps = M_pad / 16; t0 = lo * tps; t1 = hi * tps; }
+                runs.push_back({t0, t1});
+            }
+            std::sort(runs.begin(), runs.end());
+            size_t w = 0;
+            for (size_t i = 0; i < runs.size(); ++i) {
+                if (w > 0 && runs[i].first <= runs[w - 1].second) runs[w - 1].second = std::max(runs[w - 1].second, runs[i].second);
+                else runs[w++] = runs[i];
+            }
+            runs.resize(w);
+            for (const auto& tr : runs) {
+                const int t0 = tr.first, t1 = tr.second;
+                const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
+                if (span > SC) return 1;   // run wider than one LDS chunk: the caller computes the full matrix
+                max_tiles = std::max(max_tiles, t1 - t0);
+                for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
+                    tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), t0, t1, 0});
+            }
         }
         n_blk = (int64_t)tabv.size();
         if (n_blk == 0) return GH_OK;
@@ -599,8 +618,9 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
 }  // namespace
 
 // returns 1 when the shape is not covered (caller uses the VALU kernel), <0 on error
-int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi) {
+int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
+                          const int64_t* rng_off) {
     if (!g->dApk64) return 1;
-    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr);
-    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32);
+    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr, rng_off);
+    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32, rng_off);
 }

@@ -266,9 +266,14 @@ extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_ho
     return GH_OK;
 }
 
-extern "C" int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo, const int32_t* state_hi) {
-    GH_REQUIRE(ctx && g && b && state_lo && state_hi, "gh_loglik_subset: NULL argument");
-    GH_REQUIRE(g->D == b->D, "gh_loglik_subset: feature dim %d != model dim %d (hmm_state.py:45)", b->D, g->D);
+static int loglik_subset_impl(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo, const int32_t* state_hi,
+                              const int64_t* range_off, const char* who) {
+    GH_REQUIRE(ctx && g && b && state_lo && state_hi, "%s: NULL argument", who);
+    GH_REQUIRE(g->D == b->D, "%s: feature dim %d != model dim %d (hmm_state.py:45)", who, b->D, g->D);
+    if (range_off) {
+        GH_REQUIRE(range_off[0] == 0, "%s: range_off must start at 0", who);
+        for (int64_t u = 0; u < b->U; ++u) GH_REQUIRE(range_off[u + 1] >= range_off[u], "%s: range_off not monotone at %lld", who, (long long)u);
+    }
     GH_HIP(hipSetDevice(ctx->device));
     const size_t esz = b->dtype == GH_F64 ? 8 : 4;
     if (b->nll && b->nll_S != g->S) {
@@ -281,9 +286,19 @@ extern "C" int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const
         GH_HIP(hipMemsetAsync(b->nll, 0, (size_t)b->N * g->S * esz, ctx->stream));   // entries outside the ranges stay defined
         b->nll_S = g->S;
     }
-    int rc = gh_launch_loglik_mfma(ctx, g, b, state_lo, state_hi);
+    int rc = gh_launch_loglik_mfma(ctx, g, b, state_lo, state_hi, range_off);
     if (rc == 1) return gh_loglik(ctx, g, b, nullptr);   // shape / range not covered: the full matrix is a superset
     return rc;
+}
+
+extern "C" int gh_loglik_subset(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* state_lo, const int32_t* state_hi) {
+    return loglik_subset_impl(ctx, g, b, state_lo, state_hi, nullptr, "gh_loglik_subset");
+}
+
+extern "C" int gh_loglik_sets(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int64_t* range_off, const int32_t* state_lo,
+                              const int32_t* state_hi) {
+    GH_REQUIRE(range_off, "gh_loglik_sets: NULL argument");
+    return loglik_subset_impl(ctx, g, b, state_lo, state_hi, range_off, "gh_loglik_sets");
 }
 
 extern "C" void* gh_loglik_dev_ptr(gh_batch* b) { return b ? b->nll : nullptr; }

@@ -55,6 +55,7 @@ SIGNATURES = {
                                            C.c_double, C.c_double, C.c_int64, C.c_void_p, _c_i64p, _c_i64p,
                                            C.POINTER(C.c_void_p)]),
     "gh_loglik": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gh_loglik_sets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i64p, _c_i32p, _c_i32p]),
     "gh_loglik_subset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p]),
     "gh_loglik_dev_ptr": (C.c_void_p, [C.c_void_p]),
     "gh_loglik_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -362,10 +363,24 @@ class Batch:
         _check(self.ctx.lib, self.ctx.lib.gh_batch_fetch_features(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
         return [out[self.offsets[u]:self.offsets[u + 1]] for u in range(self.U)]
 
-    def loglik(self, gmm, fetch=True, state_ranges=None):
+    def loglik(self, gmm, fetch=True, state_ranges=None, state_sets=None):
         """A3 for every frame x state; the [N,S] matrix stays resident for the DPs.
         state_ranges = (lo [U], hi [U]): only the states [lo[u], hi[u]) of utterance u are needed (forced alignment /
-        EM with known transcripts); the other entries of the matrix are then unspecified."""
+        EM with known transcripts); the other entries of the matrix are then unspecified.
+        state_sets = (range_off [U+1], lo, hi): several ranges per utterance (the words of its transcript)."""
+        if state_sets is not None:
+            off = np.ascontiguousarray(state_sets[0], dtype=np.int64)
+            lo = np.ascontiguousarray(state_sets[1], dtype=np.int32)
+            hi = np.ascontiguousarray(state_sets[2], dtype=np.int32)
+            assert len(off) == self.U + 1 and len(lo) == len(hi) == int(off[-1])
+            _check(self.ctx.lib, self.ctx.lib.gh_loglik_sets(self.ctx.h, gmm.h, self.h, _ptr(off, _c_i64p), _ptr(lo, _c_i32p),
+                                                             _ptr(hi, _c_i32p)))
+            self.S = gmm.S
+            if not fetch:
+                return None
+            out = np.empty((self.N, gmm.S), dtype=self.np_dtype)
+            _check(self.ctx.lib, self.ctx.lib.gh_loglik_fetch(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
+            return out
         if state_ranges is not None:
             lo = np.ascontiguousarray(state_ranges[0], dtype=np.int32)
             hi = np.ascontiguousarray(state_ranges[1], dtype=np.int32)

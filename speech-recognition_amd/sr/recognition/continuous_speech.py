@@ -159,16 +159,35 @@ def packed_loop_lattice(word_transitions, n_per_word, word_penalty=0.0, state_ba
                 end_rows=np.asarray(ends, dtype=np.int32)), [0, loop_row]
 
 
+def transcript_state_sets(label_seqs, n, n_words):
+    """(range_off [U+1], lo, hi) for `Batch.loglik(state_sets=...)`: the state ranges of the DISTINCT words of every
+    transcript (word w owns the states [w * n, (w + 1) * n)), consecutive words merged; an empty transcript asks for
+    every state."""
+    off, lo, hi = [0], [], []
+    for labels in label_seqs:
+        words = sorted(set(int(l) for l in labels)) if len(labels) else list(range(n_words))
+        start = prev = None
+        for w in words:
+            if prev is not None and w == prev + 1:
+                prev = w
+                continue
+            if start is not None:
+                lo.append(start * n); hi.append((prev + 1) * n)
+            start = prev = w
+        if start is not None:
+            lo.append(start * n); hi.append((prev + 1) * n)
+        off.append(len(lo))
+    return np.asarray(off, dtype=np.int64), np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
+
+
 def _alignment_lattices(frames, models, label_seqs):
     """Likelihoods of every utterance against the states of its own words, and its one-word-per-layer lattice
     (continuous_speech.py:80-82): (device lattices, distinct transcripts, transcript index per utterance)."""
     ctx = frames.ctx
     n = len(models[0].gmm_states)
     gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
-    # an utterance's lattice only contains the states of its own words: likelihoods for that state range only
-    lo = np.array([min(labels) * n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
-    hi = np.array([(max(labels) + 1) * n if len(labels) else len(models) * n for labels in label_seqs], dtype=np.int32)
-    frames.loglik(gmm, fetch=False, state_ranges=(lo, hi))
+    # an utterance's lattice only contains the states of its own words: likelihoods for those states only
+    frames.loglik(gmm, fetch=False, state_sets=transcript_state_sets(label_seqs, n, len(models)))
     keys, transcripts, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
     for u, labels in enumerate(label_seqs):
         key = tuple(int(l) for l in labels)

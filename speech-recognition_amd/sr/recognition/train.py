@@ -65,11 +65,9 @@ class BaumWelchTrainer:
             self.utt_graph[u] = keys[key]
         self.lat = None
         self._build_lattices()
-        # an utterance's alignment only involves the states of its own words: likelihoods for that range only
-        lo = np.array([min(int(l) for l in labels) * self.n if len(labels) else 0 for labels in label_seqs], dtype=np.int32)
-        hi = np.array([(max(int(l) for l in labels) + 1) * self.n if len(labels) else self.S for labels in label_seqs],
-                      dtype=np.int32)
-        self.state_ranges = (lo, hi)
+        # an utterance's alignment only involves the states of its own words: likelihoods for those states only
+        from .continuous_speech import transcript_state_sets
+        self.state_sets = transcript_state_sets(label_seqs, self.n, self.W)
         self.history = []
         self.converged = False
         self.n_stats = self.S * self.M * (1 + 2 * self.D)
@@ -98,7 +96,7 @@ class BaumWelchTrainer:
         try:
             if self.batch.U == 0:
                 return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), np.zeros(self.S), 0.0
-            self.batch.loglik(gmm, fetch=False, state_ranges=self.state_ranges)
+            self.batch.loglik(gmm, fetch=False, state_sets=self.state_sets)
             r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False,
                                           want_self_xi=True)
             stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor, stats_dev=stats_dev, fetch=stats_dev is None)

@@ -94,7 +94,7 @@ class Batch:
     def features(self):
         return [self.utt(u).astype(self.np_dtype) for u in range(self.U)]
 
-    def loglik(self, gmm, fetch=True, state_ranges=None):
+    def loglik(self, gmm, fetch=True, state_ranges=None, state_sets=None):
         with np.errstate(divide="ignore", invalid="ignore"):
             self.nll = np.array([[O.gmm_evaluate(x, gmm.mean[s], gmm.var[s], gmm.w[s]) for s in range(gmm.S)]
                                  for x in self.feats]).reshape(self.N, gmm.S)

@@ -133,7 +133,7 @@ def test_c3_em_statistics_of_sampled_states_vs_numpy():
     assert xi.shape == (tr.S,) and np.all(xi >= 0) and np.all(xi <= stats[:, :, 0].sum(axis=1) + 1e-6)
     assert np.isfinite(ll) and ll < 0
     gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
-    tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)
+    tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets)
     occ = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True)["occ"]
     gmm.close()
     X = np.concatenate(data)
@@ -265,7 +265,7 @@ def test_c3_training_loop_transitions_convergence_and_pickles(tmp_path):
     counts = stats[:, :, 0].sum(axis=1)
     # expected self transitions of a few states from the forward / backward matrices of the generic kernel
     gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
-    tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)
+    tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets)
     nll = tr.batch.loglik(gmm, fetch=True)
     r = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_matrices=True, want_self_xi=True)
     np.testing.assert_allclose(r["self_xi"], xi, rtol=1e-9, atol=1e-9)       # generic kernel (atomics) == chain kernel

@@ -534,3 +534,30 @@ def test_new_entry_points_edge_cases(hip, ctx):
         h.close()
     b.close(); b2.close()
     gmm.close()
+
+
+def test_loglik_state_sets(hip, ctx):
+    """gh_loglik_sets: several state ranges per utterance (the words of a transcript).  Requested entries are BITWISE those
+    of the full matrix, for fp64 and fp32, mixtures of 8 / 1 / 32 components, ranges that share a Gaussian tile, a range
+    list that covers everything, and an empty list (nothing requested for that utterance)."""
+    from sr.recognition.continuous_speech import transcript_state_sets
+    rng = np.random.default_rng(12)
+    for W, n, M, D in ((10, 5, 8, 39), (12, 3, 1, 13), (6, 4, 32, 7)):
+        S = W * n
+        gmm = hip.PackedGMM(ctx, rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D)), rng.dirichlet(np.ones(M), size=S))
+        xs = [rng.normal(size=(int(rng.integers(1, 90)), D)) for _ in range(40)]
+        seqs = [[int(v) for v in rng.integers(0, W, size=int(rng.integers(1, 8)))] for _ in xs]
+        seqs[3] = list(range(W))
+        sets = transcript_state_sets(seqs, n, W)
+        for dt in (np.float64, np.float32):
+            b = hip.Batch(ctx, xs, dtype=dt)
+            full = b.loglik(gmm, fetch=True).copy()
+            b2 = hip.Batch(ctx, xs, dtype=dt)
+            sub = b2.loglik(gmm, fetch=True, state_sets=sets)
+            for u, l in enumerate(seqs):
+                cols = np.concatenate([np.arange(w * n, (w + 1) * n) for w in sorted(set(l))])
+                np.testing.assert_array_equal(sub[b.offsets[u]:b.offsets[u + 1]][:, cols], full[b.offsets[u]:b.offsets[u + 1]][:, cols])
+            b.close(); b2.close()
+        gmm.close()
+    off, lo, hi = transcript_state_sets([[2, 3, 7, 3], [], [0]], 5, 10)
+    assert off.tolist() == [0, 2, 3, 4] and lo.tolist() == [10, 35, 0, 0] and hi.tolist() == [20, 40, 50, 5]

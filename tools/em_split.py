@@ -24,7 +24,7 @@ def tick(name, t0):
 R = 10
 for _ in range(R):
     t0 = time.perf_counter(); gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights); tick("PackedGMM", t0)
-    t0 = time.perf_counter(); tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges); tick("loglik_subset", t0)
+    t0 = time.perf_counter(); tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets); tick("loglik_subset", t0)
     t0 = time.perf_counter(); r = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True, fetch_occ=False, want_self_xi=True); tick("forward_backward", t0)
     t0 = time.perf_counter(); stats = tr.batch.bw_accumulate(gmm); tick("bw_accumulate", t0)
     t0 = time.perf_counter(); gmm.close(); tick("gmm.close", t0)

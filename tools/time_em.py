@@ -41,7 +41,7 @@ def t(fn, reps=3):
     ctx.sync(); return (time.perf_counter() - t0) / reps * 1e3
 print(json.dumps(dict(utts=U, frames=int(tr.batch.N),
                       loglik_full_ms=t(lambda: tr.batch.loglik(gmm, fetch=False)),
-                      loglik_own_states_ms=t(lambda: tr.batch.loglik(gmm, fetch=False, state_ranges=tr.state_ranges)),
+                      loglik_own_states_ms=t(lambda: tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets)),
                       fwdbwd_ms=t(lambda: tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True, fetch_occ=False, want_self_xi=True)),
                       bw_stats_ms=t(lambda: tr.batch.bw_accumulate(gmm)),
                       monotone=bool(all(b >= a - 1e-7 * abs(a) for a, b in zip(hist, hist[1:]))))))
