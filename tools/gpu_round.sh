@@ -1,6 +1,6 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02r
+O=gpurun_out/r02s
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; echo "pytest exit $?" >> $O/tests.log; tail -3 $O/tests.log
 python3 bench.py > $O/bench_f64.json 2> $O/bench_f64.err; echo "bench f64 exit $?"
