@@ -476,8 +476,8 @@ def pcie_inclusive(dev, wl, npdt, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight per GPU (one HIP stream + one host thread each): the host side of a step "
                          "overlaps the other batch's kernels")
