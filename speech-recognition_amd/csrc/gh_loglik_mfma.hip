@@ -422,6 +422,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     };
 
     const int nb = MULTI ? bpw : 1;
+    int64_t staged_n0 = -1;
     for (int ib = 0; ib < nb; ++ib, n0 += 32) {
         if (subset) {
             const int64_t k = kb0 + ib;
@@ -433,8 +434,11 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             if (MULTI && n0 >= N) break;
             nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
         }
-        stage_frames();
-        build_b();
+        if (!(subset && ib > 0 && n0 == staged_n0)) {   // (block table: the previous entry may cover the same frames)
+            stage_frames();
+            build_b();
+            staged_n0 = n0;
+        }
         chunk_s0 = (MP <= 16) ? t_lo * (16 / (MP <= 16 ? MP : 16)) : t_lo / tiles_per_state;   // 0 without a block table
         if (subset) {
             const int s_end = (MP <= 16) ? t_hi * (16 / (MP <= 16 ? MP : 16)) : t_hi / tiles_per_state;
@@ -559,9 +563,12 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
                 const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
                 if (span > SC) return 1;   // run wider than one LDS chunk: the caller computes the full matrix
                 max_tiles = std::max(max_tiles, t1 - t0);
-                for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
-                    tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), t0, t1, 0});
             }
+            // block-major: the entries of one 32-frame block (one per run) follow each other, so a wave that takes
+            // several of them stages the frames once
+            for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
+                for (const auto& tr : runs)
+                    tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), tr.first, tr.second, 0});
         }
         n_blk = (int64_t)tabv.size();
         if (n_blk == 0) return GH_OK;
