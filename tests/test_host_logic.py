@@ -133,6 +133,25 @@ def test_sequence_report_is_the_tally_of_reference_main(R):
     assert sequence_report([], [])["sequence_accuracy"] == 0
 
 
+def test_transcript_helpers_match_the_packed_lattice(R):
+    """`transcript_row_state` / `transcript_state_sets` (what the transcripts handle and gh_loglik_sets are fed with)
+    against the rows and states of the graph `packed_lattice` builds for the same label string."""
+    from sr.recognition.continuous_speech import packed_lattice, transcript_row_state, transcript_state_sets
+    rng = np.random.default_rng(0)
+    n, W = 4, 9
+    wt = [np.where(np.tri(n, n, 0, dtype=bool) & ~np.tri(n, n, -3, dtype=bool), 1.0, np.inf).T for _ in range(W)]
+    seqs = [[int(v) for v in rng.integers(0, W, size=int(rng.integers(1, 9)))] for _ in range(20)]
+    off, lo, hi = transcript_state_sets(seqs, n, W)
+    for u, l in enumerate(seqs):
+        g = packed_lattice(wt, n, [[w] for w in l])[0]
+        np.testing.assert_array_equal(transcript_row_state(l, n), g["row_state"])
+        want = sorted(set(int(s) for s in g["row_state"] if s >= 0))
+        got = sorted(s for r in range(off[u], off[u + 1]) for s in range(lo[r], hi[r]))
+        assert got == want
+        assert all(hi[r] < lo[r + 1] for r in range(off[u], off[u + 1] - 1))        # disjoint, ascending, merged
+    assert transcript_state_sets([[]], n, W)[1:] == (0, n * W) or list(transcript_state_sets([[]], n, W)[2]) == [n * W]
+
+
 def test_cut_segments_matches_reference_rule(R):
     """The frame ranges cut from the reference's own alignment path, against the oracle's
     restatement of continuous_speech.py:90-106."""
