@@ -41,5 +41,6 @@ test_kmeans = G.test_kmeans
 test_hmm_fit_single_gaussian = G.test_hmm_fit_single_gaussian
 test_hmm_fit_gmm = G.test_hmm_fit_gmm
 test_continuous_train = G.test_continuous_train
+test_continuous_train_8mix = G.test_continuous_train_8mix
 test_reference_pickle_scores_identically = G.test_reference_pickle_scores_identically
 test_feature_stack_matches_reference = G.test_feature_stack_matches_reference

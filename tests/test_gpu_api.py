@@ -345,6 +345,39 @@ def test_continuous_train(R, iters, tmp_path):
         np.testing.assert_allclose(h.transitions, g[p + "transitions"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("iters", [1, 2])
+def test_continuous_train_8mix(R, iters, tmp_path):
+    """G17: the reference's continuous_train at 13 dims / 8 mixtures (three binary splits) / 4 words of 3 states, strings
+    of 2-4 words with repeats -- the whole device pipeline (own-state likelihoods, forced alignment + regrouping,
+    lock-step split k-means with device centroid sums, EM) against the models the reference wrote."""
+    g = load_golden("G17_continuous_train_8mix")
+    W, U, ng, nseg = int(g["n_words"]), int(g["n_utts"]), int(g["n_gaussians"]), int(g["n_segments"])
+    data = [g["x%d" % i] for i in range(U)]
+    labels = [list(g["labels%d" % i]) for i in range(U)]
+    models = []
+    for wi in range(W):
+        h = make_hmm(R, g["init%d_means" % wi], g["init%d_vars" % wi], g["init%d_w" % wi],
+                     g["init%d_transitions" % wi])
+        for s, st in enumerate(h.gmm_states):
+            st.mu_old[:] = g["init%d_mu_old" % wi][s]
+            st.sigma_old[:] = g["init%d_sigma_old" % wi][s]
+            st.w_old[:] = g["init%d_w_old" % wi][s]
+            st.parent = h
+        models.append(h)
+    np.random.seed(19)
+    with quiet():
+        R.continuous_train(data, models, labels, str(tmp_path), n_gaussians=ng, n_segments=nseg, max_iteration=iters)
+    for wi in range(W):
+        with open(os.path.join(str(tmp_path), "%d.pkl" % wi), "rb") as f:
+            h = pickle.load(f)
+        m, v, w = pack_hmm(h)
+        p = "it%d_%d_" % (iters, wi)
+        np.testing.assert_allclose(m, g[p + "means"], rtol=1e-6)
+        np.testing.assert_allclose(v, g[p + "vars"], rtol=1e-6)
+        np.testing.assert_allclose(w, g[p + "w"], rtol=1e-6)
+        np.testing.assert_allclose(h.transitions, g[p + "transitions"], rtol=1e-9)
+
+
 # ------------------------------------------------------- A13 + 8(e): soft EM loop
 def test_baum_welch_trainer_increases_likelihood(R):
     """Forward-backward E-step + statistics + M-step: the total log-likelihood is monotone

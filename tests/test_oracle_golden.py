@@ -351,6 +351,34 @@ def test_G11_continuous_train(iters):
         close(out[wi]["transitions"], g[p + "transitions"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("iters", [1, 2])
+def test_G17_continuous_train_8mix(iters):
+    """A second capture of the reference's continuous_train: 13-dim, 8 mixtures (three binary splits), 4 words of 3
+    states, label strings of 2-4 words with repeats."""
+    g = load_golden("G17_continuous_train_8mix")
+    W, U, ng, nseg = int(g["n_words"]), int(g["n_utts"]), int(g["n_gaussians"]), int(g["n_segments"])
+    data = [g["x%d" % i] for i in range(U)]
+    labels = [list(g["labels%d" % i]) for i in range(U)]
+    models = []
+    for wi in range(W):
+        n = g["init%d_means" % wi].shape[0]
+        models.append(dict(transitions=g["init%d_transitions" % wi].copy(), gmm=[
+            dict(means=g["init%d_means" % wi][s].copy(), vars=g["init%d_vars" % wi][s].copy(),
+                 w=g["init%d_w" % wi][s].copy(), mu_old=g["init%d_mu_old" % wi][s].copy(),
+                 sigma_old=g["init%d_sigma_old" % wi][s].copy(), w_old=g["init%d_w_old" % wi][s].copy())
+            for s in range(n)]))
+    np.random.seed(19)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out, n_it, _ = O.continuous_train(data, models, labels, n_gaussians=ng, n_segments=nseg, max_iteration=iters)
+    for wi in range(W):
+        p = "it%d_%d_" % (iters, wi)
+        close(np.array([s["means"] for s in out[wi]["gmm"]]), g[p + "means"], rtol=1e-7)
+        close(np.array([s["vars"] for s in out[wi]["gmm"]]), g[p + "vars"], rtol=1e-7)
+        close(np.array([s["w"] for s in out[wi]["gmm"]]), g[p + "w"], rtol=1e-7)
+        close(out[wi]["transitions"], g[p + "transitions"], rtol=1e-9)
+
+
 # --------------------------------------------------------------------------- A13
 def _brute_force(E, is_nes, trans, end_rows):
     """Enumerate every path of the A6 lattice semantics explicitly."""

@@ -434,7 +434,51 @@ def g11(R):
     save("G11_continuous_train", **out)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G16=g16)
+def g17(R):
+    """continuous_train once more, at a shape closer to the real task: 13-dim features, 8 mixtures (three binary splits),
+    4 words of 3 states, label strings of 2-4 words with repeats; 1 and 2 outer iterations."""
+    rng = np.random.default_rng(1717)
+    W, n, D, ng = 4, 3, 13, 8
+    means, vars_, w, _ = synth_model(rng, W, n, 2, D)
+    means *= 2.0
+    iso = [[synth_utt(rng, means, vars_, [wd], 40, 60) for _ in range(10)] for wd in range(W)]
+    np.random.seed(17)
+    with quiet():
+        hmms = [R.HMM(n).fit([y.copy() for y in iso[wd]], ng) for wd in range(W)]
+    for h in hmms:
+        for s in h.gmm_states:
+            s.parent = h
+    label_seqs = [[0, 1, 2], [3, 3], [2, 0, 1, 3], [1, 1, 0], [3, 2], [0, 3, 1], [2, 2, 2], [1, 0], [3, 1, 2, 0], [0, 0, 3],
+                  [2, 3, 1], [1, 2]]
+    data = [synth_utt(rng, means, vars_, ls, 40, 60) for ls in label_seqs]
+    out = dict(n_utts=np.array(len(data)), n_words=np.array(W), n_gaussians=np.array(ng), n_segments=np.array(n))
+    for i, (x, ls) in enumerate(zip(data, label_seqs)):
+        out["x%d" % i] = x
+        out["labels%d" % i] = np.array(ls)
+    for wi, h in enumerate(hmms):
+        m, v, ww = pack_hmm(h)
+        out.update({"init%d_means" % wi: m, "init%d_vars" % wi: v, "init%d_w" % wi: ww,
+                    "init%d_transitions" % wi: h.transitions,
+                    "init%d_mu_old" % wi: np.array([g.mu_old for g in h.gmm_states]),
+                    "init%d_sigma_old" % wi: np.array([g.sigma_old for g in h.gmm_states]),
+                    "init%d_w_old" % wi: np.array([g.w_old for g in h.gmm_states])})
+    import copy
+    import pickle
+    for iters in (1, 2):
+        models = copy.deepcopy(hmms)
+        np.random.seed(19)
+        with tempfile.TemporaryDirectory() as tmp, quiet():
+            R.continuous_train([x.copy() for x in data], models, label_seqs, tmp, n_gaussians=ng,
+                               n_segments=n, max_iteration=iters)
+            res = [pickle.load(open(os.path.join(tmp, "%d.pkl" % i), "rb")) for i in range(W)]
+        for wi, h in enumerate(res):
+            m, v, ww = pack_hmm(h)
+            out.update({"it%d_%d_means" % (iters, wi): m, "it%d_%d_vars" % (iters, wi): v,
+                        "it%d_%d_w" % (iters, wi): ww, "it%d_%d_transitions" % (iters, wi): h.transitions})
+    save("G17_continuous_train_8mix", **out)
+
+
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G16=g16, G17=g17)
 
 
 def g12(R):
