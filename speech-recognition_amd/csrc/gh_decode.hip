@@ -185,8 +185,9 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             GH_REQUIRE(path_off[u + 1] - path_off[u] >= (T > 1 ? T * lat->lat[l].nlev : 0),
                        "gh_viterbi: path capacity of utterance %lld too small", (long long)u);
         }
-    // back-pointer scratch is chunked (<= 4 GiB per launch)
-    const size_t BP_BUDGET = (size_t)4 << 30;
+    // back-pointer scratch is chunked (<= 24 GiB per launch)
+    // (sized for a 288 GB part: C5's 125 000 utterances need 5.1 GB of decision words -- one launch instead of two)
+    const size_t BP_BUDGET = (size_t)24 << 30;
     std::vector<int64_t> bp_off(U, 0);
     std::vector<int64_t> chunk_begin{0};
     size_t bp_max = 0;
@@ -583,8 +584,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
         b->occ_S = S;
     }
-    // alpha scratch, chunked (<= 4 GiB per launch), launch order = longest first
-    const size_t BUDGET = (size_t)4 << 30;
+    // alpha scratch, chunked (<= 24 GiB per launch), launch order = longest first
+    const size_t BUDGET = (size_t)24 << 30;
     const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
     GH_REQUIRE(!lat->deferred_src || use_fbseq, "gh_forward_backward: internal: a transcripts handle left the sequence-form path unexpanded");
     std::vector<int64_t> soff(U, 0), chunk_begin{0};
