@@ -15,9 +15,15 @@ import numpy as np
 from . import _hip
 
 
+_NES = None
+
+
 def is_nes(state):
-    from .hmm_state import NES
-    return type(state) == NES  # the reference tests the exact type (decode.py:109)
+    global _NES
+    if _NES is None:          # (hmm_state imports this module: resolved on first use, not once per row)
+        from .hmm_state import NES
+        _NES = NES
+    return type(state) == _NES  # the reference tests the exact type (decode.py:109)
 
 
 def gmm_arrays(g):
@@ -64,12 +70,18 @@ def stack_gmms(gmms):
     return means, vars_, w
 
 
+try:                      # content keys of the handle caches: a 128-bit non-cryptographic hash is all that is needed
+    import xxhash as _xx     # (blake2b took 2 ms for the 1 MB transition matrix of a K = 7 lattice: twice the decode itself)
+except ImportError:          # pragma: no cover
+    _xx = None
+
+
 def _digest(*arrays):
-    h = hashlib.blake2b(digest_size=16)
+    h = _xx.xxh3_128() if _xx is not None else hashlib.blake2b(digest_size=16)
     for a in arrays:
         a = np.ascontiguousarray(a)
-        h.update(str(a.shape).encode())
-        h.update(a.tobytes())
+        h.update(("%s%s" % (a.dtype.str, a.shape)).encode())
+        h.update(memoryview(a).cast("B") if a.size else b"")
     return h.digest()
 
 
