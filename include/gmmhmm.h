@@ -358,6 +358,33 @@ int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b,
 int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor,
                      double* out_stats /*[S,M,1+2D] or NULL*/, double* stats_dev /*or NULL*/);
 
+/* --------------------------------------------- multi-GPU: the exchange step (RCCL over xGMI)
+ * No reference counterpart (the reference is one process).  One process per GPU;
+ * utterances are sharded, models replicated, and the ONLY data-path collective is the sum of the EM sufficient
+ * statistics (the sums of hmm_state.py:134-148) over the ranks -- enqueued on the context's stream, so the kernels
+ * that produce the statistics and the M-step that consumes them order themselves around it without a host sync.
+ * librccl is opened on the first call (from the directory of the HIP runtime this library is bound to), never at
+ * load time.
+ *   gh_comm_unique_id  rank 0 makes the 128-byte id; the host side hands it to the other ranks (a TCP
+ *                      socket on MASTER_ADDR, like the launcher's rendezvous)
+ *   gh_comm_create     ncclCommInitRank on the context's GPU; collective over all ranks
+ *   gh_stats_allreduce in-place fp64 sum of stats_dev[0..n) over the ranks, asynchronous on ctx's stream
+ *   gh_comm_allreduce_host  the same for a small host buffer (sum, or max when op_max != 0), synchronous
+ *   gh_comm_barrier    a one-element all-reduce + stream sync
+ *   gh_comm_count      ncclCommCount: the number of ranks RCCL itself reports */
+#define GH_COMM_ID_BYTES 128
+typedef struct gh_comm gh_comm;
+int gh_comm_unique_id(char* out_id /*[GH_COMM_ID_BYTES]*/);
+int gh_comm_create(gh_ctx* ctx, int rank, int world, const char* unique_id /*[GH_COMM_ID_BYTES]*/, gh_comm** out);
+void gh_comm_destroy(gh_comm* comm);
+int gh_comm_count(const gh_comm* comm);
+int gh_comm_rank(const gh_comm* comm);
+int gh_comm_version(void);            /* ncclGetVersion, 0 when librccl cannot be opened */
+const char* gh_comm_library(void);    /* path librccl was opened from ("" when it cannot be) */
+int gh_stats_allreduce(gh_ctx* ctx, gh_comm* comm, double* stats_dev, int64_t n);
+int gh_comm_allreduce_host(gh_ctx* ctx, gh_comm* comm, double* host_io, int64_t n, int op_max);
+int gh_comm_barrier(gh_ctx* ctx, gh_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

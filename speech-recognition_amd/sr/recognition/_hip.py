@@ -91,6 +91,16 @@ SIGNATURES = {
     "gh_bw_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _c_f64p, C.c_void_p]),
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
+    "gh_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gh_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "gh_comm_destroy": (None, [C.c_void_p]),
+    "gh_comm_count": (C.c_int, [C.c_void_p]),
+    "gh_comm_rank": (C.c_int, [C.c_void_p]),
+    "gh_comm_version": (C.c_int, []),
+    "gh_comm_library": (C.c_char_p, []),
+    "gh_stats_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gh_comm_allreduce_host": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, C.c_int64, C.c_int]),
+    "gh_comm_barrier": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 
@@ -210,6 +220,59 @@ def default_context(device=None):
     if ctx is None:
         ctx = _default_ctx[device] = Context(device)
     return ctx
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """RCCL communicator of this rank on a context's GPU (gh_comm): the collectives run on the context's stream."""
+
+    @staticmethod
+    def unique_id():
+        """The 128-byte id rank 0 makes and hands to every other rank (gh_comm_unique_id)."""
+        lib = load_library()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib, lib.gh_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        h = C.c_void_p()
+        _check(ctx.lib, ctx.lib.gh_comm_create(ctx.h, self.rank, self.world, unique_id, C.byref(h)))
+        self.h = h
+
+    @property
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL reports for this communicator."""
+        return int(self.ctx.lib.gh_comm_count(self.h))
+
+    def allreduce_device(self, dev_ptr, n):
+        """In-place fp64 sum of n doubles at device pointer dev_ptr over all ranks, asynchronous on the context's stream."""
+        _check(self.ctx.lib, self.ctx.lib.gh_stats_allreduce(self.ctx.h, self.h, C.c_void_p(int(dev_ptr)), int(n)))
+
+    def allreduce_host(self, a, op="sum"):
+        """Sum (or max) of a small fp64 host array over all ranks; returns a new array of the same shape."""
+        out = np.array(a, dtype=np.float64, order="C")
+        _check(self.ctx.lib, self.ctx.lib.gh_comm_allreduce_host(self.ctx.h, self.h, _ptr(out.reshape(-1), _c_f64p), out.size,
+                                                                 1 if op == "max" else 0))
+        return out
+
+    def barrier(self):
+        _check(self.ctx.lib, self.ctx.lib.gh_comm_barrier(self.ctx.h, self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.gh_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PackedGMM:

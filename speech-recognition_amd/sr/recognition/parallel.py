@@ -15,7 +15,8 @@ caller (the HIP E-step in production, anything in tests).
 """
 import numpy as np
 
-__all__ = ["shard_utterances", "StatsAllReducer", "m_step", "distributed_em_iteration"]
+__all__ = ["shard_utterances", "StatsAllReducer", "NativeReducer", "exchange_from_rank0", "m_step",
+           "distributed_em_iteration"]
 
 
 def shard_utterances(lengths, world_size):
@@ -99,6 +100,148 @@ class StatsAllReducer:
         self.calls += 1
         self.seconds += time.perf_counter() - t0
         return out
+
+
+_MAGIC = b"GHCOMM1\0"
+
+
+def _comm_ports():
+    """Candidate TCP ports of the id hand-over: GMMHMM_COMM_PORT, else MASTER_PORT + 1 .. + 8 (MASTER_PORT itself
+    belongs to the launcher's store)."""
+    import os
+    if os.environ.get("GMMHMM_COMM_PORT"):
+        return [int(os.environ["GMMHMM_COMM_PORT"])]
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    return [base + 1 + i if base + 1 + i < 65536 else base - 1 - i for i in range(8)]
+
+
+def exchange_from_rank0(rank, world, make_payload, addr=None, ports=None, timeout=180.0, token=b""):
+    """Rank 0 calls make_payload() -> bytes and hands the result to every other rank over a plain TCP socket on
+    MASTER_ADDR (the rendezvous of `gh_comm_create`: the 128-byte RCCL id must reach every rank before the first
+    collective exists).  Every connection opens with a magic word, the world size, the caller's rank and `token`
+    (e.g. the launcher's run id); a peer that answers anything else is not ours and the next candidate port is
+    tried.  Returns the payload on every rank."""
+    import os
+    import socket
+    import struct
+    import time
+    if world <= 1:
+        return make_payload()
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    ports = list(ports) if ports is not None else _comm_ports()
+    hello = _MAGIC + struct.pack("<ii", world, 0) + struct.pack("<i", len(token)) + token
+    deadline = time.monotonic() + timeout
+    if rank == 0:
+        payload = make_payload()
+        srv, err = None, None
+        for port in ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(world)
+                break
+            except OSError as e:
+                err = e
+                srv.close()
+                srv = None
+        if srv is None:
+            raise RuntimeError("exchange_from_rank0: no free port among %s on %s (%s)" % (ports, addr, err))
+        served = set()
+        try:
+            while len(served) < world - 1:
+                srv.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise RuntimeError("exchange_from_rank0: %d of %d ranks reported within %.0f s"
+                                       % (len(served), world - 1, timeout))
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        head = _recv_exact(conn, len(hello))
+                    except (OSError, EOFError):
+                        continue
+                    peer = struct.unpack("<i", head[12:16])[0]
+                    if head[:12] != hello[:12] or head[16:] != hello[16:] or not 0 < peer < world:
+                        continue                          # not one of ours
+                    conn.sendall(struct.pack("<q", len(payload)) + payload)
+                    served.add(peer)
+        finally:
+            srv.close()
+        return payload
+    mine = _MAGIC + struct.pack("<ii", world, rank) + struct.pack("<i", len(token)) + token
+    k = 0
+    while True:
+        port = ports[k % len(ports)]
+        k += 1
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as c:
+                c.settimeout(10.0)
+                c.sendall(mine)
+                n = struct.unpack("<q", _recv_exact(c, 8))[0]
+                if 0 < n < (1 << 24):
+                    return _recv_exact(c, n)
+        except (OSError, EOFError):
+            pass
+        if time.monotonic() > deadline:
+            raise RuntimeError("exchange_from_rank0: rank %d could not reach rank 0 on %s ports %s within %.0f s"
+                               % (rank, addr, ports, timeout))
+        time.sleep(0.05 if k < 40 else 0.5)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise EOFError("peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+class NativeReducer:
+    """The exchange step through the library's own RCCL communicator (`gh_comm_create` / `gh_stats_allreduce`): no
+    torch in the process.  One rank per GPU; rank / world size come from the launcher's environment (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR, MASTER_PORT) unless given.  Same surface as `StatsAllReducer` where the trainers use it:
+    `enabled`, `world_size`, `rank`, `__call__(ndarray)` (small host buffers), plus `comm` for the device-resident
+    paths (`_hip.EMSession.iteration(comm=...)`)."""
+
+    on_gpu = True
+    native = True
+
+    def __init__(self, ctx=None, rank=None, world=None, timeout=180.0):
+        import os
+        from . import _hip
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.ctx = ctx if ctx is not None else _hip.default_context()
+        token = os.environ.get("TORCHELASTIC_RUN_ID", "").encode()
+        uid = exchange_from_rank0(self.rank, self.world, _hip.Comm.unique_id, timeout=timeout, token=token)
+        self.comm = _hip.Comm(self.ctx, self.rank, self.world, uid)
+        self.enabled = True
+        self.calls, self.seconds = 0, 0.0
+
+    @property
+    def world_size(self):
+        return self.world
+
+    def __call__(self, stats):
+        import time
+        t0 = time.perf_counter()
+        out = self.comm.allreduce_host(stats)
+        self.calls += 1
+        self.seconds += time.perf_counter() - t0
+        return out
+
+    def max(self, a):
+        return self.comm.allreduce_host(a, op="max")
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def close(self):
+        self.comm.close()
 
 
 def m_step(stats, counts, means):
