@@ -385,6 +385,45 @@ int gh_stats_allreduce(gh_ctx* ctx, gh_comm* comm, double* stats_dev, int64_t n)
 int gh_comm_allreduce_host(gh_ctx* ctx, gh_comm* comm, double* host_io, int64_t n, int op_max);
 int gh_comm_barrier(gh_ctx* ctx, gh_comm* comm);
 
+/* In-place re-estimation of a packed model: the same packing as gh_gmm_create, done by kernels on the context's
+ * stream into the arrays the handle already owns (a trainer updates its model every iteration; hmm_state.py:150-154
+ * update_models).  Shapes are those of the handle; var == 0 is rejected as in gh_gmm_create. */
+int gh_gmm_update(gh_ctx* ctx, gh_gmm* g, const double* mean /*[S,M,D]*/, const double* var /*[S,M,D]*/,
+                  const double* weight /*[S,M]*/);
+
+/* ------------------------------- soft-EM session: one DEVICE-RESIDENT, STREAM-ORDERED iteration per call
+ * The Baum-Welch loop of the trainer (no reference counterpart as a whole: the reference trains by Viterbi alignment;
+ * the statistics are GMM.em's, hmm_state.py:122-159, the transition update and stop rule continuous_train's in soft
+ * form, continuous_speech.py:144-179) for utterances with ONE-WORD transcripts (isolated-word training, BASELINE
+ * configs[2]).  Everything that does not change between iterations is built once at gh_em_create (block table of the
+ * own-state likelihoods, forward-backward launch order and scratch, work lists of the statistics kernel); the model,
+ * the transition costs and the convergence test live on the device.  gh_em_iteration enqueues
+ *     likelihoods -> forward-backward -> statistics -> [all-reduce over `comm`] -> M-step -> model re-pack
+ * on the context's stream without a host synchronisation in between:
+ *   - word models: W words x n states (n <= 8, arcs from s, s-1, s-2 only), mixtures [W*n, M, D], M <= 8, D <= 47,
+ *     fp64 batch; anything else: GH_ERR_UNSUPPORTED (callers keep the call-by-call path)
+ *   - utt_word[u]: the word utterance u is an example of
+ *   - var_floor: lower bound of re-estimated variances; occ_floor: occupancies <= it are dropped from the statistics;
+ *     min_occupancy: a component keeps its parameters unless its summed responsibility exceeds it
+ *   - update_transitions != 0: cost(s -> s) = -log p_stay, cost(s -> s+1) = -log(1 - p_stay),
+ *     p_stay = expected self transitions / expected frames of the state (states nobody visited keep theirs)
+ *   - comm (may be NULL): the packed buffer [statistics | self transitions | log P | utterances] is summed over its
+ *     ranks between the statistics and the M-step, so every rank ends the iteration with the same model
+ *   - out_tail (may be NULL) [4]: total log P BEFORE the update, utterances, converged (every parameter allclose to
+ *     the one it replaced, numpy's default tolerances), error bits -- passing it costs one 32-byte copy + stream
+ *     sync; with NULL the call returns as soon as the work is enqueued and gh_em_history reads the rows later. */
+typedef struct gh_em gh_em;
+int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* mean /*[W*n,M,D]*/,
+                 const double* var /*[W*n,M,D]*/, const double* weight /*[W*n,M]*/, const double* word_trans /*[W,n,n]*/,
+                 const int32_t* utt_word /*[U]*/, double var_floor, double occ_floor, double min_occupancy,
+                 int update_transitions, gh_em** out);
+void gh_em_destroy(gh_em* em);
+int gh_em_iteration(gh_ctx* ctx, gh_em* em, gh_comm* comm /*or NULL*/, double* out_tail /*[4] or NULL*/);
+int gh_em_iterations_done(const gh_em* em);
+int gh_em_history(gh_ctx* ctx, gh_em* em, int first, int count, double* out /*[count,4]*/);
+int gh_em_get_model(gh_ctx* ctx, gh_em* em, double* mean, double* var, double* weight, double* word_trans /*any may be NULL*/);
+int gh_em_packed(gh_ctx* ctx, gh_em* em, double* out /*[n] or NULL*/, int64_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

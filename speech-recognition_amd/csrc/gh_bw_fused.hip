@@ -417,6 +417,28 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
             v.swap(sorted);
         }
     }
+    gh_bwf_plan plan;
+    int rc = gh_bwf_plan_build(ctx, S, M, D, g->KP, chains, seg_first, seg_len, by_graph, /*persistent=*/false, &plan);
+    if (rc) return rc;
+    double* d_out = stats_dev ? stats_dev : plan.d_own;
+    *d_result = d_out;
+    rc = gh_bwf_launch(ctx, plan, g, (const double*)b->feats, seq ? b->occ : b->gam, seq ? S : 8, seq ? 1 : 0, occ_floor, nullptr, d_out);
+    if (rc) return rc;
+    GH_HIP(hipStreamSynchronize(ctx->stream));   // the plan lives in the context's scratch: the next call may overwrite it
+    return GH_OK;
+}
+
+// Work lists of the fused statistics kernel -> device.  persistent: own allocation (a trainer builds them once: the
+// utterance -> word grouping never changes between EM iterations); else carved from the context's scratch.
+int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vector<gh_fbchain>& chains,
+                      const std::vector<int64_t>& seg_first, const std::vector<int32_t>& seg_len,
+                      const std::vector<std::vector<int32_t>>& by_graph, bool persistent, gh_bwf_plan* out) {
+    memset(out, 0, sizeof *out);
+    const int KS = KP / 2;
+    const int lt = (D + 1 + 15) / 16;
+    const int L = (int)chains.size();
+    if (chains.empty() || M > 8 || lt > 3) return 1;
+    if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
     const int64_t n_seg = (int64_t)seg_first.size();
     // workgroups of 3 waves (5 states = 3 pairs): FOUR per CU put exactly three waves on every SIMD (with three per CU
     // one SIMD carries three waves, the others two: the kernel ran at the pace of the fullest one)
@@ -440,38 +462,59 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
         for (int p = 0; 2 * p < fc.n; ++p)
             pairs.push_back(bwf_pair{fc.state[2 * p], 2 * p + 1 < fc.n ? fc.state[2 * p + 1] : -1, wg_begin, (int32_t)wgs.size(), p, 0});
     }
-    hipStream_t st = ctx->stream;
     const int W = 1 + 2 * D;
     const int tile_len = 2 * lt * 16 * 16;
-    int32_t *d_ulist, *d_seglen; int64_t* d_segfirst; bwf_wg* d_wgs; bwf_pair* d_pairs; gh_fbchain* d_chains; double *d_part, *d_own;
-    Carver cv;
-    cv.add(&d_own, (size_t)S * M * W);
-    cv.add(&d_ulist, std::max<size_t>(1, ulist.size())); cv.add(&d_wgs, std::max<size_t>(1, wgs.size()));
-    cv.add(&d_pairs, std::max<size_t>(1, pairs.size())); cv.add(&d_chains, (size_t)L);
-    cv.add(&d_segfirst, std::max<size_t>(1, seg_first.size())); cv.add(&d_seglen, std::max<size_t>(1, seg_len.size()));
-    cv.add(&d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len);
-    double* d_gsum;
-    cv.add(&d_gsum, std::max<size_t>(1, pairs.size()) * (size_t)tile_len);
-    int rc = cv.commit(ctx);
-    if (rc) return rc;
-    double* d_out = stats_dev ? stats_dev : d_own;
-    *d_result = d_out;
+    out->KS = KS; out->lt = lt; out->S = S; out->M = M; out->D = D; out->L = L;
+    out->n_wgs = (int)wgs.size(); out->n_pairs = (int)pairs.size(); out->tile_len = tile_len;
+    bwf_wg* d_wgs; bwf_pair* d_pairs;
+    // layout: [own result | lists (one upload) | partial tiles | pair sums]
+    UploadLayout lay;
+    lay.add((void**)&out->d_own, (size_t)S * M * W * 8, nullptr);
+    lay.add((void**)&out->d_ulist, std::max<size_t>(1, ulist.size()) * 4, ulist.data(), ulist.size() * 4);
+    lay.add((void**)&d_wgs, std::max<size_t>(1, wgs.size()) * sizeof(bwf_wg), wgs.data(), wgs.size() * sizeof(bwf_wg));
+    lay.add((void**)&d_pairs, std::max<size_t>(1, pairs.size()) * sizeof(bwf_pair), pairs.data(), pairs.size() * sizeof(bwf_pair));
+    lay.add((void**)&out->d_chains, (size_t)L * sizeof(gh_fbchain), chains.data(), (size_t)L * sizeof(gh_fbchain));
+    lay.add((void**)&out->d_segfirst, std::max<size_t>(1, seg_first.size()) * 8, seg_first.data(), seg_first.size() * 8);
+    lay.add((void**)&out->d_seglen, std::max<size_t>(1, seg_len.size()) * 4, seg_len.data(), seg_len.size() * 4);
+    lay.add((void**)&out->d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len * 8, nullptr);
+    lay.add((void**)&out->d_gsum, std::max<size_t>(1, pairs.size()) * (size_t)tile_len * 8, nullptr);
+    void* base = nullptr;
+    if (persistent) {
+        GH_HIP(hipMalloc(&base, lay.total));
+        out->d_arena = base;
+    } else {
+        int rc = gh_scratch(ctx, lay.total, &base);
+        if (rc) return rc;
+    }
+    int rc = lay.commit(base, ctx->stream, /*sync=*/true);
+    if (rc) { if (persistent) { hipFree(base); out->d_arena = nullptr; } return rc; }
+    out->d_wgs = d_wgs; out->d_pairs = d_pairs;
+    return GH_OK;
+}
+
+void gh_bwf_plan_free(gh_bwf_plan* p) {
+    if (p && p->d_arena) hipFree(p->d_arena);
+    if (p) memset(p, 0, sizeof *p);
+}
+
+// enqueue the fused statistics kernel + its two reduction kernels on the context's stream (no host sync).
+// d_chains: the chains (n, state[]) on the device, or null for the copy the plan was built with.
+int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
+                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out) {
+    hipStream_t st = ctx->stream;
+    const int S = pl.S, M = pl.M, D = pl.D, KS = pl.KS, lt = pl.lt;
+    const int W = 1 + 2 * D;
     GH_HIP(hipMemsetAsync(d_out, 0, (size_t)S * M * W * 8, st));
-    if (wgs.empty()) return GH_OK;
-    GH_HIP(hipMemcpyAsync(d_ulist, ulist.data(), ulist.size() * 4, hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_wgs, wgs.data(), wgs.size() * sizeof(bwf_wg), hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * sizeof(bwf_pair), hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_chains, chains.data(), (size_t)L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_segfirst, seg_first.data(), seg_first.size() * 8, hipMemcpyHostToDevice, st));
-    GH_HIP(hipMemcpyAsync(d_seglen, seg_len.data(), seg_len.size() * 4, hipMemcpyHostToDevice, st));
+    if (pl.n_wgs == 0) return GH_OK;
     const size_t lds = ((size_t)BWF_TF * ((2 * KS) | 1) + BWF_TF * 8 + 128) * 8;
-    const dim3 grid((unsigned)wgs.size()), blk(256);   // 256 threads always: see the staging loop of the kernel
-    const double* gam = seq ? b->occ : b->gam;
-    const int gam_stride = seq ? S : 8;
+    const dim3 grid((unsigned)pl.n_wgs), blk(256);   // 256 threads always: see the staging loop of the kernel
+    const gh_fbchain* chains = d_chains ? d_chains : pl.d_chains;
+    const bwf_wg* d_wgs = (const bwf_wg*)pl.d_wgs;
+    const bwf_pair* d_pairs = (const bwf_pair*)pl.d_pairs;
 #define GH_BWF(ks, nc)                                                                                                   \
-    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, (const double*)b->feats, D, M, g->dMean, g->dIvar,  \
-                       g->dLogc, gam, occ_floor, gam_stride, seq ? 1 : 0, d_segfirst, d_seglen, d_ulist, d_wgs, d_chains,             \
-                       ctx->d_fp64_tables, d_part)
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                   \
+                       g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
+                       ctx->d_fp64_tables, pl.d_part)
 #define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;
@@ -483,10 +526,9 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
 #undef GH_BWF_N
 #undef GH_BWF
     GH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pairs.size(), (unsigned)((tile_len + 255) / 256)), dim3(256), 0, st, d_part,
-                       d_pairs, 4, tile_len, d_gsum);
-    hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pairs.size()), dim3(256), 0, st, d_gsum, d_pairs, lt, D, M, g->dMean, d_out);
+    hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pl.n_pairs, (unsigned)((pl.tile_len + 255) / 256)), dim3(256), 0, st, pl.d_part,
+                       d_pairs, 4, pl.tile_len, pl.d_gsum);
+    hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pl.n_pairs), dim3(256), 0, st, pl.d_gsum, d_pairs, lt, D, M, g->dMean, d_out);
     GH_HIP(hipGetLastError());
-    GH_HIP(hipStreamSynchronize(st));   // the work lists are host vectors of this call
     return GH_OK;
 }

@@ -1,0 +1,399 @@
+// C ABI: a soft-EM (Baum-Welch) training session whose ITERATION IS DEVICE-RESIDENT AND STREAM-ORDERED (gh_em_*).
+//
+// NOT in the reference as such (it trains by Viterbi alignment); the statistics are those of GMM.em
+// (hmm_state.py:122-159), the transition update and the stop rule those of continuous_train in soft form
+// (continuous_speech.py:144-179).  Round 2 ran an iteration as three synchronous C-ABI calls with host work between
+// them: a new packed model per E-step, graphs rebuilt from the re-estimated transition costs, the work lists of the
+// fused statistics kernel rebuilt and uploaded per call, M-step and convergence test in numpy -- 2.56 ms of wall time
+// around 1.31 ms of kernels.  Here everything an iteration needs that does NOT change between iterations is built once
+// (block table of the own-state likelihoods, launch order / scratch offsets of the forward-backward, work lists of the
+// statistics kernel, utterances grouped by word), and everything that does change lives in HBM and is rewritten by
+// kernels on the context's stream:
+//
+//     loglik (own states) -> fb_chain (gamma compact, self transitions, log P) -> bw_fused (+ sum, re-centre)
+//       -> tail (expected self transitions per state, total log P)   [packed buffer: stats | xi | log P | utterances]
+//       -> ncclAllReduce(packed)                                      (gh_comm, same stream; skipped without a comm)
+//       -> M-step (means / variances / weights, variance floor, transition costs -> chain costs, allclose test)
+//       -> model re-pack (gh_gmm_update_dev: plain arrays + MFMA operand fragments in place)
+//       -> history[it] = (log P, utterances, converged, error flags)
+//
+// No hipStreamSynchronize inside; the caller may fetch history[it] (one 32-byte D2H) per iteration or after many.
+// Scope: one-word transcripts (isolated-word EM, BASELINE configs[2]) on an fp64 batch, word models of n <= 8 states
+// with arcs from s, s-1, s-2 only, M <= 8 mixtures, D <= 47 -- what fb_chain_kernel / bw_fused_kernel cover; anything
+// else returns GH_ERR_UNSUPPORTED and the caller keeps the call-by-call path.
+#include "gh_internal.h"
+#include "gh_host.h"
+#include "gh_fb.h"
+
+struct gh_em {
+    gh_ctx* ctx;
+    gh_batch* b;
+    int W, n, M, D, S;
+    int64_t U, N;
+    double var_floor, occ_floor, min_occ;
+    int update_trans;
+    gh_gmm* gmm;
+    void* d_arena;
+    double *d_mean, *d_var, *d_weight, *d_trans;
+    gh_fbchain* d_chains;
+    int32_t *d_utt_word, *d_word_utts, *d_word_off;
+    int64_t* d_coff;
+    double *d_alpha, *d_logp, *d_xi_utt, *d_gam;
+    double* d_packed;
+    int64_t n_stats, n_packed;
+    int* d_flags;          // [0] entries not allclose to the previous iteration, [1] error bits (16: zero variance)
+    double* d_hist;        // [hist_cap][4]: log P, utterances, converged, error bits
+    int hist_cap, it;
+    gh_loglik_plan ll_plan;
+    bool ll_subset;
+    gh_bwf_plan bw_plan;
+    double* h_tail;        // pinned [4]
+};
+
+namespace {
+
+// one block per word (expected self transitions of its rows, summed over its utterances in a fixed order) + one block
+// for the total log-likelihood; also clears the allclose counter of the M-step that follows
+__global__ __launch_bounds__(256) void em_tail_kernel(const double* __restrict__ xi_utt, const double* __restrict__ logp,
+                                                      const int32_t* __restrict__ word_utts, const int32_t* __restrict__ word_off,
+                                                      int W, int n, int64_t U, double* __restrict__ tail, int* __restrict__ flags) {
+    __shared__ double red[256][GH_FBCHAIN_MAX + 1];
+    const int tid = threadIdx.x;
+    const int w = blockIdx.x;
+    double acc[GH_FBCHAIN_MAX];
+#pragma unroll
+    for (int j = 0; j < GH_FBCHAIN_MAX; ++j) acc[j] = 0.0;
+    if (w < W) {
+        for (int i = word_off[w] + tid; i < word_off[w + 1]; i += 256) {
+            const double* x = xi_utt + (int64_t)word_utts[i] * GH_FBCHAIN_MAX;
+#pragma unroll
+            for (int j = 0; j < GH_FBCHAIN_MAX; ++j) acc[j] += x[j];
+        }
+    } else {
+        for (int64_t u = tid; u < U; u += 256) {
+            const double l = logp[u];
+            if (l - l == 0.0) acc[0] += l;      // finite: utterances without a path do not count (train.py e_step)
+        }
+        if (tid == 0) flags[0] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < GH_FBCHAIN_MAX; ++j) red[tid][j] = acc[j];
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h)
+#pragma unroll
+            for (int j = 0; j < GH_FBCHAIN_MAX; ++j) red[tid][j] += red[tid + h][j];
+        __syncthreads();
+    }
+    if (w < W) {
+        if (tid < n) tail[w * n + tid] = red[0][tid];
+    } else if (tid == 0) {
+        tail[W * n] = red[0][0];
+        tail[W * n + 1] = (double)U;
+    }
+}
+
+__device__ __forceinline__ bool em_close(double a, double b) {   // np.isclose(a, b) with numpy's default tolerances
+    if (a == b) return true;
+    if (!(a - a == 0.0) || !(b - b == 0.0)) return false;
+    return fabs(a - b) <= 1e-8 + 1e-5 * fabs(b);
+}
+
+// M-step of one state per block from the (all-reduced) packed buffer: parallel.m_step + the floor / occupancy rules of
+// train.BaumWelchTrainer.iteration + _update_transitions, and the allclose test against the parameters it replaces.
+__global__ __launch_bounds__(256) void em_mstep_kernel(const double* __restrict__ packed, int64_t n_stats, int n, int M, int D,
+                                                       double var_floor, double min_occ, int update_trans,
+                                                       double* __restrict__ mean, double* __restrict__ var, double* __restrict__ weight,
+                                                       double* __restrict__ trans, gh_fbchain* __restrict__ chains, int* __restrict__ flags) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int W1 = 1 + 2 * D;
+    const double* st = packed + (int64_t)s * M * W1;
+    double counts = 0.0;
+    for (int m = 0; m < M; ++m) counts += st[m * W1];
+    if (!(counts > 0)) return;                 // a state nobody visited keeps everything
+    int bad = 0;
+    for (int idx = tid; idx < M * D; idx += blockDim.x) {
+        const int m = idx / D, d = idx - m * D;
+        const double s0 = st[m * W1], S1 = st[m * W1 + 1 + d], S2 = st[m * W1 + 1 + D + d];
+        const int64_t at = ((int64_t)s * M + m) * D + d;
+        const double mu0 = mean[at], v0 = var[at];
+        const double occ = (s0 == 0) ? 1e-5 : s0;
+        const double mu = (mu0 * s0 + S1) / occ;
+        const double dl = mu - mu0;
+        double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
+        if (sg == sg && sg < var_floor) sg = var_floor;      // np.maximum(sigma, var_floor): NaN stays NaN
+        const bool ok = s0 > min_occ;
+        const double mu1 = ok ? mu : mu0, v1 = ok ? sg : v0;
+        bad += !em_close(mu1, mu0) + !em_close(v1, v0);
+        mean[at] = mu1;
+        var[at] = v1;
+    }
+    if (tid < M) {
+        const double s0 = st[tid * W1];
+        const double w0 = weight[(int64_t)s * M + tid];
+        const double w1 = (s0 > min_occ) ? s0 / counts : w0;
+        bad += !em_close(w1, w0);
+        weight[(int64_t)s * M + tid] = w1;
+    }
+    if (tid == 0 && update_trans) {
+        // continuous_speech.py:146-164 with expected counts: p_stay = self transitions / frames of the state
+        const int wi = s / n, si = s - wi * n;
+        double p = packed[n_stats + s] / counts;
+        if (p == p) p = fmin(fmax(p, 0.0), 1.0);
+        double* t = trans + (int64_t)wi * n * n;
+        gh_fbchain* ch = chains + wi;
+        if (si < n - 1) {
+            const double c = -log(1.0 - p);
+            t[(si + 1) * n + si] = c;
+            ch->next_c[si + 1] = c;
+        }
+        const double c = -log(p);
+        t[si * n + si] = c;
+        ch->self_c[si] = c;
+    }
+    if (bad) atomicAdd(&flags[0], bad);
+}
+
+__global__ void em_finish_kernel(const double* __restrict__ tail /* log P, utterances */, const int* __restrict__ flags,
+                                 double* __restrict__ hist_row) {
+    hist_row[0] = tail[0];
+    hist_row[1] = tail[1];
+    hist_row[2] = flags[0] == 0 ? 1.0 : 0.0;
+    hist_row[3] = (double)flags[1];
+}
+
+}  // namespace
+
+extern "C" void gh_em_destroy(gh_em* e) {
+    if (!e) return;
+    hipSetDevice(e->ctx->device);
+    hipStreamSynchronize(e->ctx->stream);
+    if (e->gmm) gh_gmm_destroy(e->gmm);
+    gh_loglik_plan_free(&e->ll_plan);
+    gh_bwf_plan_free(&e->bw_plan);
+    if (e->d_arena) hipFree(e->d_arena);
+    if (e->h_tail) hipHostFree(e->h_tail);
+    delete e;
+}
+
+extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* mean, const double* var,
+                            const double* weight, const double* word_trans, const int32_t* utt_word, double var_floor,
+                            double occ_floor, double min_occupancy, int update_transitions, gh_em** out) {
+    GH_REQUIRE(ctx && b && mean && var && weight && word_trans && out && (utt_word || b->U == 0), "gh_em_create: NULL argument");
+    GH_REQUIRE(W > 0 && n > 0 && M > 0, "gh_em_create: W=%d n=%d M=%d", W, n, M);
+    *out = nullptr;
+    const int D = b->D, S = W * n;
+    const int64_t U = b->U;
+    // ---- what the device-resident iteration covers ----
+    if (b->dtype != GH_F64 || n > GH_FBCHAIN_MAX || M > 8 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
+        gh_set_error("gh_em_create: shape outside the device-resident path (fp64 batch, n <= 8, M <= 8, D <= 47)");
+        return GH_ERR_UNSUPPORTED;
+    }
+    std::vector<gh_fbchain> chains(W);
+    for (int w = 0; w < W; ++w) {
+        gh_fbchain& fc = chains[w];
+        memset(&fc, 0, sizeof fc);
+        fc.n = n;
+        fc.c0 = 0.0;                                    // non-emitting start row -> first state: cost 0 (continuous_speech.py:31)
+        for (int i = 0; i < GH_FBCHAIN_MAX; ++i) fc.self_c[i] = fc.next_c[i] = fc.skip_c[i] = INFINITY;
+        for (int i = 0; i < n; ++i) {
+            fc.state[i] = w * n + i;
+            for (int j = 0; j < n; ++j) {
+                const double c = word_trans[((size_t)w * n + i) * n + j];
+                if (std::isinf(c) && c > 0) continue;
+                const int d = i - j;
+                if (c != c || d < 0 || d > 2) {
+                    gh_set_error("gh_em_create: word %d has an arc %d -> %d (only s, s-1, s-2 -> s are covered)", w, j, i);
+                    return GH_ERR_UNSUPPORTED;
+                }
+                (d == 0 ? fc.self_c[i] : d == 1 ? fc.next_c[i] : fc.skip_c[i]) = c;
+                if (d == 2) fc.pad = 1;
+            }
+        }
+    }
+    for (int64_t u = 0; u < U; ++u) GH_REQUIRE(utt_word[u] >= 0 && utt_word[u] < W, "gh_em_create: utt_word[%lld]=%d", (long long)u, utt_word[u]);
+    GH_HIP(hipSetDevice(ctx->device));
+    gh_em* e = new gh_em();
+    memset((void*)e, 0, sizeof *e);
+    e->ctx = ctx; e->b = b; e->W = W; e->n = n; e->M = M; e->D = D; e->S = S; e->U = U; e->N = b->N;
+    e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
+    int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
+    if (rc) { gh_em_destroy(e); return rc; }
+    // ---- likelihoods of every utterance's own states: persistent block table (or the full matrix) ----
+    {
+        std::vector<int32_t> lo(U), hi(U);
+        for (int64_t u = 0; u < U; ++u) { lo[u] = utt_word[u] * n; hi[u] = lo[u] + n; }
+        rc = U > 0 ? gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), nullptr, &e->ll_plan) : 0;
+        if (rc < 0) { gh_em_destroy(e); return rc; }
+        e->ll_subset = rc == 0;
+        if (rc == 1) {
+            const int KS = e->gmm->KP / 2;
+            if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) {
+                gh_em_destroy(e);
+                gh_set_error("gh_em_create: D=%d is not a matrix-core likelihood shape", D);
+                return GH_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    // ---- statistics kernel: work lists built once (utterances by word, longest first) ----
+    std::vector<std::vector<int32_t>> by_word(W);
+    {
+        std::vector<int64_t> seg_first(U);
+        std::vector<int32_t> seg_len(U);
+        for (int64_t u = 0; u < U; ++u) { seg_first[u] = b->offsets[u]; seg_len[u] = (int32_t)(b->offsets[u + 1] - b->offsets[u]); }
+        std::vector<std::vector<int32_t>> by_graph(W);
+        for (int64_t k = 0; k < U; ++k) {
+            const int64_t u = b->perm[k];
+            if (seg_len[u] > 0) by_graph[utt_word[u]].push_back((int32_t)u);
+        }
+        for (int64_t u = 0; u < U; ++u) by_word[utt_word[u]].push_back((int32_t)u);
+        rc = gh_bwf_plan_build(ctx, S, M, D, e->gmm->KP, chains, seg_first, seg_len, by_graph, /*persistent=*/true, &e->bw_plan);
+        if (rc) {
+            gh_em_destroy(e);
+            if (rc == 1) { gh_set_error("gh_em_create: shape outside the fused statistics kernel"); return GH_ERR_UNSUPPORTED; }
+            return rc;
+        }
+    }
+    // ---- forward-backward: scratch offsets in launch order ----
+    std::vector<int64_t> coff(std::max<int64_t>(U, 1), 0);
+    size_t cacc = 0;
+    for (int64_t k = 0; k < U; ++k) {
+        const int64_t u = b->perm[k];
+        coff[k] = (int64_t)cacc;
+        const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * n;
+        cacc += cells + (cells + 1) / 2;            // [T, n] mantissas (double) followed by as many exponents (int32)
+    }
+    std::vector<int32_t> word_utts, word_off(W + 1, 0);
+    for (int w = 0; w < W; ++w) {
+        word_utts.insert(word_utts.end(), by_word[w].begin(), by_word[w].end());
+        word_off[w + 1] = (int32_t)word_utts.size();
+    }
+    std::vector<double> trans(word_trans, word_trans + (size_t)W * n * n);
+    e->n_stats = (int64_t)S * M * (1 + 2 * D);
+    e->n_packed = e->n_stats + S + 2;
+    e->hist_cap = 4096;
+    const size_t nd = (size_t)S * M * D;
+    UploadLayout lay;
+    lay.add((void**)&e->d_mean, nd * 8, mean, nd * 8);
+    lay.add((void**)&e->d_var, nd * 8, var, nd * 8);
+    lay.add((void**)&e->d_weight, (size_t)S * M * 8, weight, (size_t)S * M * 8);
+    lay.add((void**)&e->d_trans, trans.size() * 8, trans.data(), trans.size() * 8);
+    lay.add((void**)&e->d_chains, (size_t)W * sizeof(gh_fbchain), chains.data(), (size_t)W * sizeof(gh_fbchain));
+    lay.add((void**)&e->d_utt_word, std::max<size_t>(1, U) * 4, utt_word, (size_t)U * 4);
+    lay.add((void**)&e->d_word_utts, std::max<size_t>(1, word_utts.size()) * 4, word_utts.data(), word_utts.size() * 4);
+    lay.add((void**)&e->d_word_off, word_off.size() * 4, word_off.data(), word_off.size() * 4);
+    lay.add((void**)&e->d_coff, coff.size() * 8, coff.data(), coff.size() * 8);
+    lay.add((void**)&e->d_alpha, std::max<size_t>(1, cacc) * 8, nullptr);
+    lay.add((void**)&e->d_logp, std::max<size_t>(1, U) * 8, nullptr);
+    lay.add((void**)&e->d_xi_utt, std::max<size_t>(1, U) * GH_FBCHAIN_MAX * 8, nullptr);
+    lay.add((void**)&e->d_gam, std::max<size_t>(1, (size_t)b->N) * GH_FBCHAIN_MAX * 8, nullptr);
+    lay.add((void**)&e->d_packed, (size_t)e->n_packed * 8, nullptr);
+    lay.add((void**)&e->d_flags, 64, nullptr);
+    lay.add((void**)&e->d_hist, (size_t)e->hist_cap * 4 * 8, nullptr);
+    hipError_t he = hipMalloc(&e->d_arena, lay.total);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&e->h_tail, 64, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        gh_set_error("gh_em_create: %s", hipGetErrorString(he));
+        gh_em_destroy(e);
+        return he == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+    }
+    rc = lay.commit(e->d_arena, ctx->stream, true);
+    if (!rc && hipMemsetAsync(e->d_flags, 0, 64, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc && hipMemsetAsync(e->d_packed, 0, (size_t)e->n_packed * 8, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc) rc = gh_batch_ensure_nll(ctx, b, S, /*zero=*/true);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (rc) { gh_em_destroy(e); return rc; }
+    *out = e;
+    return GH_OK;
+}
+
+extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out_tail) {
+    GH_REQUIRE(ctx && e && e->ctx == ctx, "gh_em_iteration: NULL argument / foreign context");
+    GH_REQUIRE(e->it < e->hist_cap, "gh_em_iteration: more than %d iterations in one session", e->hist_cap);
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    gh_batch* b = e->b;
+    GH_REQUIRE(b->N == e->N && b->U == e->U, "gh_em_iteration: the batch changed under the session");
+    int rc = gh_batch_ensure_nll(ctx, b, e->S, true);
+    if (rc) return rc;
+    if (e->N > 0) {
+        rc = gh_launch_loglik_mfma(ctx, e->gmm, b, nullptr, nullptr, nullptr, e->ll_subset ? &e->ll_plan : nullptr);
+        if (rc == 1) { gh_set_error("gh_em_iteration: likelihood shape not covered"); return GH_ERR_UNSUPPORTED; }
+        if (rc) return rc;
+        gh_fbchain_args ca;
+        memset(&ca, 0, sizeof ca);
+        ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
+        ca.perm = b->d_perm; ca.U = e->U; ca.alpha_scratch = e->d_alpha; ca.scratch_off = e->d_coff; ca.logp = e->d_logp;
+        ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt;
+        rc = gh_launch_fb_chain(ctx, ca, true);
+        if (rc) return rc;
+    }
+    rc = gh_bwf_launch(ctx, e->bw_plan, e->gmm, (const double*)b->feats, e->d_gam, GH_FBCHAIN_MAX, 0, e->occ_floor, e->d_chains,
+                       e->d_packed);
+    if (rc) return rc;
+    double* tail = e->d_packed + e->n_stats;
+    hipLaunchKernelGGL(em_tail_kernel, dim3(e->W + 1), dim3(256), 0, st, e->d_xi_utt, e->d_logp, e->d_word_utts, e->d_word_off,
+                       e->W, e->n, e->U, tail, e->d_flags);
+    GH_HIP(hipGetLastError());
+    if (comm) {
+        rc = gh_comm_allreduce_enqueue(comm, e->d_packed, e->n_packed);   // the ONE collective of the iteration
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(em_mstep_kernel, dim3(e->S), dim3(256), 0, st, e->d_packed, e->n_stats, e->n, e->M, e->D, e->var_floor,
+                       e->min_occ, e->update_trans, e->d_mean, e->d_var, e->d_weight, e->d_trans, e->d_chains, e->d_flags);
+    GH_HIP(hipGetLastError());
+    rc = gh_gmm_update_dev(ctx, e->gmm, e->d_mean, e->d_var, e->d_weight, e->d_flags + 1);
+    if (rc) return rc;
+    double* row = e->d_hist + (size_t)e->it * 4;
+    hipLaunchKernelGGL(em_finish_kernel, dim3(1), dim3(1), 0, st, tail + e->S, e->d_flags, row);
+    GH_HIP(hipGetLastError());
+    e->it += 1;
+    if (out_tail) {
+        GH_HIP(hipMemcpyAsync(e->h_tail, row, 32, hipMemcpyDeviceToHost, st));
+        GH_HIP(hipStreamSynchronize(st));
+        memcpy(out_tail, e->h_tail, 32);
+        if ((int)e->h_tail[3] & 16) {
+            gh_set_error("gh_em_iteration: a re-estimated variance is 0 (singular covariance); raise var_floor");
+            return GH_ERR_INVALID;
+        }
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_em_iterations_done(const gh_em* e) { return e ? e->it : 0; }
+
+extern "C" int gh_em_history(gh_ctx* ctx, gh_em* e, int first, int count, double* out) {
+    GH_REQUIRE(ctx && e && out && first >= 0 && count >= 0 && first + count <= e->it, "gh_em_history: range [%d, %d) of %d",
+               first, first + count, e ? e->it : 0);
+    if (count == 0) return GH_OK;
+    GH_HIP(hipSetDevice(ctx->device));
+    GH_HIP(hipMemcpyAsync(out, e->d_hist + (size_t)first * 4, (size_t)count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_em_get_model(gh_ctx* ctx, gh_em* e, double* mean, double* var, double* weight, double* word_trans) {
+    GH_REQUIRE(ctx && e, "gh_em_get_model: NULL argument");
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nd = (size_t)e->S * e->M * e->D;
+    if (mean) GH_HIP(hipMemcpyAsync(mean, e->d_mean, nd * 8, hipMemcpyDeviceToHost, st));
+    if (var) GH_HIP(hipMemcpyAsync(var, e->d_var, nd * 8, hipMemcpyDeviceToHost, st));
+    if (weight) GH_HIP(hipMemcpyAsync(weight, e->d_weight, (size_t)e->S * e->M * 8, hipMemcpyDeviceToHost, st));
+    if (word_trans) GH_HIP(hipMemcpyAsync(word_trans, e->d_trans, (size_t)e->W * e->n * e->n * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}
+
+// device pointer of the packed buffer [statistics S*M*(1+2D) | expected self transitions S | log P | utterances] and its
+// length: what crosses the ranks (tests compare it with the call-by-call path)
+extern "C" int gh_em_packed(gh_ctx* ctx, gh_em* e, double* out /*[n] or NULL*/, int64_t* out_n) {
+    GH_REQUIRE(ctx && e, "gh_em_packed: NULL argument");
+    if (out_n) *out_n = e->n_packed;
+    if (out) {
+        GH_HIP(hipSetDevice(ctx->device));
+        GH_HIP(hipMemcpyAsync(out, e->d_packed, (size_t)e->n_packed * 8, hipMemcpyDeviceToHost, ctx->stream));
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GH_OK;
+}

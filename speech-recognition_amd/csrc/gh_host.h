@@ -50,6 +50,34 @@ struct UploadArena {
     }
 };
 
+// Pieces of ONE device region (scratch or an own allocation): some filled from host memory, some left as they are.
+// The host pieces are gathered into one staging buffer and travel in one copy.
+struct UploadLayout {
+    struct item { void** dst; size_t off, bytes; const void* src; size_t src_bytes; };
+    std::vector<item> items;
+    size_t total = 0;
+    void add(void** dst, size_t bytes, const void* src, size_t src_bytes = 0) {
+        items.push_back({dst, total, bytes, src, src ? src_bytes : 0});
+        total += (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+    }
+    int commit(void* base, hipStream_t st, bool sync) {
+        size_t lo = total, hi = 0;
+        for (auto& it : items) {
+            *it.dst = static_cast<char*>(base) + it.off;
+            if (it.src_bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.src_bytes); }
+        }
+        if (hi > lo) {
+            std::vector<char> stage(hi - lo, 0);
+            for (auto& it : items) if (it.src_bytes) memcpy(stage.data() + (it.off - lo), it.src, it.src_bytes);
+            GH_HIP(hipMemcpyAsync(static_cast<char*>(base) + lo, stage.data(), hi - lo, hipMemcpyHostToDevice, st));
+            GH_HIP(hipStreamSynchronize(st));    // `stage` is pageable host memory of this call
+        } else if (sync) {
+            GH_HIP(hipStreamSynchronize(st));
+        }
+        return GH_OK;
+    }
+};
+
 template <typename T> inline int upload(T** dst, const std::vector<T>& src) {
     *dst = nullptr;
     if (src.empty()) return GH_OK;

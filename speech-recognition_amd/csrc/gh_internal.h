@@ -63,7 +63,8 @@ struct gh_gmm {
     gh_ctx* ctx;
     void* d_arena;   // the one device allocation all the d* pointers below point into
     int S, M, D, KP;
-    std::vector<double> hA, hB, hC;  // host fp64 master copies [G,KP], [G,KP], [G]
+    std::vector<double> hA, hB, hC;  // host fp64 master copies [G,KP], [G,KP], [G] (of gh_gmm_create's parameters)
+    bool host_stale = false;         // gh_gmm_update[_dev] rewrote the device arrays: hA / hB / hC describe an older model
     double *dA64, *dB64, *dC64;      // device fp64
     float *dA32, *dB32, *dC32;       // device fp32 -- for CENTRED features x - cen (see dCen32)
     // fp32 only: the GEMM form cancels terms of size (x^2 + mean^2)/var, which costs fp32 its digits once the
@@ -247,6 +248,11 @@ struct gh_lattices {
     bool has_self_arc;  // a same-column self arc can raise the reference's NameError: generic kernel only
 };
 
+int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double* d_var, const double* d_weight, int* d_flag);
+int gh_batch_ensure_nll(gh_ctx* ctx, gh_batch* b, int S, bool zero);
+struct gh_comm;
+int gh_comm_allreduce_enqueue(gh_comm* c, double* dev, int64_t n);
+
 // the handle whose row-per-lane arrays are valid: `l` itself, or the lazily expanded twin of a transcripts handle
 int gh_lattices_full(const gh_lattices* l, const gh_lattices** out);
 
@@ -257,5 +263,27 @@ int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
 int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor, double* stats_dev, double** d_result,
                            bool seq = false);
 int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
+// work lists of the fused statistics kernel on the device: built per call (context scratch) or once per trainer (own arena)
+struct gh_bwf_plan {
+    int KS, lt, S, M, D, L, n_wgs, n_pairs, tile_len;
+    int32_t *d_ulist, *d_seglen;
+    int64_t* d_segfirst;
+    void *d_wgs, *d_pairs;
+    gh_fbchain* d_chains;
+    double *d_part, *d_gsum, *d_own;
+    void* d_arena;
+};
+int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vector<gh_fbchain>& chains,
+                      const std::vector<int64_t>& seg_first, const std::vector<int32_t>& seg_len,
+                      const std::vector<std::vector<int32_t>>& by_graph, bool persistent, gh_bwf_plan* out);   // 1 = shapes not covered
+void gh_bwf_plan_free(gh_bwf_plan* p);
+int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
+                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out);
+// persistent block table of the subset likelihood kernel (built once by a trainer whose transcripts never change)
+struct gh_loglik_plan { void* d_blk; int64_t n_blk; int max_tiles; };
+int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
+                         const int64_t* rng_off, gh_loglik_plan* out);   // 1 = not covered
+void gh_loglik_plan_free(gh_loglik_plan* p);
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
-                          const int32_t* st_hi = nullptr, const int64_t* rng_off = nullptr);   // rng_off: several ranges per utterance
+                          const int32_t* st_hi = nullptr, const int64_t* rng_off = nullptr,   // rng_off: several ranges per utterance
+                          const gh_loglik_plan* plan = nullptr);

@@ -507,14 +507,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
     }
 }
 
-template <typename T>
-int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk, const int32_t* st_lo,
-                  const int32_t* st_hi, const T* cen, const int64_t* rng_off) {
-    const int64_t N = b->N;
-    if (N == 0) return GH_OK;
-    const int KS = g->KP / 2;
+// states per LDS output chunk of the kernel: whole matrix rows when they fit 64 states, else 64-state chunks
+static void chunk_shape(const gh_gmm* g, int* chunk_tiles_out, int* SC_out) {
     const int M_pad = g->M_pad, n_tiles = g->n_tiles, S = g->S;
-    // states per LDS output chunk: whole matrix rows when they fit 64 states, else 64-state chunks
     int chunk_tiles;
     if (M_pad <= 16) {
         const int spt = 16 / M_pad;
@@ -523,7 +518,62 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
         const int tps = M_pad / 16;
         chunk_tiles = (S <= 64) ? n_tiles : 64 * tps;
     }
-    const int SC = (M_pad <= 16) ? chunk_tiles * (16 / M_pad) : chunk_tiles / (M_pad / 16);
+    *chunk_tiles_out = chunk_tiles;
+    *SC_out = (M_pad <= 16) ? chunk_tiles * (16 / M_pad) : chunk_tiles / (M_pad / 16);
+}
+
+// Block table of gh_loglik_subset / gh_loglik_sets.  rng_off == null: one state range per utterance; else utterance u
+// owns the ranges [rng_off[u], rng_off[u + 1]) -- the states of its transcript's words.  Ranges become runs of Gaussian
+// tiles; runs that touch are merged (two words may share a tile), and every run gets its own table entries for the
+// utterance's 32-frame blocks.  Returns 1 when a run is wider than one LDS chunk (the caller computes the full matrix).
+static int build_blk_table(const gh_gmm* g, const gh_batch* b, int SC, const int32_t* st_lo, const int32_t* st_hi,
+                           const int64_t* rng_off, std::vector<gh_loglik_blk>& tabv, int* max_tiles_out) {
+    const int M_pad = g->M_pad, S = g->S;
+    int max_tiles = 1;
+    std::vector<std::pair<int, int>> runs;
+    for (int64_t u = 0; u < b->U; ++u) {
+        runs.clear();
+        const int64_t r0 = rng_off ? rng_off[u] : u, r1 = rng_off ? rng_off[u + 1] : u + 1;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int lo = st_lo[r], hi = st_hi[r];
+            if (lo < 0 || hi > S || lo >= hi) { gh_set_error("gh_loglik_subset: utterance %lld has state range [%d, %d)", (long long)u, lo, hi); return GH_ERR_INVALID; }
+            int t0, t1;
+            if (M_pad <= 16) { const int spt = 16 / M_pad; t0 = lo / spt; t1 = (hi + spt - 1) / spt; }
+            else { const int tps = M_pad / 16; t0 = lo * tps; t1 = hi * tps; }
+            runs.push_back({t0, t1});
+        }
+        std::sort(runs.begin(), runs.end());
+        size_t w = 0;
+        for (size_t i = 0; i < runs.size(); ++i) {
+            if (w > 0 && runs[i].first <= runs[w - 1].second) runs[w - 1].second = std::max(runs[w - 1].second, runs[i].second);
+            else runs[w++] = runs[i];
+        }
+        runs.resize(w);
+        for (const auto& tr : runs) {
+            const int t0 = tr.first, t1 = tr.second;
+            const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
+            if (span > SC) return 1;
+            max_tiles = std::max(max_tiles, t1 - t0);
+        }
+        // block-major: the entries of one 32-frame block (one per run) follow each other, so a wave that takes
+        // several of them stages the frames once
+        for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
+            for (const auto& tr : runs)
+                tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), tr.first, tr.second, 0});
+    }
+    *max_tiles_out = max_tiles;
+    return GH_OK;
+}
+
+template <typename T>
+int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const T* Cpk, const int32_t* st_lo,
+                  const int32_t* st_hi, const T* cen, const int64_t* rng_off, const gh_loglik_plan* plan) {
+    const int64_t N = b->N;
+    if (N == 0) return GH_OK;
+    const int KS = g->KP / 2;
+    const int M_pad = g->M_pad, n_tiles = g->n_tiles, S = g->S;
+    int chunk_tiles, SC;
+    chunk_shape(g, &chunk_tiles, &SC);
     size_t lds = ((size_t)32 * std::max(std::min(SC, S), g->D) + 64) * sizeof(T);
     lds = (lds + 15) & ~size_t(15);
     const int tab_off = (int)lds;
@@ -533,57 +583,30 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     gh_loglik_blk* d_blk = nullptr;
     int64_t n_blk = 0;
     int max_tiles = n_tiles;
-    if (st_lo) {
+    if (plan) {   // built once by gh_loglik_plan_build (a trainer's transcripts never change)
+        d_blk = static_cast<gh_loglik_blk*>(plan->d_blk);
+        n_blk = plan->n_blk;
+        max_tiles = plan->max_tiles;
+        if (n_blk == 0) return GH_OK;
+    } else if (st_lo) {
         std::vector<gh_loglik_blk> tabv;
-        max_tiles = 1;
-        // rng_off == null: one state range per utterance; else utterance u owns the ranges [rng_off[u], rng_off[u + 1]) --
-        // the states of its transcript's words.  Ranges become runs of Gaussian tiles; runs that touch are merged (two
-        // words may share a tile), and every run gets its own table entries for the utterance's 32-frame blocks.
-        std::vector<std::pair<int, int>> runs;
-        for (int64_t u = 0; u < b->U; ++u) {
-            runs.clear();
-            const int64_t r0 = rng_off ? rng_off[u] : u, r1 = rng_off ? rng_off[u + 1] : u + 1;
-            for (int64_t r = r0; r < r1; ++r) {
-                const int lo = st_lo[r], hi = st_hi[r];
-                if (lo < 0 || hi > S || lo >= hi) { gh_set_error("gh_loglik_subset: utterance %lld has state range [%d, %d)", (long long)u, lo, hi); return GH_ERR_INVALID; }
-                int t0, t1;
-                if (M_pad <= 16) { const int spt = 16 / M_pad; t0 = lo / spt; t1 = (hi + spt - 1) / spt; }
-                else { const int tps = M_pad / 16; t0 = lo * tps; t1 = hi * tps; }
-                runs.push_back({t0, t1});
-            }
-            std::sort(runs.begin(), runs.end());
-            size_t w = 0;
-            for (size_t i = 0; i < runs.size(); ++i) {
-                if (w > 0 && runs[i].first <= runs[w - 1].second) runs[w - 1].second = std::max(runs[w - 1].second, runs[i].second);
-                else runs[w++] = runs[i];
-            }
-            runs.resize(w);
-            for (const auto& tr : runs) {
-                const int t0 = tr.first, t1 = tr.second;
-                const int span = (M_pad <= 16) ? (t1 - t0) * (16 / M_pad) : (t1 - t0) / (M_pad / 16);
-                if (span > SC) return 1;   // run wider than one LDS chunk: the caller computes the full matrix
-                max_tiles = std::max(max_tiles, t1 - t0);
-            }
-            // block-major: the entries of one 32-frame block (one per run) follow each other, so a wave that takes
-            // several of them stages the frames once
-            for (int64_t f = b->offsets[u]; f < b->offsets[u + 1]; f += 32)
-                for (const auto& tr : runs)
-                    tabv.push_back(gh_loglik_blk{f, (int32_t)std::min<int64_t>(32, b->offsets[u + 1] - f), tr.first, tr.second, 0});
-        }
+        int rc = build_blk_table(g, b, SC, st_lo, st_hi, rng_off, tabv, &max_tiles);
+        if (rc) return rc;
         n_blk = (int64_t)tabv.size();
         if (n_blk == 0) return GH_OK;
         void* base;
-        int rc = gh_scratch(ctx, tabv.size() * sizeof(gh_loglik_blk), &base);
+        rc = gh_scratch(ctx, tabv.size() * sizeof(gh_loglik_blk), &base);
         if (rc) return rc;
         d_blk = static_cast<gh_loglik_blk*>(base);
         GH_HIP(hipMemcpyAsync(d_blk, tabv.data(), tabv.size() * sizeof(gh_loglik_blk), hipMemcpyHostToDevice, ctx->stream));
         GH_HIP(hipStreamSynchronize(ctx->stream));   // tabv goes out of scope
     }
+    const bool subset = plan || st_lo;
     // blocks per wave: enough MFMAs per wave (>= ~512) to amortise its launch and the ring priming
-    const int64_t n_blocks = st_lo ? n_blk : (N + 31) / 32;
+    const int64_t n_blocks = subset ? n_blk : (N + 31) / 32;
     const int per_block = std::max(1, max_tiles * KS * 2);
     int bpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (512 + per_block - 1) / per_block));
-    if (st_lo) bpw = std::max(bpw, 2);   // the block table lives in the multi-block instantiation
+    if (subset) bpw = std::max(bpw, 2);   // the block table lives in the multi-block instantiation
     const unsigned grid = (unsigned)((n_blocks + bpw - 1) / bpw);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
@@ -626,8 +649,32 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
 
 // returns 1 when the shape is not covered (caller uses the VALU kernel), <0 on error
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
-                          const int64_t* rng_off) {
+                          const int64_t* rng_off, const gh_loglik_plan* plan) {
     if (!g->dApk64) return 1;
-    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr, rng_off);
-    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32, rng_off);
+    if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr, rng_off, plan);
+    return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32, rng_off, plan);
+}
+
+// a block table that outlives the call (own allocation): 1 = shape / ranges not covered by the subset kernel
+int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
+                         const int64_t* rng_off, gh_loglik_plan* out) {
+    out->d_blk = nullptr; out->n_blk = 0; out->max_tiles = 1;
+    if (!g->dApk64) return 1;
+    const int KS = g->KP / 2;
+    if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
+    int chunk_tiles, SC;
+    chunk_shape(g, &chunk_tiles, &SC);
+    std::vector<gh_loglik_blk> tabv;
+    int rc = build_blk_table(g, b, SC, st_lo, st_hi, rng_off, tabv, &out->max_tiles);
+    if (rc) return rc;
+    out->n_blk = (int64_t)tabv.size();
+    if (tabv.empty()) return GH_OK;
+    GH_HIP(hipMalloc(&out->d_blk, tabv.size() * sizeof(gh_loglik_blk)));
+    GH_HIP(hipMemcpy(out->d_blk, tabv.data(), tabv.size() * sizeof(gh_loglik_blk), hipMemcpyHostToDevice));
+    return GH_OK;
+}
+
+void gh_loglik_plan_free(gh_loglik_plan* p) {
+    if (p && p->d_blk) hipFree(p->d_blk);
+    if (p) { p->d_blk = nullptr; p->n_blk = 0; }
 }

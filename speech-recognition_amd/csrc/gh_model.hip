@@ -110,6 +110,128 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     return GH_OK;
 }
 
+// ---- the same packing on the device: a trainer re-estimates the model every iteration and the new parameters are
+// born in HBM (M-step kernel); packing them on the host meant a D2H, ~0.2 ms of host arithmetic, an allocation and an
+// H2D per EM iteration.  One thread per Gaussian writes the plain arrays, one thread per operand element the MFMA
+// fragments; mixture / tile padding keeps what gh_gmm_create put there (P = 0, C = OFF).
+__global__ void gmm_centre_kernel(const double* __restrict__ mean, int G, int D, int KP, float* __restrict__ cen32) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= KP) return;
+    double acc = 0;
+    int cnt = 0;
+    if (d < D)
+        for (int i = 0; i < G; ++i) {
+            const double mu = mean[(size_t)i * D + d];
+            if (mu - mu == 0.0) { acc += mu; ++cnt; }   // finite
+        }
+    float c = cnt ? (float)(acc / cnt) : 0.f;
+    if (!(c - c == 0.f)) c = 0.f;
+    cen32[d] = c;
+}
+
+struct gmm_dev_view {
+    int S, M, D, KP, M_pad, n_tiles;
+    double *A64, *B64, *C64, *Mean, *Ivar, *Logc, *Apk64, *Cpk64;
+    float *A32, *B32, *C32, *Apk32, *Cpk32;
+    const float* cen32;
+};
+
+__global__ void gmm_pack_plain_kernel(gmm_dev_view v, const double* __restrict__ mean, const double* __restrict__ var,
+                                      const double* __restrict__ weight, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = v.S * v.M;
+    if (i >= G) return;
+    const int D = v.D, KP = v.KP;
+    const double log2pi = 1.8378770664093454836;
+    double sum_logv = 0, sum_m2 = 0, sum_m2c = 0;
+    for (int d = 0; d < D; ++d) {
+        const double vv = var[(size_t)i * D + d], mu = mean[(size_t)i * D + d];
+        if (vv == 0) atomicOr(flag, 16);     // singular covariance (np.linalg.inv raises, hmm_state.py:17)
+        const double iv = 1.0 / vv;
+        const double muc = mu - (double)v.cen32[d];
+        v.Mean[(size_t)i * D + d] = mu;
+        v.Ivar[(size_t)i * D + d] = iv;
+        v.A64[(size_t)i * KP + d] = -0.5 * iv;
+        v.B64[(size_t)i * KP + d] = mu * iv;
+        v.A32[(size_t)i * KP + d] = (float)(-0.5 * iv);
+        v.B32[(size_t)i * KP + d] = (float)(muc * iv);
+        sum_logv += log(vv);
+        sum_m2 += mu * mu * iv;
+        sum_m2c += muc * muc * iv;
+    }
+    const double logc = log(weight[i]) - 0.5 * (D * log2pi + sum_logv);
+    v.Logc[i] = logc;
+    const double c = logc - 0.5 * sum_m2, c32 = logc - 0.5 * sum_m2c;
+    v.C64[i] = c;
+    v.C32[i] = (float)c32;
+    // position of the component in the padded tile layout
+    const int s = i / v.M, m = i - s * v.M;
+    const int gp = s * v.M_pad + m;
+    v.Cpk64[gp] = (c == -INFINITY) ? GH_LSE_OFF64 : fmax(c * GH_LSE_SCALE64, GH_LSE_OFF64) + (c != c ? c : 0.0);
+    v.Cpk32[gp] = (c32 == -INFINITY) ? GH_LSE_OFF32 : (float)(fmax(c32 * GH_LSE_SCALE32, (double)GH_LSE_OFF32) + (c32 != c32 ? c32 : 0.0));
+}
+
+__global__ void gmm_pack_operands_kernel(gmm_dev_view v) {
+    // one thread per (padded Gaussian gp, k index kk in [0, 2 KP))
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K2 = 2 * v.KP;
+    const int64_t total = (int64_t)v.n_tiles * 16 * K2;
+    if (idx >= total) return;
+    const int gp = (int)(idx / K2), kk = (int)(idx - (int64_t)gp * K2);
+    const int s = gp / v.M_pad, m = gp - s * v.M_pad;
+    if (s >= v.S || m >= v.M) return;
+    const int go = s * v.M + m;
+    const int t = gp >> 4, j = gp & 15;
+    const int KS = v.KP / 2, ks = kk >> 2, kq = kk & 3;
+    const int row64 = (j >> 2) + 4 * (j & 3), row32 = j;
+    const double a64 = kk < v.KP ? v.A64[(size_t)go * v.KP + kk] : v.B64[(size_t)go * v.KP + kk - v.KP];
+    double a32 = a64;                   // the centred B of the fp32 operands, from its fp64 ingredients (as the host packs it)
+    if (kk >= v.KP) {
+        const int d = kk - v.KP;
+        a32 = d < v.D ? (v.Mean[(size_t)go * v.D + d] - (double)v.cen32[d]) * v.Ivar[(size_t)go * v.D + d] : 0.0;
+    }
+    v.Apk64[((size_t)t * KS + ks) * 64 + kq * 16 + row64] = a64 * GH_LSE_SCALE64;
+    v.Apk32[((size_t)t * KS + ks) * 64 + kq * 16 + row32] = (float)(a32 * GH_LSE_SCALE32);
+}
+
+// new parameters (device arrays [S,M,D], [S,M,D], [S,M]) -> every device array of the handle, on the context's stream.
+// A zero variance raises bit 16 of *d_flag (a device int of the caller's).
+int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double* d_var, const double* d_weight, int* d_flag) {
+    const int G = g->S * g->M;
+    hipStream_t st = ctx->stream;
+    gmm_dev_view v;
+    v.S = g->S; v.M = g->M; v.D = g->D; v.KP = g->KP; v.M_pad = g->M_pad; v.n_tiles = g->n_tiles;
+    v.A64 = g->dA64; v.B64 = g->dB64; v.C64 = g->dC64; v.Mean = g->dMean; v.Ivar = g->dIvar; v.Logc = g->dLogc;
+    v.Apk64 = g->dApk64; v.Cpk64 = g->dCpk64; v.A32 = g->dA32; v.B32 = g->dB32; v.C32 = g->dC32;
+    v.Apk32 = g->dApk32; v.Cpk32 = g->dCpk32; v.cen32 = g->dCen32;
+    hipLaunchKernelGGL(gmm_centre_kernel, dim3((g->KP + 63) / 64), dim3(64), 0, st, d_mean, G, g->D, g->KP, g->dCen32);
+    hipLaunchKernelGGL(gmm_pack_plain_kernel, dim3((G + 63) / 64), dim3(64), 0, st, v, d_mean, d_var, d_weight, d_flag);
+    const int64_t total = (int64_t)g->n_tiles * 16 * 2 * g->KP;
+    hipLaunchKernelGGL(gmm_pack_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v);
+    GH_HIP(hipGetLastError());
+    g->host_stale = true;
+    return GH_OK;
+}
+
+extern "C" int gh_gmm_update(gh_ctx* ctx, gh_gmm* g, const double* mean, const double* var, const double* weight) {
+    GH_REQUIRE(ctx && g && mean && var && weight, "gh_gmm_update: NULL argument");
+    GH_HIP(hipSetDevice(ctx->device));
+    const size_t G = (size_t)g->S * g->M, nd = G * g->D;
+    for (size_t i = 0; i < nd; ++i)
+        GH_REQUIRE(var[i] != 0, "gh_gmm_update: var[%zu,%zu,%zu]=0 (singular covariance)", i / g->D / g->M, i / g->D % g->M, i % g->D);
+    void* base;
+    int rc = gh_scratch(ctx, (2 * nd + G) * 8, &base);
+    if (rc) return rc;
+    double* d = static_cast<double*>(base);
+    GH_HIP(hipMemcpyAsync(d, mean, nd * 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(hipMemcpyAsync(d + nd, var, nd * 8, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(hipMemcpyAsync(d + 2 * nd, weight, G * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = gh_gmm_update_dev(ctx, g, d, d + nd, d + 2 * nd, ctx->d_flag);   // (zero variances were rejected above: the flag stays clear)
+    if (rc) return rc;
+    GH_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays are the caller's, the staging area the context's
+    return GH_OK;
+}
+
 extern "C" void gh_gmm_destroy(gh_gmm* g) {
     if (!g) return;
     hipSetDevice(g->ctx->device);
@@ -262,6 +384,22 @@ extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_ho
     if (out_host && b->N > 0) {
         GH_HIP(hipMemcpyAsync(out_host, b->nll, (size_t)b->N * g->S * esz, hipMemcpyDeviceToHost, ctx->stream));
         GH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GH_OK;
+}
+
+// the resident [N, S] likelihood matrix of a batch, (re)allocated for S states; zero: entries nobody computes stay defined
+int gh_batch_ensure_nll(gh_ctx* ctx, gh_batch* b, int S, bool zero) {
+    const size_t esz = b->dtype == GH_F64 ? 8 : 4;
+    if (b->nll && b->nll_S != S) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        GH_HIP(hipFree(b->nll));
+        b->nll = nullptr;
+    }
+    if (!b->nll && b->N > 0) {
+        GH_HIP(hipMalloc(&b->nll, (size_t)b->N * S * esz));
+        if (zero) GH_HIP(hipMemsetAsync(b->nll, 0, (size_t)b->N * S * esz, ctx->stream));
+        b->nll_S = S;
     }
     return GH_OK;
 }

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("GMMHMM_LIB") or os.path.normpath(
 
 GH_F32, GH_F64 = 0, 1
 GH_ERR_SELF_POINTER = -5
+GH_ERR_UNSUPPORTED = -6
 
 _c_i32p = C.POINTER(C.c_int32)
 _c_i64p = C.POINTER(C.c_int64)
@@ -91,6 +92,15 @@ SIGNATURES = {
     "gh_bw_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, _c_f64p, C.c_void_p]),
     "gh_em_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _c_f64p, _c_f64p,
                                    _c_f64p, _c_f64p, _c_f64p]),
+    "gh_gmm_update": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_f64p, _c_f64p]),
+    "gh_em_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_i32p,
+                               C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_em_destroy": (None, [C.c_void_p]),
+    "gh_em_iteration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_f64p]),
+    "gh_em_iterations_done": (C.c_int, [C.c_void_p]),
+    "gh_em_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_f64p]),
+    "gh_em_get_model": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_f64p, _c_f64p, _c_f64p]),
+    "gh_em_packed": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_i64p]),
     "gh_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gh_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "gh_comm_destroy": (None, [C.c_void_p]),
@@ -291,6 +301,15 @@ class PackedGMM:
         _check(ctx.lib, rc)
         self.h = h
 
+    def update(self, mean, var, weight):
+        """New parameters of the same shape, packed by kernels into the arrays the handle already owns (gh_gmm_update)."""
+        mean, var, weight = _f64(mean), _f64(var), _f64(weight)
+        assert mean.shape == (self.S, self.M, self.D) and var.shape == mean.shape and weight.shape == (self.S, self.M)
+        rc = self.ctx.lib.gh_gmm_update(self.ctx.h, self.h, _ptr(mean, _c_f64p), _ptr(var, _c_f64p), _ptr(weight, _c_f64p))
+        if rc == -1 and b"singular" in self.ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(self.ctx.lib, rc)
+
     def component_loglik(self, state, x):
         x = _f64(x)
         out = np.empty((x.shape[0], self.M))
@@ -302,6 +321,86 @@ class PackedGMM:
         if getattr(self, "h", None):
             if getattr(self.ctx, "h", None):  # a handle must not outlive its context (interpreter shutdown order)
                 self.ctx.lib.gh_gmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Unsupported(BackendError):
+    """The shapes are outside what a device-resident fast path covers; the caller keeps the general path."""
+
+
+class EMSession:
+    """Device-resident soft-EM over one-word transcripts (gh_em): `iteration()` enqueues likelihoods -> forward-backward
+    -> statistics -> [all-reduce] -> M-step -> model re-pack on the context's stream."""
+
+    def __init__(self, ctx, batch, means, vars_, weights, word_trans, utt_word, var_floor, occ_floor=0.0,
+                 min_occupancy=1e-8, update_transitions=True):
+        means, vars_, weights = _f64(means), _f64(vars_), _f64(weights)
+        wt = _f64(word_trans)
+        W, n = wt.shape[0], wt.shape[1]
+        S, M, D = means.shape
+        assert S == W * n and wt.shape == (W, n, n) and vars_.shape == means.shape and weights.shape == (S, M) and D == batch.D
+        uw = np.ascontiguousarray(utt_word, dtype=np.int32)
+        assert len(uw) == batch.U
+        self.ctx, self.batch, self.W, self.n, self.S, self.M, self.D = ctx, batch, W, n, S, M, D
+        h = C.c_void_p()
+        rc = ctx.lib.gh_em_create(ctx.h, batch.h, W, n, M, _ptr(means, _c_f64p), _ptr(vars_, _c_f64p), _ptr(weights, _c_f64p),
+                                  _ptr(wt, _c_f64p), _ptr(uw, _c_i32p), float(var_floor), float(occ_floor),
+                                  float(min_occupancy), int(bool(update_transitions)), C.byref(h))
+        if rc == GH_ERR_UNSUPPORTED:
+            raise Unsupported(ctx.lib.gh_last_error().decode("utf-8", "replace"))
+        if rc == -1 and b"singular" in ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(ctx.lib, rc)
+        self.h = h
+        batch.S = S
+
+    def iteration(self, comm=None, sync=True):
+        """One EM iteration; comm: a `Comm` whose ranks' statistics are summed before the M-step.  sync=True returns
+        (log P before the update, utterances, converged); sync=False returns None as soon as the work is enqueued."""
+        tail = np.empty(4) if sync else None
+        rc = self.ctx.lib.gh_em_iteration(self.ctx.h, self.h, None if comm is None else comm.h, _ptr(tail, _c_f64p))
+        if rc == -1 and b"singular" in self.ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(self.ctx.lib, rc)
+        return None if tail is None else (float(tail[0]), float(tail[1]), bool(tail[2]))
+
+    @property
+    def iterations_done(self):
+        return int(self.ctx.lib.gh_em_iterations_done(self.h))
+
+    def history(self, first=0, count=None):
+        """[count, 4] rows (log P before the update, utterances, converged, error bits) of iterations first .."""
+        count = self.iterations_done - first if count is None else count
+        out = np.empty((count, 4))
+        _check(self.ctx.lib, self.ctx.lib.gh_em_history(self.ctx.h, self.h, int(first), int(count), _ptr(out, _c_f64p)))
+        return out
+
+    def model(self):
+        """(means [S,M,D], vars [S,M,D], weights [S,M], word transition costs [W,n,n]) copied from the device."""
+        mean, var = np.empty((self.S, self.M, self.D)), np.empty((self.S, self.M, self.D))
+        w, t = np.empty((self.S, self.M)), np.empty((self.W, self.n, self.n))
+        _check(self.ctx.lib, self.ctx.lib.gh_em_get_model(self.ctx.h, self.h, _ptr(mean, _c_f64p), _ptr(var, _c_f64p),
+                                                          _ptr(w, _c_f64p), _ptr(t, _c_f64p)))
+        return mean, var, w, t
+
+    def packed(self):
+        """The buffer that crosses the ranks, as the last iteration left it: [statistics | self transitions | log P | utterances]."""
+        n = C.c_int64()
+        _check(self.ctx.lib, self.ctx.lib.gh_em_packed(self.ctx.h, self.h, None, C.byref(n)))
+        out = np.empty(n.value)
+        _check(self.ctx.lib, self.ctx.lib.gh_em_packed(self.ctx.h, self.h, _ptr(out, _c_f64p), C.byref(n)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.gh_em_destroy(self.h)
             self.h = None
 
     def __del__(self):

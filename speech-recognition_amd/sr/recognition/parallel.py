@@ -207,7 +207,7 @@ class NativeReducer:
     `enabled`, `world_size`, `rank`, `__call__(ndarray)` (small host buffers), plus `comm` for the device-resident
     paths (`_hip.EMSession.iteration(comm=...)`)."""
 
-    on_gpu = True
+    on_gpu = False      # (no torch tensor to reduce: device-resident paths take `comm`, host arrays go through __call__)
     native = True
 
     def __init__(self, ctx=None, rank=None, world=None, timeout=180.0):

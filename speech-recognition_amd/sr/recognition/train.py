@@ -14,6 +14,11 @@ One EM iteration, per rank (utterances are sharded, models replicated):
     gh_bw_accumulate     [S, M, 1+2D] centred statistics of the rank                            (HIP)
     all-reduce           ONE packed fp64 buffer (statistics + self transitions + log P + count) (RCCL / gloo)
     m_step               new means / variances / weights, new transition costs                  (host, tiny)
+With one-word transcripts (isolated-word training, BASELINE configs[2]) the whole iteration -- including the all-reduce
+(the library's own RCCL communicator, `parallel.NativeReducer`), the M-step, the transition update, the model re-pack
+and the stop rule -- is ONE call that enqueues kernels on the context's stream (`_hip.EMSession`, gh_em_iteration):
+no host arithmetic, no synchronisation between the steps; the call-by-call form above remains for multi-word
+transcripts and for process groups that are not RCCL (gloo in the CPU tests).
 The loop around it is the reference's training loop in its soft form (continuous_speech.py:144-179): transition
 costs re-estimated every iteration (-log p_jump / -log(1 - p_jump), :146-164, with expected instead of counted
 segments), one pickle per word model and iteration (:167-170), stop when every mixture is `allclose` to the previous
@@ -40,20 +45,25 @@ class BaumWelchTrainer:
     written by rank 0 only."""
 
     def __init__(self, means, vars_, weights, transitions, data, label_seqs, device=None, reducer=None,
-                 var_floor=None, occ_floor=0.0, min_occupancy=1e-8, update_transitions=True, output_path=None):
+                 var_floor=None, occ_floor=0.0, min_occupancy=1e-8, update_transitions=True, output_path=None,
+                 device_resident=True):
         self.ctx = _hip.default_context(device)
         self.W, self.n, self.M, self.D = means.shape
         self.S = self.W * self.n
-        self.means = np.array(means, dtype=np.float64).reshape(self.S, self.M, self.D)
-        self.vars = np.array(vars_, dtype=np.float64).reshape(self.S, self.M, self.D)
-        self.weights = np.array(weights, dtype=np.float64).reshape(self.S, self.M)
-        self.transitions = [np.array(t, dtype=np.float64) for t in transitions]
+        self._means = np.array(means, dtype=np.float64).reshape(self.S, self.M, self.D)
+        self._vars = np.array(vars_, dtype=np.float64).reshape(self.S, self.M, self.D)
+        self._weights = np.array(weights, dtype=np.float64).reshape(self.S, self.M)
+        self._transitions = [np.array(t, dtype=np.float64) for t in transitions]
+        self._stale = False           # the device-resident session holds a newer model than the host copies
+        self.session = None
+        self._gmm = None
         self.update_transitions = bool(update_transitions)
         self.output_path = output_path
         self.var_floor = 1e-6 * float(np.mean(self.vars)) if var_floor is None else float(var_floor)
         self.occ_floor, self.min_occupancy = occ_floor, float(min_occupancy)
         self.reducer = reducer if reducer is not None else StatsAllReducer(gpu_index=self.ctx.device)
-        self.batch = _hip.Batch(self.ctx, data)
+        # (a rank may hold no utterances: its batch still has the model's feature dimension)
+        self.batch = _hip.Batch(self.ctx, data) if len(data) else _hip.Batch(self.ctx, feats=np.zeros((0, self.D)), offsets=[0])
         keys = {}
         self.graph_labels = []
         self.utt_graph = np.empty(len(label_seqs), dtype=np.int32)
@@ -64,14 +74,47 @@ class BaumWelchTrainer:
                 self.graph_labels.append(key)
             self.utt_graph[u] = keys[key]
         self.lat = None
-        self._build_lattices()
-        # an utterance's alignment only involves the states of its own words: likelihoods for those states only
-        from .continuous_speech import transcript_state_sets
-        self.state_sets = transcript_state_sets(label_seqs, self.n, self.W)
         self.history = []
         self.converged = False
         self.n_stats = self.S * self.M * (1 + 2 * self.D)
         self.last_timing = {}
+        # one-word transcripts + a reducer that is the library's own communicator (or none): the device-resident session
+        red = self.reducer
+        native = getattr(red, "native", False)
+        alone = not getattr(red, "enabled", False) or red.world_size == 1
+        if device_resident and all(len(l) == 1 for l in label_seqs) and (native or alone) and self.batch.np_dtype == np.float64:
+            try:
+                self.session = _hip.EMSession(self.ctx, self.batch, self._means, self._vars, self._weights,
+                                              np.asarray(self._transitions), [int(l[0]) for l in label_seqs], self.var_floor,
+                                              occ_floor=self.occ_floor, min_occupancy=self.min_occupancy,
+                                              update_transitions=self.update_transitions)
+            except _hip.Unsupported:
+                self.session = None
+        self._label_seqs = label_seqs
+        self.state_sets = None
+        if self.session is None:
+            self._ensure_call_path()
+
+    def _ensure_call_path(self):
+        """Graphs and state sets of the call-by-call E-step (built on first use when the session runs the iterations)."""
+        if self.state_sets is None:
+            self._build_lattices()
+            # an utterance's alignment only involves the states of its own words: likelihoods for those states only
+            from .continuous_speech import transcript_state_sets
+            self.state_sets = transcript_state_sets(self._label_seqs, self.n, self.W)
+
+    # the model on the host; with a device-resident session the copies are refreshed when somebody looks
+    def _pull(self):
+        if self._stale and self.session is not None:
+            m, v, w, t = self.session.model()
+            self._means, self._vars, self._weights = m, v, w
+            self._transitions = [t[i] for i in range(self.W)]
+            self._stale = False
+
+    means = property(lambda self: (self._pull(), self._means)[1], lambda self, v: setattr(self, "_means", v))
+    vars = property(lambda self: (self._pull(), self._vars)[1], lambda self, v: setattr(self, "_vars", v))
+    weights = property(lambda self: (self._pull(), self._weights)[1], lambda self, v: setattr(self, "_weights", v))
+    transitions = property(lambda self: (self._pull(), self._transitions)[1], lambda self, v: setattr(self, "_transitions", v))
 
     def _build_lattices(self):
         """One forced-alignment graph per distinct label sequence, from the current transition costs."""
@@ -92,23 +135,47 @@ class BaumWelchTrainer:
     def e_step(self, stats_dev=None):
         """Returns (stats [S,M,1+2D] or None when they were left in `stats_dev`, expected self transitions [S],
         total log-likelihood) of this rank."""
-        gmm = _hip.PackedGMM(self.ctx, self.means, self.vars, self.weights)
-        try:
-            if self.batch.U == 0:
-                return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), np.zeros(self.S), 0.0
-            self.batch.loglik(gmm, fetch=False, state_sets=self.state_sets)
-            r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False,
-                                          want_self_xi=True)
-            stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor, stats_dev=stats_dev, fetch=stats_dev is None)
-            logp = r["logp"]
-            return stats, r["self_xi"], float(np.sum(logp[np.isfinite(logp)]))
-        finally:
-            gmm.close()
+        self._ensure_call_path()
+        if self.session is not None and self.lat is not None:
+            self._build_lattices()      # (the session may have moved the transition costs since the graphs were built)
+        if self._gmm is None:           # packed once; later E-steps re-pack in place on the device (gh_gmm_update)
+            self._gmm = _hip.PackedGMM(self.ctx, self.means, self.vars, self.weights)
+        else:
+            self._gmm.update(self.means, self.vars, self.weights)
+        gmm = self._gmm
+        if self.batch.U == 0:
+            return (None if stats_dev else np.zeros((self.S, self.M, 1 + 2 * self.D))), np.zeros(self.S), 0.0
+        self.batch.loglik(gmm, fetch=False, state_sets=self.state_sets)
+        r = self.lat.forward_backward(self.batch, utt_lattice=self.utt_graph, want_occ=True, fetch_occ=False,
+                                      want_self_xi=True)
+        stats = self.batch.bw_accumulate(gmm, occ_floor=self.occ_floor, stats_dev=stats_dev, fetch=stats_dev is None)
+        logp = r["logp"]
+        return stats, r["self_xi"], float(np.sum(logp[np.isfinite(logp)]))
 
-    def iteration(self):
-        """One EM iteration over all ranks; returns the total log-likelihood BEFORE the update."""
+    def _comm(self):
+        red = self.reducer
+        return red.comm if getattr(red, "native", False) else None
+
+    def iteration(self, sync=True):
+        """One EM iteration over all ranks; returns the total log-likelihood BEFORE the update.
+        sync=False (device-resident session only): the iteration is enqueued and None is returned; `drain()` collects
+        the log-likelihoods of all iterations enqueued so far."""
         import time
         t0 = time.perf_counter()
+        if self.session is not None:
+            out = self.session.iteration(comm=self._comm(), sync=sync)
+            self._stale = True
+            if not sync:
+                return None
+            self._drain_to(self.session.iterations_done - 1)
+            ll, _, self.converged = out
+            self.history.append(ll)
+            if self.output_path is not None and self._is_writer():
+                self.save(self.output_path)
+            dt = time.perf_counter() - t0
+            self.last_timing = dict(e_step_s=dt, allreduce_s=0.0, m_step_s=0.0)
+            return ll
+        assert sync, "sync=False needs the device-resident session"
         red = self.reducer
         if red.on_gpu:
             # statistics go from the kernel's slabs straight into the tensor RCCL reduces: no host bounce
@@ -168,8 +235,26 @@ class BaumWelchTrainer:
         if changed:
             self._build_lattices()
 
+    def _drain_to(self, upto):
+        """history rows of enqueued-but-unread iterations [len(history), upto) (device-resident session)."""
+        have = len(self.history)
+        if upto > have:
+            rows = self.session.history(have, upto - have)
+            self.history.extend(float(x) for x in rows[:, 0])
+            self.converged = bool(rows[-1, 2])
+            if np.any(rows[:, 3].astype(np.int64) & 16):
+                raise np.linalg.LinAlgError("Singular matrix")
+
+    def drain(self):
+        """Wait for every enqueued iteration; returns the history (total log-likelihood before each update)."""
+        if self.session is not None:
+            self._drain_to(self.session.iterations_done)
+        return self.history
+
     def _is_writer(self):
         red = self.reducer
+        if getattr(red, "native", False):
+            return red.rank == 0
         return not (red.enabled and red.dist.get_rank() != 0)
 
     def models(self):
@@ -191,13 +276,21 @@ class BaumWelchTrainer:
     def fit(self, n_iterations=5, until_converged=False):
         """n_iterations EM iterations; with until_converged the loop ends early once an iteration leaves every mixture
         allclose to the previous one (continuous_speech.py:172-179), the reference's max_iteration otherwise."""
+        stream_all = self.session is not None and not until_converged and self.output_path is None
         for _ in range(n_iterations):
-            self.iteration()
+            self.iteration(sync=not stream_all)      # nothing on the host needs the result in between: enqueue them all
             if until_converged and self.converged:
                 break
-        return self.history
+        return self.drain()
 
     def close(self):
+        if self.session is not None:
+            self._pull()
+            self.session.close()
+            self.session = None
+        if self._gmm is not None:
+            self._gmm.close()
+            self._gmm = None
         self.batch.close()
         if self.lat is not None:
             self.lat.close()

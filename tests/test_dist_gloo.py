@@ -121,7 +121,7 @@ def _ct_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     import fake_hip
     from sr.recognition import _hip
-    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc"):
+    for name in fake_hip.NAMES:
         setattr(_hip, name, getattr(fake_hip, name))          # what fake_hip.install does through monkeypatch
     import sr.recognition as R
     from sr.recognition.parallel import StatsAllReducer, shard_utterances
@@ -198,7 +198,7 @@ def _bw_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     import fake_hip
     from sr.recognition import _hip
-    for name in ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc"):
+    for name in fake_hip.NAMES:
         setattr(_hip, name, getattr(fake_hip, name))
     from sr.recognition.parallel import StatsAllReducer, shard_utterances
     from sr.recognition.train import BaumWelchTrainer

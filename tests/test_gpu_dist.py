@@ -113,7 +113,8 @@ def _one_rank_rccl(rank, port, out_dir):
         means, vars_, w, trans, data, labels = _problem()
         red = StatsAllReducer(gpu_index=0)
         assert red.enabled and red.on_gpu and dist.get_backend() == "nccl"
-        tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, device=0, reducer=red, var_floor=1e-3)
+        tr = BaumWelchTrainer(means, vars_, w, trans, data, labels, device=0, reducer=red, var_floor=1e-3,
+                              device_resident=False)       # the torch-tensor path (the native one: test_gpu_em_session.py)
         hist = tr.fit(2)
         np.savez(os.path.join(out_dir, "rccl1.npz"), means=tr.means, vars=tr.vars, w=tr.weights, hist=np.array(hist),
                  collectives=red.calls)
