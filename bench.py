@@ -8,8 +8,11 @@ Headline benchmark: frame-state log-likelihoods/s + utterances/s Viterbi decode
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK /
 LOCAL_RANK / WORLD_SIZE in the environment), or started directly -- then this process only spawns the N rank
-processes (before anything touches HIP or torch.cuda) and relays their exit code.  One rank per GPU, backend
-"nccl" (= RCCL over xGMI); `--backend gloo --device 0` rehearses the N-rank path on a one-GPU box.
+processes (before anything touches HIP or torch.cuda) and relays their exit code.  One rank per GPU, each pinned to
+the host cores next to its GPU.  The ranks talk through the LIBRARY'S OWN RCCL communicator (`--comm native`:
+gh_comm_create / gh_stats_allreduce, collectives on the library's stream, no torch in the data path; `--comm torch`
+is the torch.distributed form of round 2).  `--same-gpu` rehearses N native RCCL ranks on a one-GPU box (every rank
+on GPU 0 with a host id of its own, socket transport); `--backend gloo --device 0` is the gloo rehearsal.
 
 One "step" = one pass of the hot path over the batch: batched GMM log-likelihood
 of every frame against every state (A3) + isolated-word Viterbi of every
@@ -50,9 +53,10 @@ PEAK_F32 = 157.3e12    # flop/s, fp32 MFMA == fp32 vector (MI355X_MICROARCH.md)
 PEAK_F64 = 78.6e12     # flop/s, fp64 vector == fp64 MFMA on MI355X (AMD spec; half the fp32 rate)
 
 
-def synth_workload(seed, n_utts, W=10, n=5, M=8, D=39, tmin=50, tmax=150, utt_seed=None):
+def synth_workload(seed, n_utts, W=10, n=5, M=8, D=39, tmin=50, tmax=150, utt_seed=None, words=None, T=None):
     """means ~ N(0,1), vars ~ U[.5,1.5], w ~ Dirichlet(1); left-to-right
-    costs (self -log .9, next -log .1, last self 0); frames from a uniform segmentation."""
+    costs (self -log .9, next -log .1, last self 0); frames from a uniform segmentation.
+    words / T given: those utterances (a rank's shard of a globally drawn list) instead of drawing n_utts."""
     rng = np.random.default_rng(seed)
     means = rng.normal(size=(W, n, M, D))
     vars_ = rng.uniform(0.5, 1.5, size=(W, n, M, D))
@@ -64,8 +68,12 @@ def synth_workload(seed, n_utts, W=10, n=5, M=8, D=39, tmin=50, tmax=150, utt_se
             trans[i + 1, i] = -np.log(0.1)
     if utt_seed is not None:
         rng = np.random.default_rng(utt_seed)
-    words = rng.integers(0, W, size=n_utts)
-    T = rng.integers(tmin, tmax + 1, size=n_utts)
+    if words is None:
+        words = rng.integers(0, W, size=n_utts)
+        T = rng.integers(tmin, tmax + 1, size=n_utts)
+    else:
+        words, T = np.asarray(words), np.asarray(T)
+        n_utts = len(words)
     off = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
     N = int(off[-1])
     utt = np.repeat(np.arange(n_utts), T)
@@ -169,7 +177,7 @@ class native_stdout_to_stderr:
 
 
 # ------------------------------------------------------------------------------------------ N-rank launch
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, same_gpu=False):
     """`bench.py --gpus N` started without a launcher: start N rank processes with the torchrun environment and
     relay the worst exit code.  This parent never imports torch and never calls HIP (a process that has touched the
     GPU must not fork / exec rank processes on this pool)."""
@@ -183,91 +191,284 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if same_gpu:
+            # N native RCCL ranks on ONE GPU: RCCL refuses two ranks of one host on one device, so every rank announces
+            # a host id of its own and the ranks talk over the socket transport on the loopback interface
+            env.update(NCCL_HOSTID="gmmhmm-bench-%d" % r, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                       NCCL_SHM_DISABLE="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:            # a rank that dies leaves the others waiting in a collective: end them with it
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = max(rc, abs(r))
+        if rc and live:
+            time.sleep(2.0)
+            for p in live:
+                p.kill()
+        time.sleep(0.05)
     return rc
 
 
-# ------------------------------------------------------------------------------------------------ EM leg
-def em_leg(args, rank, world, dev, backend):
-    """configs[2]: soft-EM iterations (E-step = own-state likelihoods -> forward-backward -> statistics, all HIP;
-    ONE all-reduce of the packed fp64 statistics buffer per iteration; host M-step) on this rank's shard of
-    `--em-utts` utterances (100k / 8 GPUs = 12 500 by default; weak scaling).  With backend nccl the buffer is
-    reduced where the kernels left it (torch tensor in HBM handed to gh_bw_accumulate as `stats_dev`)."""
-    import torch
-    import torch.distributed as dist
-    from sr.recognition.train import BaumWelchTrainer
-    from sr.recognition.parallel import StatsAllReducer
-    info = {}
-    own_group = False
-    if not dist.is_initialized() and backend == "nccl" and torch.cuda.is_available():
-        # single-GPU run: a one-rank RCCL group, so that the collective of the training path runs on every bench
-        try:
-            import socket
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-            torch.cuda.set_device(dev)
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index):
+    """Host cores next to GPU `index` WITHOUT touching the GPU: the KFD topology lists the GPUs in the order HIP
+    enumerates them (minus *_VISIBLE_DEVICES filtering) with their PCI address; sysfs knows that device's local
+    cpulist.  Returns a set of CPU numbers or None."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(l.split(None, 1) for l in open(os.path.join(base, node, "properties")).read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("gfx_target_version", "0")) > 0:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            gpus = [gpus[int(v)] for v in vis.split(",") if int(v) < len(gpus)]
+        g = gpus[index]
+        loc, dom = int(g["location_id"]), int(g.get("domain", "0"))
+        addr = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        cpus = _parse_cpulist(open("/sys/bus/pci/devices/%s/local_cpulist" % addr).read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def pin_rank(local_rank, local_world, dev):
+    """Pin this rank process to the host cores of its GPU's NUMA node (shared evenly with the other ranks whose GPUs
+    sit on the same node); without topology information: an even slice of the allowed cores.  Called before anything
+    touches the GPU.  Returns a description for the JSON line."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    if local_world <= 1 or len(allowed) < 2 * local_world:
+        return {"cpus": len(allowed), "how": "unpinned"}
+    near = gpu_local_cpus(dev)
+    how = "numa"
+    mine = None
+    if near:
+        near = sorted(near & set(allowed))
+        sharers = [r for r in range(local_world) if (gpu_local_cpus(r) or set()) & set(near)] or [local_rank]
+        if local_rank in sharers and len(near) >= 2 * len(sharers):
+            k = sharers.index(local_rank)
+            per = len(near) // len(sharers)
+            mine = near[k * per:(k + 1) * per]
+    if not mine:
+        per = len(allowed) // local_world
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+        how = "even slice"
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {"cpus": len(allowed), "how": "unpinned"}
+    return {"cpus": len(mine), "first": mine[0], "last": mine[-1], "how": how}
+
+
+class Group:
+    """What the bench needs from the ranks of a run: barrier, max / sum of a few host numbers, a device-wide sync.
+    kind "native": the library's own RCCL communicator (parallel.NativeReducer; torch is never imported);
+    kind "torch": torch.distributed (nccl or gloo), the form of round 2; kind "single": one rank."""
+
+    def __init__(self, args, rank, world, dev):
+        from sr.recognition import _hip
+        self.rank, self.world, self.dev = rank, world, dev
+        self.torch = self.dist = self.native = None
+        self.kind = "single"
+        self.red_dev = "cpu"
+        if world > 1 and args.comm == "torch":
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist, self.kind = torch, dist, "torch"
             with native_stdout_to_stderr():
-                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                                        device_id=torch.device("cuda", dev))
-                dist.barrier()
-            own_group = True
-        except Exception as e:  # reported, not fatal: the EM leg then runs without a process group
+                if args.backend == "nccl":
+                    torch.cuda.set_device(dev)
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+                    self.red_dev = "cuda"
+                else:
+                    dist.init_process_group("gloo")
+                dist.barrier()      # communicators come up here (and RCCL's banner is printed), not inside the timed region
+        self.ctx = _hip.default_context(dev)
+        if world > 1 and args.comm == "native":
+            from sr.recognition.parallel import NativeReducer
+            if self.ctx.lib.gh_comm_version() <= 0:
+                raise RuntimeError("librccl cannot be opened by libgmmhmm.so (use --comm torch): %s"
+                                   % self.ctx.lib.gh_last_error().decode())
+            with native_stdout_to_stderr():
+                self.native = NativeReducer(self.ctx, rank, world)
+                self.native.barrier()
+            self.kind = "native"
+
+    def sync_device(self):
+        self.ctx.device_sync()
+        if self.torch is not None and self.red_dev == "cuda":
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.kind == "native":
+            self.native.barrier()
+        elif self.kind == "torch":
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.kind == "native":
+            return float(self.native.max(np.array([float(x)]))[0])
+        if self.kind == "torch":
+            t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.red_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return float(x)
+
+    def maxv(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        if self.kind == "native":
+            return self.native.max(a)
+        if self.kind == "torch":
+            t = self.torch.from_numpy(a.copy()).to(self.red_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return t.cpu().numpy()
+        return a
+
+    def sum(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        if self.kind == "native":
+            return self.native(a)
+        if self.kind == "torch":
+            t = self.torch.from_numpy(a.copy()).to(self.red_dev)
+            self.dist.all_reduce(t)
+            return t.cpu().numpy()
+        return a
+
+    def close(self):
+        if self.kind == "native":
+            self.native.barrier()
+            self.native.close()
+        elif self.kind == "torch":
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ EM leg
+def em_leg(args, group):
+    """configs[2]: soft-EM iterations on this rank's shard.  Default (weak scaling): `--em-utts` utterances per GPU
+    (100k / 8 GPUs = 12 500); `--em-total T` (strong scaling): T utterances drawn once, sharded over the ranks by
+    parallel.shard_utterances (greedy longest-first by frames).  The iteration is the device-resident session
+    (gh_em_iteration): own-state likelihoods -> forward-backward -> statistics -> ONE ncclAllReduce of the packed fp64
+    buffer on the same stream -> M-step -> model re-pack; the host only reads (log P, converged) back."""
+    from sr.recognition import _hip
+    from sr.recognition.train import BaumWelchTrainer
+    from sr.recognition.parallel import NativeReducer, StatsAllReducer, shard_utterances
+    rank, world, dev = group.rank, group.world, group.dev
+    info = {}
+    own_red = None
+    if group.kind == "native":
+        red = group.native
+    elif group.kind == "torch":
+        red = StatsAllReducer(gpu_index=dev)
+    else:
+        # single-GPU run: a one-rank RCCL communicator, so that the collective of the training path runs on every bench
+        try:
+            with native_stdout_to_stderr():
+                red = own_red = NativeReducer(group.ctx, 0, 1)
+        except Exception as e:  # reported, not fatal: the EM leg then runs without a communicator
             info["rccl_error"] = repr(e)[:200]
-    wl = synth_workload(1003, args.em_utts, utt_seed=None if rank == 0 else 1003 + 7919 * rank)
+            red = None
+    if args.em_total:
+        rng = np.random.default_rng(1003)
+        g_words = rng.integers(0, 10, size=args.em_total)
+        g_T = rng.integers(50, 151, size=args.em_total)
+        mine = shard_utterances(g_T, world)[rank]
+        wl = synth_workload(1003, len(mine), utt_seed=1003 + 7919 * rank, words=g_words[mine], T=g_T[mine])
+        U = len(mine)
+    else:
+        U = args.em_utts
+        wl = synth_workload(1003, U, utt_seed=None if rank == 0 else 1003 + 7919 * rank)
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
-    U = args.em_utts
     data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
     labels = [[int(w)] for w in wl["words"]]
     means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)   # perturbed start, same on every rank
-    red = StatsAllReducer(gpu_index=dev)
     tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=dev, reducer=red)
     del data
-    sync_dev = "cuda" if (dist.is_initialized() and dist.get_backend() == "nccl") else "cpu"
 
     def fence():
         tr.ctx.sync()
-        if dist.is_initialized():
-            if sync_dev == "cuda":
-                torch.cuda.synchronize()
-            dist.barrier()
+        group.sync_device()
+        group.barrier()
     hist = [tr.iteration()]                       # warm-up iteration (allocations, RCCL channel set-up)
-    red.calls, red.seconds = 0, 0.0
+    if red is not None:
+        red.calls, red.seconds = 0, 0.0
+    # (a) one 32-byte D2H of (log P, converged) per iteration -- what a training loop with a stop rule does
     fence()
     t0 = time.perf_counter()
-    e_s = 0.0
     for _ in range(args.em_iters):
         hist.append(tr.iteration())
-        e_s += tr.last_timing["e_step_s"]
     fence()
-    dt = time.perf_counter() - t0
+    dt = group.max(time.perf_counter() - t0)
+    # (b) the same iterations enqueued back to back, history read once at the end (no stop rule to evaluate in between)
+    dt_q = None
+    if tr.session is not None:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.em_iters):
+            tr.iteration(sync=False)
+        tr.drain()
+        fence()
+        dt_q = group.max(time.perf_counter() - t0)
+        hist = list(tr.history)
     frames = float(tr.batch.N)
-    if dist.is_initialized():
-        t = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tot = torch.tensor([float(U), frames], dtype=torch.float64, device=sync_dev)
-        dist.all_reduce(tot)
-        dt, all_utts, all_frames = float(t.item()), float(tot[0].item()), float(tot[1].item())
-    else:
-        all_utts, all_frames = float(U), frames
+    tot = group.sum([float(U), frames])
+    all_utts, all_frames = float(tot[0]), float(tot[1])
+    # the collective by itself: the packed buffer's size through the same communicator, stream-synchronised
+    ar_ms, n_ranks = None, 0
+    comm = tr._comm()
+    if comm is not None:
+        n_ranks = comm.count                                   # ncclCommCount
+        buf = np.zeros(tr._packed_len())
+        red(buf)
+        group.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            red(buf)
+        ar_ms = group.max((time.perf_counter() - t0) / 10) * 1e3
+    elif group.kind == "torch":
+        ar_ms = (red.seconds / red.calls * 1e3) if red.calls else None
+        n_ranks = group.dist.get_world_size() if group.dist.get_backend() == "nccl" else 0
+    per_it = dt / args.em_iters
     info.update({
         "workload": "configs[2]: soft EM (fwd-bwd E-step + all-reduced statistics + M-step), 10x5 states, 8-mix, 39-dim, "
-                    "%d utterances per GPU" % U,
-        "iterations": args.em_iters, "ms_per_iteration": dt / args.em_iters * 1e3,
-        "em_utterances_per_s": all_utts * args.em_iters / dt, "em_frames_per_s": all_frames * args.em_iters / dt,
-        "e_step_ms": e_s / args.em_iters * 1e3,
-        "allreduce_ms": (red.seconds / red.calls * 1e3) if red.calls else None,
-        "allreduce_bytes": tr._packed_len() * 8,
-        "allreduce_on_device_buffer": bool(red.on_gpu),
-        "backend": dist.get_backend() if dist.is_initialized() else None,
-        "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+                    + ("%d utterances sharded over %d GPUs (strong scaling)" % (args.em_total, world) if args.em_total
+                       else "%d utterances per GPU (weak scaling)" % U),
+        "scaling": "strong" if args.em_total else "weak",
+        "iterations": args.em_iters, "ms_per_iteration": per_it * 1e3,
+        "ms_per_iteration_enqueued": None if dt_q is None else dt_q / args.em_iters * 1e3,
+        "em_utterances_per_s": all_utts / per_it, "em_frames_per_s": all_frames / per_it,
+        "device_resident_iteration": tr.session is not None,
+        "host_syncs_per_iteration": 1 if tr.session is not None else 3,
+        "allreduce_ms": ar_ms, "allreduce_bytes": tr._packed_len() * 8,
+        "allreduce_note": "host-staged round trip of the same buffer through the same communicator; inside the iteration "
+                          "the collective sits on the kernels' stream (gh_stats_allreduce)" if comm is not None else None,
+        "allreduce_on_device_buffer": bool(comm is not None or getattr(red, "on_gpu", False)),
+        "comm": group.kind if group.kind != "single" else ("native" if comm is not None else None),
+        "backend": "nccl" if comm is not None else (group.dist.get_backend() if group.kind == "torch" else None),   # ("nccl" IS RCCL on ROCm)
+        "rccl_ranks": n_ranks, "rccl_library": tr.ctx.lib.gh_comm_library().decode() if comm is not None else None,
         "loglik_per_frame": [h / all_frames for h in hist],
         "loglik_monotone": bool(all(b >= a - 1e-9 * abs(a) for a, b in zip(hist, hist[1:]))),
     })
     tr.close()
-    if own_group:
-        dist.destroy_process_group()
+    if own_red is not None:
+        own_red.close()
     return info
 
 
@@ -284,13 +485,14 @@ def _timeit(fn, reps=3, ramp=0.3):
     return (time.perf_counter() - t0) / reps, out
 
 
-def _isolated_config(ctx, name, seed, U, W, n, M, D, npdt, peak_flops):
+def _isolated_config(ctx, group, name, seed, U, W, n, M, D, npdt, peak_flops, mismatch=False):
     from sr.recognition import _hip
-    wl = synth_workload(seed, U, W=W, n=n, M=M, D=D)
+    wl = synth_workload(seed, U, W=W, n=n, M=M, D=D, utt_seed=None if group.rank == 0 else seed + 7919 * group.rank)
     S = W * n
     gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
     b = _hip.Batch(ctx, feats=wl["X"], offsets=wl["off"], dtype=npdt)
     lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
+    group.barrier()
     t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()))
     t_vit, r = _timeit(lambda: lat.viterbi(b, want_path=False))
     words = np.argmin(r["end_cost_flat"].reshape(U, W), axis=1)
@@ -298,29 +500,57 @@ def _isolated_config(ctx, name, seed, U, W, n, M, D, npdt, peak_flops):
     N = b.N
     flops, bytes_ll, bytes_vit = 2.0 * 2 * D * S * M * N, float(esz * (D + S) * N), float(esz * S * N)
     hbm_bound = flops / bytes_ll < peak_flops / PEAK_HBM
-    out = {"workload": name, "utterances": U, "frames": int(N), "states": S, "mixtures": M, "dim": D,
-           "ms": (t_ll + t_vit) * 1e3, "loglik_ms": t_ll * 1e3, "viterbi_ms": t_vit * 1e3,
-           "value": N * S / (t_ll + t_vit), "unit": "frame-state loglik/s", "utterances_per_s": U / (t_ll + t_vit),
-           "decode_accuracy": float(np.mean(words == wl["words"])),
+    tm = group.maxv([t_ll, t_vit])
+    tot = group.sum([float(U), float(N), float(np.mean(words == wl["words"]))])
+    g_ll, g_vit = float(tm[0]), float(tm[1])
+    out = {"workload": name, "n_gpus": group.world, "utterances": int(tot[0]), "frames": int(tot[1]), "states": S, "mixtures": M, "dim": D,
+           "ms": (g_ll + g_vit) * 1e3, "loglik_ms": g_ll * 1e3, "viterbi_ms": g_vit * 1e3,
+           "value": tot[1] * S / (g_ll + g_vit), "unit": "frame-state loglik/s", "utterances_per_s": tot[0] / (g_ll + g_vit),
+           "decode_accuracy": tot[2] / group.world,
            "roofline": ({"kernel": "loglik", "bound": "hbm", "achieved": bytes_ll / t_ll / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": bytes_ll / t_ll / PEAK_HBM} if hbm_bound else
                         {"kernel": "loglik", "bound": "mfma", "achieved": flops / t_ll / 1e12, "peak": peak_flops / 1e12,
                          "unit": "TFLOP/s", "frac": flops / t_ll / peak_flops}),
            "viterbi_roofline": {"kernel": "viterbi_chain", "bound": "hbm", "achieved": bytes_vit / t_vit / 1e9,
                                 "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_vit / t_vit / PEAK_HBM},
-           "timing": "wall time of the synchronous C-ABI calls (includes their host side), mean of 3 after a 0.3 s ramp"}
+           "timing": "wall time of the synchronous C-ABI calls (includes their host side), mean of 3 after a 0.3 s ramp; "
+                     "rooflines are rank 0's, times the slowest rank's"}
     lat.close(); b.close(); gmm.close()
     return out
 
 
-def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
-    """configs[4] at its per-GPU size (1 M utterances / 8 GPUs): `U_base` distinct synthetic K-word utterances,
-    tiled on the device to `U_total`; K-layer lattice (the reference's grammar, main.py:35) and the word-loop
-    grammar, decoded to label sequences on the device (gh_viterbi_labels)."""
-    import torch
+def fp32_mismatch_c2(ctx, wl):
+    """configs[1] at bench size: how often the isolated-word decode from FP32 likelihoods (fp64 DP) differs from the fp64
+    decode -- the recognised word, and the Viterbi state path through the whole stacked graph (best end)."""
+    from sr.recognition import _hip
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    S = W * n
+    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
+    lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
+    res = {}
+    for dt in (np.float64, np.float32):
+        b = _hip.Batch(ctx, feats=wl["X"], offsets=wl["off"], dtype=dt)
+        b.loglik(gmm, fetch=False)
+        r = lat.viterbi(b, want_path=True)
+        res[dt] = (np.argmin(r["end_cost_flat"].reshape(b.U, W), axis=1), r["paths"])
+        b.close()
+    lat.close(); gmm.close()
+    (w64, p64), (w32, p32) = res[np.float64], res[np.float32]
+    return {"utterances": int(len(w64)), "fp32_word_mismatch_rate": float(np.mean(w64 != w32)),
+            "fp32_path_mismatch_rate": float(np.mean([not np.array_equal(x, y) for x, y in zip(p64, p32)]))}
+
+
+def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
+    """configs[4] at its per-GPU size (1 M utterances / 8 GPUs): `U_base` distinct synthetic K-word utterances per
+    rank, tiled on the device to `U_total` (synthesising 39 M distinct frames costs ~12 GB of host memory and ~1 min
+    of numpy per rank -- x8 ranks on one host; the decode does not care that utterances repeat); K-layer lattice (the
+    reference's grammar, main.py:35) and the word-loop grammar, decoded to label sequences on the device
+    (gh_viterbi_labels).  Every rank runs its own share (main.py:60 shards by utterance: no data-path collective);
+    reported: all ranks' utterances / the slowest rank's time.  Also: how often a decode from FP32 likelihoods
+    differs from the fp64 decode (paths and label sequences, on the distinct utterances)."""
     from sr.recognition import _hip
     from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
-    rng = np.random.default_rng(1005)
+    rng = np.random.default_rng(1005 + 7919 * group.rank)
     wl = synth_workload(1005, 1, W=W, n=n, M=M, D=D)
     means, vars_, trans = wl["means"], wl["vars"], wl["trans"]
     S = W * n
@@ -337,20 +567,20 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
     T = Tw.sum(axis=1)
     reps = max(1, int(round(U_total / U_base)))
     U = U_base * reps
-    dev = torch.device("cuda", ctx.device)
-    tdt = torch.float64 if npdt == np.float64 else torch.float32
-    xb = torch.from_numpy(np.ascontiguousarray(X, dtype=npdt)).to(dev)
-    xt = xb.repeat(reps, 1).contiguous()
-    del xb
-    torch.cuda.synchronize(dev)
-    off = np.concatenate([[0], np.cumsum(np.tile(T, reps))]).astype(np.int64)
-    N = int(off[-1])
-    b = _hip.Batch(ctx, feats_dev=xt.data_ptr(), dim=D, offsets=off, dtype=npdt)
+    off_b = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+    base = _hip.Batch(ctx, feats=np.ascontiguousarray(X, dtype=npdt), offsets=off_b, dtype=npdt)
+    b = base.tile(reps)
+    N = b.N
     gmm = _hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), wl["w"].reshape(S, M))
+    group.barrier()
     t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()), reps=3, ramp=0.2)
     esz = np.dtype(npdt).itemsize
     out = {}
     truth = [list(w) for w in words]
+    other = np.float32 if npdt == np.float64 else np.float64     # the decode from the OTHER precision's likelihoods
+    base_o = _hip.Batch(ctx, feats=np.ascontiguousarray(X, dtype=other), offsets=off_b, dtype=other)
+    base.loglik(gmm, fetch=False)
+    base_o.loglik(gmm, fetch=False)
     for key, (graph, _nes), max_labels in (
             ("C5_K7_lattice", packed_lattice([trans] * W, n, [list(range(W))] * K), K + 1),
             ("C5_loop_grammar", packed_loop_lattice([trans] * W, n), None)):
@@ -358,24 +588,38 @@ def _continuous_config(ctx, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
         R = len(graph["row_state"])
         row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
         ml = max_labels if max_labels is not None else b.lengths // (n - 1) + 2
+        group.barrier()
         t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False), reps=5, ramp=0.25)   # (the first calls grow the scratch arenas)
         lf, lo, ln = r["labels_flat"], r["label_off"], r["n_labels"]
         acc = float(np.mean([[int(v) for v in lf[lo[u]:lo[u] + ln[u]]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
+        # fp32-likelihood decode against the fp64 one, on the distinct utterances: state paths and label sequences
+        pa = lat.viterbi(base, want_path=True)["paths"]
+        pb = lat.viterbi(base_o, want_path=True)["paths"]
+        path_mis = float(np.mean([not np.array_equal(x, y) for x, y in zip(pa, pb)]))
+        mlb = max_labels if max_labels is not None else base.lengths // (n - 1) + 2
+        la = lat.viterbi_labels(base, row_word, max_labels=mlb)["labels"]
+        lb = lat.viterbi_labels(base_o, row_word, max_labels=mlb)["labels"]
+        lab_mis = float(np.mean([not np.array_equal(x, y) for x, y in zip(la, lb)]))
+        del pa, pb
         bytes_dp = float((esz * S + 4) * N)     # un-fused Viterbi over materialised likelihoods
+        # all ranks: utterances / slowest rank (each leg's times are max'ed over the ranks)
+        tm = group.maxv([t_ll, t_dec])
+        tot = group.sum([float(U), float(N), acc, path_mis, lab_mis])
+        g_ll, g_dec = float(tm[0]), float(tm[1])
         out[key] = {"workload": "configs[4] per-GPU share: %d utterances (%d distinct, tiled x%d on the device), K=%d words, "
                                 "%d lattice rows" % (U, U_base, reps, K, R),
-                    "utterances": U, "frames": N, "lattice_rows": R,
-                    "ms": (t_ll + t_dec) * 1e3, "loglik_ms": t_ll * 1e3, "viterbi_labels_ms": t_dec * 1e3,
-                    "value": U / (t_ll + t_dec), "unit": "utterances/s", "dp_cells_per_s": N * R / t_dec,
-                    "sequence_accuracy_sampled": acc,
+                    "n_gpus": group.world, "utterances": int(tot[0]), "frames": int(tot[1]), "lattice_rows": R,
+                    "ms": (g_ll + g_dec) * 1e3, "loglik_ms": g_ll * 1e3, "viterbi_labels_ms": g_dec * 1e3,
+                    "value": tot[0] / (g_ll + g_dec), "unit": "utterances/s", "dp_cells_per_s": tot[1] * R / g_dec,
+                    "sequence_accuracy_sampled": tot[2] / group.world,
+                    "fp32_path_mismatch_rate": tot[3] / group.world, "fp32_label_mismatch_rate": tot[4] / group.world,
+                    "fp32_mismatch_sample": "%d distinct utterances per rank, fp32 vs fp64 likelihoods, fp64 DP" % U_base,
                     "roofline": {"kernel": "viterbi (lattice)", "bound": "hbm", "achieved": bytes_dp / t_dec / 1e9,
                                  "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_dp / t_dec / PEAK_HBM,
-                                 "note": "algorithmic bytes (esz*S + 4) per frame over the wall time of gh_viterbi_labels "
+                                 "note": "rank 0: algorithmic bytes (esz*S + 4) per frame over the wall time of gh_viterbi_labels "
                                          "(kernels + label copy-back + host slicing)"}}
         lat.close()
-    b.close(); gmm.close()
-    del xt
-    torch.cuda.empty_cache()
+    b.close(); base.close(); base_o.close(); gmm.close()
     return out
 
 
@@ -422,17 +666,61 @@ def _training_config(ctx, U, K=7):
                                   "loglik_monotone": bool(all(y >= x - 1e-7 * abs(x) for x, y in zip(hist, hist[1:])))}}
 
 
-def extra_configs(args, dev, npdt, peak_flops):
+def _c4_em_config(ctx, group, U):
+    """Soft-EM iterations at the configs[3] shape (64 words x 16 states x 32 mixtures): M = 32 and n = 16 are outside the
+    fused matrix-core statistics kernel and the one-lane-group chain forward-backward, so this leg runs the GENERIC
+    kernels (fb_kernel: one workgroup per utterance; bw_stats_kernel: densities on the VALU) call by call, with the
+    20.7 MB statistics buffer reduced through the group's communicator."""
+    from sr.recognition.train import BaumWelchTrainer
+    wl = synth_workload(1004, U, W=64, n=16, M=32, D=39, utt_seed=None if group.rank == 0 else 1004 + 7919 * group.rank)
+    W = wl["W"]
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    labels = [[int(w)] for w in wl["words"]]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)
+    red = group.native if group.kind == "native" else None
+    if group.kind == "torch":
+        from sr.recognition.parallel import StatsAllReducer
+        red = StatsAllReducer(gpu_index=group.dev)
+    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device, reducer=red)
+    hist = [tr.iteration()]
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        hist.append(tr.iteration())
+    dt = group.max((time.perf_counter() - t0) / 2)
+    tot = group.sum([float(U), float(tr.batch.N)])
+    out = {"workload": "configs[3] shape, soft EM: 64 x 16 states x 32 mixtures, 39-dim, %d utterances per GPU (generic kernels)" % U,
+           "n_gpus": group.world, "utterances": int(tot[0]), "frames": int(tot[1]), "ms_per_iteration": dt * 1e3,
+           "em_frames_per_s": tot[1] / dt, "device_resident_iteration": tr.session is not None,
+           "allreduce_bytes": tr._packed_len() * 8,
+           "loglik_monotone": bool(all(y >= x - 1e-9 * abs(x) for x, y in zip(hist, hist[1:])))}
+    tr.close()
+    return out
+
+
+def extra_configs(args, group, npdt, peak_flops, wl):
+    """The other BASELINE configs, after the timed region.  With several ranks every rank runs its share of the legs
+    that BASELINE defines on 8 GPUs (configs[4]: C5 K-layer lattice and loop grammar at 125 000 utterances per rank;
+    configs[3]: C4) and rank 0 reports all ranks' units over the slowest rank's time; the single-GPU-only legs (C1 x1000,
+    the word-string training step, the fp32-vs-fp64 decode comparison of configs[1]) run when there is one rank."""
     from sr.recognition import _hip
-    ctx = _hip.Context(dev)
+    ctx = _hip.Context(group.dev)
     out = {}
-    for key, fn in (
-            ("C1x1000", lambda: _isolated_config(ctx, "configs[0] x1000: 10x5 states, 1 Gaussian, 13-dim, 100 000 utterances",
-                                                 1001, 100000, 10, 5, 1, 13, npdt, peak_flops)),
-            ("C4", lambda: _isolated_config(ctx, "configs[3] (reduced utterance count): 64 HMMs x 16 states x 32 mixtures, 39-dim",
-                                            1004, args.c4_utts, 64, 16, 32, 39, npdt, peak_flops)),
-            ("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)),
-            ("C5", lambda: _continuous_config(ctx, args.c5_utts, min(args.c5_utts, 5000), npdt))):
+    one = group.world == 1
+    c4_utts = args.c4_utts if args.c4_utts else (50000 if one else 10000)
+    c4_name = ("configs[3]: 64 HMMs x 16 states x 32 mixtures, 39-dim, %d utterances%s"
+               % (c4_utts, "" if c4_utts >= 50000 else " per GPU (reduced from 50 000)"))
+    legs = []
+    if one:
+        legs.append(("C1x1000", lambda: _isolated_config(ctx, group, "configs[0] x1000: 10x5 states, 1 Gaussian, 13-dim, 100 000 utterances",
+                                                         1001, 100000, 10, 5, 1, 13, npdt, peak_flops)))
+    legs.append(("C4", lambda: _isolated_config(ctx, group, c4_name, 1004, c4_utts, 64, 16, 32, 39, npdt, peak_flops)))
+    legs.append(("C4_em", lambda: _c4_em_config(ctx, group, args.c4_em_utts)))
+    if one:
+        legs.append(("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)))
+        legs.append(("C2_fp32_decode", lambda: fp32_mismatch_c2(ctx, wl)))
+    legs.append(("C5", lambda: _continuous_config(ctx, group, args.c5_utts, min(args.c5_utts, 5000), npdt)))
+    for key, fn in legs:
         t0 = time.perf_counter()
         try:
             r = fn()
@@ -440,8 +728,10 @@ def extra_configs(args, dev, npdt, peak_flops):
                 out.update(r)
             else:
                 out[key] = r
-        except Exception as e:   # an extra must never take the headline line down with it
-            out[key] = {"error": repr(e)[:300]}
+        except Exception as e:
+            if not one:
+                raise            # a rank that drops out of a leg's collectives would hang the others: fail loudly
+            out[key] = {"error": repr(e)[:300]}    # a single-rank extra must never take the headline line down with it
         out.setdefault("_seconds", {})[key] = round(time.perf_counter() - t0, 1)
     ctx.close()
     return out
@@ -491,18 +781,32 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=80)
     # rehearsal of the N > 1 path on a box with fewer GPUs: --backend gloo --device 0 lets every rank share GPU 0
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--comm", default=None, choices=["native", "torch"],
+                    help="process group of an N-rank run: native = the library's own RCCL communicator (gh_comm_*; default "
+                         "with --backend nccl), torch = torch.distributed (default with --backend gloo)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank on GPU 0, native RCCL over the socket transport (one "
+                         "NCCL_HOSTID per rank); only when bench.py starts its own ranks")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores of its GPU's NUMA node")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (default: LOCAL_RANK)")
     ap.add_argument("--no-em", action="store_true", help="skip the EM leg (configs[2])")
     ap.add_argument("--em-utts", type=int, default=12500, help="utterances per GPU of the EM leg (100k / 8 GPUs)")
     ap.add_argument("--em-iters", type=int, default=5)
+    ap.add_argument("--em-total", type=int, default=0,
+                    help="strong scaling of the EM leg: this many utterances in total, sharded over the ranks by frames "
+                         "(configs[2]: 100000); default 0 = --em-utts per GPU (weak)")
+    ap.add_argument("--c4-em-utts", type=int, default=1000, help="utterances per GPU of the C4-shape EM leg")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip C1 x1000 / C4 / C5 / PCIe legs (single-GPU runs only)")
-    ap.add_argument("--c4-utts", type=int, default=10000, help="utterances of the C4 leg (~1 M frames)")
+    ap.add_argument("--c4-utts", type=int, default=0, help="utterances of the C4 leg (default: 50 000 = configs[3] on one "
+                                                         "GPU, 10 000 per GPU in an N-rank run)")
     ap.add_argument("--c5-utts", type=int, default=125000, help="utterances of the C5 legs (1 M / 8 GPUs)")
     ap.add_argument("--c3-utts", type=int, default=2000, help="7-word utterances of the training-step leg (C3_word_strings)")
     args = ap.parse_args()
 
+    if args.comm is None:
+        args.comm = "native" if args.backend == "nccl" else "torch"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing above this line touches HIP or torch
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], same_gpu=args.same_gpu))      # nothing above this line touches HIP or torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -510,25 +814,11 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: torch.distributed.run "
                  "--nproc-per-node %d, or start bench.py --gpus %d without a launcher)" % (args.gpus, world, args.gpus, args.gpus))
-    dist = None
-    dev = local_rank if args.device is None else args.device
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        with native_stdout_to_stderr():
-            if args.backend == "nccl":
-                torch.cuda.set_device(dev)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-            else:
-                dist.init_process_group("gloo")
-            dist.barrier()      # communicators come up here (and RCCL's banner is printed), not inside the timed region
-    try:
-        import torch
-        have_torch_cuda = torch.cuda.is_available()
-    except Exception:
-        torch, have_torch_cuda = None, False
-    red_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
+    dev = (0 if args.same_gpu else local_rank) if args.device is None else args.device
+    # host cores: before anything touches the GPU (and before numpy / the ranks' host threads start working)
+    pinned = None if args.no_pin else pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), dev)
     from sr.recognition import _hip
+    group = Group(args, rank, world, dev)
     npdt = np.float64 if args.dtype == "f64" else np.float32
     wl = synth_workload(1002, args.utts, utt_seed=None if rank == 0 else 1002 + 7919 * rank)
     W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
@@ -606,16 +896,16 @@ def main():
             raise state["err"]
 
     def fence():
+        """Barrier + device-wide synchronisation on both sides of the timed region: every lane's stream, then
+        hipDeviceSynchronize through the library's runtime (all contexts of this GPU; plus torch.cuda.synchronize when the
+        group is torch's), then the barrier over the ranks (RCCL all-reduce + stream sync, or dist.barrier), then again."""
         for l in lanes:
             l.ctx.sync()
-        if have_torch_cuda:
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        group.sync_device()
+        group.barrier()
         for l in lanes:
             l.ctx.sync()
-        if have_torch_cuda:
-            torch.cuda.synchronize()
+        group.sync_device()
 
     run_steps(0, False, seconds=args.ramp_seconds)   # clock ramp, untimed (see --ramp-seconds)
     run_steps(args.warmup, False)
@@ -626,15 +916,9 @@ def main():
     dt = time.perf_counter() - t0
     decoded = next(l.decoded for l in lanes if l.decoded is not None)
     ll_times = [lanes[0].ctx.elapsed_ms(a, b) for l in lanes for a, b in l.ll_ms]   # HIP events, the library's own runtime
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = torch.tensor([float(N_frames), float(U)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tot)
-        dt = float(tmax.item())
-        all_frames, all_utts = float(tot[0].item()), float(tot[1].item())
-    else:
-        all_frames, all_utts = float(N_frames), float(U)
+    dt = group.max(dt)                                   # the slowest rank's time
+    tot = group.sum([float(N_frames), float(U)])         # all ranks' units
+    all_frames, all_utts = float(tot[0]), float(tot[1])
     accuracy = float(np.mean(decoded == wl["words"]))
 
     if rank == 0:
@@ -654,7 +938,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 10-digit HMM, 5 states/digit, 8-mix GMM, 39-dim, "
                                    "%d utterances/GPU (%d frames on rank 0), isolated-word decode" % (U, N_frames),
-                       "states": S, "mixtures": M, "dim": D, "parallelism": "utterance-sharded x%d" % world, "batches_in_flight": len(lanes)},
+                       "states": S, "mixtures": M, "dim": D, "parallelism": "utterance-sharded x%d" % world, "batches_in_flight": len(lanes),
+                       "process_group": group.kind, "host_cores": pinned},
             "utterances_per_s": all_utts * args.steps / dt,
             "frames_per_s": all_frames * args.steps / dt,
             "decode_accuracy": accuracy,
@@ -677,25 +962,26 @@ def main():
     em = None
     if not args.no_em:
         try:
-            em = em_leg(args, rank, world, dev, args.backend)
+            em = em_leg(args, group)
         except Exception as e:
             if world > 1:
                 raise             # a rank that drops out of a collective would hang the others: fail loudly
             em = {"error": repr(e)[:300]}
+    configs = None
+    if not args.no_extra_configs:
+        configs = extra_configs(args, group, npdt, PEAK_F64 if args.dtype == "f64" else PEAK_F32, wl)
     if rank == 0:
         if em is not None:
             out["em"] = em
+        if configs is not None:
+            out["configs"] = configs
         if world == 1 and not args.no_extra_configs:
-            peak = PEAK_F64 if args.dtype == "f64" else PEAK_F32
-            out["configs"] = extra_configs(args, dev, npdt, peak)
             try:
                 out["pcie_inclusive"] = pcie_inclusive(dev, wl, npdt)
             except Exception as e:
                 out["pcie_inclusive"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

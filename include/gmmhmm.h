@@ -56,6 +56,9 @@ int gh_version(void);
 int gh_ctx_create(int device, gh_ctx** out);
 void gh_ctx_destroy(gh_ctx* ctx);
 int gh_ctx_sync(gh_ctx* ctx);
+/* hipDeviceSynchronize on the context's GPU: every stream of this library's runtime has drained (the bracket of a
+ * timed region when several contexts are in flight) */
+int gh_device_sync(gh_ctx* ctx);
 /* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);
 /* number of GPUs the library's HIP runtime sees (<= 0: none).  Callers must not dlopen a HIP runtime of their own
@@ -95,6 +98,9 @@ int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
  * segments) without a trip through the host. */
 int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* idx /*[n]*/, int64_t n, int64_t U,
                     const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
+/* `reps` copies of a resident batch back to back as a new resident batch of reps * U utterances (device-to-device
+ * copies; measurement plumbing: a large batch from a small upload; no reference counterpart) */
+int gh_batch_tile(gh_ctx* ctx, const gh_batch* src, int reps, gh_batch** out);
 void gh_batch_destroy(gh_batch* b);
 /* N3 front-end: cepstra [N, C] (fp64, ragged by utt_offsets) -> [cepstra | delta | delta-delta]
  * (delta_feature, sr/core.py:13-22) -> per-utterance (x - mean) / std (standardize,

@@ -150,6 +150,8 @@ extern "C" int gh_comm_count(const gh_comm* c) {
 
 extern "C" int gh_comm_rank(const gh_comm* c) { return c ? c->rank : -1; }
 
+gh_ctx* gh_comm_context(const gh_comm* c) { return c ? c->ctx : nullptr; }
+
 extern "C" const char* gh_comm_library(void) {
     std::call_once(g_rccl_once, open_rccl);
     return g_rccl.handle ? g_rccl.path.c_str() : "";

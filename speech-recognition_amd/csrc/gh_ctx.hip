@@ -74,6 +74,13 @@ extern "C" int gh_ctx_sync(gh_ctx* c) {
     return GH_OK;
 }
 
+extern "C" int gh_device_sync(gh_ctx* c) {
+    GH_REQUIRE(c, "gh_device_sync: ctx is NULL");
+    GH_HIP(hipSetDevice(c->device));
+    GH_HIP(hipDeviceSynchronize());
+    return GH_OK;
+}
+
 extern "C" void* gh_ctx_stream(gh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 extern "C" int gh_device_count(void) {

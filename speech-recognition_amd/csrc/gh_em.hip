@@ -310,6 +310,8 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
 extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out_tail) {
     GH_REQUIRE(ctx && e && e->ctx == ctx, "gh_em_iteration: NULL argument / foreign context");
     GH_REQUIRE(e->it < e->hist_cap, "gh_em_iteration: more than %d iterations in one session", e->hist_cap);
+    GH_REQUIRE(!comm || gh_comm_context(comm) == ctx, "gh_em_iteration: the communicator belongs to another context (its "
+               "collective must sit on the stream of the kernels around it)");
     GH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     gh_batch* b = e->b;

@@ -252,6 +252,7 @@ int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double
 int gh_batch_ensure_nll(gh_ctx* ctx, gh_batch* b, int S, bool zero);
 struct gh_comm;
 int gh_comm_allreduce_enqueue(gh_comm* c, double* dev, int64_t n);
+gh_ctx* gh_comm_context(const gh_comm* c);
 
 // the handle whose row-per-lane arrays are valid: `l` itself, or the lazily expanded twin of a transcripts handle
 int gh_lattices_full(const gh_lattices* l, const gh_lattices** out);

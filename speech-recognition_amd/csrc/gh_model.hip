@@ -346,6 +346,33 @@ extern "C" int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* 
     return GH_OK;
 }
 
+// `reps` copies of a resident batch back to back (device-to-device): a large batch from a small upload
+extern "C" int gh_batch_tile(gh_ctx* ctx, const gh_batch* src, int reps, gh_batch** out) {
+    GH_REQUIRE(ctx && src && out && reps >= 1, "gh_batch_tile: NULL argument / reps=%d", reps);
+    const int64_t U = src->U * reps, N = src->N * reps;
+    std::vector<int64_t> off((size_t)U + 1, 0);
+    for (int r = 0; r < reps; ++r)
+        for (int64_t u = 0; u < src->U; ++u) off[(size_t)r * src->U + u + 1] = (int64_t)r * src->N + src->offsets[u + 1];
+    int rc = batch_common(ctx, src->dtype, src->D, N, U, off.data(), out);
+    if (rc) return rc;
+    gh_batch* b = *out;
+    const size_t bytes = (size_t)src->N * src->D * (src->dtype == GH_F64 ? 8 : 4);
+    b->owns_feats = true;
+    if (bytes) {
+        hipError_t e = hipMalloc(&b->feats, bytes * reps);
+        for (int r = 0; e == hipSuccess && r < reps; ++r)
+            e = hipMemcpyAsync((char*)b->feats + (size_t)r * bytes, src->feats, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            gh_set_error("gh_batch_tile: %s", hipGetErrorString(e));
+            gh_batch_destroy(b);
+            *out = nullptr;
+            return e == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+        }
+    }
+    return GH_OK;
+}
+
 extern "C" void gh_batch_destroy(gh_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "gh_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                   C.POINTER(C.c_void_p)]),
     "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
+    "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_device_sync": (C.c_int, [C.c_void_p]),
     "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_batch_destroy": (None, [C.c_void_p]),
@@ -185,6 +187,10 @@ class Context:
 
     def sync(self):
         _check(self.lib, self.lib.gh_ctx_sync(self.h))
+
+    def device_sync(self):
+        """hipDeviceSynchronize through the library's runtime: every context's stream on this GPU has drained."""
+        _check(self.lib, self.lib.gh_device_sync(self.h))
 
     @property
     def stream(self):
@@ -629,6 +635,18 @@ class Batch:
         h = C.c_void_p()
         _check(self.ctx.lib, self.ctx.lib.gh_batch_gather(self.ctx.h, self.h, _ptr(rows, _c_i64p), len(rows), new.U,
                                                           _ptr(off, _c_i64p), C.byref(h)))
+        new.h = h
+        return new
+
+    def tile(self, reps):
+        """`reps` copies of this batch back to back as a new resident batch (gh_batch_tile: device-to-device)."""
+        new = Batch.__new__(Batch)
+        new.ctx, new.np_dtype, new.D, new.S = self.ctx, self.np_dtype, self.D, None
+        new.N, new.U = self.N * reps, self.U * reps
+        T = np.tile(np.diff(self.offsets), reps)
+        new.offsets = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
+        h = C.c_void_p()
+        _check(self.ctx.lib, self.ctx.lib.gh_batch_tile(self.ctx.h, self.h, int(reps), C.byref(h)))
         new.h = h
         return new
 

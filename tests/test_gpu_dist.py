@@ -141,13 +141,14 @@ def test_rccl_allreduce_on_the_device_resident_statistics(tmp_path):
     tr.close()
 
 
-def _run_bench(extra):
+def _run_bench(extra, extras=False):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--ramp-seconds", "0.1",
-           "--utts", "400", "--em-utts", "300", "--em-iters", "2", "--no-cpu-baseline", "--no-extra-configs"] + extra
+           "--utts", "400", "--em-utts", "300", "--em-iters", "2", "--no-cpu-baseline"] + extra
+    cmd += ["--c5-utts", "1000", "--c4-utts", "60", "--c4-em-utts", "40", "--c3-utts", "50"] if extras else ["--no-extra-configs"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -156,21 +157,46 @@ def _run_bench(extra):
 
 
 def test_bench_gpus_2_is_one_command():
-    """`python bench.py --gpus 2` without a launcher starts its own two ranks.  RCCL when the box
-    has two GPUs, otherwise the gloo rehearsal with both ranks on GPU 0."""
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks, which talk through the
+    library's own RCCL communicator (two GPUs: xGMI; a one-GPU box: both ranks on GPU 0, socket transport), and the
+    N-rank line carries every 8-GPU config of BASELINE.json: configs[4] (C5, K-layer lattice and loop grammar) and
+    configs[3] (C4) with `n_gpus` and all ranks' utterances."""
     two = _n_gpus() >= 2
-    out = _run_bench(["--gpus", "2"] + ([] if two else ["--backend", "gloo", "--device", "0"]))
-    assert out["n_gpus"] == 2 and out["config"]["parallelism"].endswith("x2")
+    out = _run_bench(["--gpus", "2"] + ([] if two else ["--same-gpu"]), extras=True)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"].endswith("x2") and out["config"]["process_group"] == "native"
     assert out["decode_accuracy"] == 1.0
     em = out["em"]
-    assert em["backend"] == ("nccl" if two else "gloo") and em["rccl_ranks"] == (2 if two else 0)
+    assert em["backend"] == "nccl" and em["comm"] == "native" and em["rccl_ranks"] == 2       # ncclCommCount
+    assert em["device_resident_iteration"] and em["host_syncs_per_iteration"] == 1
     assert em["loglik_monotone"] and em["em_utterances_per_s"] > 0 and em["allreduce_ms"] > 0
+    cfg = out["configs"]
+    for key in ("C5_K7_lattice", "C5_loop_grammar"):
+        assert cfg[key]["n_gpus"] == 2 and cfg[key]["utterances"] == 2000 and cfg[key]["value"] > 0, cfg[key]
+        assert cfg[key]["sequence_accuracy_sampled"] == 1.0
+        assert 0.0 <= cfg[key]["fp32_path_mismatch_rate"] <= 0.05 and cfg[key]["fp32_label_mismatch_rate"] <= 0.01
+    assert cfg["C4"]["n_gpus"] == 2 and cfg["C4"]["utterances"] == 120
+    assert cfg["C4_em"]["n_gpus"] == 2 and cfg["C4_em"]["loglik_monotone"] and not cfg["C4_em"]["device_resident_iteration"]
+
+
+def test_bench_gpus_2_strong_scaling_em_and_gloo_rehearsal():
+    """--em-total: configs[2]'s utterances drawn once and sharded over the ranks by frames (strong scaling); run here
+    through the torch.distributed / gloo form with both ranks on GPU 0."""
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0", "--em-total", "500"])
+    assert out["n_gpus"] == 2 and out["config"]["process_group"] == "torch"
+    em = out["em"]
+    assert em["scaling"] == "strong" and em["backend"] == "gloo" and em["rccl_ranks"] == 0
+    assert not em["device_resident_iteration"] and em["loglik_monotone"]
+    assert abs(em["em_utterances_per_s"] * em["ms_per_iteration"] * 1e-3 - 500) < 1e-6
 
 
 def test_bench_single_gpu_runs_the_collective_on_rccl():
-    out = _run_bench(["--gpus", "1"])
+    out = _run_bench(["--gpus", "1"], extras=True)
     assert out["n_gpus"] == 1
     em = out["em"]
     assert "rccl_error" not in em, em
     assert em["backend"] == "nccl" and em["rccl_ranks"] == 1 and em["allreduce_on_device_buffer"]
-    assert em["loglik_monotone"]
+    assert em["device_resident_iteration"] and em["loglik_monotone"]
+    cfg = out["configs"]
+    assert not any("error" in v for v in cfg.values() if isinstance(v, dict)), cfg
+    assert cfg["C2_fp32_decode"]["fp32_word_mismatch_rate"] == 0.0
+    assert cfg["C5_loop_grammar"]["n_gpus"] == 1
