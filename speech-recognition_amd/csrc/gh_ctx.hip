@@ -121,6 +121,25 @@ extern "C" int gh_event_elapsed_ms(void* start, void* stop, float* out_ms) {
     return GH_OK;
 }
 
+// Bytes of DP scratch (back-pointers / decision words, alpha columns) one launch may take; larger batches are chunked.
+// GMMHMM_SCRATCH_BUDGET=<bytes>[K|M|G] (read at every call: the tests force several chunks with it); else a quarter of
+// what is free on the device (counting the arena this context already holds, which is reused), within [256 MiB, 24 GiB]:
+// several contexts or several ranks on one GPU each take their share instead of a fixed 24 GiB.
+size_t gh_scratch_budget(gh_ctx* ctx) {
+    if (const char* e = getenv("GMMHMM_SCRATCH_BUDGET")) {
+        char* end = nullptr;
+        double v = strtod(e, &end);
+        if (end && (*end == 'K' || *end == 'k')) v *= 1024.0;
+        else if (end && (*end == 'M' || *end == 'm')) v *= 1048576.0;
+        else if (end && (*end == 'G' || *end == 'g')) v *= 1073741824.0;
+        if (v >= 1.0) return (size_t)v;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4 << 30;
+    const size_t avail = free_b + ctx->scratch_bytes;
+    return std::min((size_t)24 << 30, std::max((size_t)256 << 20, avail / 4));
+}
+
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->scratch_bytes) {
         GH_HIP(hipStreamSynchronize(ctx->stream));

@@ -80,7 +80,9 @@ __global__ void pack_labels_kernel(const int32_t* __restrict__ labels, const int
     if (u >= U) return;
     const int32_t* src = labels + label_off[u];
     int32_t* dst = packed + pack_off[u];
-    const int n = n_labels[u];
+    // (an utterance whose labels overflowed its slot reports count > capacity together with flag 8: copy what the slot holds)
+    const int64_t cap = label_off[u + 1] - label_off[u];
+    const int n = (int)(n_labels[u] < cap ? n_labels[u] : cap);
     for (int i = 0; i < n; ++i) dst[i] = src[i];
 }
 
@@ -185,33 +187,37 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             GH_REQUIRE(path_off[u + 1] - path_off[u] >= (T > 1 ? T * lat->lat[l].nlev : 0),
                        "gh_viterbi: path capacity of utterance %lld too small", (long long)u);
         }
-    // back-pointer scratch is chunked (<= 24 GiB per launch)
-    // (sized for a 288 GB part: C5's 125 000 utterances need 5.1 GB of decision words -- one launch instead of two)
-    const size_t BP_BUDGET = (size_t)24 << 30;
+    // back-pointer scratch is chunked: at most gh_scratch_budget() bytes per launch (a quarter of the free HBM, <= 24 GiB
+    // -- C5's 125 000 utterances need 5.1 GB of decision words: one launch on a 288 GB part; GMMHMM_SCRATCH_BUDGET
+    // overrides it, the tests force several chunks with it), halved and re-planned when the allocation fails
     std::vector<int64_t> bp_off(U, 0);
-    std::vector<int64_t> chunk_begin{0};
+    std::vector<int64_t> chunk_begin;
     size_t bp_max = 0;
     const bool want_bp = want_path || (use_chain && out_costs);
-    if (want_bp) {
-        size_t acc = 0;
-        for (int64_t k = 0; k < U; ++k) {
-            const int64_t u = perm[k];
-            const int l = utt_lattice ? utt_lattice[u] : 0;
-            // (blocks padded to 8 entries = 16 bytes: the lean kernel flushes back-pointers with 16-byte stores)
-            const size_t need = use_layers ? gh_layers_bp_entries(lat->h_layers, b->offsets[u + 1] - b->offsets[u])
-                                : use_seq ? gh_seq_bp_entries(lat->seq_N, lat->seq_skip, b->offsets[u + 1] - b->offsets[u])
-                                           : ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
-            if (acc && (acc + need) * 2 > BP_BUDGET) {
-                chunk_begin.push_back(k);
-                bp_max = std::max(bp_max, acc);
-                acc = 0;
+    auto plan_chunks = [&](size_t BP_BUDGET) {
+        chunk_begin.assign(1, 0);
+        bp_max = 0;
+        if (want_bp) {
+            size_t acc = 0;
+            for (int64_t k = 0; k < U; ++k) {
+                const int64_t u = perm[k];
+                const int l = utt_lattice ? utt_lattice[u] : 0;
+                // (blocks padded to 8 entries = 16 bytes: the lean kernel flushes back-pointers with 16-byte stores)
+                const size_t need = use_layers ? gh_layers_bp_entries(lat->h_layers, b->offsets[u + 1] - b->offsets[u])
+                                    : use_seq ? gh_seq_bp_entries(lat->seq_N, lat->seq_skip, b->offsets[u + 1] - b->offsets[u])
+                                               : ((size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->lat[l].R + 7) & ~size_t(7);
+                if (acc && (acc + need) * 2 > BP_BUDGET) {
+                    chunk_begin.push_back(k);
+                    bp_max = std::max(bp_max, acc);
+                    acc = 0;
+                }
+                bp_off[k] = (int64_t)acc;
+                acc += need;
             }
-            bp_off[k] = (int64_t)acc;
-            acc += need;
+            bp_max = std::max(bp_max, acc);
         }
-        bp_max = std::max(bp_max, acc);
-    }
-    chunk_begin.push_back(U);
+        chunk_begin.push_back(U);
+    };
     const int64_t n_path = (want_path && !labels_direct) ? path_off[U] : 0;
     const int64_t n_costs = out_costs ? costs_off[U] : 0;
 
@@ -221,29 +227,43 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     int32_t *d_uttlat = nullptr, *d_bestend, *d_path = nullptr, *d_pathlen = nullptr;
     double *d_endcost, *d_costs = nullptr;
     uint16_t* d_bp = nullptr;
-    Carver cv;
     int* d_flag2;  // [flag | best_end | end_cost] are carved back to back: ONE D2H copy into pinned memory
-    cv.add(&d_flag2, 64); cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
-    const size_t small_bytes = cv.total;
-    if (want_bp) cv.add(&d_bpoff, U);
-    if (!uniform) cv.add(&d_endoff, U + 1);
-    if (utt_lattice) cv.add(&d_uttlat, U);
-    if (want_path && !labels_direct) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
-    if (want_bp) cv.add(&d_bp, bp_max);
-    if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+    size_t small_bytes = 0;
     int32_t* d_framestate = nullptr;
-    if (want_segments) cv.add(&d_framestate, b->N);
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
     int64_t *d_labeloff = nullptr, *d_poff = nullptr;
     int32_t* d_packed = nullptr;
     int64_t n_rows_total = 0;
     for (auto& lh : lat->lat) n_rows_total = std::max<int64_t>(n_rows_total, lh.row_base + lh.R);
-    if (want_labels) {
-        cv.add(&d_rowlabel, n_rows_total); cv.add(&d_labeloff, U + 1);
-        cv.add(&d_nlabels, U); cv.add(&d_labels, label_off[U]);   // [n_labels | labels] back to back: one copy
-        if (packed_cap >= 0) { cv.add(&d_poff, U + 1); cv.add(&d_packed, label_off[U]); }
+    auto carve = [&]() -> int {
+        Carver cv;
+        cv.add(&d_flag2, 64); cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
+        small_bytes = cv.total;
+        if (want_bp) cv.add(&d_bpoff, U);
+        if (!uniform) cv.add(&d_endoff, U + 1);
+        if (utt_lattice) cv.add(&d_uttlat, U);
+        if (want_path && !labels_direct) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
+        if (want_bp) cv.add(&d_bp, bp_max);
+        if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
+        if (want_segments) cv.add(&d_framestate, b->N);
+        if (want_labels) {
+            cv.add(&d_rowlabel, n_rows_total); cv.add(&d_labeloff, U + 1);
+            cv.add(&d_nlabels, U); cv.add(&d_labels, label_off[U]);   // [n_labels | labels] back to back: one copy
+            if (packed_cap >= 0) { cv.add(&d_poff, U + 1); cv.add(&d_packed, label_off[U]); }
+        }
+        return cv.commit(ctx);
+    };
+    int rc;
+    for (size_t budget = gh_scratch_budget(ctx);;) {
+        plan_chunks(budget);
+        rc = carve();
+        const size_t floor_b = (size_t)64 << 20;
+        if (rc == GH_ERR_NOMEM && want_bp && bp_max * 2 > floor_b && budget > floor_b) {   // smaller chunks, same result
+            budget = std::min(budget, bp_max * 2) / 2;
+            continue;
+        }
+        break;
     }
-    int rc = cv.commit(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     GH_HIP(hipMemsetAsync(d_flag2, 0, sizeof(int), st));
@@ -396,7 +416,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             // word string the grammar allows -- 40 MB of slots against 3.5 MB of labels for 125 000 loop-grammar decodes)
             GH_HIP(hipStreamSynchronize(st));
             std::vector<int64_t> poff(U + 1, 0);
-            for (int64_t u = 0; u < U; ++u) poff[u + 1] = poff[u] + std::max(0, out_n_labels[u]);
+            for (int64_t u = 0; u < U; ++u)
+                poff[u + 1] = poff[u] + std::min<int64_t>(std::max(0, out_n_labels[u]), label_off[u + 1] - label_off[u]);
             GH_REQUIRE(poff[U] <= packed_cap, "gh_viterbi_labels_packed: %lld labels, capacity %lld", (long long)poff[U], (long long)packed_cap);
             GH_HIP(hipMemcpyAsync(d_poff, poff.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(pack_labels_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, d_labels, d_labeloff, d_nlabels,
@@ -584,8 +605,8 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         GH_HIP(hipMalloc((void**)&b->occ, (size_t)b->N * S * 8));
         b->occ_S = S;
     }
-    // alpha scratch, chunked (<= 24 GiB per launch), launch order = longest first
-    const size_t BUDGET = (size_t)24 << 30;
+    // alpha scratch, chunked (<= gh_scratch_budget() bytes per launch), launch order = longest first
+    const size_t BUDGET = gh_scratch_budget(ctx);
     const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
     GH_REQUIRE(!lat->deferred_src || use_fbseq, "gh_forward_backward: internal: a transcripts handle left the sequence-form path unexpanded");
     std::vector<int64_t> soff(U, 0), chunk_begin{0};

@@ -53,6 +53,7 @@ struct gh_ctx {
 };
 
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out);
+size_t gh_scratch_budget(gh_ctx* ctx);
 int gh_pinned(gh_ctx* ctx, size_t bytes, void** out);
 
 // Parameter layout shared by the likelihood kernels (GEMM form):

@@ -9,6 +9,7 @@
 // matrices, GMMHMM_VITERBI / GMMHMM_FB overrides -- is expanded lazily into a second, ordinary handle.
 #include "gh_internal.h"
 #include "gh_host.h"
+#include <mutex>
 
 struct gh_transcripts_src {
     int W, n;
@@ -57,6 +58,10 @@ int gh_lattices_full(const gh_lattices* l, const gh_lattices** out) {
     *out = l;
     if (!l->deferred_src) return GH_OK;
     gh_lattices* self = const_cast<gh_lattices*>(l);
+    // the expansion happens inside calls the ABI presents as read-only (gh_viterbi / gh_forward_backward on a const
+    // handle): two host threads sharing the handle must not both build the twin
+    static std::mutex expand_lock;
+    std::lock_guard<std::mutex> guard(expand_lock);
     if (!self->full) {
         const int rc = create_expanded(l->ctx, *l->deferred_src, &self->full);
         if (rc) return rc;

@@ -285,8 +285,12 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     first_copy = [list(m.gmm_states) for m in new_models]
     n = len(new_models[0].gmm_states)
 
-    frames = _hip.Batch(_hip.default_context(), data)
-    all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, 1))
+    # feature dimension from the MODELS: a rank of a sharded run may hold no utterances at all, and it still has to take
+    # part in every collective with buffers of the same shape as everybody else's
+    dim = len(np.asarray(models[0].gmm_states[0].dists[0].mean).reshape(-1))
+    ctx = _hip.default_context()
+    frames = _hip.Batch(ctx, data) if len(data) else _hip.Batch(ctx, feats=np.zeros((0, dim)), offsets=[0])
+    all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
     try:
         for it in range(max_iteration):
             print('=' * 25)
@@ -295,7 +299,10 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             print('Rearranging data, this may take a while...')
             # alignment + regrouping on the device; per state, its frames in utterance / time order -- what the
             # reference's vstack of the segments holds (:90-113) -- and the states in first-visit order
-            frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs)
+            if len(data):
+                frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs)
+            else:       # nothing to align on this rank: it only contributes zeros to the collectives below
+                frame_state, seg_start = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)
             used = np.flatnonzero(frame_state >= 0)
             sid_of = frame_state[used]
             by_state = np.argsort(sid_of, kind="stable")
@@ -315,7 +322,6 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             seg_counts = {sid: (int(n_runs[sid]), len(seg_of[sid])) for sid in keys}
             if sharded:
                 # which states were visited anywhere, their frame sums (start centroids) and segment / frame counts
-                dim = data[0].shape[1] if len(data) else frames.D
                 loc = np.zeros((n_models * n, dim + 2))
                 for sid, x in seg_of.items():
                     loc[sid, :dim], loc[sid, dim], loc[sid, dim + 1] = x.sum(axis=0), x.shape[0], n_runs[sid]
@@ -351,8 +357,13 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                     new_models[mi].transitions[si, si] = -np.log(1 - p_jump)
 
             for i, m in enumerate(new_models):
-                with open(os.path.join(output_path, str(i) + '.pkl'), 'wb') as f:
+                # (written under a private name and renamed: the ranks of a sharded run may share `output_path`, and
+                #  they all hold the same models)
+                final = os.path.join(output_path, str(i) + '.pkl')
+                tmp = final + '.%d.tmp' % os.getpid()
+                with open(tmp, 'wb') as f:
                     pickle.dump(m, f)
+                os.replace(tmp, final)
             if all(new_m == old_m for new_m, old_m in zip(new_models, old_models)):
                 print('Continuous training converged')
                 break

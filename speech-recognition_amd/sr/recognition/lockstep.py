@@ -50,7 +50,8 @@ class LockstepFitter:
         self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
         self.collectives = 0
         # frames per state over all ranks (weights are counts / n)
-        self.n_global = self._reduce(np.diff(self.seg_off).astype(np.float64)) if self.sharded else np.diff(self.seg_off)
+        self.n_global = (self._reduce(np.diff(self.seg_off).astype(np.float64)) if self.sharded and self.S
+                         else np.diff(self.seg_off))
 
     def _reduce(self, a):
         self.collectives += 1
@@ -67,6 +68,8 @@ class LockstepFitter:
         partitions: the random partition of every state's frames (kmeans.py:171), drawn by the caller when the order
         of draws matters; default: drawn here, state after state."""
         S, D, off = self.S, self.D, self.seg_off
+        if S == 0:        # no state was visited (continuous_train: "No MFCC data" for every state)
+            return [], np.zeros((0, k, D)), np.zeros((0, k, D))
         cov = np.empty((S, k, D))
         part_stats = np.zeros((S, 2 * D + 1))
         for s, x in enumerate(self.segs):
@@ -137,6 +140,8 @@ class LockstepFitter:
     def em(self, states, k, max_iteration=10000):
         """Run GMM.em(data_s, k) for every state object in `states` (one per segment), in lock-step."""
         S, off = self.S, self.seg_off
+        if S == 0:
+            return
         active = np.ones(S, dtype=np.uint8)
         for it in range(max_iteration):
             means = np.array([[np.asarray(d.mean, dtype=np.float64) for d in g.dists[:k]] for g in states])
@@ -161,6 +166,8 @@ class LockstepFitter:
         n_splits = int(np.log(n_gaussians))
         assert n_splits > 0
         S = self.S
+        if S == 0:
+            return
         centroids = np.asarray(start_centroids, dtype=np.float64).reshape(S, 1, self.D)
         div = np.asarray(weight_divisor, dtype=np.float64)
         weights = np.repeat((1.0 / div)[:, None], n_gaussians, axis=1)

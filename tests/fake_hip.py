@@ -120,6 +120,8 @@ class Batch:
 
     def kmeans_assign(self, centroids, var=None, first=0, count=None):
         x = self.feats[first:first + (self.N - first if count is None else count)]
+        if len(x) == 0:
+            return np.zeros(0, dtype=np.int64)
         d = np.array([[O.euclid(c, f) if var is None else O.mahalanobis(c, f, var) for c in centroids] for f in x])
         return np.argmin(d, axis=1).astype(np.int64)
 

@@ -137,6 +137,8 @@ def _ct_worker(rank, world, port, out_dir):
         models = [make_hmm(R, g["init%d_means" % wi], g["init%d_vars" % wi], g["init%d_w" % wi], g["init%d_transitions" % wi])
                   for wi in range(W)]
         mine = shard_utterances([len(x) for x in data], world)[rank] if world > 1 else list(range(U))
+        if os.environ.get("GMMHMM_TEST_EMPTY_RANK") is not None:     # one rank holds everything, the other nothing
+            mine = [] if rank == int(os.environ["GMMHMM_TEST_EMPTY_RANK"]) else list(range(U))
         out = os.path.join(out_dir, "world%d_rank%d" % (world, rank))
         os.makedirs(out, exist_ok=True)
         np.random.seed(7 + rank)
@@ -172,6 +174,26 @@ def test_continuous_train_sharded_world2_on_the_test_double(tmp_path, built_libr
                 np.testing.assert_array_equal(np.asarray(da.mean), np.asarray(db.mean))
                 np.testing.assert_array_equal(np.asarray(da.cov), np.asarray(db.cov))
                 assert np.all(np.isfinite(np.asarray(da.mean))) and np.all(np.asarray(da.cov) > 0)
+
+
+def test_continuous_train_with_a_rank_that_holds_no_utterances(tmp_path, built_library, monkeypatch):
+    """a rank without utterances used to size its first all-reduce buffer from its (empty) data and to fail
+    building lattices, leaving the other rank waiting in the collective.  It now takes part in every collective with
+    zeros of the models' shape, and both ranks end with the same models."""
+    import pickle
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("GMMHMM_TEST_EMPTY_RANK", "1")
+    mp.spawn(_ct_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = load_golden("G11_continuous_train")
+    m0, m1 = np.load(tmp_path / "world2_rank0" / "meta.npz"), np.load(tmp_path / "world2_rank1" / "meta.npz")
+    assert len(m1["mine"]) == 0 and len(m0["mine"]) == int(g["n_utts"]) and int(m0["calls"]) == int(m1["calls"])
+    for wi in range(int(g["n_words"])):
+        a = pickle.load(open(tmp_path / "world2_rank0" / ("%d.pkl" % wi), "rb"))
+        b = pickle.load(open(tmp_path / "world2_rank1" / ("%d.pkl" % wi), "rb"))
+        np.testing.assert_array_equal(a.transitions, b.transitions)
+        for sa, sb in zip(a.gmm_states, b.gmm_states):
+            for da, db in zip(sa.dists, sb.dists):
+                np.testing.assert_array_equal(np.asarray(da.mean), np.asarray(db.mean))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
