@@ -59,6 +59,10 @@ int gh_ctx_sync(gh_ctx* ctx);
 /* hipDeviceSynchronize on the context's GPU: every stream of this library's runtime has drained (the bracket of a
  * timed region when several contexts are in flight) */
 int gh_device_sync(gh_ctx* ctx);
+/* Number of launches the last gh_viterbi* / gh_forward_backward call on this context was cut into: the DP scratch
+ * (back-pointers, alpha columns) of one launch is bounded by a quarter of the free HBM (<= 24 GiB), or by
+ * GMMHMM_SCRATCH_BUDGET=<bytes>[K|M|G]; larger batches run as several launches with identical results. */
+int gh_ctx_last_chunks(const gh_ctx* ctx);
 /* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);
 /* number of GPUs the library's HIP runtime sees (<= 0: none).  Callers must not dlopen a HIP runtime of their own

@@ -35,6 +35,7 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     c->scratch_bytes = 0;
     c->pinned = nullptr;
     c->pinned_bytes = 0;
+    c->last_chunks = 0;
     hipDeviceProp_t prop;
     GH_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -80,6 +81,8 @@ extern "C" int gh_device_sync(gh_ctx* c) {
     GH_HIP(hipDeviceSynchronize());
     return GH_OK;
 }
+
+extern "C" int gh_ctx_last_chunks(const gh_ctx* c) { return c ? c->last_chunks : 0; }
 
 extern "C" void* gh_ctx_stream(gh_ctx* c) { return c ? (void*)c->stream : nullptr; }
 

@@ -265,6 +265,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         break;
     }
     if (rc) return rc;
+    ctx->last_chunks = (int)chunk_begin.size() - 1;
     hipStream_t st = ctx->stream;
     GH_HIP(hipMemsetAsync(d_flag2, 0, sizeof(int), st));
     if (want_bp) GH_HIP(hipMemcpyAsync(d_bpoff, bp_off.data(), U * 8, hipMemcpyHostToDevice, st));
@@ -625,12 +626,14 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     }
     smax = std::max(smax, acc);
     chunk_begin.push_back(U);
+    ctx->last_chunks = (int)chunk_begin.size() - 1;
     const bool mats = out_alpha || out_beta || out_gamma;
     const int64_t n_mat = mats ? mat_off[U] : 0;
     // one-word chain graphs and no matrices asked for: one lane per utterance (GMMHMM_FB=generic forces the other)
     {
         const char* e = getenv("GMMHMM_FB");
         if (lat->fbchain_ok && !mats && !(e && !strcmp(e, "generic"))) {
+            ctx->last_chunks = 1;     // (one lane group per utterance, 12 bytes of alpha per cell: never chunked)
             std::vector<int64_t> coff(U, 0);
             size_t cacc = 0;
             for (int64_t k = 0; k < U; ++k) {

@@ -45,6 +45,7 @@ SIGNATURES = {
     "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
     "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gh_device_sync": (C.c_int, [C.c_void_p]),
+    "gh_ctx_last_chunks": (C.c_int, [C.c_void_p]),
     "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_batch_destroy": (None, [C.c_void_p]),
@@ -187,6 +188,11 @@ class Context:
 
     def sync(self):
         _check(self.lib, self.lib.gh_ctx_sync(self.h))
+
+    @property
+    def last_chunks(self):
+        """Launches the last viterbi / forward_backward call on this context was cut into (scratch budget)."""
+        return int(self.lib.gh_ctx_last_chunks(self.h))
 
     def device_sync(self):
         """hipDeviceSynchronize through the library's runtime: every context's stream on this GPU has drained."""

@@ -158,6 +158,53 @@ def test_c3_em_statistics_of_sampled_states_vs_numpy():
     tr.close()
 
 
+def test_c4_shape_em_statistics_generic_kernels_vs_numpy():
+    """EM at the configs[3] shape -- 64 words x 16 states x 32 mixtures, ~100 k frames: M = 32 and n = 16 are outside
+    the fused matrix-core statistics kernel and the chain forward-backward, so this is the GENERIC route (fb_kernel,
+    bw_stats_kernel<false, ...>: densities on the VALU) that round 2 never ran at this shape.  Statistics of sampled
+    states against numpy on the same occupancies; one full iteration raises the likelihood."""
+    import bench
+    from sr.recognition.train import BaumWelchTrainer
+    from sr.recognition import _hip
+    U = 1000
+    wl = bench.synth_workload(1004, U, W=64, n=16, M=32, D=39)
+    W = wl["W"]
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    labels = [[int(w)] for w in wl["words"]]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)
+    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels)
+    assert tr.session is None and tr.batch.N >= 95000            # (the device-resident session does not cover M = 32)
+    stats, xi, ll = tr.e_step()
+    assert stats.shape == (1024, 32, 79) and np.isfinite(ll) and ll < 0
+    gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
+    tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets)
+    occ = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True)["occ"]
+    gmm.close()
+    X = wl["X"]
+    N, D = X.shape
+    np.testing.assert_allclose(stats[:, :, 0].sum(), N, rtol=1e-9)
+    np.testing.assert_allclose(stats[:, :, 0].sum(axis=1), occ.sum(axis=0), rtol=1e-9, atol=1e-9)
+    for s in (0, 17, 333, 640, 1023):
+        m_, v_, w_ = tr.means[s], tr.vars[s], tr.weights[s]
+        logc = np.log(w_) - 0.5 * (D * np.log(2 * np.pi) + np.log(v_).sum(axis=1))
+        sel = np.nonzero(occ[:, s] > 0)[0]
+        x = X[sel]
+        ll_c = logc[None, :] - 0.5 * (((x[:, None, :] - m_[None]) ** 2) / v_[None]).sum(axis=2)
+        r = np.exp(ll_c - ll_c.max(axis=1, keepdims=True))
+        r = occ[sel, s][:, None] * r / r.sum(axis=1, keepdims=True)
+        ref = np.zeros((tr.M, 1 + 2 * D))
+        for m in range(tr.M):
+            d = x - m_[m]
+            ref[m, 0] = r[:, m].sum()
+            ref[m, 1:1 + D] = (r[:, [m]] * d).sum(axis=0)
+            ref[m, 1 + D:] = (r[:, [m]] * d * d).sum(axis=0)
+        np.testing.assert_allclose(stats[s], ref, rtol=1e-8, atol=1e-9)
+    del occ
+    h = tr.fit(2)
+    assert h[1] > h[0] and np.all(tr.vars > 0)
+    tr.close()
+
+
 def test_c3_em_likelihood_is_monotone_and_recovers_the_model():
     from sr.recognition.train import BaumWelchTrainer
     means, vars_, w, trans, data, labels = c3_problem()
