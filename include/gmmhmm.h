@@ -434,6 +434,42 @@ int gh_em_history(gh_ctx* ctx, gh_em* em, int first, int count, double* out /*[c
 int gh_em_get_model(gh_ctx* ctx, gh_em* em, double* mean, double* var, double* weight, double* word_trans /*any may be NULL*/);
 int gh_em_packed(gh_ctx* ctx, gh_em* em, double* out /*[n] or NULL*/, int64_t* out_n);
 
+/* ----------------------- device-resident refit of ALL states: binary-split k-means + mixture EM in lock-step
+ * What hmm.py:97-124 (inside HMM.fit) and continuous_speech.py:114-142 (inside continuous_train) do one state after the
+ * other.  The frames of every state sit back to back in `b` (fp64; state s owns [seg_off[s], seg_off[s+1]), e.g. from
+ * gh_batch_gather); tile lists, centroids, variances, mixture parameters, the allclose test's "old" parameters, the
+ * active mask and the iteration counters live on the device, an iteration is a few kernel launches on the context's
+ * stream, and the host reads ONE counter (states still active) every `check_every` iterations.  Per state the
+ * arithmetic and the stopping rule are the sequential algorithm's.  D in [2, 64], k <= kmax <= 32.
+ *   gh_fit_segment_means  out [S, D+1]: per state the sum of its frames in frame order (np.mean's order) | frame count
+ *   gh_fit_kmeans         kmeans(data_s, k, centroids_s) of kmeans.py:167-193 for every state at once:
+ *       part [N] (uint8): the random partition np.random.randint(0, k, N_s) of every state's frames, concatenated (the
+ *         caller draws it from numpy's generator in the reference's order); partition variances = two passes per
+ *         (state, cluster), ddof 1 (np.cov(...).diagonal() without the D x D matrix);
+ *       assignment by mahalanobis distance under the variance of partition cluster 0 (kmeans.py:183), centroids = mean
+ *         of the assigned frames in frame order, a state stops when its centroids repeat (np.array_equal);
+ *       out_centroids / out_cov [S,k,D], out_counts [S,k] (cluster sizes, as doubles), out_iters [S]
+ *   gh_fit_clusters       the final assignments [N] (cluster id per frame)
+ *   gh_fit_em             GMM.em(data_s, k) of hmm_state.py:122-159 for every state at once: E-step statistics, then
+ *       GMM.em_update per state on the device (M-step, parameters installed, allclose against mu_old / sigma_old /
+ *       w_old, which are updated unless the state converged); all six arrays are in/out [S,k,D] / [S,k];
+ *       n_frames [S]: frames of the state over all ranks; out_converged_at [S]: iteration of the `break`, -1: none.
+ *       A zero variance is GH_ERR_INVALID ("singular").
+ *   comm (may be NULL): every rank holds part of each state's frames; cluster sums / changed counts / cluster sizes /
+ *       partition sums / EM statistics are summed over the ranks on the device buffers (one collective per lock-step
+ *       iteration); with a communicator the partition variance is cluster 0's, from global sums, for every cluster. */
+typedef struct gh_fit gh_fit;
+int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off /*[S+1]*/, int kmax, gh_fit** out);
+void gh_fit_destroy(gh_fit* fit);
+int gh_fit_segment_means(gh_ctx* ctx, gh_fit* fit, double* out /*[S,D+1]*/);
+int gh_fit_kmeans(gh_ctx* ctx, gh_fit* fit, gh_comm* comm, int k, const double* centroids_in /*[S,k,D]*/,
+                  const uint8_t* part /*[N]*/, int max_iteration, int check_every, double* out_centroids, double* out_cov,
+                  double* out_counts, int32_t* out_iters);
+int gh_fit_clusters(gh_ctx* ctx, gh_fit* fit, int32_t* out /*[N]*/);
+int gh_fit_em(gh_ctx* ctx, gh_fit* fit, gh_comm* comm, int k, double* mean_io, double* var_io, double* weight_io,
+              double* mu_old_io, double* sigma_old_io, double* w_old_io, const double* n_frames /*[S]*/, int max_iteration,
+              int check_every, int32_t* out_converged_at);
+
 #ifdef __cplusplus
 }
 #endif

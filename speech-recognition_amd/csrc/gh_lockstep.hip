@@ -58,8 +58,10 @@ constexpr int RS_B = 64;
 // exclusive scan of the per-tile cluster counts over the tiles of every state (in tile = frame order); also the
 // number of frames of every (state, cluster) and where its list starts inside the state's segment
 __global__ void kmeans_scan_kernel(const int32_t* __restrict__ tile_ptr /*[S+1]*/, int k, int32_t* __restrict__ tilecnt /*[tiles][k] -> offsets*/,
-                                   int32_t* __restrict__ counts /*[S,k]*/, int32_t* __restrict__ cbase /*[S,k]*/) {
+                                   int32_t* __restrict__ counts /*[S,k]*/, int32_t* __restrict__ cbase /*[S,k]*/,
+                                   const uint8_t* __restrict__ active = nullptr) {
     const int s = blockIdx.x, c = threadIdx.x;
+    if (active && !active[s]) return;      // (a state that has stopped keeps its lists and counts)
     __shared__ int tot[64];
     int run = 0;
     if (c < k)
@@ -81,8 +83,10 @@ __global__ void kmeans_scan_kernel(const int32_t* __restrict__ tile_ptr /*[S+1]*
 // every tile writes the (segment-local) numbers of its frames into their clusters' lists, keeping frame order
 __global__ __launch_bounds__(64) void kmeans_scatter_kernel(const ls_tile* __restrict__ tiles, int k, const int32_t* __restrict__ clusters,
                                                             const int64_t* __restrict__ seg_off, const int32_t* __restrict__ tileoff,
-                                                            const int32_t* __restrict__ cbase, int32_t* __restrict__ lists /*[N]*/) {
+                                                            const int32_t* __restrict__ cbase, int32_t* __restrict__ lists /*[N]*/,
+                                                            const uint8_t* __restrict__ active = nullptr) {
     const ls_tile tl = tiles[blockIdx.x];
+    if (active && !active[tl.state]) return;
     const int lane = threadIdx.x;
     const bool act = lane < tl.count;
     const int id = act ? clusters[tl.first + lane] : -1;
@@ -96,39 +100,51 @@ __global__ __launch_bounds__(64) void kmeans_scatter_kernel(const ls_tile* __res
     }
 }
 
-// grid (S, k), block = D rounded up to waves: the chain of (state, cluster, dimension = thread)
+// grid (S, k), block = D rounded up to waves: the chain of (state, cluster, dimension = thread).
+// MODE 0: sum of x (and the count in column D); 1: sum of (x - centre)^2 with centre = csum / count (the two-pass
+// variance of a partition); 2: sum of x^2.  sstride: doubles per state in `sums` (>= k (D + 1)).
+template <int MODE>
 __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restrict__ X, int D, int k,
                                                            const int64_t* __restrict__ seg_off, const uint8_t* __restrict__ active,
                                                            const int32_t* __restrict__ lists, const int32_t* __restrict__ counts,
-                                                           const int32_t* __restrict__ cbase, double* __restrict__ sums) {
+                                                           const int32_t* __restrict__ cbase, double* __restrict__ sums, int sstride,
+                                                           const double* __restrict__ csum = nullptr, int cstride = 0) {
     const int s = blockIdx.x, c = blockIdx.y;
     if (active && !active[s]) return;
     const int d = blockIdx.z * 64 + threadIdx.x, lane = threadIdx.x;
     const bool live = d < D;
     const int64_t f0 = seg_off[s];
     const int n = counts[s * k + c];
-    if (d == 0) sums[((int64_t)s * k + c) * (D + 1) + D] = (double)n;
-    if (n <= 0) return;
+    double* out = sums + (int64_t)s * sstride + (int64_t)c * (D + 1);
+    if (d == 0 && MODE == 0) out[D] = (double)n;
+    if (n <= 0) { if (live && MODE != 0) out[d] = 0.0; return; }
+    double ctr = 0.0;
+    if (MODE == 1) ctr = csum[(int64_t)s * cstride + (int64_t)c * (D + 1) + (live ? d : 0)] / (double)n;
     const double* col = X + f0 * D + (live ? d : 0);
     const int32_t* li = lists + f0 + cbase[s * k + c];
     int id = li[min(lane, n - 1)];
     double x[RS_B];
 #pragma unroll
     for (int j = 0; j < RS_B; ++j) x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
+    auto term = [&](double v) -> double {
+        if (MODE == 0) return v;
+        if (MODE == 1) { const double t = v - ctr; return t * t; }
+        return v * v;
+    };
     double acc = 0.0;
     int b = 0;
     for (; b + RS_B <= n; b += RS_B) {                        // full rounds: the chain is one add per frame
         id = li[min(b + RS_B + lane, n - 1)];                 // the next 64 entries (clamped: re-reads the last frame, never summed)
 #pragma unroll
         for (int j = 0; j < RS_B; ++j) {
-            acc += x[j];
+            acc += term(x[j]);
             x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
         }
     }
     const int left = n - b;                                   // the last, partial round
 #pragma unroll
-    for (int j = 0; j < RS_B; ++j) acc += (j < left) ? x[j] : 0.0;
-    if (live) sums[((int64_t)s * k + c) * (D + 1) + d] = acc;
+    for (int j = 0; j < RS_B; ++j) acc += (j < left) ? term(x[j]) : 0.0;
+    if (live) out[d] = acc;
 }
 
 template <int DR>
@@ -138,16 +154,18 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
                                                           const double* __restrict__ logdet /*[S]*/,
                                                           int32_t* __restrict__ clusters /*[N] in/out*/,
                                                           int32_t* __restrict__ changed /*[S] or null*/,
-                                                          int32_t* __restrict__ counts /*[tiles][k] or null*/) {
+                                                          int32_t* __restrict__ counts /*[tiles][k] or null*/,
+                                                          const uint8_t* __restrict__ active = nullptr, int vstride = 0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sc = sm;                  // [k][D]
     double* sv = sc + k * D;          // [D]
     double* tile = sv + D;            // [64][D+1]
     const ls_tile tl = tiles[blockIdx.x];
+    if (active && !active[tl.state]) return;
     const int lane = threadIdx.x;
     const double* c0 = cent + (int64_t)tl.state * k * D;
     for (int i = lane; i < k * D; i += 64) sc[i] = c0[i];
-    if (var) for (int i = lane; i < D; i += 64) sv[i] = var[(int64_t)tl.state * D + i];
+    if (var) for (int i = lane; i < D; i += 64) sv[i] = var[(int64_t)tl.state * (vstride ? vstride : D) + i];   // (vstride: [S,k,D] variances, cluster 0's row)
     double x[DR];
     stage_tile<DR>(X, tl.first, tl.count, D, tile, x);
     double best = 0;
@@ -181,8 +199,9 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
 
 // partial[tile][len] summed over the tiles of each state (contiguous, in order) -> out[state][len]
 __global__ void tiles_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ tile_ptr /*[S+1]*/, int len,
-                                    double* __restrict__ out) {
+                                    double* __restrict__ out, const uint8_t* __restrict__ active = nullptr) {
     const int s = blockIdx.y;
+    if (active && !active[s]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     double acc = 0;
@@ -198,7 +217,8 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
                                                       const double* __restrict__ mean /*[S,k,D]*/,
                                                       const double* __restrict__ ivar /*[S,k,D]*/,
                                                       const double* __restrict__ logc /*[S,k]*/,
-                                                      double* __restrict__ partial /*[tiles][k*(1+2D) + 1]*/) {
+                                                      double* __restrict__ partial /*[tiles][k*(1+2D) + 1]*/,
+                                                      const uint8_t* __restrict__ active = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* pm = sm;                  // [k][D]
     double* pv = pm + k * D;          // [k][D]
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
     double* rt = pc + k;              // [k][64] responsibilities
     double* tile = rt + k * 64;       // [64][D+1]
     const ls_tile tl = tiles[blockIdx.x];
+    if (active && !active[tl.state]) return;
     const int lane = threadIdx.x;
     const int64_t pbase = (int64_t)tl.state * k;
     for (int i = lane; i < k * D; i += 64) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
@@ -365,7 +386,7 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     GH_REQUIRE(lds <= 150 * 1024, "gh_kmeans_assign_multi: k=%d x D=%d does not fit LDS", k, D);
     const dim3 grid((unsigned)tiles.size()), blk(64);
 #define GH_KM(DR) hipLaunchKernelGGL((kmeans_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_cent, \
-                                     d_var, d_ld, d_cl, out_changed ? d_changed : nullptr, d_tilecnt)
+                                     d_var, d_ld, d_cl, out_changed ? d_changed : nullptr, d_tilecnt, nullptr)
     if (D <= 16) GH_KM(16); else if (D <= 40) GH_KM(40); else GH_KM(64);
 #undef GH_KM
     GH_HIP(hipGetLastError());
@@ -374,10 +395,10 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
         if (active) GH_HIP(hipMemcpyAsync(d_active, active, (size_t)S, hipMemcpyHostToDevice, st));
         GH_HIP(hipMemsetAsync(d_sums, 0, (size_t)S * plen * 8, st));
         GH_HIP(hipMemcpyAsync(d_tptr, tile_ptr.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(64), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase);
-        hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists);
-        hipLaunchKernelGGL(kmeans_rowsum_kernel, dim3((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64)), dim3(64), 0, st,
-                           (const double*)b->feats, D, k, d_segoff, d_active, d_lists, d_counts, d_cbase, d_sums);
+        hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(64), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase, nullptr);
+        hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists, nullptr);
+        hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, dim3((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64)), dim3(64), 0, st,
+                           (const double*)b->feats, D, k, d_segoff, d_active, d_lists, d_counts, d_cbase, d_sums, plen, nullptr, 0);
         GH_HIP(hipGetLastError());
         GH_HIP(hipMemcpyAsync(out_sums, d_sums, (size_t)S * plen * 8, hipMemcpyDeviceToHost, st));
     }
@@ -435,13 +456,13 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     if (!tiles.empty()) {
         const dim3 grid((unsigned)tiles.size()), blk(64);
 #define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_mean, d_ivar, \
-                                     d_logc, d_part)
+                                     d_logc, d_part, nullptr)
         if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
 #undef GH_EM
         GH_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, d_part, d_tptr,
-                       plen, d_out);
+                       plen, d_out, nullptr);
     GH_HIP(hipGetLastError());
     std::vector<double> host((size_t)S * plen);
     GH_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * 8, hipMemcpyDeviceToHost, st));
@@ -453,5 +474,518 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
         if (out_stats) memcpy(out_stats + (size_t)s * k * Wd, host.data() + (size_t)s * plen, (size_t)k * Wd * 8);
         if (out_loglik) out_loglik[s] = host[(size_t)s * plen + k * Wd];
     }
+    return GH_OK;
+}
+
+// =====================================================================================================================
+// gh_fit: the refit of ALL states -- binary-split k-means + mixture EM, hmm.py:97-124 / continuous_speech.py:114-142 --
+// as a DEVICE-RESIDENT session.  Round 2 advanced the states in lock-step but kept the loop on the host: per k-means /
+// EM iteration one synchronous call (tile lists rebuilt and uploaded, parameters uploaded, statistics copied back), the
+// M-step and convergence test of GMM.em_update per state in numpy, the partition variances as np.cov per (state,
+// cluster) -- 0.19 s + 0.3 s of every 0.75 s continuous_train iteration against 75 ms of kernels.  Here the tile list,
+// centroids, variances, mixture parameters, "old" parameters of the allclose test, the active mask and the iteration
+// counters live in HBM; one k-means / EM iteration is a handful of kernel launches on the context's stream with NO host
+// synchronisation, and the host looks at one counter (states still active) every `check_every` iterations.  Per state
+// the arithmetic and the stopping rule are those of the sequential algorithm, so a state's result does not depend on
+// how many iterations the others take.
+//   * partition variances (kmeans.py:171-177): two passes per (state, cluster) over the cluster's frames in frame order
+//     -- mean (the sum numpy's np.average takes, bit for bit), then sum (x - mean)^2 / (n - 1).  np.cov forms the whole
+//     D x D matrix with a BLAS product to read its diagonal: O(N D^2) instead of O(N D), and the diagonal's last bits
+//     are the BLAS library's summation order (callers that want exactly those bits keep np.cov: compat_cov=True).
+//   * sharded (comm != NULL): cluster sums + changed counts, cluster counts, partition sums and EM statistics are summed
+//     over the ranks with gh_comm's all-reduce ON THE DEVICE BUFFERS, between the kernels that produce and consume them.
+struct gh_fit {
+    gh_ctx* ctx;
+    const gh_batch* b;
+    int S, D, kmax, n_tiles;
+    int64_t N;
+    void* d_arena;
+    ls_tile* d_tiles;
+    int32_t* d_tptr;
+    int64_t* d_segoff;
+    uint8_t* d_active;
+    int32_t *d_ids, *d_tilecnt, *d_counts, *d_cbase, *d_lists, *d_changed, *d_iters;
+    double *d_cent, *d_cov, *d_logdet, *d_sums, *d_sq;
+    int* d_counter;      // [0] states still active after the last iteration, [1] error bits (16: zero variance)
+    double *d_mean, *d_var, *d_weight, *d_ivar, *d_logc, *d_old_mu, *d_old_sigma, *d_old_w, *d_nframes, *d_part, *d_stats;
+    int* h_pin;          // pinned [4]
+};
+
+namespace {
+
+__global__ __launch_bounds__(64) void fit_tilecount_kernel(const ls_tile* __restrict__ tiles, int k, const int32_t* __restrict__ ids,
+                                                           int32_t* __restrict__ tilecnt) {
+    const ls_tile tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x;
+    const bool act = lane < tl.count;
+    const int id = act ? ids[tl.first + lane] : -1;
+    for (int c = 0; c < k; ++c) {
+        const int nc = __popcll(__ballot(act && id == c));
+        if (lane == 0) tilecnt[(int64_t)blockIdx.x * k + c] = nc;
+    }
+}
+
+__global__ void fit_u8_to_i32_kernel(const uint8_t* __restrict__ src, int64_t n, int32_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// mean of every state's frames in numpy's order (np.mean(seg, axis=0): the rows added one after the other)
+__global__ __launch_bounds__(64) void fit_segsum_kernel(const double* __restrict__ X, int D, const int64_t* __restrict__ seg_off,
+                                                        double* __restrict__ out /*[S, D+1]: sums | count*/) {
+    const int s = blockIdx.x, d = blockIdx.y * 64 + threadIdx.x;
+    const int64_t f0 = seg_off[s], n = seg_off[s + 1] - f0;
+    if (d == 0) out[(int64_t)s * (D + 1) + D] = (double)n;
+    if (d >= D) return;
+    const double* col = X + f0 * D + d;
+    double acc = 0.0;
+    int64_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        double x[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x[j] = col[(i + j) * D];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc += x[j];
+    }
+    for (; i < n; ++i) acc += col[i * D];
+    out[(int64_t)s * (D + 1) + d] = acc;
+}
+
+// partition variances from (sum x | n) and sum (x - mean)^2: ddof = 1 (np.cov's default); n <= 1 -> NaN like numpy's
+// 0 * (1 / 0).  one_pass: from global sums over all ranks, cluster 0 only, copied to every cluster (the sharded rule).
+__global__ void fit_partvar_kernel(int S, int k, int D, int sstride, const double* __restrict__ sums /*[S][sstride]: [k][D+1]*/,
+                                   const double* __restrict__ sq /*same layout*/, int one_pass, double* __restrict__ cov /*[S,k,D]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * k * D) return;
+    const int s = i / (k * D), c = (i / D) % k, d = i % D;
+    const int cs = one_pass ? 0 : c;
+    const double* su = sums + (int64_t)s * sstride + (int64_t)cs * (D + 1);
+    const double n = su[D];
+    const double q = sq[(int64_t)s * sstride + (int64_t)cs * (D + 1) + d];
+    double v;
+    if (one_pass) v = (q - su[d] * su[d] / n) / (n - 1.0);
+    else v = n > 1.0 ? q * (1.0 / (n - 1.0)) : NAN;
+    cov[i] = v;
+}
+
+__global__ void fit_logdet_kernel(int S, int k, int D, const double* __restrict__ cov, double* __restrict__ logdet) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    double prod = 1.0;
+    for (int d = 0; d < D; ++d) prod *= cov[(int64_t)s * k * D + d];
+    logdet[s] = 0.5 * log(pow(2.0 * M_PI, (double)D) * prod);   // hmm_state.py:58
+}
+
+__global__ void fit_pack_changed_kernel(int S, int sstride, int at, const int32_t* __restrict__ changed, const uint8_t* __restrict__ active,
+                                        double* __restrict__ sums) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) sums[(int64_t)s * sstride + at] = active[s] ? (double)changed[s] : 0.0;
+}
+
+// a stopped state contributes zeros to the all-reduced cluster sums (its frames are not re-summed)
+__global__ void fit_zero_inactive_kernel(int S, int sstride, const uint8_t* __restrict__ active, double* __restrict__ buf) {
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < sstride && !active[s]) buf[(int64_t)s * sstride + i] = 0.0;
+}
+
+// centroid update + stop rule of one state per block (kmeans.py:187-192; sharded: lockstep's "nobody's assignment changed")
+__global__ __launch_bounds__(64) void fit_kmeans_update_kernel(int k, int D, int sstride, const double* __restrict__ sums,
+                                                               int sharded, double* __restrict__ cent, uint8_t* __restrict__ active,
+                                                               int32_t* __restrict__ changed, int32_t* __restrict__ iters,
+                                                               int* __restrict__ counter) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (!active[s]) return;
+    const double* su = sums + (int64_t)s * sstride;
+    double* ce = cent + (int64_t)s * k * D;
+    bool same = true;
+    for (int i = lane; i < k * D; i += 64) {
+        const int c = i / D, d = i - c * D;
+        const double nv = su[c * (D + 1) + d] / su[c * (D + 1) + D];    // an empty cluster: 0 / 0 = NaN, like np.mean of nothing
+        if (!(nv == ce[i])) same = false;                              // np.array_equal: NaN never equals
+        if (sharded) ce[i] = nv;
+    }
+    const bool all_same = __ballot(!same) == 0ull;
+    const bool stop = sharded ? (su[k * (D + 1)] == 0.0) : all_same;
+    if (!sharded && !stop)
+        for (int i = lane; i < k * D; i += 64) { const int c = i / D, d = i - c * D; ce[i] = su[c * (D + 1) + d] / su[c * (D + 1) + D]; }
+    if (lane == 0) {
+        iters[s] += 1;
+        changed[s] = 0;
+        if (stop) active[s] = 0; else atomicAdd(counter, 1);
+    }
+}
+
+__global__ void fit_counts_kernel(int n, const int32_t* __restrict__ counts, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)counts[i];
+}
+
+__global__ void fit_em_prepare_kernel(int S, int k, int D, const double* __restrict__ var, const double* __restrict__ weight,
+                                      const uint8_t* __restrict__ active, double* __restrict__ ivar, double* __restrict__ logc,
+                                      int* __restrict__ counter) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= S * k || !active[g / k]) return;
+    const double log2pi = 1.8378770664093454836;
+    double sl = 0;
+    for (int d = 0; d < D; ++d) {
+        const double v = var[(int64_t)g * D + d];
+        if (v == 0) atomicOr(counter + 1, 16);            // np.linalg.inv raises LinAlgError (hmm_state.py:17)
+        ivar[(int64_t)g * D + d] = 1.0 / v;
+        sl += log(v);
+    }
+    logc[g] = log(weight[g]) - 0.5 * (D * log2pi + sl);
+}
+
+__device__ __forceinline__ bool fit_close(double a, double b) {   // np.isclose(a, b), default tolerances
+    if (a == b) return true;
+    if (!(a - a == 0.0) || !(b - b == 0.0)) return false;
+    return fabs(a - b) <= 1e-8 + 1e-5 * fabs(b);
+}
+
+// GMM.em_update (hmm_state.py:134-159) of one state per block: M-step from the centred statistics, parameters installed,
+// then the allclose test against the previous iteration's; a state that passes stops, the others remember the new values
+__global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int plen, const double* __restrict__ stats,
+                                                            const double* __restrict__ nframes, double* __restrict__ mean,
+                                                            double* __restrict__ var, double* __restrict__ weight,
+                                                            double* __restrict__ old_mu, double* __restrict__ old_sigma,
+                                                            double* __restrict__ old_w, uint8_t* __restrict__ active,
+                                                            int32_t* __restrict__ conv_at, int it, int* __restrict__ counter) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (!active[s]) return;
+    __shared__ int bad;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    const int Wd = 1 + 2 * D;
+    const double* st = stats + (int64_t)s * plen;
+    int mine = 0;
+    for (int i = tid; i < k * D; i += blockDim.x) {
+        const int c = i / D, d = i - c * D;
+        const double s0 = st[c * Wd], S1 = st[c * Wd + 1 + d], S2 = st[c * Wd + 1 + D + d];
+        const int64_t at = ((int64_t)s * k + c) * D + d;
+        const double m0 = mean[at];
+        const double occ = (s0 == 0) ? 1e-5 : s0;
+        const double mu = (m0 * s0 + S1) / occ;
+        const double dl = mu - m0;
+        const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
+        mean[at] = mu;
+        var[at] = sg;
+        mine += !fit_close(mu, old_mu[at]) + !fit_close(sg, old_sigma[at]);
+    }
+    if (tid < k) {
+        const double w = st[tid * Wd] / nframes[s];
+        weight[(int64_t)s * k + tid] = w;
+        mine += !fit_close(w, old_w[(int64_t)s * k + tid]);
+    }
+    if (mine) atomicAdd(&bad, mine);
+    __syncthreads();
+    if (bad == 0) {
+        if (tid == 0) { active[s] = 0; conv_at[s] = it; }
+        return;
+    }
+    for (int i = tid; i < k * D; i += blockDim.x) {
+        const int64_t at = (int64_t)s * k * D + i;
+        old_mu[at] = mean[at];
+        old_sigma[at] = var[at];
+    }
+    if (tid < k) old_w[(int64_t)s * k + tid] = weight[(int64_t)s * k + tid];
+    if (tid == 0) atomicAdd(counter, 1);
+}
+
+}  // namespace
+
+extern "C" void gh_fit_destroy(gh_fit* f) {
+    if (!f) return;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    if (f->d_arena) hipFree(f->d_arena);
+    if (f->h_pin) hipHostFree(f->h_pin);
+    delete f;
+}
+
+extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_t* seg_off, int kmax, gh_fit** out) {
+    GH_REQUIRE(ctx && b && out, "gh_fit_create: NULL argument");
+    *out = nullptr;
+    int rc = check_segments(b, S, seg_off, "gh_fit_create");
+    if (rc) return rc;
+    GH_REQUIRE(seg_off[0] == 0 && seg_off[S] == b->N, "gh_fit_create: the segments must cover the batch");
+    if (kmax < 1 || kmax > 32 || b->D < 2) {
+        gh_set_error("gh_fit_create: kmax=%d (1..32), D=%d (2..%d) outside the device-resident refit", kmax, b->D, LS_MAXD);
+        return GH_ERR_UNSUPPORTED;
+    }
+    GH_HIP(hipSetDevice(ctx->device));
+    const int D = b->D, Wd = 1 + 2 * D;
+    std::vector<ls_tile> tiles;
+    std::vector<int32_t> tile_ptr;
+    build_tiles(S, seg_off, nullptr, tiles, tile_ptr);
+    gh_fit* f = new gh_fit();
+    memset((void*)f, 0, sizeof *f);
+    f->ctx = ctx; f->b = b; f->S = S; f->D = D; f->kmax = kmax; f->N = b->N; f->n_tiles = (int)tiles.size();
+    const size_t nt = std::max<size_t>(1, tiles.size()), N1 = std::max<int64_t>(1, b->N);
+    const size_t skd = (size_t)S * kmax * D, sstride = (size_t)kmax * (D + 1) + 1, plen = (size_t)kmax * Wd + 1;
+    // LDS of the two tile kernels at kmax
+    const size_t lds_km = ((size_t)kmax * D + D + 64 * (size_t)(D + 1)) * 8 + 64 * 4 + 16;
+    const size_t lds_em = ((size_t)2 * kmax * D + kmax + (size_t)kmax * 64 + 64 * (size_t)(D + 1)) * 8 + 16;
+    if (lds_km > 150 * 1024 || lds_em > 150 * 1024) {
+        delete f;
+        gh_set_error("gh_fit_create: k=%d x D=%d does not fit LDS", kmax, D);
+        return GH_ERR_UNSUPPORTED;
+    }
+    UploadLayout lay;
+    lay.add((void**)&f->d_tiles, nt * sizeof(ls_tile), tiles.data(), tiles.size() * sizeof(ls_tile));
+    lay.add((void**)&f->d_tptr, (size_t)(S + 1) * 4, tile_ptr.data(), (size_t)(S + 1) * 4);
+    lay.add((void**)&f->d_segoff, (size_t)(S + 1) * 8, seg_off, (size_t)(S + 1) * 8);
+    lay.add((void**)&f->d_active, (size_t)S, nullptr);
+    lay.add((void**)&f->d_ids, N1 * 4, nullptr);
+    lay.add((void**)&f->d_tilecnt, nt * kmax * 4, nullptr);
+    lay.add((void**)&f->d_counts, (size_t)S * kmax * 4, nullptr);
+    lay.add((void**)&f->d_cbase, (size_t)S * kmax * 4, nullptr);
+    lay.add((void**)&f->d_lists, N1 * 4, nullptr);
+    lay.add((void**)&f->d_changed, (size_t)S * 4, nullptr);
+    lay.add((void**)&f->d_iters, (size_t)S * 4, nullptr);
+    lay.add((void**)&f->d_cent, skd * 8, nullptr);
+    lay.add((void**)&f->d_cov, skd * 8, nullptr);
+    lay.add((void**)&f->d_logdet, (size_t)S * 8, nullptr);
+    lay.add((void**)&f->d_sums, (size_t)S * sstride * 8, nullptr);
+    lay.add((void**)&f->d_sq, (size_t)S * sstride * 8, nullptr);
+    lay.add((void**)&f->d_counter, 64, nullptr);
+    lay.add((void**)&f->d_mean, skd * 8, nullptr);
+    lay.add((void**)&f->d_var, skd * 8, nullptr);
+    lay.add((void**)&f->d_weight, (size_t)S * kmax * 8, nullptr);
+    lay.add((void**)&f->d_ivar, skd * 8, nullptr);
+    lay.add((void**)&f->d_logc, (size_t)S * kmax * 8, nullptr);
+    lay.add((void**)&f->d_old_mu, skd * 8, nullptr);
+    lay.add((void**)&f->d_old_sigma, skd * 8, nullptr);
+    lay.add((void**)&f->d_old_w, (size_t)S * kmax * 8, nullptr);
+    lay.add((void**)&f->d_nframes, (size_t)S * 8, nullptr);
+    lay.add((void**)&f->d_part, nt * plen * 8, nullptr);
+    lay.add((void**)&f->d_stats, (size_t)S * plen * 8, nullptr);
+    hipError_t he = hipMalloc(&f->d_arena, lay.total);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_pin, 64, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        gh_set_error("gh_fit_create: %s", hipGetErrorString(he));
+        gh_fit_destroy(f);
+        return he == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+    }
+    rc = lay.commit(f->d_arena, ctx->stream, true);
+    if (!rc && hipMemsetAsync(f->d_counter, 0, 64, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc && hipMemsetAsync(f->d_changed, 0, (size_t)S * 4, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (rc) { gh_fit_destroy(f); return rc; }
+    *out = f;
+    return GH_OK;
+}
+
+extern "C" int gh_fit_segment_means(gh_ctx* ctx, gh_fit* f, double* out /*[S, D+1]: sums | count*/) {
+    GH_REQUIRE(ctx && f && out && f->ctx == ctx, "gh_fit_segment_means: NULL argument / foreign context");
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(fit_segsum_kernel, dim3((unsigned)f->S, (unsigned)((f->D + 63) / 64)), dim3(64), 0, st, (const double*)f->b->feats,
+                       f->D, f->d_segoff, f->d_sums);
+    GH_HIP(hipGetLastError());
+    GH_HIP(hipMemcpyAsync(out, f->d_sums, (size_t)f->S * (f->D + 1) * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}
+
+// lists of every (state, cluster)'s frames from f->d_ids, for the states that are active (all: active == nullptr)
+static int fit_build_lists(gh_fit* f, int k, bool from_assign_counts, const uint8_t* active) {
+    hipStream_t st = f->ctx->stream;
+    if (f->n_tiles == 0) return GH_OK;
+    const dim3 grid((unsigned)f->n_tiles), blk(64);
+    if (!from_assign_counts) hipLaunchKernelGGL(fit_tilecount_kernel, grid, blk, 0, st, f->d_tiles, k, f->d_ids, f->d_tilecnt);
+    hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)f->S), dim3(64), 0, st, f->d_tptr, k, f->d_tilecnt, f->d_counts, f->d_cbase, active);
+    hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, f->d_tiles, k, f->d_ids, f->d_segoff, f->d_tilecnt, f->d_cbase, f->d_lists, active);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
+
+static int fit_poll(gh_fit* f, int* n_active, int* flags) {
+    hipStream_t st = f->ctx->stream;
+    GH_HIP(hipMemcpyAsync(f->h_pin, f->d_counter, 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    *n_active = f->h_pin[0];
+    *flags = f->h_pin[1];
+    return GH_OK;
+}
+
+extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const double* centroids_in, const uint8_t* part,
+                             int max_iteration, int check_every, double* out_centroids, double* out_cov, double* out_counts,
+                             int32_t* out_iters) {
+    GH_REQUIRE(ctx && f && centroids_in && part && f->ctx == ctx, "gh_fit_kmeans: NULL argument / foreign context");
+    GH_REQUIRE(k >= 1 && k <= f->kmax, "gh_fit_kmeans: k=%d (1..%d)", k, f->kmax);
+    GH_REQUIRE(!comm || gh_comm_context(comm) == ctx, "gh_fit_kmeans: the communicator belongs to another context");
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int S = f->S, D = f->D;
+    const int sstride = k * (D + 1) + 1;
+    const double* X = (const double*)f->b->feats;
+    const dim3 skz((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64));
+    int rc;
+    // ---- the random partition and its variances (kmeans.py:171-177) ----
+    {
+        void* stage;
+        rc = gh_scratch(ctx, (size_t)std::max<int64_t>(1, f->N), &stage);
+        if (rc) return rc;
+        if (f->N > 0) {
+            GH_HIP(hipMemcpyAsync(stage, part, (size_t)f->N, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(fit_u8_to_i32_kernel, dim3((unsigned)((f->N + 255) / 256)), dim3(256), 0, st, (const uint8_t*)stage, f->N, f->d_ids);
+        }
+        GH_HIP(hipMemsetAsync(f->d_counts, 0, (size_t)S * k * 4, st));
+        GH_HIP(hipMemsetAsync(f->d_cbase, 0, (size_t)S * k * 4, st));
+        rc = fit_build_lists(f, k, false, nullptr);
+        if (rc) return rc;
+        GH_HIP(hipMemsetAsync(f->d_sums, 0, (size_t)S * sstride * 8, st));
+        GH_HIP(hipMemsetAsync(f->d_sq, 0, (size_t)S * sstride * 8, st));
+        hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists, f->d_counts,
+                           f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0);
+        if (!comm) {
+            hipLaunchKernelGGL(kmeans_rowsum_kernel<1>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists,
+                               f->d_counts, f->d_cbase, f->d_sq, sstride, (const double*)f->d_sums, sstride);
+        } else {   // sharded: (n, sum x, sum x^2) of cluster 0 over all ranks, one-pass variance (lockstep.py)
+            hipLaunchKernelGGL(kmeans_rowsum_kernel<2>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists,
+                               f->d_counts, f->d_cbase, f->d_sq, sstride, (const double*)nullptr, 0);
+            rc = gh_comm_allreduce_enqueue(comm, f->d_sums, (int64_t)S * sstride);
+            if (!rc) rc = gh_comm_allreduce_enqueue(comm, f->d_sq, (int64_t)S * sstride);
+            if (rc) return rc;
+        }
+        GH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(fit_partvar_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
+                           (const double*)f->d_sums, (const double*)f->d_sq, comm ? 1 : 0, f->d_cov);
+        hipLaunchKernelGGL(fit_logdet_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, k, D, (const double*)f->d_cov, f->d_logdet);
+        GH_HIP(hipGetLastError());
+    }
+    // ---- lock-step k-means ----
+    GH_HIP(hipMemcpyAsync(f->d_cent, centroids_in, (size_t)S * k * D * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
+    GH_HIP(hipMemsetAsync(f->d_iters, 0, (size_t)S * 4, st));
+    GH_HIP(hipMemsetAsync(f->d_changed, 0, (size_t)S * 4, st));
+    if (f->N > 0) GH_HIP(hipMemsetAsync(f->d_ids, 0xFF, (size_t)f->N * 4, st));
+    const size_t lds = ((size_t)k * D + D + 64 * (size_t)(D + 1)) * 8 + 64 * 4 + 16;
+    const int n_it = std::max(max_iteration, 1);
+    check_every = std::max(1, check_every);
+    for (int it = 0; it < n_it;) {
+        const int blkn = std::min(check_every, n_it - it);
+        for (int j = 0; j < blkn; ++j) {
+            if (f->n_tiles > 0) {
+                const dim3 grid((unsigned)f->n_tiles), blk(64);
+#define GH_KM(DR) hipLaunchKernelGGL((kmeans_multi_kernel<DR>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_cent, \
+                                     (const double*)f->d_cov, (const double*)f->d_logdet, f->d_ids, f->d_changed, f->d_tilecnt, (const uint8_t*)f->d_active, k * D)
+                if (D <= 16) GH_KM(16); else if (D <= 40) GH_KM(40); else GH_KM(64);
+#undef GH_KM
+            }
+            rc = fit_build_lists(f, k, true, f->d_active);
+            if (rc) return rc;
+            hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)f->d_active, f->d_lists,
+                               f->d_counts, f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0);
+            hipLaunchKernelGGL(fit_pack_changed_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, sstride, k * (D + 1),
+                               (const int32_t*)f->d_changed, (const uint8_t*)f->d_active, f->d_sums);
+            if (comm) {
+                hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((sstride + 127) / 128), (unsigned)S), dim3(128), 0, st, S, sstride,
+                                   (const uint8_t*)f->d_active, f->d_sums);
+                rc = gh_comm_allreduce_enqueue(comm, f->d_sums, (int64_t)S * sstride);
+                if (rc) return rc;
+            }
+            GH_HIP(hipMemsetAsync(f->d_counter, 0, 4, st));
+            hipLaunchKernelGGL(fit_kmeans_update_kernel, dim3((unsigned)S), dim3(64), 0, st, k, D, sstride, (const double*)f->d_sums, comm ? 1 : 0,
+                               f->d_cent, f->d_active, f->d_changed, f->d_iters, f->d_counter);
+            GH_HIP(hipGetLastError());
+        }
+        it += blkn;
+        int n_active = 0, flags = 0;
+        rc = fit_poll(f, &n_active, &flags);
+        if (rc) return rc;
+        if (n_active == 0) break;
+    }
+    // ---- results: centroids, partition variances, cluster sizes (np.unique counts; over all ranks when sharded) ----
+    hipLaunchKernelGGL(fit_counts_kernel, dim3((unsigned)((S * k + 255) / 256)), dim3(256), 0, st, S * k, (const int32_t*)f->d_counts, f->d_sq);
+    GH_HIP(hipGetLastError());
+    if (comm) { rc = gh_comm_allreduce_enqueue(comm, f->d_sq, (int64_t)S * k); if (rc) return rc; }
+    if (out_centroids) GH_HIP(hipMemcpyAsync(out_centroids, f->d_cent, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
+    if (out_cov) GH_HIP(hipMemcpyAsync(out_cov, f->d_cov, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
+    if (out_counts) GH_HIP(hipMemcpyAsync(out_counts, f->d_sq, (size_t)S * k * 8, hipMemcpyDeviceToHost, st));
+    if (out_iters) GH_HIP(hipMemcpyAsync(out_iters, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}
+
+extern "C" int gh_fit_clusters(gh_ctx* ctx, gh_fit* f, int32_t* out /*[N]*/) {
+    GH_REQUIRE(ctx && f && out && f->ctx == ctx, "gh_fit_clusters: NULL argument / foreign context");
+    if (f->N == 0) return GH_OK;
+    GH_HIP(hipSetDevice(ctx->device));
+    GH_HIP(hipMemcpyAsync(out, f->d_ids, (size_t)f->N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* mean_io, double* var_io, double* weight_io,
+                         double* mu_old_io, double* sigma_old_io, double* w_old_io, const double* n_frames, int max_iteration,
+                         int check_every, int32_t* out_converged_at) {
+    GH_REQUIRE(ctx && f && mean_io && var_io && weight_io && mu_old_io && sigma_old_io && w_old_io && n_frames && f->ctx == ctx,
+               "gh_fit_em: NULL argument / foreign context");
+    GH_REQUIRE(k >= 1 && k <= f->kmax, "gh_fit_em: k=%d (1..%d)", k, f->kmax);
+    GH_REQUIRE(!comm || gh_comm_context(comm) == ctx, "gh_fit_em: the communicator belongs to another context");
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int S = f->S, D = f->D, Wd = 1 + 2 * D, plen = k * Wd + 1;
+    const size_t skd = (size_t)S * k * D * 8, sk = (size_t)S * k * 8;
+    const double* X = (const double*)f->b->feats;
+    GH_HIP(hipMemcpyAsync(f->d_mean, mean_io, skd, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_var, var_io, skd, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_weight, weight_io, sk, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_old_mu, mu_old_io, skd, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_old_sigma, sigma_old_io, skd, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_old_w, w_old_io, sk, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(f->d_nframes, n_frames, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
+    GH_HIP(hipMemsetAsync(f->d_iters, 0xFF, (size_t)S * 4, st));        // -1: did not converge within max_iteration
+    GH_HIP(hipMemsetAsync(f->d_counter, 0, 8, st));
+    GH_HIP(hipMemsetAsync(f->d_stats, 0, (size_t)S * plen * 8, st));
+    const size_t lds = ((size_t)2 * k * D + k + (size_t)k * 64 + 64 * (size_t)(D + 1)) * 8 + 16;
+    check_every = std::max(1, check_every);
+    int rc;
+    for (int it = 0; it < max_iteration;) {
+        const int blkn = std::min(check_every, max_iteration - it);
+        for (int j = 0; j < blkn; ++j) {
+            hipLaunchKernelGGL(fit_em_prepare_kernel, dim3((unsigned)((S * k + 63) / 64)), dim3(64), 0, st, S, k, D, (const double*)f->d_var,
+                               (const double*)f->d_weight, (const uint8_t*)f->d_active, f->d_ivar, f->d_logc, f->d_counter);
+            if (f->n_tiles > 0) {
+                const dim3 grid((unsigned)f->n_tiles), blk(64);
+#define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_mean, \
+                                     (const double*)f->d_ivar, (const double*)f->d_logc, f->d_part, (const uint8_t*)f->d_active)
+                if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
+#undef GH_EM
+            }
+            hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, (const double*)f->d_part,
+                               (const int32_t*)f->d_tptr, plen, f->d_stats, (const uint8_t*)f->d_active);
+            if (comm) {
+                hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, S, plen,
+                                   (const uint8_t*)f->d_active, f->d_stats);
+                rc = gh_comm_allreduce_enqueue(comm, f->d_stats, (int64_t)S * plen);
+                if (rc) return rc;
+            }
+            GH_HIP(hipMemsetAsync(f->d_counter, 0, 4, st));
+            hipLaunchKernelGGL(fit_em_update_kernel, dim3((unsigned)S), dim3(256), 0, st, k, D, plen, (const double*)f->d_stats,
+                               (const double*)f->d_nframes, f->d_mean, f->d_var, f->d_weight, f->d_old_mu, f->d_old_sigma, f->d_old_w,
+                               f->d_active, f->d_iters, it + j, f->d_counter);
+            GH_HIP(hipGetLastError());
+        }
+        it += blkn;
+        int n_active = 0, flags = 0;
+        rc = fit_poll(f, &n_active, &flags);
+        if (rc) return rc;
+        if (flags & 16) {
+            gh_set_error("gh_fit_em: a variance is 0 (singular covariance)");
+            return GH_ERR_INVALID;
+        }
+        if (n_active == 0) break;
+    }
+    GH_HIP(hipMemcpyAsync(mean_io, f->d_mean, skd, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(var_io, f->d_var, skd, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(weight_io, f->d_weight, sk, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(mu_old_io, f->d_old_mu, skd, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(sigma_old_io, f->d_old_sigma, skd, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(w_old_io, f->d_old_w, sk, hipMemcpyDeviceToHost, st));
+    if (out_converged_at) GH_HIP(hipMemcpyAsync(out_converged_at, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
     return GH_OK;
 }

@@ -104,6 +104,14 @@ SIGNATURES = {
     "gh_em_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_f64p]),
     "gh_em_get_model": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_f64p, _c_f64p, _c_f64p]),
     "gh_em_packed": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_i64p]),
+    "gh_fit_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_i64p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_fit_destroy": (None, [C.c_void_p]),
+    "gh_fit_segment_means": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p]),
+    "gh_fit_kmeans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _c_f64p, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                _c_f64p, _c_f64p, _c_f64p, _c_i32p]),
+    "gh_fit_clusters": (C.c_int, [C.c_void_p, C.c_void_p, _c_i32p]),
+    "gh_fit_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_f64p,
+                            _c_f64p, C.c_int, C.c_int, _c_i32p]),
     "gh_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gh_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "gh_comm_destroy": (None, [C.c_void_p]),
@@ -413,6 +421,75 @@ class EMSession:
         if getattr(self, "h", None):
             if getattr(self.ctx, "h", None):
                 self.ctx.lib.gh_em_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FitSession:
+    """Device-resident refit of all states (gh_fit): frames of state s = rows [seg_off[s], seg_off[s+1]) of `batch`."""
+
+    available = True
+
+    def __init__(self, ctx, batch, seg_off, kmax):
+        self.ctx, self.batch = ctx, batch
+        self.seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        self.S, self.D, self.N, self.kmax = len(self.seg_off) - 1, batch.D, batch.N, int(kmax)
+        h = C.c_void_p()
+        rc = ctx.lib.gh_fit_create(ctx.h, batch.h, self.S, _ptr(self.seg_off, _c_i64p), self.kmax, C.byref(h))
+        if rc == GH_ERR_UNSUPPORTED:
+            raise Unsupported(ctx.lib.gh_last_error().decode("utf-8", "replace"))
+        _check(ctx.lib, rc)
+        self.h = h
+
+    def segment_means(self):
+        """(sums [S, D] in frame order, counts [S]): sums / counts is np.mean(segment, axis=0), bit for bit."""
+        out = np.empty((self.S, self.D + 1))
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_segment_means(self.ctx.h, self.h, _ptr(out, _c_f64p)))
+        return out[:, :self.D], out[:, self.D]
+
+    def kmeans(self, k, centroids, part, max_iteration=1000, check_every=8, comm=None):
+        """-> (centroids [S,k,D], cov [S,k,D], counts [S,k], iterations [S])"""
+        centroids = _f64(centroids)
+        assert centroids.shape == (self.S, k, self.D)
+        part = np.ascontiguousarray(part, dtype=np.uint8)
+        assert part.shape == (self.N,)
+        cen, cov = np.empty((self.S, k, self.D)), np.empty((self.S, k, self.D))
+        cnt, its = np.empty((self.S, k)), np.empty(self.S, dtype=np.int32)
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_kmeans(
+            self.ctx.h, self.h, None if comm is None else comm.h, int(k), _ptr(centroids, _c_f64p),
+            part.ctypes.data_as(C.POINTER(C.c_uint8)), int(max_iteration), int(check_every), _ptr(cen, _c_f64p), _ptr(cov, _c_f64p),
+            _ptr(cnt, _c_f64p), _ptr(its, _c_i32p)))
+        return cen, cov, cnt, its
+
+    def clusters(self):
+        out = np.empty(self.N, dtype=np.int32)
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_clusters(self.ctx.h, self.h, _ptr(out, _c_i32p)))
+        return out
+
+    def em(self, k, mean, var, weight, mu_old, sigma_old, w_old, n_frames, max_iteration=10000, check_every=8, comm=None):
+        """In-place on the six [S,k,..] arrays (float64, C-contiguous); returns converged_at [S] (-1: not converged)."""
+        for a, shp in ((mean, (self.S, k, self.D)), (var, (self.S, k, self.D)), (weight, (self.S, k)), (mu_old, (self.S, k, self.D)),
+                       (sigma_old, (self.S, k, self.D)), (w_old, (self.S, k))):
+            assert a.dtype == np.float64 and a.flags.c_contiguous and a.shape == shp
+        nf = _f64(n_frames)
+        conv = np.empty(self.S, dtype=np.int32)
+        rc = self.ctx.lib.gh_fit_em(self.ctx.h, self.h, None if comm is None else comm.h, int(k), _ptr(mean, _c_f64p),
+                                    _ptr(var, _c_f64p), _ptr(weight, _c_f64p), _ptr(mu_old, _c_f64p), _ptr(sigma_old, _c_f64p),
+                                    _ptr(w_old, _c_f64p), _ptr(nf, _c_f64p), int(max_iteration), int(check_every), _ptr(conv, _c_i32p))
+        if rc == -1 and b"singular" in self.ctx.lib.gh_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        _check(self.ctx.lib, rc)
+        return conv
+
+    def close(self):
+        if getattr(self, "h", None):
+            if getattr(self.ctx, "h", None):
+                self.ctx.lib.gh_fit_destroy(self.h)
             self.h = None
 
     def __del__(self):

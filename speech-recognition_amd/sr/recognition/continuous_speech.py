@@ -258,7 +258,8 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                      n_gaussians: int = 4,
                      n_segments: int = 5,
                      max_iteration: int = 1000,
-                     reducer=None):
+                     reducer=None,
+                     compat_cov: bool = False):
     """Embedded Viterbi training (continuous_speech.py:56-179).
 
     Per outer iteration: forced alignment of every utterance, frames regrouped per visited
@@ -272,7 +273,12 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     regrouping stay local, the refit runs in lock-step over the ranks (one collective per k-means / EM iteration,
     `lockstep.LockstepFitter`), segment / frame counts for the transition costs are all-reduced, and every rank ends
     each iteration with the same models (states are then visited in ascending order; parity with the single-process
-    run is statistical)."""
+    run is statistical).
+
+    compat_cov (extension): the k-means variances of the random partitions are `np.cov(...).diagonal()` on the host, as
+    in the reference (kmeans.py:6-12,171-177), instead of the two-pass per-dimension variance on the device -- the same
+    number up to the summation order of the BLAS product behind np.cov (parameters agree to ~1e-13, cluster ids are
+    identical on every golden); it brings the frames and the refit loop back to the host (round 2's path)."""
     sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
     old_models = models
     new_models = copy.deepcopy(models)
@@ -290,7 +296,17 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     dim = len(np.asarray(models[0].gmm_states[0].dists[0].mean).reshape(-1))
     ctx = _hip.default_context()
     frames = _hip.Batch(ctx, data) if len(data) else _hip.Batch(ctx, feats=np.zeros((0, dim)), offsets=[0])
-    all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
+    # The refit of the states runs as a device-resident session (lockstep.LockstepFitter / gh_fit_*) on frames gathered
+    # on the device from the resident utterance batch: no frame visits the host.  compat_cov (np.cov for the partition
+    # variances, the host loop of round 2), one feature dimension, the test double of the binding, or a process group
+    # that is not the library's own communicator keep the frames on the host as well.
+    kmax = 2 ** max(1, int(np.log(n_gaussians)))
+    native = bool(getattr(reducer, "native", False))
+    on_device = (not compat_cov and 2 <= dim <= 64 and kmax <= 32 and getattr(getattr(_hip, "FitSession", None), "available", False)
+                 and frames.np_dtype == np.float64 and (not sharded or native))
+    all_frames = None
+    if not on_device:
+        all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
     try:
         for it in range(max_iteration):
             print('=' * 25)
@@ -309,7 +325,8 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             uniq, first, n_frames = np.unique(sid_of, return_index=True, return_counts=True)
             cuts = np.concatenate([[0], np.cumsum(n_frames)])
             n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
-            seg_of = {int(sid): all_frames[used[by_state[cuts[i]:cuts[i + 1]]]] for i, sid in enumerate(uniq)}
+            rows_of = {int(sid): used[by_state[cuts[i]:cuts[i + 1]]] for i, sid in enumerate(uniq)}
+            n_of = {int(sid): int(c) for sid, c in zip(uniq, n_frames)}
             print('Complete data rearrangement')
             print("=" * 25)
 
@@ -317,23 +334,31 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             # every visited state refit in lock-step (one launch per k-means / EM iteration for all of them); the
             # states are taken in first-visit order, the order in which the reference consumes numpy's global RNG
             keys = [int(sid) for sid in uniq[np.argsort(first, kind="stable")]]
-            segs = [seg_of[sid] for sid in keys]
-            starts = [np.mean(seg, axis=0) for seg in segs]
-            seg_counts = {sid: (int(n_runs[sid]), len(seg_of[sid])) for sid in keys}
+            seg_counts = {sid: (int(n_runs[sid]), n_of[sid]) for sid in keys}
             if sharded:
-                # which states were visited anywhere, their frame sums (start centroids) and segment / frame counts
-                loc = np.zeros((n_models * n, dim + 2))
-                for sid, x in seg_of.items():
-                    loc[sid, :dim], loc[sid, dim], loc[sid, dim + 1] = x.sum(axis=0), x.shape[0], n_runs[sid]
+                # which states were visited anywhere, and their segment / frame counts over all ranks
+                loc = np.zeros((n_models * n, 2))
+                for sid in keys:
+                    loc[sid] = n_of[sid], n_runs[sid]
                 glob = reducer(loc)
-                keys = [sid for sid in range(n_models * n) if glob[sid, dim] > 0]
-                segs = [seg_of[sid] if sid in seg_of else np.zeros((0, dim)) for sid in keys]
-                starts = [glob[sid, :dim] / glob[sid, dim] for sid in keys]
-                seg_counts = {sid: (glob[sid, dim + 1], glob[sid, dim]) for sid in keys}
-            rows_of = {int(sid): used[by_state[cuts[i]:cuts[i + 1]]] for i, sid in enumerate(uniq)}
+                keys = [sid for sid in range(n_models * n) if glob[sid, 0] > 0]
+                seg_counts = {sid: (glob[sid, 1], glob[sid, 0]) for sid in keys}
             rows = np.concatenate([rows_of.get(sid, np.zeros(0, dtype=np.int64)) for sid in keys]) if keys else np.zeros(0, np.int64)
-            fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None, source=(frames, rows))
+            lengths = [n_of.get(sid, 0) for sid in keys]
+            segs = None if on_device else [all_frames[rows_of[sid]] if sid in rows_of else np.zeros((0, dim)) for sid in keys]
+            fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None, source=(frames, rows),
+                                    lengths=lengths, dim=dim, kmax=kmax, compat_cov=compat_cov)
             try:
+                # start centroids: the mean of every state's frames (:116), over all ranks when sharded
+                if sharded and keys:
+                    if fitter.fit is not None:
+                        sums = fitter.fit.segment_means()[0]           # per state, this rank's frames summed on the device
+                    else:
+                        sums = np.array([seg.sum(axis=0) for seg in fitter.segs])
+                    tot = reducer(np.ascontiguousarray(sums))
+                    starts = tot / np.array([seg_counts[sid][1] for sid in keys], dtype=np.float64)[:, None]
+                else:
+                    starts = fitter.segment_means() if keys else np.zeros((0, dim))
                 fitter.split_and_fit([new_models[sid // n].gmm_states[sid % n] for sid in keys],
                                      start_centroids=starts,
                                      weight_divisor=[n_segments] * len(keys),          # (:127, :135-137)

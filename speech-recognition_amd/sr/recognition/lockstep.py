@@ -10,6 +10,16 @@ would `break`.  The results are the reference's: the random partitions behind th
 numpy's global generator in the order the sequential algorithm consumes it (they only depend on the frame counts), the
 centroid means are numpy's, the M-step / convergence test is `GMM.em_update`.
 
+DEVICE-RESIDENT form (round 3, `_hip.FitSession` = gh_fit_*): centroids, variances, mixture parameters, the allclose
+test's "old" parameters, the active mask and the iteration counters live in HBM; a k-means / EM iteration is a handful
+of kernel launches with no host synchronisation, the M-step + convergence test of `GMM.em_update` and the centroid
+update + `np.array_equal` stop rule are kernels, and the host reads one counter every 8 iterations.  The partition
+variances behind the k-means distance (kmeans.py:171-177) are two passes over each (state, cluster)'s frames on the
+device (ddof 1) instead of `np.cov(...).diagonal()`, which forms the D x D matrix by a BLAS product to read its diagonal:
+same value up to the library's summation order (`compat_cov=True` keeps np.cov and the host loop).  Taken whenever the
+library is there, D >= 2, and the reducer is absent or the library's own communicator (`parallel.NativeReducer`: the
+collectives then run on the device buffers); anything else keeps the host loop below.
+
 Sharded over ranks (`reducer` = `parallel.StatsAllReducer` of a process group with more than one rank) every rank holds
 part of each state's frames; cluster sums / counts and the EM statistics are all-reduced -- ONE collective per
 lock-step iteration.  Summation order then differs from the single-process run, and the random
@@ -33,21 +43,39 @@ class LockstepFitter:
     source: (resident batch, row indices) -- the rows of an fp64 batch that, in this order, ARE the concatenated
     segments; the fitter's batch is then gathered on the device instead of uploaded again."""
 
-    def __init__(self, segments, ctx=None, reducer=None, source=None):
+    def __init__(self, segments, ctx=None, reducer=None, source=None, lengths=None, dim=None, kmax=None, compat_cov=False):
+        """segments: the states' frames as host arrays -- or None with `lengths` [S] and `dim` when `source` names them
+        as rows of a resident batch (nothing is copied to or from the host then; needs the device-resident form)."""
         self.ctx = ctx if ctx is not None else _hip.default_context()
-        self.segs = [np.ascontiguousarray(s, dtype=np.float64) for s in segments]
-        self.S = len(self.segs)
-        self.D = self.segs[0].shape[1] if self.S else 0
+        if segments is not None:
+            self.segs = [np.ascontiguousarray(s, dtype=np.float64) for s in segments]
+            lengths = [len(s) for s in self.segs]
+            dim = self.segs[0].shape[1] if self.segs else 0
+        else:
+            assert source is not None and lengths is not None and dim is not None
+            self.segs = None
+        self.S = len(lengths)
+        self.D = int(dim) if self.S else 0
         self.seg_off = np.zeros(self.S + 1, dtype=np.int64)
-        np.cumsum([len(s) for s in self.segs], out=self.seg_off[1:])
+        np.cumsum(lengths, out=self.seg_off[1:])
+        self.reducer = reducer
+        self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
         if self.S and source is not None and hasattr(source[0], "gather") and source[0].np_dtype == np.float64:
             assert len(source[1]) == int(self.seg_off[-1])
             self.batch = source[0].gather(source[1])
         else:
+            assert self.segs is not None, "LockstepFitter: frames neither on the host nor in a resident fp64 batch"
             self.batch = _hip.Batch(self.ctx, feats=np.concatenate(self.segs) if self.S else np.zeros((0, 1)),
                                     offsets=[0, int(self.seg_off[-1])]) if self.S else None
-        self.reducer = reducer
-        self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
+        # the device-resident session (see the module docstring)
+        self.fit = None
+        self.comm = reducer.comm if (self.sharded and getattr(reducer, "native", False)) else None
+        if self.S and not compat_cov and self.D >= 2 and (not self.sharded or self.comm is not None) and hasattr(_hip, "FitSession"):
+            try:
+                self.fit = _hip.FitSession(self.ctx, self.batch, self.seg_off, kmax if kmax else 8)
+            except _hip.Unsupported:
+                self.fit = None
+        assert self.fit is not None or self.segs is not None, "LockstepFitter: this shape needs the frames on the host"
         self.collectives = 0
         # frames per state over all ranks (weights are counts / n)
         self.n_global = (self._reduce(np.diff(self.seg_off).astype(np.float64)) if self.sharded and self.S
@@ -58,18 +86,53 @@ class LockstepFitter:
         return self.reducer(np.ascontiguousarray(a, dtype=np.float64))
 
     def close(self):
+        if self.fit is not None:
+            self.fit.close()
+            self.fit = None
         if self.batch is not None:
             self.batch.close()
             self.batch = None
 
+    def segment_means(self):
+        """np.mean(segment, axis=0) of every state (the start centroids of continuous_train, continuous_speech.py:116)."""
+        if self.fit is not None:
+            sums, counts = self.fit.segment_means()
+            with np.errstate(all="ignore"):
+                return sums / counts[:, None]
+        return np.array([np.mean(seg, axis=0) for seg in self.segs])
+
+    def _ensure_session(self, k):
+        """The session is sized for kmax components at creation; a larger k builds a new one."""
+        if self.fit is not None and k > self.fit.kmax:
+            self.fit.close()
+            try:
+                self.fit = _hip.FitSession(self.ctx, self.batch, self.seg_off, k)
+            except _hip.Unsupported:
+                self.fit = None
+                assert self.segs is not None, "LockstepFitter: this shape needs the frames on the host"
+
     # ------------------------------------------------------------------ k-means (kmeans.py:167-193), all states
-    def kmeans(self, k, centroids, max_iteration=1000, partitions=None):
+    def kmeans(self, k, centroids, max_iteration=1000, partitions=None, want_clusters=True):
         """centroids [S, k, D] -> (clusters: list of int64 [N_s], centroids [S, k, D], cov [S, k, D]).
         partitions: the random partition of every state's frames (kmeans.py:171), drawn by the caller when the order
         of draws matters; default: drawn here, state after state."""
         S, D, off = self.S, self.D, self.seg_off
         if S == 0:        # no state was visited (continuous_train: "No MFCC data" for every state)
             return [], np.zeros((0, k, D)), np.zeros((0, k, D))
+        self._ensure_session(k)
+        if self.fit is not None:
+            lens = np.diff(off)
+            if partitions is None:
+                partitions = [np.random.randint(0, k, int(n)) for n in lens]
+            part = np.concatenate([np.asarray(p, dtype=np.uint8) for p in partitions]) if S else np.zeros(0, np.uint8)
+            cen, cov, cnt, its = self.fit.kmeans(k, centroids, part, max_iteration=max_iteration, comm=self.comm)
+            if self.comm is not None:
+                self.collectives += 3 + int(its.max(initial=0))   # partition sums (2), per iteration one, cluster sizes
+            self.last_counts = cnt
+            if not want_clusters:
+                return None, cen, cov
+            cl = self.fit.clusters()
+            return [cl[off[s]:off[s + 1]].astype(np.int64) for s in range(S)], cen, cov
         cov = np.empty((S, k, D))
         part_stats = np.zeros((S, 2 * D + 1))
         for s, x in enumerate(self.segs):
@@ -142,6 +205,24 @@ class LockstepFitter:
         S, off = self.S, self.seg_off
         if S == 0:
             return
+        self._ensure_session(k)
+        if self.fit is not None:
+            D = self.D
+            mean = np.array([[np.asarray(d.mean, dtype=np.float64) for d in g.dists[:k]] for g in states]).reshape(S, k, D)
+            var = np.array([[np.asarray(d.cov, dtype=np.float64) for d in g.dists[:k]] for g in states]).reshape(S, k, D)
+            w = np.array([np.asarray(g.w[:k], dtype=np.float64) for g in states]).reshape(S, k)
+            mu_old = np.ascontiguousarray(np.array([g.mu_old[:k, :] for g in states], dtype=np.float64))
+            sg_old = np.ascontiguousarray(np.array([g.sigma_old[:k, :] for g in states], dtype=np.float64))
+            w_old = np.ascontiguousarray(np.array([g.w_old[:k] for g in states], dtype=np.float64))
+            conv = self.fit.em(k, mean, var, w, mu_old, sg_old, w_old, self.n_global, max_iteration=max_iteration, comm=self.comm)
+            if self.comm is not None:
+                self.collectives += int(np.where(conv >= 0, conv + 1, max_iteration).max(initial=0))
+            for s, g in enumerate(states):
+                g.update_models(mean[s], var[s], w[s])
+                g.mu_old[:k, :], g.sigma_old[:k, :], g.w_old[:k] = mu_old[s], sg_old[s], w_old[s]
+                if conv[s] >= 0:
+                    print("EM converged at iteration:", int(conv[s]))
+            return
         active = np.ones(S, dtype=np.uint8)
         for it in range(max_iteration):
             means = np.array([[np.asarray(d.mean, dtype=np.float64) for d in g.dists[:k]] for g in states])
@@ -174,12 +255,14 @@ class LockstepFitter:
         # numpy's global generator is consumed the way the sequential algorithm consumes it: state after state, and
         # inside a state split after split (one draw of N_s cluster ids per kmeans call, kmeans.py:171; nothing else
         # in the refit draws) -- the draws only depend on the frame counts, so they can all be made up front
-        parts = [[np.random.randint(0, 2 ** (i + 1), x.shape[0]) for i in range(n_splits)] for x in self.segs]
+        parts = [[np.random.randint(0, 2 ** (i + 1), int(n_s)) for i in range(n_splits)] for n_s in np.diff(self.seg_off)]
         for i in range(n_splits):
             k = 2 ** (i + 1)
             centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=1)
-            clusters, centroids, cov = self.kmeans(k, centroids, partitions=[p[i] for p in parts])
-            if self.sharded:
+            clusters, centroids, cov = self.kmeans(k, centroids, partitions=[p[i] for p in parts], want_clusters=False)
+            if self.fit is not None:
+                counts = self.last_counts                      # cluster sizes (over all ranks when sharded), from the device
+            elif self.sharded:
                 counts = np.zeros((S, k))
                 for s in range(S):
                     counts[s] = np.bincount(clusters[s], minlength=k)[:k]
@@ -188,6 +271,11 @@ class LockstepFitter:
                 if self.sharded:
                     for c in np.nonzero(counts[s])[0]:
                         weights[s, c] = counts[s, c] / div[s]
+                elif self.fit is not None:
+                    ids = np.nonzero(counts[s])[0]             # np.unique(clusters): the ids that occur, ascending ...
+                    cnt = counts[s][ids]                       # ... and their sizes
+                    for c in ids:
+                        weights[s, c] = cnt[c] / div[s]        # looked up by cluster ID (hmm.py:116-118): the reference's indexing
                 else:
                     ids, cnt = np.unique(clusters[s], return_counts=True)
                     for c in ids:

@@ -410,7 +410,16 @@ class EMSession:
         raise _hip.Unsupported("no device-resident session on the test double")
 
 
-NAMES = ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc", "EMSession")
+class FitSession:
+    """No test double of the device-resident refit: callers keep the host loop (and the frames on the host)."""
+    available = False
+
+    def __init__(self, *a, **k):
+        from sr.recognition import _hip
+        raise _hip.Unsupported("no device-resident refit on the test double")
+
+
+NAMES = ("Context", "PackedGMM", "Batch", "Lattices", "distance_matrix", "default_context", "mfcc", "EMSession", "FitSession")
 
 
 def install(monkeypatch, hip_module):

@@ -316,3 +316,50 @@ def test_batch_gather_and_resident_clusters():
                     cent[s, c] = sums_h[s, c, :7] / sums_h[s, c, 7]
     assert (b.resident_clusters(reset=True) == -1).all()
     b.close()
+
+
+def test_device_session_equals_the_host_loop():
+    """The device-resident refit (gh_fit_*: partition variances, lock-step k-means and EM with the stop rules on the
+    device) against the host-orchestrated loop with np.cov (compat_cov=True): same cluster ids, same iteration counts,
+    centroids bit for bit (they are sums of the same frames in the same order), variances / EM parameters to 1e-9."""
+    import sr.recognition as R
+    from sr.recognition.lockstep import LockstepFitter
+    from test_gpu_api import quiet
+    rng = np.random.default_rng(3)
+    D, k = 7, 4
+    segs = [rng.normal(size=(int(n), D)) * rng.uniform(0.5, 2.0, size=D) + rng.normal(size=D) * 3 for n in (400, 130, 900, 65, 64, 257)]
+    S = len(segs)
+    dev, host = LockstepFitter(segs), LockstepFitter(segs, compat_cov=True)
+    assert dev.fit is not None and host.fit is None
+    np.testing.assert_array_equal(dev.segment_means(), host.segment_means())
+    parts = [rng.integers(0, k, size=len(x)) for x in segs]
+    c0 = np.stack([np.stack([x.mean(axis=0) * f for f in (0.8, 0.9, 1.1, 1.2)]) for x in segs])
+    cl_d, ce_d, cov_d = dev.kmeans(k, c0, partitions=parts)
+    cl_h, ce_h, cov_h = host.kmeans(k, c0, partitions=parts)
+    np.testing.assert_allclose(cov_d, cov_h, rtol=1e-12)
+    for a, b in zip(cl_d, cl_h):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ce_d, ce_h)
+    np.testing.assert_array_equal(dev.last_counts, np.array([np.bincount(c, minlength=k) for c in cl_h]))
+    # EM from the k-means result, "old" parameters as a fresh GMM holds them
+    def states():
+        out = []
+        for s in range(S):
+            g = R.GMM(segs[s].mean(axis=0), segs[s].var(axis=0), k)
+            g.update_models(ce_h[s].copy(), cov_h[s].copy(), np.bincount(cl_h[s], minlength=k) / len(segs[s]))
+            out.append(g)
+        return out
+    sd, sh = states(), states()
+    with quiet():
+        dev.em(sd, k, max_iteration=60)
+        host.em(sh, k, max_iteration=60)
+    for a, b in zip(sd, sh):
+        np.testing.assert_allclose(a.w, b.w, rtol=1e-9)
+        np.testing.assert_allclose(a.w_old, b.w_old, rtol=1e-9)
+        np.testing.assert_allclose(a.mu_old, b.mu_old, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(a.sigma_old, b.sigma_old, rtol=1e-9)
+        for da, db in zip(a.dists, b.dists):
+            np.testing.assert_allclose(da.mean, db.mean, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(da.cov, db.cov, rtol=1e-9)
+    dev.close()
+    host.close()
