@@ -698,6 +698,49 @@ def _c4_em_config(ctx, group, U):
     return out
 
 
+def _ctrain_config(ctx, U, K=7, iters=6):
+    """The reference's ACTUAL training algorithm on configs[2]'s model: continuous_train (continuous_speech.py:56-179) --
+    per outer iteration forced alignment of every utterance, frames regrouped per state, every state refit by
+    binary-split k-means + EM, transition costs re-estimated, models pickled -- on `U` synthetic K-word utterances.
+    Alignment, regrouping gather, partition variances, lock-step k-means / EM with their stop rules all run on the
+    device (gh_align_segments, gh_batch_gather, gh_fit_*); reported: wall time per outer iteration in steady state."""
+    import contextlib
+    import io
+    import tempfile
+    from sr.recognition import continuous_speech as cs
+    from sr.recognition.model_io import models_from_arrays
+    wl = synth_workload(1003, U * K)
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    iso = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U * K)]
+    data = [np.concatenate(iso[i * K:(i + 1) * K]) for i in range(U)]
+    labels = [[int(w) for w in wl["words"][i * K:(i + 1) * K]] for i in range(U)]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)
+    models = models_from_arrays(means0, wl["vars"], wl["w"], [wl["trans"]] * W, mu=means0[:, :, 0], sigma=wl["vars"][:, :, 0])
+
+    class Stamps(io.StringIO):
+        def __init__(self):
+            super().__init__()
+            self.t = []
+
+        def write(self, text):
+            if text.startswith("Continuous training iteration:"):
+                self.t.append(time.perf_counter())
+            return len(text)
+    np.random.seed(0)
+    stamps = Stamps()
+    import warnings
+    with contextlib.redirect_stdout(stamps), warnings.catch_warnings(), tempfile.TemporaryDirectory() as out:
+        warnings.simplefilter("ignore")
+        cs.continuous_train(data, models, labels, out, n_gaussians=M, n_segments=n, max_iteration=iters)
+    per = np.diff(stamps.t + [time.perf_counter()])
+    N = int(sum(len(x) for x in data))
+    steady = float(np.median(per[len(per) // 2:]))
+    return {"workload": "configs[2] model, continuous_train on %d utterances of %d words (%d frames), %d mixtures" % (U, K, N, M),
+            "outer_iterations": int(len(per)), "ms_per_outer_iteration": [round(1e3 * float(x), 1) for x in per],
+            "ms_per_outer_iteration_steady": steady * 1e3, "frames_per_s": N / steady, "utterances_per_s": U / steady,
+            "note": "steady = median of the second half of the iterations (the first ones grow the scratch arenas); round 2: 750 ms"}
+
+
 def extra_configs(args, group, npdt, peak_flops, wl):
     """The other BASELINE configs, after the timed region.  With several ranks every rank runs its share of the legs
     that BASELINE defines on 8 GPUs (configs[4]: C5 K-layer lattice and loop grammar at 125 000 utterances per rank;
@@ -718,6 +761,7 @@ def extra_configs(args, group, npdt, peak_flops, wl):
     legs.append(("C4_em", lambda: _c4_em_config(ctx, group, args.c4_em_utts)))
     if one:
         legs.append(("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)))
+        legs.append(("C3_continuous_train", lambda: _ctrain_config(ctx, args.c3_utts)))
         legs.append(("C2_fp32_decode", lambda: fp32_mismatch_c2(ctx, wl)))
     legs.append(("C5", lambda: _continuous_config(ctx, group, args.c5_utts, min(args.c5_utts, 5000), npdt)))
     for key, fn in legs:

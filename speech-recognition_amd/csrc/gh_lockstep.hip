@@ -56,26 +56,40 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ X, int64_t
 constexpr int RS_B = 64;
 
 // exclusive scan of the per-tile cluster counts over the tiles of every state (in tile = frame order); also the
-// number of frames of every (state, cluster) and where its list starts inside the state's segment
-__global__ void kmeans_scan_kernel(const int32_t* __restrict__ tile_ptr /*[S+1]*/, int k, int32_t* __restrict__ tilecnt /*[tiles][k] -> offsets*/,
+// number of frames of every (state, cluster) and where its list starts inside the state's segment.
+// One block of 4 waves per state; a wave takes the clusters c = wave, wave + 4, ... and scans a cluster's tiles 64 at a
+// time (lane = tile, shuffle prefix sum, running carry) -- the first version walked the ~440 tiles of a state one after
+// the other per cluster thread (44 us per launch, latency bound).
+__global__ __launch_bounds__(256) void kmeans_scan_kernel(const int32_t* __restrict__ tile_ptr /*[S+1]*/, int k, int32_t* __restrict__ tilecnt /*[tiles][k] -> offsets*/,
                                    int32_t* __restrict__ counts /*[S,k]*/, int32_t* __restrict__ cbase /*[S,k]*/,
                                    const uint8_t* __restrict__ active = nullptr) {
-    const int s = blockIdx.x, c = threadIdx.x;
+    const int s = blockIdx.x;
     if (active && !active[s]) return;      // (a state that has stopped keeps its lists and counts)
     __shared__ int tot[64];
-    int run = 0;
-    if (c < k)
-        for (int t = tile_ptr[s]; t < tile_ptr[s + 1]; ++t) {
-            const int v = tilecnt[(int64_t)t * k + c];
-            tilecnt[(int64_t)t * k + c] = run;
-            run += v;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = tile_ptr[s], t1 = tile_ptr[s + 1];
+    for (int c = wave; c < k; c += 4) {
+        int run = 0;
+        for (int t = t0; t < t1; t += 64) {
+            const bool in = t + lane < t1;
+            const int v = in ? tilecnt[(int64_t)(t + lane) * k + c] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (in) tilecnt[(int64_t)(t + lane) * k + c] = run + inc - v;
+            run += __shfl(inc, 63);
         }
-    tot[c] = c < k ? run : 0;
+        if (lane == 0) tot[c] = run;
+    }
     __syncthreads();
+    const int c = threadIdx.x;
     if (c < k) {
         int base = 0;
         for (int j = 0; j < c; ++j) base += tot[j];
-        counts[s * k + c] = run;
+        counts[s * k + c] = tot[c];
         cbase[s * k + c] = base;
     }
 }
@@ -108,24 +122,44 @@ __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restr
                                                            const int64_t* __restrict__ seg_off, const uint8_t* __restrict__ active,
                                                            const int32_t* __restrict__ lists, const int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ cbase, double* __restrict__ sums, int sstride,
-                                                           const double* __restrict__ csum = nullptr, int cstride = 0) {
+                                                           const double* __restrict__ csum = nullptr, int cstride = 0,
+                                                           int chunk = 0, int nch = 0) {
     const int s = blockIdx.x, c = blockIdx.y;
     if (active && !active[s]) return;
-    const int d = blockIdx.z * 64 + threadIdx.x, lane = threadIdx.x;
+    // chunk == 0: the whole list of (state, cluster) in frame order -- numpy's sum, bit for bit (D <= 64: one block);
+    // chunk > 0: blockIdx.z-th piece of `chunk` list entries into partial[s][c][z][D+1] (summed by fit_chunk_reduce_kernel:
+    // a FIXED order, but not numpy's -- the lock-step iterations use it, the final centroids never)
+    const int d = threadIdx.x, lane = threadIdx.x;
     const bool live = d < D;
     const int64_t f0 = seg_off[s];
-    const int n = counts[s * k + c];
-    double* out = sums + (int64_t)s * sstride + (int64_t)c * (D + 1);
-    if (d == 0 && MODE == 0) out[D] = (double)n;
-    if (n <= 0) { if (live && MODE != 0) out[d] = 0.0; return; }
+    const int n_all = counts[s * k + c];
+    const int skip = chunk > 0 ? blockIdx.z * chunk : 0;
+    const int n = chunk > 0 ? min(chunk, n_all - skip) : n_all;
+    double* out = chunk > 0 ? sums + (((int64_t)s * k + c) * nch + blockIdx.z) * (D + 1)
+                            : sums + (int64_t)s * sstride + (int64_t)c * (D + 1);
+    if (d == 0 && MODE == 0 && chunk == 0) out[D] = (double)n_all;
+    if (n <= 0) { if (live && MODE != 0 && chunk == 0) out[d] = 0.0; return; }
     double ctr = 0.0;
-    if (MODE == 1) ctr = csum[(int64_t)s * cstride + (int64_t)c * (D + 1) + (live ? d : 0)] / (double)n;
-    const double* col = X + f0 * D + (live ? d : 0);
-    const int32_t* li = lists + f0 + cbase[s * k + c];
-    int id = li[min(lane, n - 1)];
+    if (MODE == 1) ctr = csum[(int64_t)s * cstride + (int64_t)c * (D + 1) + (live ? d : 0)] / (double)n_all;
+    // Rows through BUFFER loads: address = descriptor base (the state's first frame) + scalar offset (the row, handed
+    // out of the lane-held list by v_readlane) + vector offset (the lane's dimension) -- readlane, buffer_load, add: three
+    // instructions per frame.  With flat loads the 64-bit row address was rebuilt by scalar arithmetic for every frame
+    // (~10 instructions): the kernel was ISSUE bound at ~50 cycles per frame (292 us per launch for the longest chains),
+    // not memory bound -- fetching the frame numbers a round earlier changed nothing.
+    const int64_t seg_bytes = (seg_off[s + 1] - f0) * (int64_t)D * 8;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(X + f0 * D), 0, (int)seg_bytes, 0x00020000);
+    const int voff = (live ? d : 0) * 8;
+    const int row_bytes = D * 8;
+    const int32_t* li = lists + f0 + cbase[s * k + c] + skip;
+    int id = li[min(lane, n - 1)] * row_bytes;
+    int id_next = li[min(RS_B + lane, n - 1)] * row_bytes;    // the frame numbers travel two rounds ahead of the adds
+    typedef int rs_v2i __attribute__((ext_vector_type(2)));
+    auto row = [&](int ids, int j) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, __builtin_amdgcn_readlane(ids, j), 0));
+    };
     double x[RS_B];
 #pragma unroll
-    for (int j = 0; j < RS_B; ++j) x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
+    for (int j = 0; j < RS_B; ++j) x[j] = row(id, j);
     auto term = [&](double v) -> double {
         if (MODE == 0) return v;
         if (MODE == 1) { const double t = v - ctr; return t * t; }
@@ -134,11 +168,12 @@ __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restr
     double acc = 0.0;
     int b = 0;
     for (; b + RS_B <= n; b += RS_B) {                        // full rounds: the chain is one add per frame
-        id = li[min(b + RS_B + lane, n - 1)];                 // the next 64 entries (clamped: re-reads the last frame, never summed)
+        id = id_next;                                         // entries b + 64 .. (clamped: re-reads the last frame, never summed)
+        id_next = li[min(b + 2 * RS_B + lane, n - 1)] * row_bytes;
 #pragma unroll
         for (int j = 0; j < RS_B; ++j) {
             acc += term(x[j]);
-            x[j] = col[(int64_t)__builtin_amdgcn_readlane(id, j) * D];
+            x[j] = row(id, j);
         }
     }
     const int left = n - b;                                   // the last, partial round
@@ -197,16 +232,33 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
         }
 }
 
-// partial[tile][len] summed over the tiles of each state (contiguous, in order) -> out[state][len]
-__global__ void tiles_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ tile_ptr /*[S+1]*/, int len,
+// partial[tile][len] summed over the tiles of each state -> out[state][len].  One block per (state, 64 columns): wave w
+// takes the tiles t0 + w, t0 + w + 4, ... with four accumulators per thread (16 loads in flight per column instead of
+// one thread walking all ~440 tiles: 105 -> ~10 us), and the 16 partial sums are combined in a fixed order --
+// deterministic for a given tile list, which is all the EM statistics need (their summation order is ours).
+__global__ __launch_bounds__(256) void tiles_reduce_kernel(const double* __restrict__ partial, const int32_t* __restrict__ tile_ptr /*[S+1]*/, int len,
                                     double* __restrict__ out, const uint8_t* __restrict__ active = nullptr) {
     const int s = blockIdx.y;
     if (active && !active[s]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    double acc = 0;
-    for (int t = tile_ptr[s]; t < tile_ptr[s + 1]; ++t) acc += partial[(int64_t)t * len + i];
-    out[(int64_t)s * len + i] = acc;
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int t0 = tile_ptr[s], t1 = tile_ptr[s + 1];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (i < len) {
+        const double* src = partial + i;
+        int t = t0 + wave;
+        for (; t + 12 < t1; t += 16) {
+            a0 += src[(int64_t)t * len];
+            a1 += src[(int64_t)(t + 4) * len];
+            a2 += src[(int64_t)(t + 8) * len];
+            a3 += src[(int64_t)(t + 12) * len];
+        }
+        for (; t < t1; t += 4) a0 += src[(int64_t)t * len];
+    }
+    red[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && i < len) out[(int64_t)s * len + i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------ EM E-step
@@ -303,6 +355,9 @@ int check_segments(const gh_batch* b, int S, const int64_t* seg_off, const char*
     GH_REQUIRE(b->dtype == GH_F64, "%s: needs an fp64 batch", who);
     GH_REQUIRE(S > 0 && seg_off && seg_off[0] >= 0 && seg_off[S] <= b->N, "%s: segment offsets outside the batch", who);
     for (int s = 0; s < S; ++s) GH_REQUIRE(seg_off[s + 1] >= seg_off[s], "%s: segment offsets not monotone at %d", who, s);
+    for (int s = 0; s < S; ++s)    // (the centroid sums address a state's rows by 31-bit byte offsets from its first frame)
+        GH_REQUIRE((seg_off[s + 1] - seg_off[s]) * (int64_t)b->D * 8 < ((int64_t)1 << 31), "%s: state %d holds %lld frames (< 2 GiB per state)",
+                   who, s, (long long)(seg_off[s + 1] - seg_off[s]));
     GH_REQUIRE(b->D <= LS_MAXD, "%s: D=%d (<= %d supported)", who, b->D, LS_MAXD);
     return GH_OK;
 }
@@ -395,7 +450,7 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
         if (active) GH_HIP(hipMemcpyAsync(d_active, active, (size_t)S, hipMemcpyHostToDevice, st));
         GH_HIP(hipMemsetAsync(d_sums, 0, (size_t)S * plen * 8, st));
         GH_HIP(hipMemcpyAsync(d_tptr, tile_ptr.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(64), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase, nullptr);
+        hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(256), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase, nullptr);
         hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists, nullptr);
         hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, dim3((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64)), dim3(64), 0, st,
                            (const double*)b->feats, D, k, d_segoff, d_active, d_lists, d_counts, d_cbase, d_sums, plen, nullptr, 0);
@@ -461,7 +516,7 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
 #undef GH_EM
         GH_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, d_part, d_tptr,
+    hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 63) / 64), (unsigned)S), dim3(256), 0, st, d_part, d_tptr,
                        plen, d_out, nullptr);
     GH_HIP(hipGetLastError());
     std::vector<double> host((size_t)S * plen);
@@ -494,6 +549,8 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
 //     are the BLAS library's summation order (callers that want exactly those bits keep np.cov: compat_cov=True).
 //   * sharded (comm != NULL): cluster sums + changed counts, cluster counts, partition sums and EM statistics are summed
 //     over the ranks with gh_comm's all-reduce ON THE DEVICE BUFFERS, between the kernels that produce and consume them.
+constexpr int FIT_CHUNK = 512;   // list entries per wave of the chunked cluster sums (see gh_fit_kmeans)
+
 struct gh_fit {
     gh_ctx* ctx;
     const gh_batch* b;
@@ -505,7 +562,8 @@ struct gh_fit {
     int64_t* d_segoff;
     uint8_t* d_active;
     int32_t *d_ids, *d_tilecnt, *d_counts, *d_cbase, *d_lists, *d_changed, *d_iters;
-    double *d_cent, *d_cov, *d_logdet, *d_sums, *d_sq;
+    double *d_cent, *d_cov, *d_logdet, *d_sums, *d_sq, *d_psum;
+    int nch;             // pieces of FIT_CHUNK list entries the longest state's lists are cut into (d_psum [S][kmax][nch][D+1])
     int* d_counter;      // [0] states still active after the last iteration, [1] error bits (16: zero variance)
     double *d_mean, *d_var, *d_weight, *d_ivar, *d_logc, *d_old_mu, *d_old_sigma, *d_old_w, *d_nframes, *d_part, *d_stats;
     int* h_pin;          // pinned [4]
@@ -591,7 +649,8 @@ __global__ void fit_zero_inactive_kernel(int S, int sstride, const uint8_t* __re
 
 // centroid update + stop rule of one state per block (kmeans.py:187-192; sharded: lockstep's "nobody's assignment changed")
 __global__ __launch_bounds__(64) void fit_kmeans_update_kernel(int k, int D, int sstride, const double* __restrict__ sums,
-                                                               int sharded, double* __restrict__ cent, uint8_t* __restrict__ active,
+                                                               int sharded /*1: all-reduced sums; 2: one rank, stop when no assignment changed*/,
+                                                               double* __restrict__ cent, uint8_t* __restrict__ active,
                                                                int32_t* __restrict__ changed, int32_t* __restrict__ iters,
                                                                int* __restrict__ counter) {
     const int s = blockIdx.x, lane = threadIdx.x;
@@ -614,6 +673,34 @@ __global__ __launch_bounds__(64) void fit_kmeans_update_kernel(int k, int D, int
         changed[s] = 0;
         if (stop) active[s] = 0; else atomicAdd(counter, 1);
     }
+}
+
+// partial[s][c][z][D+1] (pieces of `chunk` list entries, in list order) -> sums[s][c][D+1] with the count in column D
+__global__ void fit_chunk_reduce_kernel(int S, int k, int D, int nch, int chunk, const int32_t* __restrict__ counts,
+                                        const double* __restrict__ partial, const uint8_t* __restrict__ active,
+                                        double* __restrict__ sums, int sstride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * k * (D + 1)) return;
+    const int s = i / (k * (D + 1)), c = (i / (D + 1)) % k, d = i % (D + 1);
+    if (active && !active[s]) return;
+    const int n = counts[s * k + c];
+    double acc = 0.0;
+    if (d == D) acc = (double)n;
+    else {
+        const int pieces = (n + chunk - 1) / chunk;
+        const double* p = partial + ((int64_t)s * k + c) * nch * (D + 1) + d;
+        for (int z = 0; z < pieces; ++z) acc += p[(int64_t)z * (D + 1)];
+    }
+    sums[(int64_t)s * sstride + (int64_t)c * (D + 1) + d] = acc;
+}
+
+// centroids = (sum of the cluster's frames in frame order) / count for every state: the values the reference returns
+__global__ void fit_final_centroids_kernel(int S, int k, int D, int sstride, const double* __restrict__ sums, double* __restrict__ cent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * k * D) return;
+    const int s = i / (k * D), c = (i / D) % k, d = i % D;
+    const double* su = sums + (int64_t)s * sstride + (int64_t)c * (D + 1);
+    cent[i] = su[d] / su[D];
 }
 
 __global__ void fit_counts_kernel(int n, const int32_t* __restrict__ counts, double* __restrict__ out) {
@@ -713,6 +800,11 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
         gh_set_error("gh_fit_create: kmax=%d (1..32), D=%d (2..%d) outside the device-resident refit", kmax, b->D, LS_MAXD);
         return GH_ERR_UNSUPPORTED;
     }
+    for (int s = 0; s < S; ++s)
+        if ((seg_off[s + 1] - seg_off[s]) * (int64_t)b->D * 8 >= ((int64_t)1 << 31)) {
+            gh_set_error("gh_fit_create: state %d holds %lld frames (a segment must stay below 2 GiB)", s, (long long)(seg_off[s + 1] - seg_off[s]));
+            return GH_ERR_UNSUPPORTED;
+        }
     GH_HIP(hipSetDevice(ctx->device));
     const int D = b->D, Wd = 1 + 2 * D;
     std::vector<ls_tile> tiles;
@@ -748,6 +840,12 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
     lay.add((void**)&f->d_logdet, (size_t)S * 8, nullptr);
     lay.add((void**)&f->d_sums, (size_t)S * sstride * 8, nullptr);
     lay.add((void**)&f->d_sq, (size_t)S * sstride * 8, nullptr);
+    {
+        int64_t longest = 1;
+        for (int s = 0; s < S; ++s) longest = std::max(longest, seg_off[s + 1] - seg_off[s]);
+        f->nch = (int)((longest + FIT_CHUNK - 1) / FIT_CHUNK);
+    }
+    lay.add((void**)&f->d_psum, (size_t)S * kmax * f->nch * (D + 1) * 8, nullptr);
     lay.add((void**)&f->d_counter, 64, nullptr);
     lay.add((void**)&f->d_mean, skd * 8, nullptr);
     lay.add((void**)&f->d_var, skd * 8, nullptr);
@@ -793,7 +891,7 @@ static int fit_build_lists(gh_fit* f, int k, bool from_assign_counts, const uint
     if (f->n_tiles == 0) return GH_OK;
     const dim3 grid((unsigned)f->n_tiles), blk(64);
     if (!from_assign_counts) hipLaunchKernelGGL(fit_tilecount_kernel, grid, blk, 0, st, f->d_tiles, k, f->d_ids, f->d_tilecnt);
-    hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)f->S), dim3(64), 0, st, f->d_tptr, k, f->d_tilecnt, f->d_counts, f->d_cbase, active);
+    hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)f->S), dim3(256), 0, st, f->d_tptr, k, f->d_tilecnt, f->d_counts, f->d_cbase, active);
     hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, f->d_tiles, k, f->d_ids, f->d_segoff, f->d_tilecnt, f->d_cbase, f->d_lists, active);
     GH_HIP(hipGetLastError());
     return GH_OK;
@@ -855,6 +953,15 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         GH_HIP(hipGetLastError());
     }
     // ---- lock-step k-means ----
+    // The reference recomputes every centroid as np.mean(data[clusters == c]) -- the cluster's frames added in frame
+    // order, a serial chain per (state, cluster) that no amount of hardware shortens (207 us per iteration for 14 000
+    // frame clusters: a wave has at most 64 loads in flight) -- and stops when the centroids repeat bit for bit.
+    // Default here: the iterations use sums over 512-frame pieces of the cluster lists (a fixed order, 15 us) and stop
+    // when no assignment of the state changed -- the same iteration, since equal assignments give equal sums -- and ONE
+    // frame-order pass over the final assignment produces the centroids, which are then numpy's bit for bit.  What can
+    // differ: a frame whose two nearest centroids tie to within an ulp might be assigned differently in an intermediate
+    // iteration.  GMMHMM_KMEANS_EXACT=1 keeps the frame-order sums and the np.array_equal rule in every iteration.
+    const bool exact_order = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }() && !comm;
     GH_HIP(hipMemcpyAsync(f->d_cent, centroids_in, (size_t)S * k * D * 8, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
     GH_HIP(hipMemsetAsync(f->d_iters, 0, (size_t)S * 4, st));
@@ -875,8 +982,16 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
             }
             rc = fit_build_lists(f, k, true, f->d_active);
             if (rc) return rc;
-            hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)f->d_active, f->d_lists,
-                               f->d_counts, f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0);
+            if (exact_order) {
+                hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)f->d_active, f->d_lists,
+                                   f->d_counts, f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0, 0, 0);
+            } else {
+                hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, dim3((unsigned)S, (unsigned)k, (unsigned)f->nch), dim3(64), 0, st, X, D, k, f->d_segoff,
+                                   (const uint8_t*)f->d_active, f->d_lists, f->d_counts, f->d_cbase, f->d_psum, 0, (const double*)nullptr, 0,
+                                   FIT_CHUNK, f->nch);
+                hipLaunchKernelGGL(fit_chunk_reduce_kernel, dim3((unsigned)((S * k * (D + 1) + 255) / 256)), dim3(256), 0, st, S, k, D, f->nch, FIT_CHUNK,
+                                   (const int32_t*)f->d_counts, (const double*)f->d_psum, (const uint8_t*)f->d_active, f->d_sums, sstride);
+            }
             hipLaunchKernelGGL(fit_pack_changed_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, sstride, k * (D + 1),
                                (const int32_t*)f->d_changed, (const uint8_t*)f->d_active, f->d_sums);
             if (comm) {
@@ -886,7 +1001,7 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
                 if (rc) return rc;
             }
             GH_HIP(hipMemsetAsync(f->d_counter, 0, 4, st));
-            hipLaunchKernelGGL(fit_kmeans_update_kernel, dim3((unsigned)S), dim3(64), 0, st, k, D, sstride, (const double*)f->d_sums, comm ? 1 : 0,
+            hipLaunchKernelGGL(fit_kmeans_update_kernel, dim3((unsigned)S), dim3(64), 0, st, k, D, sstride, (const double*)f->d_sums, exact_order ? 0 : 1,
                                f->d_cent, f->d_active, f->d_changed, f->d_iters, f->d_counter);
             GH_HIP(hipGetLastError());
         }
@@ -895,6 +1010,15 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         rc = fit_poll(f, &n_active, &flags);
         if (rc) return rc;
         if (n_active == 0) break;
+    }
+    if (!exact_order && !comm) {
+        // the centroids the reference returns: the mean of every cluster's frames summed IN FRAME ORDER (one sequential
+        // pass per k-means call instead of one per iteration)
+        hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists, f->d_counts,
+                           f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0, 0, 0);
+        hipLaunchKernelGGL(fit_final_centroids_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
+                           (const double*)f->d_sums, f->d_cent);
+        GH_HIP(hipGetLastError());
     }
     // ---- results: centroids, partition variances, cluster sizes (np.unique counts; over all ranks when sharded) ----
     hipLaunchKernelGGL(fit_counts_kernel, dim3((unsigned)((S * k + 255) / 256)), dim3(256), 0, st, S * k, (const int32_t*)f->d_counts, f->d_sq);
@@ -955,7 +1079,7 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
                 if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
 #undef GH_EM
             }
-            hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, (const double*)f->d_part,
+            hipLaunchKernelGGL(tiles_reduce_kernel, dim3((unsigned)((plen + 63) / 64), (unsigned)S), dim3(256), 0, st, (const double*)f->d_part,
                                (const int32_t*)f->d_tptr, plen, f->d_stats, (const uint8_t*)f->d_active);
             if (comm) {
                 hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, S, plen,

@@ -180,23 +180,58 @@ def transcript_state_sets(label_seqs, n, n_words):
     return np.asarray(off, dtype=np.int64), np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
 
 
-def _alignment_lattices(frames, models, label_seqs):
+class AlignmentPlan:
+    """What the alignment step of every outer iteration needs and that never changes between iterations: the distinct
+    transcripts (one forced-alignment graph each), every utterance's graph, the flattened label strings the library
+    takes, the state sets whose likelihoods an utterance needs -- and ONE packed model that is re-packed in place
+    (gh_gmm_update) instead of being rebuilt.  Built once per `continuous_train` call (it used to be rebuilt, label
+    string by label string, in every iteration)."""
+
+    def __init__(self, label_seqs, n, n_words):
+        self.n, self.n_words = n, n_words
+        self.state_sets = transcript_state_sets(label_seqs, n, n_words)
+        keys, self.transcripts, self.utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
+        for u, labels in enumerate(label_seqs):
+            key = tuple(int(l) for l in labels)
+            if key not in keys:
+                keys[key] = len(self.transcripts)
+                self.transcripts.append(key)
+            self.utt_graph[u] = keys[key]
+        self.flat = _hip.Lattices.flatten_transcripts(self.transcripts) if hasattr(_hip.Lattices, "flatten_transcripts") else None
+        self.gmm = None
+
+    def packed_model(self, ctx, models):
+        states = [s for m in models for s in m.gmm_states]
+        if not hasattr(_hip.PackedGMM, "update"):
+            return _pack.device_gmm(ctx, states)
+        means, vars_, w = _pack.stack_gmms(states)
+        if self.gmm is None or (self.gmm.S, self.gmm.M, self.gmm.D) != means.shape:
+            self.close()
+            self.gmm = _hip.PackedGMM(ctx, means, vars_, w)
+        else:
+            self.gmm.update(means, vars_, w)
+        return self.gmm
+
+    def close(self):
+        if self.gmm is not None:
+            self.gmm.close()
+            self.gmm = None
+
+
+def _alignment_lattices(frames, models, label_seqs, plan=None):
     """Likelihoods of every utterance against the states of its own words, and its one-word-per-layer lattice
     (continuous_speech.py:80-82): (device lattices, distinct transcripts, transcript index per utterance)."""
     ctx = frames.ctx
     n = len(models[0].gmm_states)
-    gmm = _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
+    own = plan is None
+    if own:
+        plan = AlignmentPlan(label_seqs, n, len(models))
+    gmm = plan.packed_model(ctx, models) if not own else _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
     # an utterance's lattice only contains the states of its own words: likelihoods for those states only
-    frames.loglik(gmm, fetch=False, state_sets=transcript_state_sets(label_seqs, n, len(models)))
-    keys, transcripts, utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
-    for u, labels in enumerate(label_seqs):
-        key = tuple(int(l) for l in labels)
-        if key not in keys:
-            keys[key] = len(transcripts)
-            transcripts.append(key)
-        utt_graph[u] = keys[key]
-    lat = _hip.Lattices.from_transcripts(ctx, [m.transitions for m in models], n, transcripts)
-    return lat, transcripts, utt_graph
+    frames.loglik(gmm, fetch=False, state_sets=plan.state_sets)
+    kw = {"flat": plan.flat} if plan.flat is not None else {}
+    lat = _hip.Lattices.from_transcripts(ctx, [m.transitions for m in models], n, plan.transcripts, **kw)
+    return lat, plan.transcripts, plan.utt_graph
 
 
 def transcript_row_state(labels, n):
@@ -223,11 +258,11 @@ def forced_alignments(frames, models, label_seqs):
     return res["paths"], [row_states[g] for g in utt_graph]
 
 
-def aligned_frame_states(frames, models, label_seqs):
+def aligned_frame_states(frames, models, label_seqs, plan=None):
     """Alignment AND regrouping (continuous_speech.py:80-106) in one launch sequence, nothing but one int per frame
     coming back: (frame_state [N]: word * n + state of the training data the frame joins, -1 for none;
     segment_start bool [N]: first frame of a segment).  Equals `cut_segments` applied to `forced_alignments`."""
-    lat, _, utt_graph = _alignment_lattices(frames, models, label_seqs)
+    lat, _, utt_graph = _alignment_lattices(frames, models, label_seqs, plan)
     try:
         res = lat.align_segments(frames, utt_lattice=utt_graph)
     finally:
@@ -307,6 +342,7 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     all_frames = None
     if not on_device:
         all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
+    plan = AlignmentPlan(label_seqs, n, n_models)
     try:
         for it in range(max_iteration):
             print('=' * 25)
@@ -316,14 +352,21 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             # alignment + regrouping on the device; per state, its frames in utterance / time order -- what the
             # reference's vstack of the segments holds (:90-113) -- and the states in first-visit order
             if len(data):
-                frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs)
+                frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs, plan)
             else:       # nothing to align on this rank: it only contributes zeros to the collectives below
                 frame_state, seg_start = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)
             used = np.flatnonzero(frame_state >= 0)
             sid_of = frame_state[used]
-            by_state = np.argsort(sid_of, kind="stable")
-            uniq, first, n_frames = np.unique(sid_of, return_index=True, return_counts=True)
+            # stable grouping by state: 16-bit keys take numpy's radix sort (a comparison sort of 1.4 M int32 keys plus
+            # np.unique's second sort were 30 ms of every outer iteration); the first occurrence of a state is the first
+            # entry of its group because the sort is stable
+            key = sid_of.astype(np.uint16) if n_models * n < 65536 else sid_of
+            by_state = np.argsort(key, kind="stable")
+            per_state = np.bincount(sid_of, minlength=n_models * n)
+            uniq = np.flatnonzero(per_state)
+            n_frames = per_state[uniq]
             cuts = np.concatenate([[0], np.cumsum(n_frames)])
+            first = by_state[cuts[:-1]] if len(uniq) else np.zeros(0, dtype=np.int64)
             n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
             rows_of = {int(sid): used[by_state[cuts[i]:cuts[i + 1]]] for i, sid in enumerate(uniq)}
             n_of = {int(sid): int(c) for sid, c in zip(uniq, n_frames)}
@@ -395,4 +438,5 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             old_models = new_models
             new_models = copy.deepcopy(old_models)
     finally:
+        plan.close()
         frames.close()

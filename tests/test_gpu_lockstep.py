@@ -341,6 +341,17 @@ def test_device_session_equals_the_host_loop():
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ce_d, ce_h)
     np.testing.assert_array_equal(dev.last_counts, np.array([np.bincount(c, minlength=k) for c in cl_h]))
+    # frame-order sums and the np.array_equal stop rule in EVERY iteration (GMMHMM_KMEANS_EXACT=1) against the default
+    # (sums over 512-frame pieces while iterating, one frame-order pass at the end): same assignments, same centroid bits
+    os.environ["GMMHMM_KMEANS_EXACT"] = "1"
+    try:
+        cl_e, ce_e, cov_e = dev.kmeans(k, c0, partitions=parts)
+    finally:
+        del os.environ["GMMHMM_KMEANS_EXACT"]
+    for a, b in zip(cl_e, cl_h):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ce_e, ce_h)
+    np.testing.assert_array_equal(cov_e, cov_d)
     # EM from the k-means result, "old" parameters as a fresh GMM holds them
     def states():
         out = []

@@ -25,14 +25,33 @@ models = models_from_arrays(means0, wl["vars"], wl["w"], [wl["trans"]] * W, mu=m
 print("%d utterances x %d words, %d frames, %d-dim, %d mixtures" % (U, K, sum(len(x) for x in data), D, M), flush=True)
 np.random.seed(0)
 out = tempfile.mkdtemp()
+class Stamps(io.StringIO):
+    """stdout of continuous_train: remembers when every outer iteration started"""
+    def __init__(self):
+        super().__init__()
+        self.t = []
+    def write(self, text):
+        if text.startswith("Continuous training iteration:"):
+            self.t.append(time.perf_counter())
+        return len(text)
 pr = cProfile.Profile()
+stamps = Stamps()
+profile = os.environ.get("CTRAIN_PROFILE", "1") != "0"
 t0 = time.perf_counter()
-with contextlib.redirect_stdout(io.StringIO()):
-    pr.enable()
+with contextlib.redirect_stdout(stamps):
+    if profile:
+        pr.enable()
     cs.continuous_train(data, models, labels, out, n_gaussians=M, n_segments=n, max_iteration=iters)
-    pr.disable()
-dt = time.perf_counter() - t0
+    if profile:
+        pr.disable()
+t_end = time.perf_counter()
+dt = t_end - t0
+per = np.diff(stamps.t + [t_end])
 print("%.2f s for %d outer iterations (%.2f s each)" % (dt, iters, dt / iters))
+print("per outer iteration [ms]: " + " ".join("%.0f" % (1e3 * x) for x in per) + "   (the first ones grow the scratch arenas)")
+print("steady state: %.1f ms per outer iteration (median of the last %d)" % (1e3 * float(np.median(per[len(per) // 2:])), len(per) - len(per) // 2))
+if not profile:
+    sys.exit(0)
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
 print("\n".join(l for l in s.getvalue().splitlines() if l.strip())[:6000])
