@@ -74,8 +74,11 @@ __device__ __forceinline__ double bwf_exp2s(double y, const double* __restrict__
 }
 
 // KS = k-steps of the density GEMM (K = 4 KS = 2 KP), LT = 16-column tiles of each half of Z (D + 1 <= 16 LT)
-template <int KS, int LT>
-__global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
+// NW = waves per workgroup: 3 when no word has more than three state pairs (n <= 6: FOUR resident workgroups per CU put
+// three COMPUTING waves on every SIMD; with a fourth, staging-only wave per workgroup a CU held three workgroups = nine
+// computing waves), else 4
+template <int KS, int LT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 3 ? 4 : 3) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
                                                        const double* __restrict__ mean, const double* __restrict__ ivar,
                                                        const double* __restrict__ logc, const double* __restrict__ gam,
                                                        double occ_floor, int gam_stride, int gam_by_state, const int64_t* __restrict__ seg_first,
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
                                                        const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
                                                        double* __restrict__ partial) {
     constexpr int KP = 2 * KS;            // padded feature length
+    constexpr int NT = 64 * NW;           // threads of the workgroup
 #ifndef BWF_TF
 #define BWF_TF 32
 #endif
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
     const bwf_wg wg = wgs[blockIdx.x];
     const gh_fbchain* ch = chains + wg.graph;
     const int n = ch->n;
-    for (int i = tid; i < 128; i += blockDim.x) tab[i] = tables[i];
-    for (int i = tid; i < TF * DP; i += blockDim.x) xt[i] = 0.0;
+    for (int i = tid; i < 128; i += NT) tab[i] = tables[i];
+    for (int i = tid; i < TF * DP; i += NT) xt[i] = 0.0;
     // ---- this wave's pair of states: operands that stay in registers for the whole workgroup ----
     const bool wave_on = 2 * p < n;
     const int sa = wave_on ? ch->state[2 * p] : 0;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
     // travelling from HBM into registers while the current tile is computed: staging a tile used to park all waves of
     // the workgroup for a full memory round trip (SQ_WAIT_ANY was 42 % of the wave cycles).  256 threads always (the
     // waves without a state pair only help to stage): 5 frame elements + 1 gamma per thread cover a 32 x 40 tile.
-    constexpr int PX = (TF * KP + 255) / 256;
+    constexpr int PX = (TF * KP + NT - 1) / NT;
     int ui = wg.u_begin, t0 = 0, T = 0;
     int64_t f0 = 0;
     // gamma of the tile: compact [N, 8] (column = chain row) or the frame x state occupancy matrix (gam_by_state:
@@ -168,19 +172,19 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
         }
         return false;
     };
-    constexpr int PG = TF * 8 / 256;       // gamma entries per thread
+    constexpr int PG = (TF * 8 + NT - 1) / NT;       // gamma entries per thread
     double pre_x[PX], pre_g[PG];
     auto prefetch = [&]() {   // tile (f0 + t0, min(TF, T - t0) frames) -> registers
         const int nf_ = (T - t0 < TF) ? T - t0 : TF;
         const double* src = X + (f0 + t0) * D;
 #pragma unroll
         for (int e = 0; e < PX; ++e) {
-            const int i = tid + 256 * e;
+            const int i = tid + NT * e;
             pre_x[e] = (i < nf_ * D) ? src[i] : 0.0;
         }
 #pragma unroll
         for (int e = 0; e < PG; ++e) {
-            const int i = tid + 256 * e;
+            const int i = tid + NT * e;
             pre_g[e] = (i < nf_ * 8 && gcol >= 0) ? gam[(f0 + t0 + (i >> 3)) * gam_stride + gcol] : 0.0;
         }
     };
@@ -191,11 +195,11 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
         __syncthreads();                      // every wave is done with the previous tile
 #pragma unroll
         for (int e = 0; e < PX; ++e) {
-            const int i = tid + 256 * e;
+            const int i = tid + NT * e;
             if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = pre_x[e]; }   // rows >= nf arrive as zeros
         }
 #pragma unroll
-        for (int e = 0; e < PG; ++e) gt[tid + 256 * e] = pre_g[e];
+        for (int e = 0; e < PG; ++e) { const int i = tid + NT * e; if (i < TF * 8) gt[i] = pre_g[e]; }
         // the tile after this one
         t0 += TF;
         if (t0 >= T) { ++ui; have = open_utt(); }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 3) void bw_fused_kernel(const double* __restri
         }
     }
     // ---- one raw tile per wave: partial[wg][p][Zcol = 16 ct + q + 4 reg][comp j] ----
-    double* out = partial + ((int64_t)blockIdx.x * (blockDim.x >> 6) + p) * (NCT * 16 * 16);
+    double* out = partial + ((int64_t)blockIdx.x * 4 + p) * (NCT * 16 * 16);   // (4 tile slots per workgroup whatever NW is)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -466,6 +470,8 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
     const int tile_len = 2 * lt * 16 * 16;
     out->KS = KS; out->lt = lt; out->S = S; out->M = M; out->D = D; out->L = L;
     out->n_wgs = (int)wgs.size(); out->n_pairs = (int)pairs.size(); out->tile_len = tile_len;
+    out->max_pairs = 1;
+    for (const gh_fbchain& fc : chains) out->max_pairs = std::max(out->max_pairs, (fc.n + 1) / 2);
     bwf_wg* d_wgs; bwf_pair* d_pairs;
     // layout: [own result | lists (one upload) | partial tiles | pair sums]
     UploadLayout lay;
@@ -507,15 +513,19 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
     GH_HIP(hipMemsetAsync(d_out, 0, (size_t)S * M * W * 8, st));
     if (pl.n_wgs == 0) return GH_OK;
     const size_t lds = ((size_t)BWF_TF * ((2 * KS) | 1) + BWF_TF * 8 + 128) * 8;
-    const dim3 grid((unsigned)pl.n_wgs), blk(256);   // 256 threads always: see the staging loop of the kernel
+    // (NW = 3 -- 192-thread workgroups, four per CU = twelve computing waves instead of nine -- was measured: the statistics
+    //  kernel went from 0.72 to 0.89 ms; the fourth wave's share of the tile staging is worth more than the occupancy)
+    const int nw = 4;
+    const dim3 grid((unsigned)pl.n_wgs), blk(64 * nw);
     const gh_fbchain* chains = d_chains ? d_chains : pl.d_chains;
     const bwf_wg* d_wgs = (const bwf_wg*)pl.d_wgs;
     const bwf_pair* d_pairs = (const bwf_pair*)pl.d_pairs;
-#define GH_BWF(ks, nc)                                                                                                   \
-    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                   \
+#define GH_BWF(ks, nc, w)                                                                                                \
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc, w>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                \
                        g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
                        ctx->d_fp64_tables, pl.d_part)
-#define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
+#define GH_BWF_W(ks, nc) GH_BWF(ks, nc, 4)
+#define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF_W(ks, 1); break; case 2: GH_BWF_W(ks, 2); break; default: GH_BWF_W(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;
         case 4: GH_BWF_N(4) break;
@@ -524,6 +534,7 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
         default: GH_BWF_N(20) break;
     }
 #undef GH_BWF_N
+#undef GH_BWF_W
 #undef GH_BWF
     GH_HIP(hipGetLastError());
     hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pl.n_pairs, (unsigned)((pl.tile_len + 255) / 256)), dim3(256), 0, st, pl.d_part,

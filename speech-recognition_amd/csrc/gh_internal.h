@@ -268,7 +268,7 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
 int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
 // work lists of the fused statistics kernel on the device: built per call (context scratch) or once per trainer (own arena)
 struct gh_bwf_plan {
-    int KS, lt, S, M, D, L, n_wgs, n_pairs, tile_len;
+    int KS, lt, S, M, D, L, n_wgs, n_pairs, tile_len, max_pairs;
     int32_t *d_ulist, *d_seglen;
     int64_t* d_segfirst;
     void *d_wgs, *d_pairs;

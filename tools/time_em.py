@@ -33,7 +33,14 @@ for it in range(4):
     dt = time.perf_counter() - t0
     hist.append(ll)
     print("iteration %d: %.1f ms  loglik %.6e" % (it, dt * 1e3, ll), flush=True)
-# split of the E-step
+if tr.session is not None:   # the device-resident iteration: 20 more, enqueued back to back
+    ctx.sync(); t0 = time.perf_counter()
+    for _ in range(20):
+        tr.iteration(sync=False)
+    tr.drain(); dt = time.perf_counter() - t0
+    print("device-resident session: %.3f ms per iteration (20 enqueued)" % (dt / 20 * 1e3), flush=True)
+# split of the E-step (call by call)
+tr._ensure_call_path()
 gmm = _hip.PackedGMM(ctx, tr.means, tr.vars, tr.weights)
 def t(fn, reps=3):
     fn(); ctx.sync(); t0 = time.perf_counter()
