@@ -466,6 +466,22 @@ int gh_fit_kmeans(gh_ctx* ctx, gh_fit* fit, gh_comm* comm, int k, const double* 
                   const uint8_t* part /*[N]*/, int max_iteration, int check_every, double* out_centroids, double* out_cov,
                   double* out_counts, int32_t* out_iters);
 int gh_fit_clusters(gh_ctx* ctx, gh_fit* fit, int32_t* out /*[N]*/);
+/* Segmental k-means of MANY word models in lock-step (skmeans, kmeans.py:111-155, for every word at once; the reference
+ * trains word after word, sr/core.py:57-60).  The session's "states" are then the WORDS (a word's templates back to back
+ * in the batch) and the "clusters" the n segments of a word:
+ *   gh_fit_set_ids      the segment of every frame [N] (the initial uniform segmentation, kmeans.py:122-127)
+ *   gh_fit_dtw          dtw (decode.py:7-77, Euclidean distance, no beam) of every template against the segment means
+ *                       y [W,n,D] of ITS word (utt_model [U]) under that word's transition costs trans [W,n,n], one launch;
+ *                       the path stays on the device as the segment of every frame (what get_segments_from_path,
+ *                       kmeans.py:98-108, counts); words whose `active` entry is 0 are skipped
+ *   gh_fit_group_stats  combine_templates (kmeans.py:15-30) from the resident segment ids: per (word, segment) the mean of
+ *                       its frames summed in template / frame order, the variance (two passes, ddof 1) and the frame
+ *                       count; words whose `active` entry is 0 keep their previous rows */
+int gh_fit_set_ids(gh_ctx* ctx, gh_fit* fit, const int32_t* ids /*[N]*/);
+int gh_fit_dtw(gh_ctx* ctx, gh_fit* fit, int n, const double* y /*[S,n,D]*/, const double* trans /*[S,n,n]*/,
+               const int32_t* utt_model /*[U]*/, const uint8_t* active /*[S] or NULL*/);
+int gh_fit_group_stats(gh_ctx* ctx, gh_fit* fit, int k, const uint8_t* active /*[S] or NULL*/, double* out_mean /*[S,k,D]*/,
+                       double* out_var /*[S,k,D]*/, double* out_count /*[S,k]*/);
 int gh_fit_em(gh_ctx* ctx, gh_fit* fit, gh_comm* comm, int k, double* mean_io, double* var_io, double* weight_io,
               double* mu_old_io, double* sigma_old_io, double* w_old_io, const double* n_frames /*[S]*/, int max_iteration,
               int check_every, int32_t* out_converged_at);

@@ -20,6 +20,13 @@ struct gh_dtw_args {
     const int64_t* path_off;  // [U+1]
     int32_t* path_len;
     int* flag;
+    // several template sets in one launch (gh_fit_dtw: the segmental k-means of many word models in lock-step):
+    // utterance u is matched against set utt_model[u] -- y / var / logdet / trans are then [W, ...] arrays -- and sets
+    // whose model_active entry is 0 are skipped; frame_row (optional, [N]): the template row every frame is aligned to
+    // (the path as one int per frame: rows of columns 0 .. T-2 from the back-trace, the last frame on row n - 1)
+    const int32_t* utt_model;
+    const uint8_t* model_active;
+    int32_t* frame_row;
 };
 
 int gh_launch_dtw(gh_ctx* ctx, const gh_dtw_args& a, int64_t U);

@@ -42,10 +42,17 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
     double* costs = a.costs ? a.costs + a.costs_off[u] : nullptr;
     BPT* bp = reinterpret_cast<BPT*>(a.bp) + a.bp_off[u];
     const bool act = i < n;
+    const int model = a.utt_model ? a.utt_model[u] : 0;
+    if (a.model_active && !a.model_active[model]) return;     // (uniform for the workgroup)
     if (T <= 0) {
         if (i == 0 && a.path_len) a.path_len[u] = 0;
         return;
     }
+    // this utterance's template set
+    const double* m_y = a.y ? a.y + (int64_t)model * n * D : nullptr;
+    const double* m_var = a.var ? a.var + (int64_t)model * n * D : nullptr;
+    const double* m_logdet = a.logdet ? a.logdet + (int64_t)model * n : nullptr;
+    const double* m_trans = a.trans + (int64_t)model * n * n;
     // built-in distances: the template rows (and their variances) are staged in LDS once when they fit, and the frame
     // of column j + 1 travels from HBM into registers while column j is computed -- the distance loop itself only
     // reads LDS.  (Reading template row and frame element by element from global memory inside the loop cost one
@@ -56,17 +63,17 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
     double* ts = vs + ((STAGED && a.var) ? n * D : 0);        // [n][n] arc costs
     const bool own_dist = a.E == nullptr;
     if (STAGED) {
-        for (int k = i; k < n * n; k += np) ts[k] = a.trans[k];
-        if (own_dist) for (int k = i; k < n * D; k += np) { ys[k] = a.y[k]; if (a.var) vs[k] = a.var[k]; }
+        for (int k = i; k < n * n; k += np) ts[k] = m_trans[k];
+        if (own_dist) for (int k = i; k < n * D; k += np) { ys[k] = m_y[k]; if (a.var) vs[k] = m_var[k]; }
     }
-    const double* g_trow = a.trans + (int64_t)(act ? i : 0) * n;
-    const double* g_yrow = own_dist ? a.y + (int64_t)(act ? i : 0) * D : nullptr;
-    const double* g_vrow = (own_dist && a.var) ? a.var + (int64_t)(act ? i : 0) * D : nullptr;
+    const double* g_trow = m_trans + (int64_t)(act ? i : 0) * n;
+    const double* g_yrow = own_dist ? m_y + (int64_t)(act ? i : 0) * D : nullptr;
+    const double* g_vrow = (own_dist && a.var) ? m_var + (int64_t)(act ? i : 0) * D : nullptr;
     const double* l_trow = ts + (act ? i : 0) * n;
     const double* l_yrow = ys + (act ? i : 0) * D;
     const double* l_vrow = vs + (act ? i : 0) * D;
     double logdet = 0;
-    if (a.var && act) logdet = a.logdet[i];
+    if (a.var && act) logdet = m_logdet[i];
     col(0)[i] = INF; col(1)[i] = INF;
     mark(0)[i] = 0; mark(1)[i] = 0;
     constexpr int XR = 4;                                     // frame elements per thread (D <= 4 * threads; else global reads)
@@ -162,16 +169,17 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
         pb = cb;
     }
     __syncthreads();   // (full barrier: the back-pointers written above are read back below)
-    if (a.path) {
+    if (a.path || a.frame_row) {
         // the walk is a chain of dependent reads (one per column): blocks of back-pointer columns are staged into LDS
         // by all threads (coalesced) and thread 0 walks them there
         BPT* win = reinterpret_cast<BPT*>(dtw_lds);            // the column buffers are free now
         const int cap_cols = (int)(((size_t)2 * np * 8 + (size_t)2 * np) / sizeof(BPT) / n);   // columns that fit (>= 8)
         __shared__ int s_state[3];                            // r, j, done
-        int32_t* path = a.path + 2 * a.path_off[u];
-        const int64_t cap = a.path_off[u + 1] - a.path_off[u];
+        int32_t* path = a.path ? a.path + 2 * a.path_off[u] : nullptr;
+        const int64_t cap = a.path ? a.path_off[u + 1] - a.path_off[u] : (int64_t)T;
+        int32_t* frow = a.frame_row ? a.frame_row + f0 : nullptr;
         int len = 0;
-        if (i == 0) { s_state[0] = n - 1; s_state[1] = T - 1; s_state[2] = 0; }
+        if (i == 0) { s_state[0] = n - 1; s_state[1] = T - 1; s_state[2] = 0; if (frow) frow[T - 1] = n - 1; }
         __syncthreads();
         while (!s_state[2]) {
             const int jhi = s_state[1];                        // highest column still to be read
@@ -188,15 +196,15 @@ __global__ __launch_bounds__(1024) void dtw_kernel(gh_dtw_args a) {
                     if (j < jlo) break;                                                // next block
                     r = win[(j - jlo) * n + r];
                     --j;
-                    path[2 * len] = r;
-                    path[2 * len + 1] = j;
+                    if (path) { path[2 * len] = r; path[2 * len + 1] = j; }
+                    if (frow) frow[j] = r;
                     ++len;
                 }
                 s_state[0] = r; s_state[1] = j; s_state[2] = done ? 1 : 0;
             }
             __syncthreads();
         }
-        if (i == 0) a.path_len[u] = len;
+        if (i == 0 && a.path_len) a.path_len[u] = len;
     }
 }
 

@@ -1113,3 +1113,104 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
     GH_HIP(hipStreamSynchronize(st));
     return GH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Segmental k-means of MANY word models in lock-step (kmeans.py:111-155 for every word at once; sr/core.py:57-60 trains
+// word after word).  The session's "states" are the words (a word's templates back to back in the batch), the
+// "clusters" the n segments of the word: gh_fit_dtw aligns every template against ITS word's segment means in one launch
+// and leaves the segment of every frame on the device; gh_fit_group_stats turns those into the segment means (the
+// frames of a segment summed in template / frame order: np.mean of segment_data's concatenation) and variances
+// (two-pass, ddof 1: np.cov(...).diagonal()) of combine_templates (kmeans.py:15-30).
+#include "gh_dtw.h"
+
+extern "C" int gh_fit_set_ids(gh_ctx* ctx, gh_fit* f, const int32_t* ids) {
+    GH_REQUIRE(ctx && f && (ids || f->N == 0) && f->ctx == ctx, "gh_fit_set_ids: NULL argument / foreign context");
+    if (f->N == 0) return GH_OK;
+    GH_HIP(hipSetDevice(ctx->device));
+    GH_HIP(hipMemcpyAsync(f->d_ids, ids, (size_t)f->N * 4, hipMemcpyHostToDevice, ctx->stream));
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_fit_dtw(gh_ctx* ctx, gh_fit* f, int n, const double* y, const double* trans, const int32_t* utt_model,
+                          const uint8_t* active) {
+    GH_REQUIRE(ctx && f && y && trans && f->ctx == ctx, "gh_fit_dtw: NULL argument / foreign context");
+    GH_REQUIRE(n > 1 && n <= 255 && n <= f->kmax, "gh_fit_dtw: n=%d (2..min(255, kmax=%d))", n, f->kmax);
+    const gh_batch* b = f->b;
+    const int64_t U = b->U, N = b->N;
+    const int W = f->S, D = f->D;
+    GH_REQUIRE(utt_model || U == 0, "gh_fit_dtw: utt_model is NULL");
+    if (U == 0) return GH_OK;
+    for (int64_t u = 0; u < U; ++u) {
+        GH_REQUIRE(utt_model[u] >= 0 && utt_model[u] < W, "gh_fit_dtw: utt_model[%lld]=%d", (long long)u, utt_model[u]);
+        GH_REQUIRE(b->offsets[u + 1] - b->offsets[u] > 1, "gh_fit_dtw: utterance %lld has fewer than 2 frames (decode.py:22)", (long long)u);
+    }
+    GH_HIP(hipSetDevice(ctx->device));
+    std::vector<int64_t> moff(U + 1);
+    for (int64_t u = 0; u <= U; ++u) moff[u] = (int64_t)n * b->offsets[u];
+    double *d_y, *d_tr;
+    int64_t* d_moff;
+    int32_t* d_um;
+    uint8_t *d_bp, *d_act = nullptr;
+    Carver cv;
+    cv.add(&d_y, (size_t)W * n * D); cv.add(&d_tr, (size_t)W * n * n); cv.add(&d_moff, U + 1); cv.add(&d_um, U);
+    cv.add(&d_bp, (size_t)n * N);
+    if (active) cv.add(&d_act, W);
+    int rc = cv.commit(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    GH_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), st));
+    GH_HIP(hipMemcpyAsync(d_y, y, (size_t)W * n * D * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_tr, trans, (size_t)W * n * n * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_moff, moff.data(), (U + 1) * 8, hipMemcpyHostToDevice, st));
+    GH_HIP(hipMemcpyAsync(d_um, utt_model, U * 4, hipMemcpyHostToDevice, st));
+    if (active) GH_HIP(hipMemcpyAsync(d_act, active, W, hipMemcpyHostToDevice, st));
+    gh_dtw_args a;
+    memset(&a, 0, sizeof a);
+    a.x = (const double*)b->feats; a.utt_off = b->d_offsets; a.n = n; a.D = D; a.beam = 0;
+    a.y = d_y; a.trans = d_tr; a.bp = d_bp; a.bp_off = d_moff; a.flag = ctx->d_flag;
+    a.utt_model = d_um; a.model_active = d_act; a.frame_row = f->d_ids;
+    rc = gh_launch_dtw(ctx, a, U);
+    if (rc) return rc;
+    int flag = 0;
+    GH_HIP(hipMemcpyAsync(&flag, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    if (flag & 2) {
+        gh_set_error("gh_fit_dtw: back-trace left the matrix: cell (0,0) is not reachable from the end cell");
+        return GH_ERR_INVALID;
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_fit_group_stats(gh_ctx* ctx, gh_fit* f, int k, const uint8_t* active, double* out_mean, double* out_var,
+                                  double* out_count) {
+    GH_REQUIRE(ctx && f && f->ctx == ctx, "gh_fit_group_stats: NULL argument / foreign context");
+    GH_REQUIRE(k >= 1 && k <= f->kmax, "gh_fit_group_stats: k=%d (1..%d)", k, f->kmax);
+    GH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int S = f->S, D = f->D, sstride = k * (D + 1) + 1;
+    const double* X = (const double*)f->b->feats;
+    const uint8_t* d_act = nullptr;
+    if (active) {
+        GH_HIP(hipMemcpyAsync(f->d_active, active, (size_t)S, hipMemcpyHostToDevice, st));
+        d_act = f->d_active;
+    }
+    int rc = fit_build_lists(f, k, false, d_act);
+    if (rc) return rc;
+    const dim3 skz((unsigned)S, (unsigned)k, 1);
+    hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, d_act, f->d_lists, f->d_counts, f->d_cbase,
+                       f->d_sums, sstride, (const double*)nullptr, 0, 0, 0);
+    hipLaunchKernelGGL(kmeans_rowsum_kernel<1>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, d_act, f->d_lists, f->d_counts, f->d_cbase,
+                       f->d_sq, sstride, (const double*)f->d_sums, sstride, 0, 0);
+    hipLaunchKernelGGL(fit_partvar_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
+                       (const double*)f->d_sums, (const double*)f->d_sq, 0, f->d_cov);
+    hipLaunchKernelGGL(fit_final_centroids_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
+                       (const double*)f->d_sums, f->d_cent);
+    hipLaunchKernelGGL(fit_counts_kernel, dim3((unsigned)((S * k + 255) / 256)), dim3(256), 0, st, S * k, (const int32_t*)f->d_counts, f->d_stats);   // (d_sq keeps the squared sums of the words that sit this round out)
+    GH_HIP(hipGetLastError());
+    if (out_mean) GH_HIP(hipMemcpyAsync(out_mean, f->d_cent, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
+    if (out_var) GH_HIP(hipMemcpyAsync(out_var, f->d_cov, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
+    if (out_count) GH_HIP(hipMemcpyAsync(out_count, f->d_stats, (size_t)S * k * 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
+}

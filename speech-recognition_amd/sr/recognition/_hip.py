@@ -110,6 +110,9 @@ SIGNATURES = {
     "gh_fit_kmeans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _c_f64p, C.POINTER(C.c_uint8), C.c_int, C.c_int,
                                 _c_f64p, _c_f64p, _c_f64p, _c_i32p]),
     "gh_fit_clusters": (C.c_int, [C.c_void_p, C.c_void_p, _c_i32p]),
+    "gh_fit_set_ids": (C.c_int, [C.c_void_p, C.c_void_p, _c_i32p]),
+    "gh_fit_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_i32p, C.POINTER(C.c_uint8)]),
+    "gh_fit_group_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), _c_f64p, _c_f64p, _c_f64p]),
     "gh_fit_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_f64p,
                             _c_f64p, C.c_int, C.c_int, _c_i32p]),
     "gh_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -465,6 +468,31 @@ class FitSession:
             part.ctypes.data_as(C.POINTER(C.c_uint8)), int(max_iteration), int(check_every), _ptr(cen, _c_f64p), _ptr(cov, _c_f64p),
             _ptr(cnt, _c_f64p), _ptr(its, _c_i32p)))
         return cen, cov, cnt, its
+
+    def set_ids(self, ids):
+        """The group (segment / cluster) of every frame, int32 [N]."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        assert ids.shape == (self.N,)
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_set_ids(self.ctx.h, self.h, _ptr(ids, _c_i32p)))
+
+    def dtw(self, n, y, trans, utt_model, active=None):
+        """dtw of every utterance against the n template rows y[utt_model[u]] under trans[utt_model[u]] (gh_fit_dtw); the
+        row every frame is aligned to stays on the device as the session's ids."""
+        y, trans = _f64(y), _f64(trans)
+        assert y.shape == (self.S, n, self.D) and trans.shape == (self.S, n, n)
+        um = np.ascontiguousarray(utt_model, dtype=np.int32)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_dtw(self.ctx.h, self.h, int(n), _ptr(y, _c_f64p), _ptr(trans, _c_f64p), _ptr(um, _c_i32p),
+                                                     None if act is None else act.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def group_stats(self, k, active=None):
+        """(mean [S,k,D], var [S,k,D] (ddof 1), count [S,k]) of the frames of every (state, group) from the resident ids."""
+        mean, var, cnt = np.empty((self.S, k, self.D)), np.empty((self.S, k, self.D)), np.empty((self.S, k))
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        _check(self.ctx.lib, self.ctx.lib.gh_fit_group_stats(self.ctx.h, self.h, int(k),
+                                                             None if act is None else act.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                             _ptr(mean, _c_f64p), _ptr(var, _c_f64p), _ptr(cnt, _c_f64p)))
+        return mean, var, cnt
 
     def clusters(self):
         out = np.empty(self.N, dtype=np.int32)

@@ -13,7 +13,7 @@ from . import _hip
 from . import _pack
 from .continuous_speech import packed_lattice, packed_loop_lattice
 
-__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_words", "sequence_report"]
+__all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_words", "sequence_report", "train_words"]
 
 
 def _stack_models(ctx, models):
@@ -21,6 +21,79 @@ def _stack_models(ctx, models):
     for m in models:
         assert len(m.gmm_states) == n
     return n, _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
+
+
+def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_em=True):
+    """`HMM(n_segments).fit(ys, n_gaussians, use_gmm, use_em)` for every word -- what sr/core.py:47-60 (make_HMM /
+    train) does digit after digit -- in ONE pass over all words:
+
+      1. segmental k-means of all words in lock-step (`kmeans.skmeans_multi`: one alignment launch and one
+         (word, segment) reduction per iteration for all templates of all words),
+      2. the mixtures of all W x n states refit in one lock-step session (`lockstep.LockstepFitter`; numpy's global
+         generator is consumed word after word, state after state -- the order of the sequential loop),
+      3. all templates re-aligned against their word's mixtures in one launch (align_gmm_states, hmm.py:95).
+
+    templates_by_word: list over words of lists of [T_r, D] arrays.  Returns the list of trained `HMM`s; under the same
+    numpy seed they equal the models of the word-after-word loop (alignment paths and cluster ids exactly, parameters to
+    rounding: the words only share launches)."""
+    import importlib
+    _km = importlib.import_module(__package__ + ".kmeans")    # (the package re-exports the FUNCTION kmeans under that name)
+    from .hmm import HMM
+    from .hmm_state import GMM
+    from .lockstep import LockstepFitter
+    W = len(templates_by_word)
+    models = [HMM(n_segments) for _ in range(W)]
+    for h in models:
+        h.use_gmm, h.use_em = use_gmm, use_em
+    if use_gmm:
+        print('Doing segmental k-means')
+    fitted = _km.skmeans_multi(templates_by_word, n_segments) if _km._device_skmeans_possible(templates_by_word[0]) and 2 <= n_segments <= 32 \
+        else None
+    for w, h in enumerate(models):
+        ys = templates_by_word[w]
+        if fitted is None:
+            h.mu, h.sigma, h.transitions, h.segments = _km.skmeans(ys, n_segments, return_segmented_data=True)
+        else:
+            h.mu, h.sigma, h.transitions, starts = fitted[w]
+            h.segments = _km.segment_data(ys, len(ys), n_segments, starts)
+    if not use_gmm:
+        return models
+    for h in models:
+        h.gmm_states = [GMM(m, s, n_gaussians) for m, s in zip(h.mu, h.sigma)]
+    fitter = LockstepFitter([seg for h in models for seg in h.segments], kmax=2 ** max(1, int(np.log(n_gaussians))))
+    try:
+        fitter.split_and_fit([g for h in models for g in h.gmm_states],
+                             start_centroids=np.concatenate([h.mu for h in models]),
+                             weight_divisor=[len(seg) for h in models for seg in h.segments],     # hmm.py:108,118
+                             n_gaussians=n_gaussians, use_em=use_em)
+    finally:
+        fitter.close()
+    # re-alignment of every template against its word's mixtures (hmm.py:95), all words in one launch
+    ctx = _hip.default_context()
+    flat = [np.asarray(t, dtype=np.float64) for ts in templates_by_word for t in ts]
+    utt_word = np.repeat(np.arange(W), [len(ts) for ts in templates_by_word]).astype(np.int32)
+    n = n_segments
+    gmm = _pack.device_gmm(ctx, [g for h in models for g in h.gmm_states])
+    graphs = []
+    for w, h in enumerate(models):
+        g = _pack.graph_from_dense(np.arange(n) + w * n, h.transitions, [0], [n - 1])
+        graphs.append(g)
+    lat = _hip.Lattices(ctx, graphs)
+    frames = _hip.Batch(ctx, flat)
+    try:
+        frames.loglik(gmm, fetch=False, state_ranges=(utt_word * n, utt_word * n + n))
+        res = lat.viterbi(frames, utt_lattice=utt_word, want_path=True)
+    finally:
+        frames.close()
+        lat.close()
+    off = np.concatenate([[0], np.cumsum([len(ts) for ts in templates_by_word])])
+    for w, h in enumerate(models):
+        ys = templates_by_word[w]
+        starts = np.zeros((len(ys), n), dtype=np.int64)
+        for r in range(len(ys)):
+            starts[r, 1:] = _km.get_segments_from_path(res["paths"][off[w] + r], n)
+        h.segments = _km.segment_data(ys, len(ys), n, starts)
+    return models
 
 
 class IsolatedWordRecognizer:

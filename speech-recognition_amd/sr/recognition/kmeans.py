@@ -5,7 +5,15 @@ Mirror of the reference's `sr/recognition/kmeans.py` (same public names and
 return values).  The inner loops -- the N x k distance/arg-min sweep of `kmeans`
 and the per-template DP of `skmeans` / `align_gmm_states` -- run in HIP
 (gh_kmeans_assign, gh_dtw, gh_loglik + gh_viterbi) over frames that stay resident
-on the GPU for the whole iteration loop; segment bookkeeping stays on the host.
+on the GPU for the whole iteration loop.
+
+Segmental k-means runs for MANY word models at once (`skmeans_multi`; the reference trains
+word after word, sr/core.py:57-60): all templates of all words in one resident batch, per
+iteration ONE alignment launch (every template against its own word's segment means,
+gh_fit_dtw) and one device reduction keyed on (word, segment) for the new means and variances
+(gh_fit_group_stats); the alignment never leaves the device -- what comes back per iteration
+is [W, n, D] means, and a word drops out of the launches when its means stop moving.
+`skmeans` is the one-word case of it.
 """
 import numpy as np
 
@@ -14,7 +22,7 @@ from .decode import dtw_batch, decode_batch
 from .hmm_state import mahalanobis, euclidean
 
 __all__ = ["calc_variance", "combine_templates", "segment_data", "calc_transition_costs",
-           "get_segments_from_path", "skmeans", "cluster_centroids", "kmeans", "align_gmm_states"]
+           "get_segments_from_path", "skmeans", "skmeans_multi", "cluster_centroids", "kmeans", "align_gmm_states"]
 
 
 def _ctx():
@@ -57,33 +65,34 @@ def combine_templates(templates, n_temps, n_segments, seg_starts):
 
 
 def calc_transition_costs(n_temps, seg_lens, max_jump_dist=2):
-    """Left-to-right transition costs from segment lengths (kmeans.py:53-95).
+    """Left-to-right transition costs from segment lengths (kmeans.py:53-95); cost[i, j] = cost of going from j to i.
 
-    Each template leaves segment i exactly once: p_jump = n_temps / (frames in segment i),
-    cost[i+jump, i] = -log p_jump, cost[i, i] = -log(1 - p_jump); the jump skips segments
-    that are empty in some template, by at most `max_jump_dist`; the last segment never
-    jumps.  cost[i, j] is the cost of going from j to i."""
-    n_segments = seg_lens.shape[1]
-    has_empty = (seg_lens == 0).sum(axis=0) != 0
-    res = np.full((n_segments, n_segments), np.inf)
-    for i in range(n_segments):
-        n_jump = 0 if i == n_segments - 1 else n_temps
-        jump = 1
-        s = i + 1
-        while s < n_segments - 1 and has_empty[s + 1]:
+    Every template leaves segment i exactly once, so with F_i frames in segment i over all templates
+    p_jump = n_temps / F_i, cost[i + jump, i] = -log p_jump, cost[i, i] = -log(1 - p_jump); the last segment never
+    jumps.  The jump is 1 unless segments behind i + 1 are empty in some template: it then grows by one per such
+    segment (checked at i + 2, i + 3, ... while that index is not the last segment), and an attempt to go beyond
+    `max_jump_dist` leaves the oversized value standing (the reference's loop increments before it tests)."""
+    seg_lens = np.asarray(seg_lens)
+    n = seg_lens.shape[1]
+    frames = seg_lens.sum(axis=0)                               # F_i
+    some_empty = (seg_lens == 0).any(axis=0)
+    cost = np.full((n, n), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p_jump = np.where(np.arange(n) == n - 1, 0, n_temps) / frames
+        stay = -np.log((frames - np.where(np.arange(n) == n - 1, 0, n_temps)) / frames)
+        leave = -np.log(p_jump)
+    for i in range(n):
+        cost[i, i] = stay[i]
+        if i == n - 1:
+            continue
+        jump, probe = 1, i + 1
+        while probe < n - 1 and some_empty[probe + 1]:
             jump += 1
             if jump > max_jump_dist:
                 break
-            s += 1
-        n_all = 0
-        for t in range(n_temps):
-            n_all += seg_lens[t, i]
-        p_stay = (n_all - n_jump) / n_all
-        p_jump = n_jump / n_all
-        if n_jump:
-            res[i + jump, i] = -np.log(p_jump)
-        res[i, i] = -np.log(p_stay)
-    return res
+            probe += 1
+        cost[i + jump, i] = leave[i]
+    return cost
 
 
 def get_segments_from_path(path, n_segments):
@@ -95,6 +104,81 @@ def get_segments_from_path(path, n_segments):
     return np.add.accumulate(counts)[:-1]
 
 
+def _uniform_segments(lengths, n_segments):
+    """The initial segmentation of kmeans.py:122-127: n equal pieces of T // n frames, the last one to the end.
+    Returns (segment of every frame [sum T], seg_lens [n_temps, n] as the reference holds them: T // n each)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    q = lengths // n_segments
+    within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+    qq = np.repeat(q, lengths)
+    ids = np.where(qq > 0, np.minimum(within // np.maximum(qq, 1), n_segments - 1), n_segments - 1)
+    return ids.astype(np.int32), np.repeat(q[:, None], n_segments, axis=1)
+
+
+def _starts_from_ids(ids, lengths, n_segments):
+    """seg_starts [n_temps, n]: frames of the template aligned to an earlier segment (what get_segments_from_path counts
+    on the path, kmeans.py:98-108)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    tpl = np.repeat(np.arange(len(lengths)), lengths)
+    counts = np.bincount(tpl * n_segments + ids, minlength=len(lengths) * n_segments).reshape(len(lengths), n_segments)
+    # (the path holds the columns 0 .. T-2: the last frame is not counted -- it sits in the last segment, whose count is
+    #  not part of any start)
+    starts = np.zeros((len(lengths), n_segments), dtype=np.int64)
+    np.cumsum(counts[:, :-1], axis=1, out=starts[:, 1:])
+    return starts
+
+
+def skmeans_multi(templates_by_word, n_segments, max_iteration=1000):
+    """Segmental k-means (kmeans.py:111-155, Euclidean frame distance) of every word model at once.
+
+    templates_by_word: list over words of lists of [T_r, D] arrays.  Returns a list over words of
+    (means [n,D], variances [n,D], transition costs [n,n], seg_starts [n_temps, n]) -- per word exactly what `skmeans`
+    computes for it alone: the words only share the launches.  As in the reference the transition costs are those of
+    the initial uniform segmentation for the whole loop (`seg_lens` is never refreshed, :139), the variances are the
+    last ones computed, and on convergence the means of the PREVIOUS iteration are returned (:146-148)."""
+    assert max_iteration > 0
+    W = len(templates_by_word)
+    flat = [np.asarray(t, dtype=np.float64) for ts in templates_by_word for t in ts]
+    n_temps = np.array([len(ts) for ts in templates_by_word], dtype=np.int64)
+    lengths = np.array([len(t) for t in flat], dtype=np.int64)
+    if np.any(lengths < 5):
+        raise NameError('template is too small, cannot do dtw on it')
+    utt_word = np.repeat(np.arange(W), n_temps).astype(np.int32)
+    ctx = _ctx()
+    frames = _hip.Batch(ctx, flat)
+    tpl_off = np.concatenate([[0], np.cumsum(n_temps)])
+    word_off = frames.offsets[tpl_off]                      # a word's templates sit back to back in the batch
+    ids, seg_lens = _uniform_segments(lengths, n_segments)
+    fit = _hip.FitSession(ctx, frames, word_off, max(n_segments, 2))
+    try:
+        fit.set_ids(ids)
+        res, vars_, _ = fit.group_stats(n_segments)
+        trans = np.array([calc_transition_costs(int(n_temps[w]), seg_lens[tpl_off[w]:tpl_off[w + 1]]) for w in range(W)])
+        active = np.ones(W, dtype=np.uint8)
+        for _ in range(max_iteration):
+            fit.dtw(n_segments, res, trans, utt_word, active)
+            new_res, new_vars, _cnt = fit.group_stats(n_segments, active)
+            for w in np.flatnonzero(active):
+                vars_[w] = new_vars[w]
+                if np.allclose(res[w], new_res[w]):
+                    active[w] = 0
+                else:
+                    res[w] = new_res[w]
+            if not active.any():
+                break
+        ids = fit.clusters()
+    finally:
+        fit.close()
+        frames.close()
+    starts = _starts_from_ids(ids, lengths, n_segments)
+    return [(res[w], vars_[w], trans[w], starts[tpl_off[w]:tpl_off[w + 1]]) for w in range(W)]
+
+
+def _device_skmeans_possible(templates):
+    fs = getattr(_hip, "FitSession", None)
+    return bool(getattr(fs, "available", False)) and len(templates) > 0 and 2 <= np.asarray(templates[0]).shape[1] <= 64
+
+
 def skmeans(templates, n_segments, dist_fun=euclidean, return_segmented_data=False, max_iteration=1000):
     """Segmental k-means (kmeans.py:111-155).
 
@@ -103,42 +187,44 @@ def skmeans(templates, n_segments, dist_fun=euclidean, return_segmented_data=Fal
     :param dist_fun: frame distance for the alignment DP (default Euclidean)
     :return: (means [n,D], variances [n,D], transition costs [n,n][, segmented data])
 
-    All templates are uploaded once; every iteration is ONE batched gh_dtw launch (one wave
-    per template).  As in the reference the transition costs are those of the initial
-    uniform segmentation for the whole loop (`seg_lens` is never refreshed, :139)."""
+    With the default distance this is `skmeans_multi` for one word: alignment and segment statistics on the device.
+    Any other `dist_fun` (and one-dimensional features) keeps the alignment launch per iteration with the segment
+    bookkeeping in numpy."""
+    n_temps = len(templates)
+    if dist_fun is euclidean and 2 <= n_segments <= 32 and _device_skmeans_possible(templates):
+        res, vars, transition_costs, seg_starts = skmeans_multi([templates], n_segments, max_iteration=max_iteration)[0]
+    else:
+        res, vars, transition_costs, seg_starts = _skmeans_host(templates, n_segments, dist_fun, max_iteration)
+    if return_segmented_data:
+        return res, vars, transition_costs, segment_data(templates, n_temps, n_segments, seg_starts)
+    return res, vars, transition_costs
+
+
+def _skmeans_host(templates, n_segments, dist_fun, max_iteration):
+    """One batched alignment launch per iteration, means / variances / starts in numpy (any distance function)."""
     assert max_iteration > 0
     n_temps = len(templates)
-    seg_lens = np.zeros((n_temps, n_segments + 1), dtype=np.int64)
-    for r in range(n_temps):
-        seg_lens[r, 1:] = len(templates[r]) // n_segments
-    seg_starts = np.add.accumulate(seg_lens, axis=1)[:, :-1]
-    seg_lens = seg_lens[:, 1:]
-
-    transition_costs = None
+    lengths = [len(t) for t in templates]
+    if min(lengths) < 5:
+        raise NameError('template is too small, cannot do dtw on it')
+    _, seg_lens = _uniform_segments(lengths, n_segments)
+    seg_starts = np.arange(n_segments)[None, :] * seg_lens[:, :1]
+    transition_costs = calc_transition_costs(n_temps, seg_lens)
     res, vars = combine_templates(templates, n_temps, n_segments, seg_starts)
-    frames = None
+    frames = _hip.Batch(_ctx(), templates)
     try:
         for _ in range(max_iteration):
-            seg_starts = np.zeros((n_temps, n_segments), dtype=np.int64)
-            transition_costs = calc_transition_costs(n_temps, seg_lens)
-            for r in range(n_temps):
-                if templates[r].shape[0] < 5:
-                    raise NameError('template is too small, cannot do dtw on it')
-            if frames is None:
-                frames = _hip.Batch(_ctx(), templates)
             _, paths = dtw_batch(templates, res, dist_fun, transition_costs, want_costs=False, batch=frames)
-            for r in range(n_temps):
-                seg_starts[r, 1:] = get_segments_from_path(paths[r], n_segments)
+            seg_starts = np.zeros((n_temps, n_segments), dtype=np.int64)
+            for r, path in enumerate(paths):
+                seg_starts[r, 1:] = get_segments_from_path(path, n_segments)
             new_res, vars = combine_templates(templates, n_temps, n_segments, seg_starts)
             if np.allclose(res, new_res):
                 break
             res = new_res
     finally:
-        if frames is not None:
-            frames.close()
-    if return_segmented_data:
-        return res, vars, transition_costs, segment_data(templates, n_temps, n_segments, seg_starts)
-    return res, vars, transition_costs
+        frames.close()
+    return res, vars, transition_costs, seg_starts
 
 
 def cluster_centroids(data, clusters, k):
