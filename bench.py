@@ -409,6 +409,18 @@ def em_leg(args, group):
     hist = [tr.iteration()]                       # warm-up iteration (allocations, RCCL channel set-up)
     if red is not None:
         red.calls, red.seconds = 0, 0.0
+    # the same iteration with occ_floor = 0 (every non-zero posterior enters the statistics), timed beside the default
+    dt_exact = None
+    if tr.session is not None and group.world == 1:
+        tr0 = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)],
+                               labels, device=dev, reducer=red, occ_floor=0.0)
+        tr0.iteration()
+        tr0.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.em_iters):
+            tr0.iteration()
+        dt_exact = (time.perf_counter() - t0) / args.em_iters
+        tr0.close()
     # (a) one 32-byte D2H of (log P, converged) per iteration -- what a training loop with a stop rule does
     fence()
     t0 = time.perf_counter()
@@ -454,6 +466,7 @@ def em_leg(args, group):
         "iterations": args.em_iters, "ms_per_iteration": per_it * 1e3,
         "ms_per_iteration_enqueued": None if dt_q is None else dt_q / args.em_iters * 1e3,
         "em_utterances_per_s": all_utts / per_it, "em_frames_per_s": all_frames / per_it,
+        "occ_floor": tr.occ_floor, "ms_per_iteration_occ_floor_0": None if dt_exact is None else dt_exact * 1e3,
         "device_resident_iteration": tr.session is not None,
         "host_syncs_per_iteration": 1 if tr.session is not None else 3,
         "allreduce_ms": ar_ms, "allreduce_bytes": tr._packed_len() * 8,

@@ -25,10 +25,6 @@
 #include "gh_internal.h"
 #include "gh_host.h"
 
-#ifndef BWF_TF
-#define BWF_TF 32   // frames staged per tile (tuning knob: -DBWF_TF=64)
-#endif
-
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -74,47 +70,51 @@ __device__ __forceinline__ double bwf_exp2s(double y, const double* __restrict__
 }
 
 // KS = k-steps of the density GEMM (K = 4 KS = 2 KP), LT = 16-column tiles of each half of Z (D + 1 <= 16 LT)
-// NW = waves per workgroup: 3 when no word has more than three state pairs (n <= 6: FOUR resident workgroups per CU put
-// three COMPUTING waves on every SIMD; with a fourth, staging-only wave per workgroup a CU held three workgroups = nine
-// computing waves), else 4
-template <int KS, int LT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 3 ? 4 : 3) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
-                                                       const double* __restrict__ mean, const double* __restrict__ ivar,
-                                                       const double* __restrict__ logc, const double* __restrict__ gam,
-                                                       double occ_floor, int gam_stride, int gam_by_state, const int64_t* __restrict__ seg_first,
-                                                       const int32_t* __restrict__ seg_len,
-                                                       const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
-                                                       const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
-                                                       double* __restrict__ partial) {
+// One WAVE per (utterance group of a word, state pair): the wave walks its utterances in 16-frame blocks, looks at the
+// pair's two gamma columns first and SKIPS a block whose 16 frames carry no occupancy for either state -- posteriors are
+// sharp: a few frames away from the aligned region gamma underflows to exactly 0.0 (fb_chain_kernel returns alpha beta / P
+// as a double), so of the 21 (block, pair) combinations of a 100-frame, 5-state utterance ~9 do any work, and a skipped
+// block would only have added exact zeros.  Blocks that do work are staged by the wave itself (16 x D frames through LDS
+// into the two MFMA operand layouts); no other wave is involved: no barrier, no idle "staging" wave, no waiting for the
+// slowest pair of a shared tile.
+// (Round 2 / early round 3: a 256-thread workgroup per utterance group -- three waves = three pairs sharing a staged
+// 32-frame tile, a fourth wave that only staged, two barriers per tile.  Diagnostic builds showed that kernel pipe bound --
+// density MFMAs 28 %, accumulation MFMAs 32 %, responsibilities 19 %, HBM 5 %, barriers 1.5 % of its 0.72 ms -- so the way
+// down was less work, not fewer stalls; skipping zero blocks inside that structure only gained 14 % because the waves of a
+// workgroup still met at every tile.)
+template <int KS, int LT>
+__global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
+                                                     const double* __restrict__ mean, const double* __restrict__ ivar,
+                                                     const double* __restrict__ logc, const double* __restrict__ gam,
+                                                     double occ_floor, int gam_stride, int gam_by_state, const int64_t* __restrict__ seg_first,
+                                                     const int32_t* __restrict__ seg_len,
+                                                     const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
+                                                     const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
+                                                     double* __restrict__ partial) {
     constexpr int KP = 2 * KS;            // padded feature length
-    constexpr int NT = 64 * NW;           // threads of the workgroup
-#ifndef BWF_TF
-#define BWF_TF 32
-#endif
-    constexpr int TF = BWF_TF;            // frames staged per tile
+    constexpr int TF = 16;                // frames per block
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int DP = KP | 1;                // odd LDS row stride >= KP: columns D .. KP-1 stay zero, so the operand reads
-                                          // below need no bounds test (a conditional ds_read costs an exec-mask branch and
-                                          // its own s_waitcnt: 25 serialised LDS round trips per 16-frame block)
+                                          // below need no bounds test
     double* xt = sm;                      // [TF][DP]
-    double* gt = xt + TF * DP;            // [TF][8]  gamma of the tile's frames
-    double* tab = gt + TF * 8;            // [128]    2^(j/128)
-    const int tid = threadIdx.x, lane = tid & 63, p = tid >> 6;
+    double* gt = xt + TF * DP;            // [TF][2]  gamma of the block's frames for the pair's two states
+    double* tab = gt + TF * 2;            // [128]    2^(j/128)
+    const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
-    const bwf_wg wg = wgs[blockIdx.x];
+    const int p = blockIdx.x & 3;         // state pair (4 slots per utterance group; slots beyond the word's pairs leave)
+    const bwf_wg wg = wgs[blockIdx.x >> 2];
     const gh_fbchain* ch = chains + wg.graph;
     const int n = ch->n;
-    for (int i = tid; i < 128; i += NT) tab[i] = tables[i];
-    for (int i = tid; i < TF * DP; i += NT) xt[i] = 0.0;
-    // ---- this wave's pair of states: operands that stay in registers for the whole workgroup ----
-    const bool wave_on = 2 * p < n;
-    const int sa = wave_on ? ch->state[2 * p] : 0;
+    if (2 * p >= n) return;
+    for (int i = lane; i < 128; i += 64) tab[i] = tables[i];
+    for (int i = lane; i < TF * DP; i += 64) xt[i] = 0.0;
+    // ---- this wave's pair of states: operands that stay in registers for all its utterances ----
+    const int sa = ch->state[2 * p];
     const int sb = (2 * p + 1 < n) ? ch->state[2 * p + 1] : -1;
     const int s_j = (j < 8) ? sa : sb;
     const int m_j = j & 7;
-    const bool valid = wave_on && s_j >= 0 && m_j < M;
+    const bool valid = s_j >= 0 && m_j < M;
     const int64_t g_j = valid ? (int64_t)s_j * M + m_j : 0;
-    const int grow = 2 * p + (j >> 3);    // chain row (gamma column) of this lane's state
     double P[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -134,7 +134,6 @@ __global__ __launch_bounds__(64 * NW, NW == 3 ? 4 : 3) void bw_fused_kernel(cons
         const double c = logc[g_j] - 0.5 * sm2;
         Cj = (c == -INFINITY) ? GH_LSE_OFF64 : bwf_vmax(c * GH_LSE_SCALE64, GH_LSE_OFF64);
     }
-    // accumulation operand A = Z^T: this lane feeds Z column 16 ct + j of every tile
     // accumulation operand A = Z^T: this lane feeds column 16 t + j of the linear tiles (x[d] - c[d]; d = D: the ones
     // column, read from the zero padding with "centre" -1) and of the squared tiles
     constexpr int NCT = 2 * LT;
@@ -145,93 +144,114 @@ __global__ __launch_bounds__(64 * NW, NW == 3 ? 4 : 3) void bw_fused_kernel(cons
     for (int t = 0; t < LT; ++t) {
         const int d = t * 16 + j;
         dd[t] = (d <= D && d < DP) ? d : D;                     // columns behind the ones column read the zero padding too
-        cs[t] = (d < D) ? (wave_on ? mean[(int64_t)sa * M * D + d] : 0.0) : (d == D ? -1.0 : 0.0);
+        cs[t] = (d < D) ? mean[(int64_t)sa * M * D + d] : (d == D ? -1.0 : 0.0);
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = (v4d){0, 0, 0, 0};
+    // gamma columns of the pair: compact [N, 8] (column = chain row) or the frame x state occupancy matrix
+    // (gam_by_state: stride S, column = the chain row's state -- sequence-form forward-backward)
+    const int st = q & 1;                                       // lanes (frame j, state st): the upper half repeats the lower
+    const int grow_l = 2 * p + st;
+    const int gcol = (grow_l < n) ? (gam_by_state ? ch->state[grow_l] : grow_l) : -1;
+    constexpr int PX = (TF * KP + 63) / 64;                    // frame elements per lane of a staged block
+    const int gcol_a = gam_by_state ? ch->state[2 * p] : 2 * p;
+    const int gcol_b = (2 * p + 1 < n) ? (gam_by_state ? ch->state[2 * p + 1] : 2 * p + 1) : -1;
     __syncthreads();
-
-    // The (utterance, 32-frame tile) sequence of the workgroup is walked with the NEXT tile's frames and gammas already
-    // travelling from HBM into registers while the current tile is computed: staging a tile used to park all waves of
-    // the workgroup for a full memory round trip (SQ_WAIT_ANY was 42 % of the wave cycles).  256 threads always (the
-    // waves without a state pair only help to stage): 5 frame elements + 1 gamma per thread cover a 32 x 40 tile.
-    constexpr int PX = (TF * KP + NT - 1) / NT;
-    int ui = wg.u_begin, t0 = 0, T = 0;
-    int64_t f0 = 0;
-    // gamma of the tile: compact [N, 8] (column = chain row) or the frame x state occupancy matrix (gam_by_state:
-    // stride S, column = the chain row's state) -- sequence-form forward-backward, segments of (utterance, layer)
-    const int gcol = !gam_by_state ? (tid & 7) : ((tid & 7) < n ? ch->state[tid & 7] : -1);
-    auto open_utt = [&]() {
-        while (ui < wg.u_end) {
-            const int32_t u = ulist[ui];
-            f0 = seg_first[u];
-            T = seg_len[u];
-            t0 = 0;
-            if (T > 0) return true;
-            ++ui;
-        }
-        return false;
-    };
-    constexpr int PG = (TF * 8 + NT - 1) / NT;       // gamma entries per thread
-    double pre_x[PX], pre_g[PG];
-    auto prefetch = [&]() {   // tile (f0 + t0, min(TF, T - t0) frames) -> registers
-        const int nf_ = (T - t0 < TF) ? T - t0 : TF;
-        const double* src = X + (f0 + t0) * D;
+    double px[PX], pg = 0.0;                                   // the staged-ahead block: frames and gamma in registers
+    for (int ui = wg.u_begin; ui < wg.u_end; ++ui) {
+        const int32_t u = ulist[ui];
+        const int64_t f0 = seg_first[u];
+        const int T = seg_len[u];
+        // 1024 frames (64 blocks) at a time: lane b looks at the pair's gamma in block b -- 32 independent loads, ONE
+        // memory round trip for the whole utterance -- and the ballot is the list of blocks that have work
+        for (int c0 = 0; c0 < T; c0 += 64 * TF) {
+            unsigned long long todo;
+            {
+                const int fb = c0 + lane * TF;
+                bool nz = false;
+#ifdef BWF_NOSTAGE   // diagnostic builds (tools/bwf_variants.sh): timing without HBM reads / MFMAs / responsibilities
+                nz = fb < T;
+#else
+                double ga[TF], gb[TF];
 #pragma unroll
-        for (int e = 0; e < PX; ++e) {
-            const int i = tid + NT * e;
-            pre_x[e] = (i < nf_ * D) ? src[i] : 0.0;
-        }
+                for (int f = 0; f < TF; ++f) {
+                    const bool in = fb + f < T;
+                    ga[f] = in ? gam[(f0 + fb + f) * gam_stride + gcol_a] : 0.0;
+                    gb[f] = (in && gcol_b >= 0) ? gam[(f0 + fb + f) * gam_stride + gcol_b] : 0.0;
+                }
 #pragma unroll
-        for (int e = 0; e < PG; ++e) {
-            const int i = tid + NT * e;
-            pre_g[e] = (i < nf_ * 8 && gcol >= 0) ? gam[(f0 + t0 + (i >> 3)) * gam_stride + gcol] : 0.0;
-        }
-    };
-    bool have = open_utt();
-    if (have) prefetch();
-    while (have) {
-        const int nf = (T - t0 < TF) ? T - t0 : TF;
-        __syncthreads();                      // every wave is done with the previous tile
+                for (int f = 0; f < TF; ++f) nz |= (ga[f] > occ_floor) | (ga[f] != ga[f]) | (gb[f] > occ_floor) | (gb[f] != gb[f]);
+#endif
+#ifdef BWF_NOSKIP
+                nz = fb < T;
+#endif
+                todo = __ballot(nz);     // same test as `wgt` below: a block without occupancy adds exact zeros -- not a pruning
+            }
+            auto fetch = [&](int blk) {   // block blk of this chunk -> registers (its X rows and the pair's gamma)
+                const int bf = c0 + blk * TF;
+                const int nf_ = (T - bf < TF) ? T - bf : TF;
+                const double* src = X + (f0 + bf) * D;
 #pragma unroll
-        for (int e = 0; e < PX; ++e) {
-            const int i = tid + NT * e;
-            if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = pre_x[e]; }   // rows >= nf arrive as zeros
-        }
+                for (int e = 0; e < PX; ++e) {
+                    const int i = lane + 64 * e;
+#ifdef BWF_NOSTAGE
+                    px[e] = (i < nf_ * D) ? 0.25 * (double)(i & 15) : 0.0;
+#else
+                    px[e] = (i < nf_ * D) ? src[i] : 0.0;
+#endif
+                }
+#ifdef BWF_NOSTAGE
+                pg = (j < nf_ && gcol >= 0) ? 0.125 : 0.0;
+#else
+                pg = (j < nf_ && gcol >= 0) ? gam[(f0 + bf + j) * gam_stride + gcol] : 0.0;
+#endif
+            };
+            int blk = todo ? __builtin_ctzll(todo) : -1;
+            if (blk >= 0) fetch(blk);
+            while (blk >= 0) {
+                const int bf = c0 + blk * TF;
+                const int nf = (T - bf < TF) ? T - bf : TF;
+                // ---- park the fetched block in LDS [16][DP] (rows >= nf zero) + gamma [16][2] ----
 #pragma unroll
-        for (int e = 0; e < PG; ++e) { const int i = tid + NT * e; if (i < TF * 8) gt[i] = pre_g[e]; }
-        // the tile after this one
-        t0 += TF;
-        if (t0 >= T) { ++ui; have = open_utt(); }
-        if (have) prefetch();
-        __syncthreads();
-        {
-            if (wave_on)
-            for (int bf = 0; bf < nf; bf += 16) {
+                for (int e = 0; e < PX; ++e) {
+                    const int i = lane + 64 * e;
+                    if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = px[e]; }
+                }
+                if (lane < 32) gt[j * 2 + st] = pg;
+                todo &= todo - 1;
+                const int nxt = todo ? __builtin_ctzll(todo) : -1;
+                if (nxt >= 0) fetch(nxt);      // travels from HBM while this block is computed
+                __syncthreads();               // (one wave: orders the LDS stores above before the operand reads below)
+            {
                 // ---- component log-densities of 16 frames x 16 components (scaled log domain) ----
                 v4d da = (v4d){Cj, Cj, Cj, Cj};
-                const double* xr = xt + (bf + j) * DP + q;       // A operand: row = frame bf + j, columns q, q + 4, ...
+                const double* xr = xt + j * DP + q;              // A operand: row = frame j, columns q, q + 4, ...
                 double xa[KS / 2];
 #pragma unroll
                 for (int ks = 0; ks < KS / 2; ++ks) xa[ks] = xr[4 * ks];             // (KS is even: k < KP <=> ks < KS / 2)
+#ifdef BWF_NODENS
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks) da[ks & 3] += xa[ks] * P[ks];
+#else
 #pragma unroll
                 for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks] * xa[ks], P[ks], da, 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], P[KS / 2 + ks], da, 0, 0, 0);
-                // ---- responsibilities: lane = component j, register r = frame bf + q + 4 r ----
+#endif
+                // ---- responsibilities: lane = component j, register r = frame q + 4 r ----
                 double R[4];
-#ifdef BWF_NOEPI     // diagnostic build: no responsibilities (MFMAs and operand traffic only)
+#ifdef BWF_NOEPI
 #pragma unroll
                 for (int r = 0; r < 4; ++r) R[r] = da[r];
 #else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int fr = bf + q + 4 * r;
+                    const int fr = q + 4 * r;
                     const double y = da[r];
                     const double mx = max8(y);
                     const double e = bwf_exp2s(y - mx, tab);
                     const double s8 = sum8(e);
-                    const double g = gt[fr * 8 + grow];
+                    const double g = gt[fr * 2 + (j >> 3)];
                     const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
                     double inv = __builtin_amdgcn_rcp(s8);
                     inv = fma(fma(-s8, inv, 1.0), inv, inv);      // two Newton steps: full double accuracy
@@ -240,26 +260,33 @@ __global__ __launch_bounds__(64 * NW, NW == 3 ? 4 : 3) void bw_fused_kernel(cons
                     R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? rv : 0.0;   // (every component off: s8 = 8, e = 1 -- killed by `valid`)
                 }
 #endif
-                // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames bf + {0..3} + 4 r ----
+                // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames {0..3} + 4 r ----
                 double zx[4][LT];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < LT; ++t) zx[r][t] = xt[(bf + q + 4 * r) * DP + dd[t]];   // all reads in flight
+                    for (int t = 0; t < LT; ++t) zx[r][t] = xt[(q + 4 * r) * DP + dd[t]];   // all reads in flight
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int t = 0; t < LT; ++t) {
                         const double xv = zx[r][t] - cs[t];
+#ifdef BWF_NOACC
+                        acc[t][r] += xv * R[r];
+#else
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, R[r], acc[t], 0, 0, 0);
                         // (the ones column squares to 1 as well: row D of the squared half holds sum r, unused)
                         acc[LT + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv * xv, R[r], acc[LT + t], 0, 0, 0);
+#endif
                     }
+            }
+                __syncthreads();               // (the next block's stores come after these reads)
+                blk = nxt;
             }
         }
     }
-    // ---- one raw tile per wave: partial[wg][p][Zcol = 16 ct + q + 4 reg][comp j] ----
-    double* out = partial + ((int64_t)blockIdx.x * 4 + p) * (NCT * 16 * 16);   // (4 tile slots per workgroup whatever NW is)
+    // ---- one raw tile per wave: partial[group][pair slot][Zcol = 16 ct + q + 4 reg][comp j] ----
+    double* out = partial + (int64_t)blockIdx.x * (NCT * 16 * 16);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -446,7 +473,10 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
     const int64_t n_seg = (int64_t)seg_first.size();
     // workgroups of 3 waves (5 states = 3 pairs): FOUR per CU put exactly three waves on every SIMD (with three per CU
     // one SIMD carries three waves, the others two: the kernel ran at the pace of the fullest one)
-    const int target_wgs = (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 4) * ctx->n_cu;
+    // utterance groups: (groups of a word) x (its state pairs) waves in all; 8 waves per CU are resident at this kernel's
+    // register count, so ~8 n_cu / 3 groups for 5-state words put every wave on the chip at once (GMMHMM_BWF_WGS: groups
+    // per CU, default 3)
+    const int target_wgs = (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 3) * ctx->n_cu;
     const int per_wg = (int)std::max<int64_t>(4, (n_seg + target_wgs - 1) / target_wgs);
     std::vector<int32_t> ulist;
     std::vector<bwf_wg> wgs;
@@ -512,20 +542,16 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
     const int W = 1 + 2 * D;
     GH_HIP(hipMemsetAsync(d_out, 0, (size_t)S * M * W * 8, st));
     if (pl.n_wgs == 0) return GH_OK;
-    const size_t lds = ((size_t)BWF_TF * ((2 * KS) | 1) + BWF_TF * 8 + 128) * 8;
-    // (NW = 3 -- 192-thread workgroups, four per CU = twelve computing waves instead of nine -- was measured: the statistics
-    //  kernel went from 0.72 to 0.89 ms; the fourth wave's share of the tile staging is worth more than the occupancy)
-    const int nw = 4;
-    const dim3 grid((unsigned)pl.n_wgs), blk(64 * nw);
+    const size_t lds = ((size_t)16 * ((2 * KS) | 1) + 16 * 2 + 128) * 8;
+    const dim3 grid((unsigned)pl.n_wgs * 4), blk(64);   // one wave per (utterance group, pair slot)
     const gh_fbchain* chains = d_chains ? d_chains : pl.d_chains;
     const bwf_wg* d_wgs = (const bwf_wg*)pl.d_wgs;
     const bwf_pair* d_pairs = (const bwf_pair*)pl.d_pairs;
-#define GH_BWF(ks, nc, w)                                                                                                \
-    hipLaunchKernelGGL((bw_fused_kernel<ks, nc, w>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                \
+#define GH_BWF(ks, nc)                                                                                                   \
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                   \
                        g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
                        ctx->d_fp64_tables, pl.d_part)
-#define GH_BWF_W(ks, nc) GH_BWF(ks, nc, 4)
-#define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF_W(ks, 1); break; case 2: GH_BWF_W(ks, 2); break; default: GH_BWF_W(ks, 3); break; }
+#define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;
         case 4: GH_BWF_N(4) break;
@@ -534,7 +560,6 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
         default: GH_BWF_N(20) break;
     }
 #undef GH_BWF_N
-#undef GH_BWF_W
 #undef GH_BWF
     GH_HIP(hipGetLastError());
     hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pl.n_pairs, (unsigned)((pl.tile_len + 255) / 256)), dim3(256), 0, st, pl.d_part,

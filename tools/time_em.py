@@ -23,7 +23,7 @@ if K > 1:   # transcripts of K words: K isolated-word utterances back to back
 rng = np.random.default_rng(0)
 means0 = wl["means"] + 0.3 * rng.normal(size=wl["means"].shape)   # perturbed start
 t0 = time.perf_counter()
-tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels)
+tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, occ_floor=float(os.environ.get("EM_OCC_FLOOR", "0")))
 print("setup s", time.perf_counter() - t0, flush=True)
 ctx = tr.ctx
 hist = []
