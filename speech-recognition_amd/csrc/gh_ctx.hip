@@ -36,6 +36,8 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     c->last_chunks = 0;
+    c->compat = 0;
+    if (const char* e = getenv("GMMHMM_COMPAT")) c->compat = strstr(e, "underflow") ? 1 : atoi(e);
     hipDeviceProp_t prop;
     GH_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
@@ -79,6 +81,12 @@ extern "C" int gh_device_sync(gh_ctx* c) {
     GH_REQUIRE(c, "gh_device_sync: ctx is NULL");
     GH_HIP(hipSetDevice(c->device));
     GH_HIP(hipDeviceSynchronize());
+    return GH_OK;
+}
+
+extern "C" int gh_ctx_set_compat(gh_ctx* c, int flags) {
+    GH_REQUIRE(c, "gh_ctx_set_compat: ctx is NULL");
+    c->compat = flags;
     return GH_OK;
 }
 

@@ -50,6 +50,7 @@ struct gh_ctx {
     void* pinned;         // growable page-locked host staging buffer (one D2H copy per call instead of several)
     size_t pinned_bytes;
     double* d_fp64_tables;  // [384] exp2 / inv / -log tables of the fp64 log-sum-exp (gh_loglik_mfma.hip)
+    int compat;             // gh_ctx_set_compat: bit 0 = linear-domain underflow of the reference's GMM.evaluate (+inf)
     int last_chunks;        // launches the last gh_viterbi* / gh_forward_backward call on this context was cut into (scratch budget)
 };
 

@@ -38,9 +38,12 @@ __device__ __forceinline__ void lse_push(T ll, T& mx, T& sm) {
     }
 }
 
+// inf_below: compat mode (gh_ctx_set_compat bit 0) -- once the largest term's logarithm is below ln 2^-1075 the
+// reference's linear-domain sum is 0 and the state costs +inf (hmm_state.py:114-120); -inf otherwise
 template <typename T>
-__device__ __forceinline__ T lse_finish(T mx, T sm) {
+__device__ __forceinline__ T lse_finish(T mx, T sm, T inf_below) {
     if (sm != sm) return T(NAN);
+    if (mx < inf_below) return T(INFINITY);
     return (sm > T(0)) ? -(mx + gh_log<T>(sm)) : T(INFINITY);
 }
 
@@ -49,7 +52,7 @@ template <typename T, int KP>
 __global__ __launch_bounds__(64) void loglik_kernel(const T* __restrict__ X, int64_t N, int D,
                                                     const T* __restrict__ A, const T* __restrict__ B,
                                                     const T* __restrict__ C, int S, int M,
-                                                    T* __restrict__ out, const T* __restrict__ cen) {
+                                                    T* __restrict__ out, const T* __restrict__ cen, T inf_below) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);  // [64][D] frames of this wave, row-major
     const int lane = threadIdx.x;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64) void loglik_kernel(const T* __restrict__ X, int
             }
             lse_push(acc0, mx, sm);
         }
-        T nll = lse_finish<T>(mx, sm);
+        T nll = lse_finish<T>(mx, sm, inf_below);
         if (lane < nrows) out[n * S + s] = nll;
     }
 }
@@ -118,7 +121,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X, int64_t N, int D, int KP,
                                                         const T* __restrict__ A, const T* __restrict__ B,
                                                         const T* __restrict__ C, int S, int M,
-                                                        T* __restrict__ out, const T* __restrict__ cen) {
+                                                        T* __restrict__ out, const T* __restrict__ cen, T inf_below) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
     const int lane = threadIdx.x;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(64) void loglik_kernel_any(const T* __restrict__ X,
             }
             lse_push(acc, mx, sm);
         }
-        T nll = lse_finish<T>(mx, sm);
+        T nll = lse_finish<T>(mx, sm, inf_below);
         if (lane < nrows) out[n * S + s] = nll;
     }
 }
@@ -158,10 +161,11 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
     const size_t lds = (size_t)64 * g->D * sizeof(T);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
+    const T inf_below = (ctx->compat & 1) ? (T)-745.1332191019412 : (T)-INFINITY;   // (natural-log domain here)
 #define GH_LL_CASE(kp)                                                                              \
     case kp:                                                                                        \
         hipLaunchKernelGGL((loglik_kernel<T, kp>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                           A, B, C, g->S, g->M, out, cen);                                          \
+                           A, B, C, g->S, g->M, out, cen, inf_below);                               \
         break;
     switch (g->KP) {
         GH_LL_CASE(4)
@@ -171,7 +175,7 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
         GH_LL_CASE(40)
         default:
             hipLaunchKernelGGL((loglik_kernel_any<T>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D,
-                               g->KP, A, B, C, g->S, g->M, out, cen);
+                               g->KP, A, B, C, g->S, g->M, out, cen, inf_below);
     }
 #undef GH_LL_CASE
     GH_HIP(hipGetLastError());

@@ -154,9 +154,12 @@ template <typename T, int W> __device__ __forceinline__ T pair_max(T v) { T a, b
 template <typename T, int W> __device__ __forceinline__ T pair_sum(T v) { T a, b; pair_of<W>(v, a, b); return a + b; }
 
 // scaled (max, sum of 2^..) -> negative log-likelihood; every component off -> +inf; NaN stays NaN
-template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm, const double* tab) {
+// inf_below: the scaled log below which the largest term counts as "off".  Default Dom<T>::off_test (only switched-off
+// components); compat mode (gh_ctx_set_compat bit 0): K ln 2^-1075 -- the reference sums w pdf in the LINEAR domain
+// (hmm_state.py:114-120), where every term whose logarithm is below that rounds to 0 and the state costs -log 0 = +inf
+template <typename T> __device__ __forceinline__ T nll_of(T mx, T sm, const double* tab, T inf_below) {
     const T v = (mx + logs(sm, tab)) * -Dom<T>::inv_k;
-    return (mx < Dom<T>::off_test) ? T(INFINITY) : v;
+    return (mx < inf_below) ? T(INFINITY) : v;
 }
 
 // max and sum-of-exp over the 4 registers of one lane, then over `width` lane groups (1, 2 or 4)
@@ -184,7 +187,7 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, co
 template <typename T, typename V, int MP>
 __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int t, int f, int q, int S, int RS,
                                               int chunk_s0, int tiles_per_state, T* lds, T* dummy,
-                                              const double* tab, T (&run_mx)[2], T (&run_sm)[2]) {
+                                              const double* tab, T (&run_mx)[2], T (&run_sm)[2], T inf_below) {
     T* orow0 = lds + f * RS - chunk_s0;
     T* orow1 = orow0 + 16 * RS;
     if (MP == 1) {
@@ -195,7 +198,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
             T* orow = c ? orow1 : orow0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                *((s + r < S) ? orow + s + r : dummy) = (acc[r] < Dom<T>::off_test) ? T(INFINITY) : acc[r] * -Dom<T>::inv_k;
+                *((s + r < S) ? orow + s + r : dummy) = (acc[r] < inf_below) ? T(INFINITY) : acc[r] * -Dom<T>::inv_k;
         }
     } else if (MP == 2) {
         const int s = 8 * t + 2 * q;
@@ -208,7 +211,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
                 const T x0 = acc[2 * h], x1 = acc[2 * h + 1];
                 const T m = vmax(x0, x1);
                 const T e = exp2s(x0 - m, tab) + exp2s(x1 - m, tab);
-                *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e, tab);
+                *((s + h < S) ? orow + s + h : dummy) = nll_of<T>(m, e, tab, inf_below);
             }
         }
 #ifdef GH_MF_NOEPI  // diagnostic build: MFMAs + loads only (tools/variant_bench.sh)
@@ -221,9 +224,9 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
         T mx, sm;
         const int s = 4 * t + q;
         tile_lse<T, V>(acc0, 1, mx, sm, tab);
-        *((s < S) ? orow0 + s : dummy) = nll_of<T>(mx, sm, tab);
+        *((s < S) ? orow0 + s : dummy) = nll_of<T>(mx, sm, tab, inf_below);
         tile_lse<T, V>(acc1, 1, mx, sm, tab);
-        *((s < S) ? orow1 + s : dummy) = nll_of<T>(mx, sm, tab);
+        *((s < S) ? orow1 + s : dummy) = nll_of<T>(mx, sm, tab, inf_below);
     } else if (MP <= 16) {
         constexpr int width = MP / 4;  // lane groups per state: 2 or 4
         T mx0, sm0, mx1, sm1;
@@ -231,7 +234,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
         tile_lse<T, V>(acc1, width, mx1, sm1, tab);
         const bool odd = q & 1;
         const int s = (16 / MP) * t + q / width;
-        const T v = nll_of<T>(odd ? mx1 : mx0, odd ? sm1 : sm0, tab);
+        const T v = nll_of<T>(odd ? mx1 : mx0, odd ? sm1 : sm0, tab, inf_below);
         *(((q & (width - 1)) < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
     } else {
         const bool last = (t + 1) % tiles_per_state == 0;
@@ -247,7 +250,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
             run_mx[c] = (d > T(0)) ? run_mx[c] : mx;
         }
         const bool odd = q & 1;
-        const T v = nll_of<T>(odd ? run_mx[1] : run_mx[0], odd ? run_sm[1] : run_sm[0], tab);
+        const T v = nll_of<T>(odd ? run_mx[1] : run_mx[0], odd ? run_sm[1] : run_sm[0], tab, inf_below);
         *((last && q < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
                                                          const double* __restrict__ tables, int tab_off,
                                                          T* __restrict__ out, int bpw,
                                                          const gh_loglik_blk* __restrict__ blk_tab, int64_t n_blk,
-                                                         const T* __restrict__ cen) {
+                                                         const T* __restrict__ cen, T inf_below) {
     typedef typename Acc<T>::type V;
 #ifndef GH_MF_RING32
 #define GH_MF_RING32 2
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         // Two tiles per iteration with the accumulator pairs swapping roles: the epilogue of tile t-1 is scheduled
         // with the MFMAs of tile t without copying accumulators (16 v_mov per tile otherwise).
         auto epi = [&](const V& e0, const V& e1, int t) {
-            tile_epilogue<T, V, MP>(e0, e1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm);
+            tile_epilogue<T, V, MP>(e0, e1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm, inf_below);
 #pragma unroll
             for (int i = 0; i < (GH_MF_SGB ? 2 * KS : 0); ++i) {   // (forced MFMA / VALU interleave: measured slower)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -579,6 +582,8 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     const int tab_off = (int)lds;
     if (sizeof(T) == 8 && M_pad != 1) lds += 384 * sizeof(double);   // exp / log tables (not needed for M = 1)
     const double* tables = ctx->d_fp64_tables;
+    // ln 2^-1075 = -745.13...: exp() of anything below rounds to +0 in fp64 (the reference's arithmetic, whatever T is)
+    const T inf_below = (ctx->compat & 1) ? (T)(-745.1332191019412 * (sizeof(T) == 8 ? GH_LSE_SCALE64 : GH_LSE_SCALE32)) : Dom<T>::off_test;
     // ---- optional block table: every utterance in blocks of <= 32 frames, only the tiles of its state range ----
     gh_loglik_blk* d_blk = nullptr;
     int64_t n_blk = 0;
@@ -614,10 +619,10 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     do {                                                                                                                 \
         if (bpw > 1)                                                                                                     \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen); \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen, inf_below); \
         else                                                                                                             \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, false>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
-                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen); \
+                               Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen, inf_below); \
     } while (0)
 #define GH_MF_CASE(ks)                                   \
     case ks:                                             \

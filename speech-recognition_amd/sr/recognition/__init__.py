@@ -14,3 +14,13 @@ from .hmm import *  # noqa: F401,F403
 from .kmeans import *  # noqa: F401,F403
 from .continuous_speech import *  # noqa: F401,F403
 from .hmm_state import *  # noqa: F401,F403
+
+
+def set_compat(underflow=True, device=None):
+    """Reference-compatible corner cases that the kernels do not reproduce by default (extension; see
+    `gh_ctx_set_compat` in include/gmmhmm.h).  underflow=True: a state whose every weighted density underflows fp64
+    costs +inf -- the reference's `GMM.evaluate` sums in the linear domain (hmm_state.py:114-120) -- instead of the
+    finite log-domain cost, so `decode_hmm_states` / `HMM.evaluate` / the batch decoders treat such frames as
+    unreachable exactly where the reference does.  Applies to the default context of `device`."""
+    from . import _hip
+    _hip.default_context(device).set_compat(underflow=underflow)

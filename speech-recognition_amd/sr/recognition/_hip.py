@@ -46,6 +46,7 @@ SIGNATURES = {
     "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gh_device_sync": (C.c_int, [C.c_void_p]),
     "gh_ctx_last_chunks": (C.c_int, [C.c_void_p]),
+    "gh_ctx_set_compat": (C.c_int, [C.c_void_p, C.c_int]),
     "gh_batch_wrap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                 C.POINTER(C.c_void_p)]),
     "gh_batch_destroy": (None, [C.c_void_p]),
@@ -199,6 +200,11 @@ class Context:
 
     def sync(self):
         _check(self.lib, self.lib.gh_ctx_sync(self.h))
+
+    def set_compat(self, underflow=False):
+        """underflow=True: likelihoods of states whose every weighted density underflows fp64 come back as +inf, like the
+        reference's linear-domain GMM.evaluate (hmm_state.py:114-120); see gh_ctx_set_compat."""
+        _check(self.lib, self.lib.gh_ctx_set_compat(self.h, 1 if underflow else 0))
 
     @property
     def last_chunks(self):

@@ -929,3 +929,35 @@ def test_dtw_long_templates(n, beam):
         np.testing.assert_allclose(costs[u], rc, rtol=1e-12)
         np.testing.assert_array_equal(paths[u], np.asarray(rp).reshape(-1, 2))
     b.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("M,D", [(4, 5), (1, 13), (8, 39), (32, 39)])
+def test_compat_linear_domain_underflow(hip, dtype, M, D):
+    """GMM.evaluate sums w pdf in the LINEAR domain (hmm_state.py:114-120): once every term underflows fp64 the state
+    costs -log 0 = +inf.  Default: the kernels stay in the log domain and return the finite cost (documented deviation);
+    gh_ctx_set_compat bit 0 reproduces the +inf (VERDICT r2 'missing' 5) -- checked against the oracle's linear-domain
+    evaluate frame by frame, together with the frames that do not underflow."""
+    ctx = hip.Context(0)                        # a context of its own: the switch is a property of the context
+    rng = np.random.default_rng(M * 100 + D)
+    S, N = 6, 96
+    means, vars_ = rng.normal(size=(S, M, D)), rng.uniform(0.5, 1.5, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    X = rng.normal(size=(N, D))
+    X[::3] += 30.0 * np.sign(rng.normal(size=(N // 3, D)))     # a third of the frames far from every mean: log p << -745
+    X = X.astype(dtype).astype(np.float64)                      # (what both sides see)
+    lin = np.array([[O.gmm_evaluate(x, means[s], vars_[s], w[s]) for s in range(S)] for x in X])
+    logdom = O.gmm_neg_loglik_batch(X, means, vars_, w)
+    assert np.isinf(lin[::3]).all() and np.isfinite(lin[1::3]).all() and np.isfinite(logdom).all()
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, feats=X, offsets=[0, N], dtype=dtype)
+    rtol = 1e-10 if dtype == np.float64 else 1e-3
+    np.testing.assert_allclose(b.loglik(gmm), logdom, rtol=rtol)             # default: finite everywhere
+    ctx.set_compat(underflow=True)
+    got = b.loglik(gmm)
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(lin))
+    fin = np.isfinite(lin)
+    np.testing.assert_allclose(got[fin], lin[fin], rtol=rtol)
+    ctx.set_compat(underflow=False)
+    np.testing.assert_allclose(b.loglik(gmm), logdom, rtol=rtol)
+    b.close(); gmm.close(); ctx.close()
