@@ -6,14 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
     sys.path.insert(0, p)
 import numpy as np
-import torch
-torch.cuda.init()   # torch's bundled HIP runtime has to come up BEFORE the library's (system ROCm) one, not after
+import argparse
 import bench
 from sr.recognition import _hip
 from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 ctx = _hip.Context(0)
-print(json.dumps(bench._continuous_config(ctx, U, min(U, int(sys.argv[2]) if len(sys.argv) > 2 else 5000), np.float64), indent=1))
+group = bench.Group(argparse.Namespace(comm="native", backend="nccl"), 0, 1, 0)      # one rank: barrier / max / sum are no-ops
+print(json.dumps(bench._continuous_config(ctx, group, U, min(U, int(sys.argv[2]) if len(sys.argv) > 2 else 5000), np.float64), indent=1))
 # the decode without a path (end costs only) on a smaller resident batch, K = 7 lattice
 K, W, n, M, D = 7, 10, 5, 8, 39
 wl = bench.synth_workload(1005, 1, W=W, n=n, M=M, D=D)
