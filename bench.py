@@ -940,6 +940,10 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: torch.distributed.run "
                  "--nproc-per-node %d, or start bench.py --gpus %d without a launcher)" % (args.gpus, world, args.gpus, args.gpus))
     dev = (0 if args.same_gpu else local_rank) if args.device is None else args.device
+    if args.same_gpu and world > 1:
+        # (also under a launcher: RCCL reads these when the communicator comes up, not when the process starts)
+        os.environ.update(NCCL_HOSTID="gmmhmm-bench-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
+                          NCCL_SHM_DISABLE="1")
     # host cores: before anything touches the GPU (and before numpy / the ranks' host threads start working)
     pinned = None if args.no_pin else pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), dev)
     from sr.recognition import _hip
