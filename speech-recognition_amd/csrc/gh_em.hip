@@ -44,9 +44,19 @@ struct gh_em {
     int* d_flags;          // [0] entries not allclose to the previous iteration, [1] error bits (16: zero variance)
     double* d_hist;        // [hist_cap][4]: log P, utterances, converged, error bits
     int hist_cap, it;
-    gh_loglik_plan ll_plan;
+    // Optionally (GMMHMM_EM_TWO_STREAMS=1) the utterances are split in TWO halves (alternating in length order) that run
+    // on two streams, so that one half's forward-backward -- 1.5 waves per SIMD, latency bound -- could hide under the
+    // other half's likelihood / statistics kernels.  Half 0 on the context's stream, half 1 on `s2`; they join before the
+    // tail kernel.  Same results; measured no faster (see gh_em_create), so one half is the default.
+    int n_half;
+    gh_loglik_plan ll_plan[2];
     bool ll_subset;
-    gh_bwf_plan bw_plan;
+    gh_bwf_plan bw_plan[2];
+    int64_t Uh[2];
+    int64_t *d_perm_h[2], *d_coff_h[2];
+    double* d_stats1;      // half 1's statistics [n_stats] (half 0 writes into the packed buffer)
+    hipStream_t s2;
+    hipEvent_t ev_start, ev_half;
     double* h_tail;        // pinned [4]
 };
 
@@ -154,6 +164,11 @@ __global__ __launch_bounds__(256) void em_mstep_kernel(const double* __restrict_
     if (bad) atomicAdd(&flags[0], bad);
 }
 
+__global__ void em_add_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ void em_finish_kernel(const double* __restrict__ tail /* log P, utterances */, const int* __restrict__ flags,
                                  double* __restrict__ hist_row) {
     hist_row[0] = tail[0];
@@ -168,9 +183,12 @@ extern "C" void gh_em_destroy(gh_em* e) {
     if (!e) return;
     hipSetDevice(e->ctx->device);
     hipStreamSynchronize(e->ctx->stream);
+    if (e->s2) hipStreamSynchronize(e->s2);
     if (e->gmm) gh_gmm_destroy(e->gmm);
-    gh_loglik_plan_free(&e->ll_plan);
-    gh_bwf_plan_free(&e->bw_plan);
+    for (int h = 0; h < 2; ++h) { gh_loglik_plan_free(&e->ll_plan[h]); gh_bwf_plan_free(&e->bw_plan[h]); }
+    if (e->ev_start) hipEventDestroy(e->ev_start);
+    if (e->ev_half) hipEventDestroy(e->ev_half);
+    if (e->s2) hipStreamDestroy(e->s2);
     if (e->d_arena) hipFree(e->d_arena);
     if (e->h_tail) hipHostFree(e->h_tail);
     delete e;
@@ -219,14 +237,36 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
     int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
     if (rc) { gh_em_destroy(e); return rc; }
-    // ---- likelihoods of every utterance's own states: persistent block table (or the full matrix) ----
+    // ---- the two halves: alternating in launch (length) order ----
+    // (measured on the configs[2] shard: 1.115 ms per iteration with two halves on two streams against 1.085 ms with one --
+    //  the forward-backward does not slide under the other half's kernels, and the half-sized launches are each a
+    //  little less efficient; off unless GMMHMM_EM_TWO_STREAMS=1)
+    e->n_half = (U >= 2048 && getenv("GMMHMM_EM_TWO_STREAMS") && atoi(getenv("GMMHMM_EM_TWO_STREAMS"))) ? 2 : 1;
+    std::vector<uint8_t> half_of(std::max<int64_t>(U, 1), 0);
+    std::vector<int64_t> perm_h[2];
+    for (int64_t k = 0; k < U; ++k) {
+        const int h = e->n_half == 2 ? (int)(k & 1) : 0;
+        half_of[b->perm[k]] = (uint8_t)h;
+        perm_h[h].push_back(b->perm[k]);
+    }
+    e->Uh[0] = (int64_t)perm_h[0].size(); e->Uh[1] = (int64_t)perm_h[1].size();
+    // ---- likelihoods of every utterance's own states: persistent block tables (or the full matrix) ----
     {
         std::vector<int32_t> lo(U), hi(U);
         for (int64_t u = 0; u < U; ++u) { lo[u] = utt_word[u] * n; hi[u] = lo[u] + n; }
-        rc = U > 0 ? gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), nullptr, &e->ll_plan) : 0;
-        if (rc < 0) { gh_em_destroy(e); return rc; }
-        e->ll_subset = rc == 0;
-        if (rc == 1) {
+        e->ll_subset = true;
+        for (int h = 0; h < e->n_half && U > 0; ++h) {
+            std::vector<uint8_t> inc(U);
+            for (int64_t u = 0; u < U; ++u) inc[u] = half_of[u] == h;
+            rc = gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), nullptr, &e->ll_plan[h], inc.data());
+            if (rc < 0) { gh_em_destroy(e); return rc; }
+            if (rc == 1) { e->ll_subset = false; break; }
+        }
+        if (!e->ll_subset) {
+            e->n_half = 1;                 // (the full-matrix kernel has no notion of halves)
+            e->Uh[0] = U; e->Uh[1] = 0;
+            perm_h[0].assign(b->perm.begin(), b->perm.end()); perm_h[1].clear();
+            std::fill(half_of.begin(), half_of.end(), 0);
             const int KS = e->gmm->KP / 2;
             if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) {
                 gh_em_destroy(e);
@@ -235,34 +275,34 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
             }
         }
     }
-    // ---- statistics kernel: work lists built once (utterances by word, longest first) ----
+    // ---- statistics kernel: work lists built once (utterances by word, longest first), per half ----
     std::vector<std::vector<int32_t>> by_word(W);
     {
         std::vector<int64_t> seg_first(U);
         std::vector<int32_t> seg_len(U);
         for (int64_t u = 0; u < U; ++u) { seg_first[u] = b->offsets[u]; seg_len[u] = (int32_t)(b->offsets[u + 1] - b->offsets[u]); }
-        std::vector<std::vector<int32_t>> by_graph(W);
-        for (int64_t k = 0; k < U; ++k) {
-            const int64_t u = b->perm[k];
-            if (seg_len[u] > 0) by_graph[utt_word[u]].push_back((int32_t)u);
-        }
         for (int64_t u = 0; u < U; ++u) by_word[utt_word[u]].push_back((int32_t)u);
-        rc = gh_bwf_plan_build(ctx, S, M, D, e->gmm->KP, chains, seg_first, seg_len, by_graph, /*persistent=*/true, &e->bw_plan);
-        if (rc) {
-            gh_em_destroy(e);
-            if (rc == 1) { gh_set_error("gh_em_create: shape outside the fused statistics kernel"); return GH_ERR_UNSUPPORTED; }
-            return rc;
+        for (int h = 0; h < e->n_half; ++h) {
+            std::vector<std::vector<int32_t>> by_graph(W);
+            for (int64_t u : perm_h[h])
+                if (seg_len[u] > 0) by_graph[utt_word[u]].push_back((int32_t)u);
+            rc = gh_bwf_plan_build(ctx, S, M, D, e->gmm->KP, chains, seg_first, seg_len, by_graph, /*persistent=*/true, &e->bw_plan[h]);
+            if (rc) {
+                gh_em_destroy(e);
+                if (rc == 1) { gh_set_error("gh_em_create: shape outside the fused statistics kernel"); return GH_ERR_UNSUPPORTED; }
+                return rc;
+            }
         }
     }
-    // ---- forward-backward: scratch offsets in launch order ----
-    std::vector<int64_t> coff(std::max<int64_t>(U, 1), 0);
+    // ---- forward-backward: scratch offsets in launch order (one arena, disjoint pieces per slot of either half) ----
+    std::vector<int64_t> coff_h[2];
     size_t cacc = 0;
-    for (int64_t k = 0; k < U; ++k) {
-        const int64_t u = b->perm[k];
-        coff[k] = (int64_t)cacc;
-        const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * n;
-        cacc += cells + (cells + 1) / 2;            // [T, n] mantissas (double) followed by as many exponents (int32)
-    }
+    for (int h = 0; h < 2; ++h)
+        for (int64_t u : perm_h[h]) {
+            coff_h[h].push_back((int64_t)cacc);
+            const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * n;
+            cacc += cells + (cells + 1) / 2;            // [T, n] mantissas (double) followed by as many exponents (int32)
+        }
     std::vector<int32_t> word_utts, word_off(W + 1, 0);
     for (int w = 0; w < W; ++w) {
         word_utts.insert(word_utts.end(), by_word[w].begin(), by_word[w].end());
@@ -282,7 +322,11 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     lay.add((void**)&e->d_utt_word, std::max<size_t>(1, U) * 4, utt_word, (size_t)U * 4);
     lay.add((void**)&e->d_word_utts, std::max<size_t>(1, word_utts.size()) * 4, word_utts.data(), word_utts.size() * 4);
     lay.add((void**)&e->d_word_off, word_off.size() * 4, word_off.data(), word_off.size() * 4);
-    lay.add((void**)&e->d_coff, coff.size() * 8, coff.data(), coff.size() * 8);
+    for (int h = 0; h < 2; ++h) {
+        lay.add((void**)&e->d_perm_h[h], std::max<size_t>(1, perm_h[h].size()) * 8, perm_h[h].data(), perm_h[h].size() * 8);
+        lay.add((void**)&e->d_coff_h[h], std::max<size_t>(1, coff_h[h].size()) * 8, coff_h[h].data(), coff_h[h].size() * 8);
+    }
+    lay.add((void**)&e->d_stats1, (size_t)e->n_stats * 8, nullptr);
     lay.add((void**)&e->d_alpha, std::max<size_t>(1, cacc) * 8, nullptr);
     lay.add((void**)&e->d_logp, std::max<size_t>(1, U) * 8, nullptr);
     lay.add((void**)&e->d_xi_utt, std::max<size_t>(1, U) * GH_FBCHAIN_MAX * 8, nullptr);
@@ -292,6 +336,9 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     lay.add((void**)&e->d_hist, (size_t)e->hist_cap * 4 * 8, nullptr);
     hipError_t he = hipMalloc(&e->d_arena, lay.total);
     if (he == hipSuccess) he = hipHostMalloc((void**)&e->h_tail, 64, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_half, hipEventDisableTiming);
     if (he != hipSuccess) {
         gh_set_error("gh_em_create: %s", hipGetErrorString(he));
         gh_em_destroy(e);
@@ -318,21 +365,42 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
     GH_REQUIRE(b->N == e->N && b->U == e->U, "gh_em_iteration: the batch changed under the session");
     int rc = gh_batch_ensure_nll(ctx, b, e->S, true);
     if (rc) return rc;
-    if (e->N > 0) {
-        rc = gh_launch_loglik_mfma(ctx, e->gmm, b, nullptr, nullptr, nullptr, e->ll_subset ? &e->ll_plan : nullptr);
-        if (rc == 1) { gh_set_error("gh_em_iteration: likelihood shape not covered"); return GH_ERR_UNSUPPORTED; }
+    // half h: own-state likelihoods -> forward-backward -> statistics, all on stream `on`
+    auto run_half = [&](int h, hipStream_t on, double* stats_out) -> int {
+        hipStream_t keep = ctx->stream;
+        ctx->stream = on;                      // (the launch helpers enqueue on the context's stream)
+        int r = GH_OK;
+        if (e->N > 0 && e->Uh[h] > 0) {
+            r = gh_launch_loglik_mfma(ctx, e->gmm, b, nullptr, nullptr, nullptr, e->ll_subset ? &e->ll_plan[h] : nullptr);
+            if (r == 1) { gh_set_error("gh_em_iteration: likelihood shape not covered"); r = GH_ERR_UNSUPPORTED; }
+            if (!r) {
+                gh_fbchain_args ca;
+                memset(&ca, 0, sizeof ca);
+                ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
+                ca.perm = e->d_perm_h[h]; ca.U = e->Uh[h]; ca.alpha_scratch = e->d_alpha; ca.scratch_off = e->d_coff_h[h];
+                ca.logp = e->d_logp; ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt;
+                r = gh_launch_fb_chain(ctx, ca, true);
+            }
+        }
+        if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, GH_FBCHAIN_MAX, 0, e->occ_floor,
+                                  e->d_chains, stats_out);
+        ctx->stream = keep;
+        return r;
+    };
+    if (e->n_half == 2) {
+        GH_HIP(hipEventRecord(e->ev_start, st));             // behind the previous iteration's model re-pack
+        GH_HIP(hipStreamWaitEvent(e->s2, e->ev_start, 0));
+        rc = run_half(1, e->s2, e->d_stats1);
         if (rc) return rc;
-        gh_fbchain_args ca;
-        memset(&ca, 0, sizeof ca);
-        ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
-        ca.perm = b->d_perm; ca.U = e->U; ca.alpha_scratch = e->d_alpha; ca.scratch_off = e->d_coff; ca.logp = e->d_logp;
-        ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt;
-        rc = gh_launch_fb_chain(ctx, ca, true);
-        if (rc) return rc;
+        GH_HIP(hipEventRecord(e->ev_half, e->s2));
     }
-    rc = gh_bwf_launch(ctx, e->bw_plan, e->gmm, (const double*)b->feats, e->d_gam, GH_FBCHAIN_MAX, 0, e->occ_floor, e->d_chains,
-                       e->d_packed);
+    rc = run_half(0, st, e->d_packed);
     if (rc) return rc;
+    if (e->n_half == 2) {
+        GH_HIP(hipStreamWaitEvent(st, e->ev_half, 0));
+        hipLaunchKernelGGL(em_add_kernel, dim3((unsigned)((e->n_stats + 255) / 256)), dim3(256), 0, st, e->d_packed, (const double*)e->d_stats1, e->n_stats);
+        GH_HIP(hipGetLastError());
+    }
     double* tail = e->d_packed + e->n_stats;
     hipLaunchKernelGGL(em_tail_kernel, dim3(e->W + 1), dim3(256), 0, st, e->d_xi_utt, e->d_logp, e->d_word_utts, e->d_word_off,
                        e->W, e->n, e->U, tail, e->d_flags);

@@ -286,7 +286,7 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
 // persistent block table of the subset likelihood kernel (built once by a trainer whose transcripts never change)
 struct gh_loglik_plan { void* d_blk; int64_t n_blk; int max_tiles; };
 int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
-                         const int64_t* rng_off, gh_loglik_plan* out);   // 1 = not covered
+                         const int64_t* rng_off, gh_loglik_plan* out, const uint8_t* include = nullptr);   // 1 = not covered; include [U]: part of the batch
 void gh_loglik_plan_free(gh_loglik_plan* p);
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo = nullptr,
                           const int32_t* st_hi = nullptr, const int64_t* rng_off = nullptr,   // rng_off: several ranges per utterance

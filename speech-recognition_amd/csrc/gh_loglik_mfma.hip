@@ -530,11 +530,13 @@ static void chunk_shape(const gh_gmm* g, int* chunk_tiles_out, int* SC_out) {
 // tiles; runs that touch are merged (two words may share a tile), and every run gets its own table entries for the
 // utterance's 32-frame blocks.  Returns 1 when a run is wider than one LDS chunk (the caller computes the full matrix).
 static int build_blk_table(const gh_gmm* g, const gh_batch* b, int SC, const int32_t* st_lo, const int32_t* st_hi,
-                           const int64_t* rng_off, std::vector<gh_loglik_blk>& tabv, int* max_tiles_out) {
+                           const int64_t* rng_off, std::vector<gh_loglik_blk>& tabv, int* max_tiles_out,
+                           const uint8_t* include = nullptr) {
     const int M_pad = g->M_pad, S = g->S;
     int max_tiles = 1;
     std::vector<std::pair<int, int>> runs;
     for (int64_t u = 0; u < b->U; ++u) {
+        if (include && !include[u]) continue;      // (a table over part of the batch: the two halves of gh_em_iteration)
         runs.clear();
         const int64_t r0 = rng_off ? rng_off[u] : u, r1 = rng_off ? rng_off[u + 1] : u + 1;
         for (int64_t r = r0; r < r1; ++r) {
@@ -662,7 +664,7 @@ int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32
 
 // a block table that outlives the call (own allocation): 1 = shape / ranges not covered by the subset kernel
 int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
-                         const int64_t* rng_off, gh_loglik_plan* out) {
+                         const int64_t* rng_off, gh_loglik_plan* out, const uint8_t* include) {
     out->d_blk = nullptr; out->n_blk = 0; out->max_tiles = 1;
     if (!g->dApk64) return 1;
     const int KS = g->KP / 2;
@@ -670,7 +672,7 @@ int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const 
     int chunk_tiles, SC;
     chunk_shape(g, &chunk_tiles, &SC);
     std::vector<gh_loglik_blk> tabv;
-    int rc = build_blk_table(g, b, SC, st_lo, st_hi, rng_off, tabv, &out->max_tiles);
+    int rc = build_blk_table(g, b, SC, st_lo, st_hi, rng_off, tabv, &out->max_tiles, include);
     if (rc) return rc;
     out->n_blk = (int64_t)tabv.size();
     if (tabv.empty()) return GH_OK;

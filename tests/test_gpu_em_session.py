@@ -105,6 +105,24 @@ def test_session_enqueued_iterations_equal_synchronous_ones():
         t.close()
 
 
+def test_session_two_halves_on_two_streams_give_the_same_numbers(monkeypatch):
+    """GMMHMM_EM_TWO_STREAMS=1: the utterances in two halves on two HIP streams that join before the tail kernel
+    (an experiment that did not pay, kept behind the switch): same statistics up to the order of one addition."""
+    from sr.recognition.train import BaumWelchTrainer
+    means, vars_, w, trans, data, labels = c3_problem(2500)
+    a = BaumWelchTrainer(means, vars_, w, trans, data, labels)
+    monkeypatch.setenv("GMMHMM_EM_TWO_STREAMS", "1")
+    b = BaumWelchTrainer(means, vars_, w, trans, data, labels)
+    monkeypatch.delenv("GMMHMM_EM_TWO_STREAMS")
+    ha, hb = a.fit(4), b.fit(4)
+    _close(hb, ha, 1e-12)
+    _close(b.means, a.means, 1e-9, 1e-12)
+    _close(b.vars, a.vars, 1e-8)
+    _close(b.weights, a.weights, 1e-9, 1e-13)
+    a.close()
+    b.close()
+
+
 def test_session_rejects_what_it_does_not_cover():
     from sr.recognition import _hip
     from sr.recognition.train import BaumWelchTrainer
