@@ -507,8 +507,9 @@ def _isolated_config(ctx, group, name, seed, U, W, n, M, D, npdt, peak_flops, mi
     lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
     group.barrier()
     t_ll, _ = _timeit(lambda: (b.loglik(gmm, fetch=False), ctx.sync()))
-    t_vit, r = _timeit(lambda: lat.viterbi(b, want_path=False))
-    words = np.argmin(r["end_cost_flat"].reshape(U, W), axis=1)
+    # (the recognised word = the cheapest word end: `best_end`, found on the device; the [U, W] end costs stay there)
+    t_vit, r = _timeit(lambda: lat.viterbi(b, want_path=False, want_end_cost=False))
+    words = r["best_end"]
     esz = np.dtype(npdt).itemsize
     N = b.N
     flops, bytes_ll, bytes_vit = 2.0 * 2 * D * S * M * N, float(esz * (D + S) * N), float(esz * S * N)
@@ -822,6 +823,32 @@ def _ctrain_config(ctx, U, K=7, iters=6):
             "note": "steady = median of the second half of the iterations (the first ones grow the scratch arenas); round 2: 750 ms"}
 
 
+def _train_words_config(ctx, W=10, templates=200, n=5, ng=4):
+    """Isolated-word training of all word models in one pass (`batch.train_words`: sr/core.py:47-60 trains word after
+    word): segmental k-means of all words in lock-step, the W x n mixtures refit in one device-resident session, all
+    templates re-aligned in one launch."""
+    import contextlib
+    import io
+    import warnings
+    from sr.recognition.batch import train_words
+    wl = synth_workload(1006, W * templates, W=W, n=n, M=ng)
+    order = np.argsort(wl["words"], kind="stable")
+    words = [[wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in order[wl["words"][order] == w]] for w in range(W)]
+    N = int(wl["off"][-1])
+
+    def run():
+        np.random.seed(0)
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return train_words(words, n, n_gaussians=ng)
+    run()
+    t0 = time.perf_counter()
+    models = run()
+    dt = time.perf_counter() - t0
+    return {"workload": "isolated-word training, %d words x ~%d templates (%d frames, 39-dim), %d states, %d mixtures" % (W, templates, N, n, ng),
+            "ms": dt * 1e3, "templates_per_s": W * templates / dt, "frames_per_s": N / dt, "models": len(models)}
+
+
 def extra_configs(args, group, npdt, peak_flops, wl):
     """The other BASELINE configs, after the timed region.  With several ranks every rank runs its share of the legs
     that BASELINE defines on 8 GPUs (configs[4]: C5 K-layer lattice and loop grammar at 125 000 utterances per rank;
@@ -844,6 +871,7 @@ def extra_configs(args, group, npdt, peak_flops, wl):
         legs.append(("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)))
         legs.append(("C3_continuous_train", lambda: _ctrain_config(ctx, args.c3_utts)))
         legs.append(("C2_fp32_decode", lambda: fp32_mismatch_c2(ctx, wl)))
+        legs.append(("C2_train_words", lambda: _train_words_config(ctx)))
     legs.append(("C5", lambda: _continuous_config(ctx, group, args.c5_utts, min(args.c5_utts, 5000), npdt)))
     for key, fn in legs:
         t0 = time.perf_counter()

@@ -230,7 +230,8 @@ int gh_lattices_forms(const gh_lattices* l);
  * rows, first-minimum tie-break among origins, last-minimum among end points,
  * and the path convention (end -> start, end cell excluded, stops on reaching
  * column 0).
- *   out_end_cost  [sum_u n_end(u)]  cost of every end row at the last column
+ *   out_end_cost  [sum_u n_end(u)]  cost of every end row at the last column (may be NULL: the costs then stay on the
+ *                 device and only out_best_end comes back -- 8 MB less copy-back for 100 000 utterances x 10 word ends)
  *   out_best_end  [U]               index (into the graph's end list) chosen
  *   out_path      [path_off[U], 2]  (row, col) pairs, utterance u at path_off[u];
  *                                   path_off[u+1]-path_off[u] >= gh_viterbi_path_cap

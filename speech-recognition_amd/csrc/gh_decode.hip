@@ -237,8 +237,10 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     for (auto& lh : lat->lat) n_rows_total = std::max<int64_t>(n_rows_total, lh.row_base + lh.R);
     auto carve = [&]() -> int {
         Carver cv;
-        cv.add(&d_flag2, 64); cv.add(&d_bestend, U); cv.add(&d_endcost, n_end_total);
-        small_bytes = cv.total;
+        cv.add(&d_flag2, 64); cv.add(&d_bestend, U);
+        if (!out_end_cost) small_bytes = cv.total;       // (nobody wants the end costs: they stay on the device -- 8 MB of
+        cv.add(&d_endcost, n_end_total);                 //  copy-back for 100 000 utterances x 10 word ends otherwise)
+        if (out_end_cost) small_bytes = cv.total;
         if (want_bp) cv.add(&d_bpoff, U);
         if (!uniform) cv.add(&d_endoff, U + 1);
         if (utt_lattice) cv.add(&d_uttlat, U);

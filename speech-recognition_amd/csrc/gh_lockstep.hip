@@ -740,12 +740,14 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
                                                             int32_t* __restrict__ conv_at, int it, int* __restrict__ counter) {
     const int s = blockIdx.x, tid = threadIdx.x;
     if (!active[s]) return;
-    __shared__ int bad;
-    if (tid == 0) bad = 0;
+    __shared__ int bad, moved;
+    if (tid == 0) { bad = 0; moved = 0; }
     __syncthreads();
     const int Wd = 1 + 2 * D;
     const double* st = stats + (int64_t)s * plen;
-    int mine = 0;
+    int mine = 0, diff = 0;
+    // `same`: identical to the previous iteration's value, NaN counting as equal to NaN
+    auto same = [](double a, double b) { return a == b || (a != a && b != b); };
     for (int i = tid; i < k * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
         const double s0 = st[c * Wd], S1 = st[c * Wd + 1 + d], S2 = st[c * Wd + 1 + D + d];
@@ -755,16 +757,19 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
         const double mu = (m0 * s0 + S1) / occ;
         const double dl = mu - m0;
         const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
+        diff += !same(mu, m0) + !same(sg, var[at]);
         mean[at] = mu;
         var[at] = sg;
         mine += !fit_close(mu, old_mu[at]) + !fit_close(sg, old_sigma[at]);
     }
     if (tid < k) {
         const double w = st[tid * Wd] / nframes[s];
+        diff += !same(w, weight[(int64_t)s * k + tid]);
         weight[(int64_t)s * k + tid] = w;
         mine += !fit_close(w, old_w[(int64_t)s * k + tid]);
     }
     if (mine) atomicAdd(&bad, mine);
+    if (diff) atomicAdd(&moved, diff);
     __syncthreads();
     if (bad == 0) {
         if (tid == 0) { active[s] = 0; conv_at[s] = it; }
@@ -776,6 +781,14 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
         old_sigma[at] = var[at];
     }
     if (tid < k) old_w[(int64_t)s * k + tid] = weight[(int64_t)s * k + tid];
+    // A state whose parameters came out bit for bit as they went in (NaN = NaN) sits at a fixed point the allclose
+    // test cannot see -- an empty cluster's NaN mean poisons the whole mixture after one iteration, and the reference
+    // then spins to max_iteration on NaN == NaN being False.  Every further iteration would reproduce the same bits:
+    // the state stops here with the values the full loop ends with (converged_at stays -1).
+    if (moved == 0) {
+        if (tid == 0) active[s] = 0;
+        return;
+    }
     if (tid == 0) atomicAdd(counter, 1);
 }
 

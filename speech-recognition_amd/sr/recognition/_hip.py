@@ -926,16 +926,17 @@ class Lattices:
     def path_cap(self, l, T):
         return int(self.ctx.lib.gh_viterbi_path_cap(self.h, int(l), int(T)))
 
-    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False):
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True):
         """A6 for every utterance.  Returns dict(end_cost [list per utt], best_end [U],
-        paths [list of int64 [K,2]], costs [list of [R,T]])."""
+        paths [list of int64 [K,2]], costs [list of [R,T]]).  want_end_cost=False: only best_end (the cheapest end
+        row, last minimum on ties: decode.py:129-134) comes back, the end costs stay on the device."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
         lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
         T = batch.lengths
         n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
         end_off = np.concatenate([[0], np.cumsum(n_end)])
-        end_cost = np.empty(int(end_off[-1]), dtype=np.float64)
+        end_cost = np.empty(int(end_off[-1]), dtype=np.float64) if want_end_cost else None
         best_end = np.empty(U, dtype=np.int32)
         path = path_off = path_len = costs = costs_off = None
         if want_path:
@@ -951,7 +952,7 @@ class Lattices:
                                    _ptr(best_end, _c_i32p), _ptr(path, _c_i32p), _ptr(path_off, _c_i64p),
                                    _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p), _ptr(costs_off, _c_i64p)))
         out = dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost,
-                   end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if U <= 2048 else None)
+                   end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if (U <= 2048 and want_end_cost) else None)
         if want_path:
             out["paths"] = [path[path_off[u]:path_off[u] + path_len[u]].astype(np.int64) for u in range(U)]
         if want_costs:

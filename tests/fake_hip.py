@@ -253,7 +253,7 @@ class Lattices:
     def path_cap(self, l, T):
         return 3 * T
 
-    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False):
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True):
         """Each start row is decoded as its own reference problem (the reference has ONE start cell,
         row 0; a stacked graph is W independent chains), then merged."""
         U = batch.U
