@@ -189,6 +189,9 @@ class AlignmentPlan:
 
     def __init__(self, label_seqs, n, n_words):
         self.n, self.n_words = n, n_words
+        for u, labels in enumerate(label_seqs):
+            if len(labels) == 0:     # (no layer, no end row: the library rejects such a graph; say which utterance it is)
+                raise ValueError("utterance %d has an empty transcript: a forced alignment needs at least one word" % u)
         self.state_sets = transcript_state_sets(label_seqs, n, n_words)
         keys, self.transcripts, self.utt_graph = {}, [], np.empty(len(label_seqs), dtype=np.int32)
         for u, labels in enumerate(label_seqs):
