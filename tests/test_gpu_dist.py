@@ -200,3 +200,26 @@ def test_bench_single_gpu_runs_the_collective_on_rccl():
     assert not any("error" in v for v in cfg.values() if isinstance(v, dict)), cfg
     assert cfg["C2_fp32_decode"]["fp32_word_mismatch_rate"] == 0.0
     assert cfg["C5_loop_grammar"]["n_gpus"] == 1
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver starts an N-rank bench as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+    the launcher only provides the environment (RANK / WORLD_SIZE / MASTER_*), the ranks use the library's own RCCL
+    communicator -- the unique id travels over MASTER_PORT + 1, next to the launcher's store on MASTER_PORT."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    two = _n_gpus() >= 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--ramp-seconds", "0.1", "--utts", "400", "--em-utts", "300", "--em-iters", "2", "--no-cpu-baseline", "--no-extra-configs"]
+    if not two:
+        cmd.append("--same-gpu")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["process_group"] == "native" and out["em"]["rccl_ranks"] == 2
+    assert out["decode_accuracy"] == 1.0 and out["em"]["loglik_monotone"]
