@@ -749,10 +749,12 @@ def _training_config(ctx, U, K=7):
 
 
 def _c4_em_config(ctx, group, U):
-    """Soft-EM iterations at the configs[3] shape (64 words x 16 states x 32 mixtures): M = 32 and n = 16 are outside the
-    fused matrix-core statistics kernel and the one-lane-group chain forward-backward, so this leg runs the GENERIC
-    kernels (fb_kernel: one workgroup per utterance; bw_stats_kernel: densities on the VALU) call by call, with the
-    20.7 MB statistics buffer reduced through the group's communicator."""
+    """Soft-EM iterations at the configs[3] shape (64 words x 16 states x 32 mixtures).  Round 3: the device-resident
+    session covers it -- own-state likelihoods (32 Gaussian tiles per 32-frame block instead of 2048), chain
+    forward-backward with 16 lanes per utterance, the matrix-core statistics kernel with one wave per 16 components of a
+    state (normalised by the likelihood kernel's per-state sums), the 20.7 MB statistics buffer all-reduced on the
+    stream by the library's communicator, M-step and model re-pack on the device.  (Round 2 and early round 3: generic
+    kernels, call by call, M-step in numpy: 36.9 ms per iteration for 1 000 utterances.)"""
     from sr.recognition.train import BaumWelchTrainer
     wl = synth_workload(1004, U, W=64, n=16, M=32, D=39, utt_seed=None if group.rank == 0 else 1004 + 7919 * group.rank)
     W = wl["W"]
@@ -763,18 +765,24 @@ def _c4_em_config(ctx, group, U):
     if group.kind == "torch":
         from sr.recognition.parallel import StatsAllReducer
         red = StatsAllReducer(gpu_index=group.dev)
-    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device, reducer=red)
+    kw = {"occ_floor": float(os.environ["EM_OCC_FLOOR"])} if "EM_OCC_FLOOR" in os.environ else {}    # (experiments: tools/time_c4_em.py)
+    tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device, reducer=red, **kw)
+    del data
     hist = [tr.iteration()]
+    iters = 4
     group.barrier()
     t0 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(iters):
         hist.append(tr.iteration())
-    dt = group.max((time.perf_counter() - t0) / 2)
+    dt = group.max((time.perf_counter() - t0) / iters)
     tot = group.sum([float(U), float(tr.batch.N)])
-    out = {"workload": "configs[3] shape, soft EM: 64 x 16 states x 32 mixtures, 39-dim, %d utterances per GPU (generic kernels)" % U,
+    resident = tr.session is not None
+    out = {"workload": "configs[3] shape, soft EM: 64 x 16 states x 32 mixtures, 39-dim, %d utterances per GPU (%s)"
+                       % (U, "device-resident iteration" if resident else "generic kernels, call by call"),
            "n_gpus": group.world, "utterances": int(tot[0]), "frames": int(tot[1]), "ms_per_iteration": dt * 1e3,
-           "em_frames_per_s": tot[1] / dt, "device_resident_iteration": tr.session is not None,
+           "em_frames_per_s": tot[1] / dt, "em_utterances_per_s": tot[0] / dt, "device_resident_iteration": resident,
            "allreduce_bytes": tr._packed_len() * 8,
+           "loglik_per_frame": [h / tot[1] for h in hist],
            "loglik_monotone": bool(all(y >= x - 1e-9 * abs(x) for x, y in zip(hist, hist[1:])))}
     tr.close()
     return out
@@ -866,7 +874,7 @@ def extra_configs(args, group, npdt, peak_flops, wl):
         legs.append(("C1x1000", lambda: _isolated_config(ctx, group, "configs[0] x1000: 10x5 states, 1 Gaussian, 13-dim, 100 000 utterances",
                                                          1001, 100000, 10, 5, 1, 13, npdt, peak_flops)))
     legs.append(("C4", lambda: _isolated_config(ctx, group, c4_name, 1004, c4_utts, 64, 16, 32, 39, npdt, peak_flops)))
-    legs.append(("C4_em", lambda: _c4_em_config(ctx, group, args.c4_em_utts)))
+    legs.append(("C4_em", lambda: _c4_em_config(ctx, group, args.c4_em_utts if args.c4_em_utts else c4_utts)))
     if one:
         legs.append(("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)))
         legs.append(("C3_continuous_train", lambda: _ctrain_config(ctx, args.c3_utts)))
@@ -973,7 +981,7 @@ def main():
     ap.add_argument("--em-total", type=int, default=0,
                     help="strong scaling of the EM leg: this many utterances in total, sharded over the ranks by frames "
                          "(configs[2]: 100000); default 0 = --em-utts per GPU (weak)")
-    ap.add_argument("--c4-em-utts", type=int, default=1000, help="utterances per GPU of the C4-shape EM leg")
+    ap.add_argument("--c4-em-utts", type=int, default=0, help="utterances per GPU of the C4-shape EM leg (default: those of the C4 leg)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip C1 x1000 / C4 / C5 / PCIe legs (single-GPU runs only)")
     ap.add_argument("--c4-utts", type=int, default=0, help="utterances of the C4 leg (default: 50 000 = configs[3] on one "
                                                          "GPU, 10 000 per GPU in an N-rank run)")

@@ -372,7 +372,11 @@ int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch* b,
  * (the same centred layout as gh_em_accumulate; [S, M, 1+2D], 253 KB for 50 x 8 x 39).
  * States whose occupancy is <= occ_floor on a whole 128-frame tile are skipped.  Deterministic
  * (per-workgroup slabs + ordered reduction).  stats_dev (may be NULL): device pointer that
- * receives the result instead of scratch, e.g. a torch tensor about to be all-reduced by RCCL. */
+ * receives the result instead of scratch, e.g. a torch tensor about to be all-reduced by RCCL.
+ * Mixtures of more than 8 components on one-word chain graphs (BASELINE configs[3]: 16 states x 32 mixtures): the
+ * matrix-core statistics kernel takes the denominators sum_m' w pdf from the batch's likelihood matrix -- the one the
+ * forward-backward consumed -- when that matrix was computed with THIS model handle in its present state (the library
+ * keeps a stamp per model and per matrix); otherwise the generic kernel recomputes the densities.  Same results. */
 int gh_bw_accumulate(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, double occ_floor,
                      double* out_stats /*[S,M,1+2D] or NULL*/, double* stats_dev /*or NULL*/);
 

@@ -22,6 +22,11 @@
 //     (= word), a wave owns a PAIR of states (16 = 2 x 8 component columns), a workgroup = the pairs of one word;
 //   * one raw [80, 16] tile per wave leaves the workgroup; a small kernel sums the tiles of a pair over its
 //     workgroups in a fixed order and converts them (deterministic, no float atomics).
+// Mixtures of more than 8 components (WIDE; BASELINE configs[3]: 16 states x 32 mixtures per word): a wave owns 16
+// CONSECUTIVE COMPONENTS OF ONE STATE (a "column group": state r, components 16 c .. 16 c + 15), so a state's mixture
+// spans several waves and the normaliser sum_m' w_m' pdf_m'(x) cannot be formed inside one; it is not recomputed either:
+// it IS the state's likelihood, which the likelihood kernel wrote into the batch's [N, S] matrix for the forward-backward
+// that produced gamma (same model: gh_gmm::serial == gh_batch::nll_serial is checked).  r = gamma exp(log(w pdf) + nll).
 #include "gh_internal.h"
 #include "gh_host.h"
 
@@ -30,7 +35,8 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct bwf_wg { int32_t graph, u_begin, u_end, pad; };           // utterances ulist[u_begin, u_end) of one graph
-struct bwf_pair { int32_t sa, sb, wg_begin, wg_end, p, pad; };    // state pair p of a graph, its workgroups
+struct bwf_pair { int32_t sa, sb, wg_begin, wg_end, p, m0; };     // column group p of a graph (states sa, sb (or -1), or -- WIDE --
+                                                                  // components m0 .. m0 + 15 of state sa), its workgroups
 
 __device__ __forceinline__ double bwf_vmax(double a, double b) {
     double r;
@@ -82,15 +88,16 @@ __device__ __forceinline__ double bwf_exp2s(double y, const double* __restrict__
 // density MFMAs 28 %, accumulation MFMAs 32 %, responsibilities 19 %, HBM 5 %, barriers 1.5 % of its 0.72 ms -- so the way
 // down was less work, not fewer stalls; skipping zero blocks inside that structure only gained 14 % because the waves of a
 // workgroup still met at every tile.)
-template <int KS, int LT>
-__global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
+template <int KS, int LT, bool WIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
                                                      const double* __restrict__ mean, const double* __restrict__ ivar,
                                                      const double* __restrict__ logc, const double* __restrict__ gam,
                                                      double occ_floor, int gam_stride, int gam_by_state, const int64_t* __restrict__ seg_first,
                                                      const int32_t* __restrict__ seg_len,
                                                      const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
                                                      const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial, int slot_shift,
+                                                     const double* __restrict__ nll, int nll_S) {
     constexpr int KP = 2 * KS;            // padded feature length
     constexpr int TF = 16;                // frames per block
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -98,21 +105,25 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
                                           // below need no bounds test
     double* xt = sm;                      // [TF][DP]
     double* gt = xt + TF * DP;            // [TF][2]  gamma of the block's frames for the pair's two states
-    double* tab = gt + TF * 2;            // [128]    2^(j/128)
+    double* nt = gt + TF * 2;             // [TF]     WIDE: K x the state's negative log-likelihood of the block's frames
+    double* tab = nt + (WIDE ? TF : 0);   // [128]    2^(j/128)
     const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
-    const int p = blockIdx.x & 3;         // state pair (4 slots per utterance group; slots beyond the word's pairs leave)
-    const bwf_wg wg = wgs[blockIdx.x >> 2];
+    const int p = blockIdx.x & ((1 << slot_shift) - 1);   // column group (slots beyond the word's groups leave)
+    const bwf_wg wg = wgs[blockIdx.x >> slot_shift];
     const gh_fbchain* ch = chains + wg.graph;
     const int n = ch->n;
-    if (2 * p >= n) return;
+    const int chunks = WIDE ? (M + 15) >> 4 : 1;          // 16-component pieces of a state's mixture
+    const int row_a = WIDE ? p / chunks : 2 * p;           // chain row(s) of this wave
+    const int row_b = (!WIDE && 2 * p + 1 < n) ? 2 * p + 1 : -1;
+    if (row_a >= n) return;
     for (int i = lane; i < 128; i += 64) tab[i] = tables[i];
     for (int i = lane; i < TF * DP; i += 64) xt[i] = 0.0;
     // ---- this wave's pair of states: operands that stay in registers for all its utterances ----
-    const int sa = ch->state[2 * p];
-    const int sb = (2 * p + 1 < n) ? ch->state[2 * p + 1] : -1;
-    const int s_j = (j < 8) ? sa : sb;
-    const int m_j = j & 7;
+    const int sa = ch->state[row_a];
+    const int sb = (row_b >= 0) ? ch->state[row_b] : -1;
+    const int s_j = (WIDE || j < 8) ? sa : sb;
+    const int m_j = WIDE ? (p - row_a * chunks) * 16 + j : (j & 7);
     const bool valid = s_j >= 0 && m_j < M;
     const int64_t g_j = valid ? (int64_t)s_j * M + m_j : 0;
     double P[KS];
@@ -151,13 +162,13 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
     // gamma columns of the pair: compact [N, 8] (column = chain row) or the frame x state occupancy matrix
     // (gam_by_state: stride S, column = the chain row's state -- sequence-form forward-backward)
     const int st = q & 1;                                       // lanes (frame j, state st): the upper half repeats the lower
-    const int grow_l = 2 * p + st;
-    const int gcol = (grow_l < n) ? (gam_by_state ? ch->state[grow_l] : grow_l) : -1;
+    const int grow_l = st ? row_b : row_a;
+    const int gcol = (grow_l >= 0) ? (gam_by_state ? ch->state[grow_l] : grow_l) : -1;
     constexpr int PX = (TF * KP + 63) / 64;                    // frame elements per lane of a staged block
-    const int gcol_a = gam_by_state ? ch->state[2 * p] : 2 * p;
-    const int gcol_b = (2 * p + 1 < n) ? (gam_by_state ? ch->state[2 * p + 1] : 2 * p + 1) : -1;
+    const int gcol_a = gam_by_state ? sa : row_a;
+    const int gcol_b = (row_b >= 0) ? (gam_by_state ? sb : row_b) : -1;
     __syncthreads();
-    double px[PX], pg = 0.0;                                   // the staged-ahead block: frames and gamma in registers
+    double px[PX], pg = 0.0, pn = 0.0;                         // the staged-ahead block: frames, gamma (and likelihoods) in registers
     for (int ui = wg.u_begin; ui < wg.u_end; ++ui) {
         const int32_t u = ulist[ui];
         const int64_t f0 = seg_first[u];
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
 #else
                 pg = (j < nf_ && gcol >= 0) ? gam[(f0 + bf + j) * gam_stride + gcol] : 0.0;
 #endif
+                if (WIDE) pn = (lane < nf_) ? nll[(f0 + bf + lane) * (int64_t)nll_S + sa] : 0.0;
             };
             int blk = todo ? __builtin_ctzll(todo) : -1;
             if (blk >= 0) fetch(blk);
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
                     if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = px[e]; }
                 }
                 if (lane < 32) gt[j * 2 + st] = pg;
+                if (WIDE && lane < TF) nt[lane] = pn * GH_LSE_SCALE64;
                 todo &= todo - 1;
                 const int nxt = todo ? __builtin_ctzll(todo) : -1;
                 if (nxt >= 0) fetch(nxt);      // travels from HBM while this block is computed
@@ -248,6 +261,13 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
                 for (int r = 0; r < 4; ++r) {
                     const int fr = q + 4 * r;
                     const double y = da[r];
+                    if (WIDE) {
+                        // log(w pdf) - log sum_m' w pdf = y + K nll: the likelihood kernel's own normaliser
+                        const double e = bwf_exp2s(y + nt[fr], tab);
+                        const double g = gt[fr * 2];
+                        const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
+                        R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? e * wgt : 0.0;
+                    } else {
                     const double mx = max8(y);
                     const double e = bwf_exp2s(y - mx, tab);
                     const double s8 = sum8(e);
@@ -258,6 +278,7 @@ __global__ __launch_bounds__(64) void bw_fused_kernel(const double* __restrict__
                     inv = fma(fma(-s8, inv, 1.0), inv, inv);
                     const double rv = e * (wgt * inv);
                     R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? rv : 0.0;   // (every component off: s8 = 8, e = 1 -- killed by `valid`)
+                    }
                 }
 #endif
                 // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames {0..3} + 4 r ----
@@ -315,12 +336,12 @@ __global__ __launch_bounds__(256) void bw_fused_reduce_kernel(const double* __re
     const int len = 2 * lt * 16 * 16;
     const double* G = gsum + (int64_t)blockIdx.x * len;   // [2*lt*16][16]: rows d < D linear, row D the occupancy, rows 16 lt + d squared
     const int W = 1 + 2 * D;
-    for (int i = threadIdx.x; i < 2 * M * (D + 1); i += blockDim.x) {
-        const int h = i / (M * (D + 1)), rem = i - h * M * (D + 1);
-        const int m = rem / (D + 1), d = rem - m * (D + 1);
-        const int s = h ? pr.sb : pr.sa;
-        if (s < 0) continue;
-        const int jj = 8 * h + m;
+    const bool wide = M > 8;
+    for (int i = threadIdx.x; i < 16 * (D + 1); i += blockDim.x) {
+        const int jj = i / (D + 1), d = i - jj * (D + 1);         // tile column jj = (state slot, component)
+        const int s = (wide || jj < 8) ? pr.sa : pr.sb;
+        const int m = wide ? pr.m0 + jj : (jj & 7);
+        if (s < 0 || m >= M) continue;
         const double s0 = G[D * 16 + jj];
         double* o = out + ((int64_t)s * M + m) * W;
         if (d == D) {
@@ -335,16 +356,16 @@ __global__ __launch_bounds__(256) void bw_fused_reduce_kernel(const double* __re
 }
 
 // compact gamma -> the [N, S] occupancy matrix of the generic statistics kernel (pre-cleared by the caller)
-__global__ void expand_gam_kernel(const double* __restrict__ gam, const int64_t* __restrict__ utt_off, const int32_t* __restrict__ utt_graph,
+__global__ void expand_gam_kernel(const double* __restrict__ gam, int lanes, const int64_t* __restrict__ utt_off, const int32_t* __restrict__ utt_graph,
                                   const gh_fbchain* __restrict__ chains, int S, double* __restrict__ occ, int32_t* __restrict__ occ_states) {
     const int64_t u = blockIdx.x;
     const gh_fbchain* ch = chains + (utt_graph ? utt_graph[u] : 0);
     const int n = ch->n;
     if (threadIdx.x < GH_FBCHAIN_MAX) occ_states[u * GH_FBCHAIN_MAX + threadIdx.x] = threadIdx.x < n ? ch->state[threadIdx.x] : -1;
     const int64_t f0 = utt_off[u], f1 = utt_off[u + 1];
-    for (int64_t i = f0 * GH_FBCHAIN_MAX + threadIdx.x; i < f1 * GH_FBCHAIN_MAX; i += blockDim.x) {
-        const int64_t f = i / GH_FBCHAIN_MAX;
-        const int jx = (int)(i - f * GH_FBCHAIN_MAX);
+    for (int64_t i = f0 * lanes + threadIdx.x; i < f1 * lanes; i += blockDim.x) {
+        const int64_t f = i / lanes;
+        const int jx = (int)(i - f * lanes);
         if (jx < n) occ[f * S + ch->state[jx]] = gam[i];
     }
 }
@@ -366,7 +387,7 @@ int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S) {
     int32_t* d_ug = (int32_t*)((char*)base + ((L * sizeof(gh_fbchain) + 255) & ~size_t(255)));
     GH_HIP(hipMemcpyAsync(d_chains, b->gam_chains.data(), L * sizeof(gh_fbchain), hipMemcpyHostToDevice, st));
     if (!b->gam_utt_graph.empty()) GH_HIP(hipMemcpyAsync(d_ug, b->gam_utt_graph.data(), (size_t)b->U * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(expand_gam_kernel, dim3((unsigned)b->U), dim3(256), 0, st, b->gam, b->d_offsets,
+    hipLaunchKernelGGL(expand_gam_kernel, dim3((unsigned)b->U), dim3(256), 0, st, b->gam, b->gam_lanes, b->d_offsets,
                        b->gam_utt_graph.empty() ? nullptr : d_ug, d_chains, S, b->occ, b->d_occ_states);
     GH_HIP(hipGetLastError());
     GH_HIP(hipStreamSynchronize(st));
@@ -383,8 +404,11 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     const int lt = (D + 1 + 15) / 16;     // 16-column tiles of each half of Z = [x - c, 1 | (x - c)^2]
     const std::vector<gh_fbchain>& chains = seq ? b->seq_word_chains : b->gam_chains;
     if (seq ? !(b->seq_seg_valid && b->occ && b->occ_valid && b->occ_S == S) : !b->gam) return 1;
-    if (chains.empty() || M > 8 || lt > 3) return 1;
+    if (chains.empty() || M > 64 || lt > 3) return 1;
     if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
+    // M > 8: the mixture normalisers are the batch's likelihoods -- they must be this model's (else: generic kernel)
+    const bool wide = M > 8;
+    if (wide && !(b->nll && b->nll_S == S && b->dtype == GH_F64 && b->nll_serial == g->serial && g->serial != 0)) return 1;
     const int L = (int)chains.size();
     // a state may only sit in one place of one graph (the re-centring kernel writes every state once)
     std::vector<int> owner(S, -1);
@@ -398,7 +422,7 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
         }
         max_pairs = std::max(max_pairs, (fc.n + 1) / 2);
     }
-    if (max_pairs > 4) return 1;
+    if (!wide && max_pairs > 8) return 1;
     // segments: (first frame, length, graph); grouped by graph, longest first inside a graph
     const int64_t U = b->U;
     std::vector<int64_t> seg_first;
@@ -453,7 +477,8 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     if (rc) return rc;
     double* d_out = stats_dev ? stats_dev : plan.d_own;
     *d_result = d_out;
-    rc = gh_bwf_launch(ctx, plan, g, (const double*)b->feats, seq ? b->occ : b->gam, seq ? S : 8, seq ? 1 : 0, occ_floor, nullptr, d_out);
+    rc = gh_bwf_launch(ctx, plan, g, (const double*)b->feats, seq ? b->occ : b->gam, seq ? S : b->gam_lanes, seq ? 1 : 0, occ_floor, nullptr,
+                       d_out, wide ? (const double*)b->nll : nullptr, S);
     if (rc) return rc;
     GH_HIP(hipStreamSynchronize(ctx->stream));   // the plan lives in the context's scratch: the next call may overwrite it
     return GH_OK;
@@ -468,15 +493,27 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
     const int KS = KP / 2;
     const int lt = (D + 1 + 15) / 16;
     const int L = (int)chains.size();
-    if (chains.empty() || M > 8 || lt > 3) return 1;
+    if (chains.empty() || M > 64 || lt > 3) return 1;
     if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
+    const bool wide = M > 8;
+    const int chunks = wide ? (M + 15) / 16 : 1;
+    int max_groups = 1;                    // column groups (= waves of a workgroup) of the widest word
+    for (const gh_fbchain& fc : chains) {
+        if (fc.n > GH_FBCHAIN_MAX) return 1;
+        max_groups = std::max(max_groups, wide ? fc.n * chunks : (fc.n + 1) / 2);
+    }
+    int slot_shift = 2;
+    while ((1 << slot_shift) < max_groups) ++slot_shift;
+    if (slot_shift > 6) return 1;
+    const int slots = 1 << slot_shift;
     const int64_t n_seg = (int64_t)seg_first.size();
     // workgroups of 3 waves (5 states = 3 pairs): FOUR per CU put exactly three waves on every SIMD (with three per CU
     // one SIMD carries three waves, the others two: the kernel ran at the pace of the fullest one)
     // utterance groups: (groups of a word) x (its state pairs) waves in all; 8 waves per CU are resident at this kernel's
     // register count, so ~8 n_cu / 3 groups for 5-state words put every wave on the chip at once (GMMHMM_BWF_WGS: groups
     // per CU, default 2: measured 1.44 / 1.09 / 1.13 / 1.12 ms per EM iteration for 1 / 2 / 3 / 4)
-    const int target_wgs = (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 2) * ctx->n_cu;
+    // (words of many column groups -- 32 for configs[3] -- fill the chip with fewer utterance groups)
+    const int target_wgs = std::max(1, (getenv("GMMHMM_BWF_WGS") ? atoi(getenv("GMMHMM_BWF_WGS")) : 2) * ctx->n_cu * 3 / std::max(3, max_groups));
     const int per_wg = (int)std::max<int64_t>(4, (n_seg + target_wgs - 1) / target_wgs);
     std::vector<int32_t> ulist;
     std::vector<bwf_wg> wgs;
@@ -493,15 +530,20 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
             wgs.push_back(x);
         }
         const gh_fbchain& fc = chains[l];
-        for (int p = 0; 2 * p < fc.n; ++p)
-            pairs.push_back(bwf_pair{fc.state[2 * p], 2 * p + 1 < fc.n ? fc.state[2 * p + 1] : -1, wg_begin, (int32_t)wgs.size(), p, 0});
+        if (wide) {
+            for (int r = 0; r < fc.n; ++r)
+                for (int c = 0; c < chunks; ++c)
+                    pairs.push_back(bwf_pair{fc.state[r], -1, wg_begin, (int32_t)wgs.size(), r * chunks + c, 16 * c});
+        } else {
+            for (int p = 0; 2 * p < fc.n; ++p)
+                pairs.push_back(bwf_pair{fc.state[2 * p], 2 * p + 1 < fc.n ? fc.state[2 * p + 1] : -1, wg_begin, (int32_t)wgs.size(), p, 0});
+        }
     }
     const int W = 1 + 2 * D;
     const int tile_len = 2 * lt * 16 * 16;
     out->KS = KS; out->lt = lt; out->S = S; out->M = M; out->D = D; out->L = L;
     out->n_wgs = (int)wgs.size(); out->n_pairs = (int)pairs.size(); out->tile_len = tile_len;
-    out->max_pairs = 1;
-    for (const gh_fbchain& fc : chains) out->max_pairs = std::max(out->max_pairs, (fc.n + 1) / 2);
+    out->max_pairs = max_groups; out->slot_shift = slot_shift;
     bwf_wg* d_wgs; bwf_pair* d_pairs;
     // layout: [own result | lists (one upload) | partial tiles | pair sums]
     UploadLayout lay;
@@ -512,7 +554,7 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
     lay.add((void**)&out->d_chains, (size_t)L * sizeof(gh_fbchain), chains.data(), (size_t)L * sizeof(gh_fbchain));
     lay.add((void**)&out->d_segfirst, std::max<size_t>(1, seg_first.size()) * 8, seg_first.data(), seg_first.size() * 8);
     lay.add((void**)&out->d_seglen, std::max<size_t>(1, seg_len.size()) * 4, seg_len.data(), seg_len.size() * 4);
-    lay.add((void**)&out->d_part, std::max<size_t>(1, wgs.size()) * (size_t)4 * tile_len * 8, nullptr);
+    lay.add((void**)&out->d_part, std::max<size_t>(1, wgs.size()) * (size_t)slots * tile_len * 8, nullptr);
     lay.add((void**)&out->d_gsum, std::max<size_t>(1, pairs.size()) * (size_t)tile_len * 8, nullptr);
     void* base = nullptr;
     if (persistent) {
@@ -536,21 +578,24 @@ void gh_bwf_plan_free(gh_bwf_plan* p) {
 // enqueue the fused statistics kernel + its two reduction kernels on the context's stream (no host sync).
 // d_chains: the chains (n, state[]) on the device, or null for the copy the plan was built with.
 int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
-                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out) {
+                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out, const double* nll, int nll_S) {
     hipStream_t st = ctx->stream;
     const int S = pl.S, M = pl.M, D = pl.D, KS = pl.KS, lt = pl.lt;
     const int W = 1 + 2 * D;
     GH_HIP(hipMemsetAsync(d_out, 0, (size_t)S * M * W * 8, st));
     if (pl.n_wgs == 0) return GH_OK;
-    const size_t lds = ((size_t)16 * ((2 * KS) | 1) + 16 * 2 + 128) * 8;
-    const dim3 grid((unsigned)pl.n_wgs * 4), blk(64);   // one wave per (utterance group, pair slot)
+    const bool wide = M > 8;
+    if (wide && !nll) { gh_set_error("gh_bwf_launch: internal: M = %d needs the batch's likelihoods", M); return GH_ERR_INVALID; }
+    const size_t lds = ((size_t)16 * ((2 * KS) | 1) + 16 * 2 + (wide ? 16 : 0) + 128) * 8;
+    const dim3 grid((unsigned)pl.n_wgs << pl.slot_shift), blk(64);   // one wave per (utterance group, column group slot)
     const gh_fbchain* chains = d_chains ? d_chains : pl.d_chains;
     const bwf_wg* d_wgs = (const bwf_wg*)pl.d_wgs;
     const bwf_pair* d_pairs = (const bwf_pair*)pl.d_pairs;
-#define GH_BWF(ks, nc)                                                                                                   \
-    hipLaunchKernelGGL((bw_fused_kernel<ks, nc>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,                   \
+#define GH_BWF_W(ks, nc, wd)                                                                                             \
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc, wd>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,               \
                        g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
-                       ctx->d_fp64_tables, pl.d_part)
+                       ctx->d_fp64_tables, pl.d_part, pl.slot_shift, nll, nll_S)
+#define GH_BWF(ks, nc) do { if (wide) GH_BWF_W(ks, nc, true); else GH_BWF_W(ks, nc, false); } while (0)
 #define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;
@@ -561,9 +606,10 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
     }
 #undef GH_BWF_N
 #undef GH_BWF
+#undef GH_BWF_W
     GH_HIP(hipGetLastError());
     hipLaunchKernelGGL(bw_fused_sum_kernel, dim3((unsigned)pl.n_pairs, (unsigned)((pl.tile_len + 255) / 256)), dim3(256), 0, st, pl.d_part,
-                       d_pairs, 4, pl.tile_len, pl.d_gsum);
+                       d_pairs, 1 << pl.slot_shift, pl.tile_len, pl.d_gsum);
     hipLaunchKernelGGL(bw_fused_reduce_kernel, dim3((unsigned)pl.n_pairs), dim3(256), 0, st, pl.d_gsum, d_pairs, lt, D, M, g->dMean, d_out);
     GH_HIP(hipGetLastError());
     return GH_OK;

@@ -584,7 +584,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         for (int64_t u = 0; u < U; ++u)
             GH_REQUIRE(utt_lattice[u] >= 0 && utt_lattice[u] < lat->L, "gh_forward_backward: utt_lattice[%lld] out of range",
                        (long long)u);
-    // chain graphs and nobody wants the [N, S] matrix on the host: gamma stays compact ([N, 8]) for the fused statistics
+    // chain graphs and nobody wants the [N, S] matrix on the host: gamma stays compact ([N, 8] or [N, 16]) for the fused statistics
     // kernel (GMMHMM_BW=generic keeps the full occupancy matrix and the generic statistics kernel)
     bool compact_gam = false;
     {
@@ -594,8 +594,10 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
         compact_gam = want_occ && !out_occ && lat->fbchain_ok && !mats_ && !(e && !strcmp(e, "generic")) && !(e2 && !strcmp(e2, "generic")) &&
                       b->dtype == GH_F64;
     }
+    const int chain_lanes = lat->fbchain_ok ? gh_fbchain_lanes(lat->h_fbchain) : 8;
     if (compact_gam) {
-        if (!b->gam && b->N > 0) GH_HIP(hipMalloc((void**)&b->gam, (size_t)b->N * GH_FBCHAIN_MAX * 8));
+        if (b->gam && b->gam_lanes != chain_lanes) { GH_HIP(hipStreamSynchronize(ctx->stream)); GH_HIP(hipFree(b->gam)); b->gam = nullptr; }
+        if (!b->gam && b->N > 0) { GH_HIP(hipMalloc((void**)&b->gam, (size_t)b->N * chain_lanes * 8)); b->gam_lanes = chain_lanes; }
         b->gam_chains = lat->h_fbchain;
         b->gam_utt_graph.assign(utt_lattice ? utt_lattice : nullptr, utt_lattice ? utt_lattice + U : nullptr);
         b->occ_valid = false;
@@ -675,6 +677,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             ca.gam = compact_gam ? b->gam : nullptr;
             if (want_occ && !compact_gam) b->occ_valid = true;
             ca.self_xi_utt = d_xi;
+            ca.lanes = chain_lanes;
             rc2 = gh_launch_fb_chain(ctx, ca, b->dtype == GH_F64);
             if (rc2) return rc2;
             if (out_logp) GH_HIP(hipMemcpyAsync(out_logp, d_lp, U * 8, hipMemcpyDeviceToHost, s2));

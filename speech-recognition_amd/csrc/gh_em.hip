@@ -18,9 +18,10 @@
 //       -> history[it] = (log P, utterances, converged, error flags)
 //
 // No hipStreamSynchronize inside; the caller may fetch history[it] (one 32-byte D2H) per iteration or after many.
-// Scope: one-word transcripts (isolated-word EM, BASELINE configs[2]) on an fp64 batch, word models of n <= 8 states
-// with arcs from s, s-1, s-2 only, M <= 8 mixtures, D <= 47 -- what fb_chain_kernel / bw_fused_kernel cover; anything
-// else returns GH_ERR_UNSUPPORTED and the caller keeps the call-by-call path.
+// Scope: one-word transcripts (isolated-word EM, BASELINE configs[2]; the configs[3] shape -- 16 states x 32 mixtures --
+// too) on an fp64 batch, word models of n <= 16 states with arcs from s, s-1, s-2 only, M <= 64 mixtures, D <= 47 --
+// what fb_chain_kernel / bw_fused_kernel cover; anything else returns GH_ERR_UNSUPPORTED and the caller keeps the
+// call-by-call path.
 #include "gh_internal.h"
 #include "gh_host.h"
 #include "gh_fb.h"
@@ -49,6 +50,7 @@ struct gh_em {
     // other half's likelihood / statistics kernels.  Half 0 on the context's stream, half 1 on `s2`; they join before the
     // tail kernel.  Same results; measured no faster (see gh_em_create), so one half is the default.
     int n_half;
+    int lanes;             // lanes per utterance of the chain forward-backward = columns of d_gam (8, or 16 when n > 8)
     gh_loglik_plan ll_plan[2];
     bool ll_subset;
     gh_bwf_plan bw_plan[2];
@@ -67,6 +69,7 @@ namespace {
 __global__ __launch_bounds__(256) void em_tail_kernel(const double* __restrict__ xi_utt, const double* __restrict__ logp,
                                                       const int32_t* __restrict__ word_utts, const int32_t* __restrict__ word_off,
                                                       int W, int n, int64_t U, double* __restrict__ tail, int* __restrict__ flags) {
+    // (xi_utt rows are GH_FBCHAIN_MAX wide; only the first n entries are written by the forward-backward)
     __shared__ double red[256][GH_FBCHAIN_MAX + 1];
     const int tid = threadIdx.x;
     const int w = blockIdx.x;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void em_tail_kernel(const double* __restrict__
         for (int i = word_off[w] + tid; i < word_off[w + 1]; i += 256) {
             const double* x = xi_utt + (int64_t)word_utts[i] * GH_FBCHAIN_MAX;
 #pragma unroll
-            for (int j = 0; j < GH_FBCHAIN_MAX; ++j) acc[j] += x[j];
+            for (int j = 0; j < GH_FBCHAIN_MAX; ++j) if (j < n) acc[j] += x[j];
         }
     } else {
         for (int64_t u = tid; u < U; u += 256) {
@@ -203,8 +206,8 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     const int D = b->D, S = W * n;
     const int64_t U = b->U;
     // ---- what the device-resident iteration covers ----
-    if (b->dtype != GH_F64 || n > GH_FBCHAIN_MAX || M > 8 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
-        gh_set_error("gh_em_create: shape outside the device-resident path (fp64 batch, n <= 8, M <= 8, D <= 47)");
+    if (b->dtype != GH_F64 || n > GH_FBCHAIN_MAX || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
+        gh_set_error("gh_em_create: shape outside the device-resident path (fp64 batch, n <= 16, M <= 64, D <= 47)");
         return GH_ERR_UNSUPPORTED;
     }
     std::vector<gh_fbchain> chains(W);
@@ -234,6 +237,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     gh_em* e = new gh_em();
     memset((void*)e, 0, sizeof *e);
     e->ctx = ctx; e->b = b; e->W = W; e->n = n; e->M = M; e->D = D; e->S = S; e->U = U; e->N = b->N;
+    e->lanes = n > 8 ? 16 : 8;
     e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
     int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
     if (rc) { gh_em_destroy(e); return rc; }
@@ -330,7 +334,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     lay.add((void**)&e->d_alpha, std::max<size_t>(1, cacc) * 8, nullptr);
     lay.add((void**)&e->d_logp, std::max<size_t>(1, U) * 8, nullptr);
     lay.add((void**)&e->d_xi_utt, std::max<size_t>(1, U) * GH_FBCHAIN_MAX * 8, nullptr);
-    lay.add((void**)&e->d_gam, std::max<size_t>(1, (size_t)b->N) * GH_FBCHAIN_MAX * 8, nullptr);
+    lay.add((void**)&e->d_gam, std::max<size_t>(1, (size_t)b->N) * e->lanes * 8, nullptr);
     lay.add((void**)&e->d_packed, (size_t)e->n_packed * 8, nullptr);
     lay.add((void**)&e->d_flags, 64, nullptr);
     lay.add((void**)&e->d_hist, (size_t)e->hist_cap * 4 * 8, nullptr);
@@ -378,12 +382,13 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
                 memset(&ca, 0, sizeof ca);
                 ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
                 ca.perm = e->d_perm_h[h]; ca.U = e->Uh[h]; ca.alpha_scratch = e->d_alpha; ca.scratch_off = e->d_coff_h[h];
-                ca.logp = e->d_logp; ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt;
+                ca.logp = e->d_logp; ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt; ca.lanes = e->lanes;
                 r = gh_launch_fb_chain(ctx, ca, true);
             }
         }
-        if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, GH_FBCHAIN_MAX, 0, e->occ_floor,
-                                  e->d_chains, stats_out);
+        // (M > 8: the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
+        if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
+                                  e->d_chains, stats_out, e->M > 8 ? (const double*)b->nll : nullptr, e->S);
         ctx->stream = keep;
         return r;
     };

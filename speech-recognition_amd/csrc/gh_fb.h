@@ -50,8 +50,10 @@ struct gh_fbchain_args {
     const int64_t* scratch_off;  // [slots]
     double* logp;                // [U]
     double* occ;                 // optional [N,S], zeroed by the caller
-    double* gam;                 // optional [N, GH_FBCHAIN_MAX]: gamma compact, column = chain row (instead of occ)
+    double* gam;                 // optional [N, lanes]: gamma compact, column = chain row (instead of occ)
     double* self_xi_utt;         // optional [U, GH_FBCHAIN_MAX]: expected self transitions of every chain row of every utterance
+                                 //   (entries behind the utterance's chain length are not written)
+    int lanes;                   // 8 or 16 lanes per utterance (gh_fbchain_lanes): >= the longest chain
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);
 

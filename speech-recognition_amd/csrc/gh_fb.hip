@@ -270,7 +270,8 @@ __device__ __forceinline__ double lse2(double x, double y) {
     return m + log1p(exp(fmin(x, y) - m));   // one exp + one log1p (three exps + a log in lse3)
 }
 
-// Lane layout: 8 lanes per utterance (lane j of the group = chain row j, idle when j >= n), 8 utterances per wave.
+// Lane layout: NL = 8 (or 16, for chains of 9 .. 16 rows) lanes per utterance (lane j of the group = chain row j, idle
+// when j >= n), 64 / NL utterances per wave.
 // A first version with one lane per utterance and all rows in registers had U/64 waves of ~800 dependent
 // instructions per column (0.85 ms for 12 500 utterances); one row per lane gives 8x the waves and 1/5 of the
 // serial work per lane.  Neighbouring rows are one DPP row shift away (the 8-lane groups sit inside 16-lane DPP rows;
@@ -286,12 +287,12 @@ template <int CTRL> __device__ __forceinline__ xnum fbc_dpp(xnum v) {
     return o;
 }
 
-template <typename ET>
+template <typename ET, int NL>
 __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
-    constexpr int NMAX = GH_FBCHAIN_MAX;   // == 8 == lanes per utterance
+    constexpr int NMAX = GH_FBCHAIN_MAX;   // capacity of the chain arrays
     constexpr int PD = 4;                  // columns of loads in flight per lane (8: no change)
-    const int j = threadIdx.x & (NMAX - 1);
-    const int64_t slot = (int64_t)blockIdx.x * (64 / NMAX) + (threadIdx.x / NMAX);
+    const int j = threadIdx.x & (NL - 1);
+    const int64_t slot = (int64_t)blockIdx.x * (64 / NL) + (threadIdx.x / NL);
     const bool has_utt = slot < a.U;
     const int64_t u = has_utt ? (a.perm ? a.perm[slot] : slot) : 0;
     const gh_fbchain* chp = a.chains + ((has_utt && a.utt_lat) ? a.utt_lat[u] : 0);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     // every lane of the wave runs to the longest utterance of the wave (cross-lane operations need converged lanes)
     int Tmax = T;
 #pragma unroll
-    for (int o = 32; o >= NMAX; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
+    for (int o = 32; o >= NL; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
     if (has_utt && j == 0 && T <= 0 && a.logp) a.logp[u] = -INF;
     const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
     const int64_t cells = (int64_t)T * n;
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
         }
     }
     xnum P;
-    P.f = __shfl(al_last.f, (n > 0 ? n - 1 : 0), NMAX);
-    P.e = __shfl(al_last.e, (n > 0 ? n - 1 : 0), NMAX);
+    P.f = __shfl(al_last.f, (n > 0 ? n - 1 : 0), NL);
+    P.e = __shfl(al_last.e, (n > 0 ? n - 1 : 0), NL);
     const double logp = xn_log(P);
     if (has_utt && j == 0 && T > 0 && a.logp) a.logp[u] = logp;
     if (!a.occ && !a.gam && !a.self_xi_utt) return;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
             const int t = tw - (Tmax - T);      // this utterance's column (negative: it has not started yet)
             if ((a.occ || a.gam) && has_utt && t >= 0) {
                 const double g = (act && reach) ? xn_ratio(ap, be, inv_pf, P.e) : 0.0;
-                if (a.gam) a.gam[(f0 + t) * NMAX + j] = g;            // all 8 columns (rows >= n: 0): one 64-byte line per frame
+                if (a.gam) a.gam[(f0 + t) * NL + j] = g;              // all NL columns (rows >= n: 0): one 64- / 128-byte line per frame
                 else if (act) a.occ[(f0 + t) * a.S + st] = g;
             }
             // beta_{t-1}(j) = sum over successors s = j, j+1, j+2 of beta_t(s) b_s(x_t) a_{j -> s}
@@ -403,9 +404,16 @@ int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, si
 
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64) {
     if (a.U <= 0) return GH_OK;
-    const dim3 grid((unsigned)((a.U + 7) / 8)), blk(64);   // 8 utterances per wave, 8 lanes each
-    if (f64) hipLaunchKernelGGL((fb_chain_kernel<double>), grid, blk, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((fb_chain_kernel<float>), grid, blk, 0, ctx->stream, a);
+    if (a.lanes != 8 && a.lanes != 16) { gh_set_error("gh_launch_fb_chain: internal: %d lanes per utterance", a.lanes); return GH_ERR_INVALID; }
+    const int per_wave = 64 / a.lanes;                     // 8 (or 4) utterances per wave, 8 (or 16) lanes each
+    const dim3 grid((unsigned)((a.U + per_wave - 1) / per_wave)), blk(64);
+    if (a.lanes == 8) {
+        if (f64) hipLaunchKernelGGL((fb_chain_kernel<double, 8>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fb_chain_kernel<float, 8>), grid, blk, 0, ctx->stream, a);
+    } else {
+        if (f64) hipLaunchKernelGGL((fb_chain_kernel<double, 16>), grid, blk, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((fb_chain_kernel<float, 16>), grid, blk, 0, ctx->stream, a);
+    }
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

@@ -82,13 +82,18 @@ struct gh_gmm {
     int M_pad, n_tiles;
     double *dApk64, *dCpk64;
     float *dApk32, *dCpk32;
+    // stamp of the parameter set (new at creation and at every in-place update): a batch remembers whose likelihoods its
+    // [N, S] matrix holds (gh_batch::nll_serial), so that a kernel that reuses them as mixture denominators can tell
+    uint64_t serial = 0;
 };
+uint64_t gh_next_serial();
 
-// A graph that is ONE left-to-right chain of <= 8 emitting rows with distinct states (arcs from r, r-1, r-2 in the
+// A graph that is ONE left-to-right chain of <= 16 emitting rows with distinct states (arcs from r, r-1, r-2 in the
 // previous column), started at its first row (directly, or through a non-emitting start row: cost c0) and ended
 // at its last row -- what a one-word forced-alignment lattice is.  gh_forward_backward runs these with one LANE
-// per utterance (fb_chain_kernel): the whole recursion lives in registers.
-#define GH_FBCHAIN_MAX 8
+// per chain row (fb_chain_kernel): 8 lanes per utterance when every chain of the call has <= 8 rows (BASELINE
+// configs[1-2]: 5), 16 otherwise (configs[3]: 16) -- gh_fbchain_lanes; the recursion lives in registers.
+#define GH_FBCHAIN_MAX 16
 struct gh_fbchain {
     int32_t n, pad;                       // pad = 1 when the chain has r-2 -> r (skip) arcs
     int32_t state[GH_FBCHAIN_MAX];
@@ -108,15 +113,17 @@ struct gh_batch {
     int64_t max_T;
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
+    uint64_t nll_serial = 0;   // gh_gmm::serial of the model whose likelihoods `nll` holds (0: none yet)
     double* occ;  // device [N,occ_S] fp64 frame x state occupancies after gh_forward_backward(want_occ)
     int occ_S;    // state count `occ` was allocated for (reallocated when a model of another size is used)
     // after a chain-form forward-backward: the states that can carry occupancy in each utterance ([U][8], -1 padded),
     // so that gh_bw_accumulate need not scan the occupancy matrix for them; null otherwise
     int32_t* d_occ_states;
     // after a chain-form forward-backward that nobody asked the full matrix of: gamma compact, one column per chain
-    // row ([N, GH_FBCHAIN_MAX]), the chains it belongs to and every utterance's chain -- what the fused Baum-Welch
-    // statistics kernel consumes (gh_bw_fused.hip); `occ` is then stale (occ_valid false)
+    // row ([N, gam_lanes], gam_lanes = 8 or 16: gh_fbchain_lanes), the chains it belongs to and every utterance's chain
+    // -- what the fused Baum-Welch statistics kernel consumes (gh_bw_fused.hip); `occ` is then stale (occ_valid false)
     double* gam;
+    int gam_lanes = 0;         // columns `gam` was allocated for
     bool occ_valid;
     std::vector<gh_fbchain> gam_chains;
     std::vector<int32_t> gam_utt_graph;
@@ -270,6 +277,7 @@ int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S);
 // work lists of the fused statistics kernel on the device: built per call (context scratch) or once per trainer (own arena)
 struct gh_bwf_plan {
     int KS, lt, S, M, D, L, n_wgs, n_pairs, tile_len, max_pairs;
+    int slot_shift;            // a workgroup's waves: 1 << slot_shift >= the most column groups any word has
     int32_t *d_ulist, *d_seglen;
     int64_t* d_segfirst;
     void *d_wgs, *d_pairs;
@@ -282,7 +290,13 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
                       const std::vector<std::vector<int32_t>>& by_graph, bool persistent, gh_bwf_plan* out);   // 1 = shapes not covered
 void gh_bwf_plan_free(gh_bwf_plan* p);
 int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
-                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out);
+                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out,
+                  const double* nll = nullptr, int nll_S = 0);   // nll: the batch's likelihoods under g (needed when M > 8)
+// lanes per utterance of the chain forward-backward (= columns of the compact gamma matrix): 8, or 16 when a chain is longer
+inline int gh_fbchain_lanes(const std::vector<gh_fbchain>& chains) {
+    for (const gh_fbchain& c : chains) if (c.n > 8) return 16;
+    return 8;
+}
 // persistent block table of the subset likelihood kernel (built once by a trainer whose transcripts never change)
 struct gh_loglik_plan { void* d_blk; int64_t n_blk; int max_tiles; };
 int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,

@@ -185,6 +185,7 @@ int launch_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* A, const T* B, 
 }  // namespace
 
 int gh_launch_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b) {
+    b->nll_serial = g->serial;
     if (b->dtype == GH_F64) return launch_t<double>(ctx, g, b, g->dA64, g->dB64, g->dC64, nullptr);
     return launch_t<float>(ctx, g, b, g->dA32, g->dB32, g->dC32, g->dCen32);
 }

@@ -658,6 +658,10 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
 int gh_launch_loglik_mfma(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const int32_t* st_lo, const int32_t* st_hi,
                           const int64_t* rng_off, const gh_loglik_plan* plan) {
     if (!g->dApk64) return 1;
+    // whose likelihoods the batch's matrix holds from here on (a subset launch overwrites the rows of its ranges; a
+    // caller that mixes models across ranges loses the stamp's meaning -- the consumer, gh_bw_accumulate with M > 8,
+    // documents that the E-step's likelihoods must come from the model it is given)
+    b->nll_serial = g->serial;
     if (b->dtype == GH_F64) return launch_mfma_t<double>(ctx, g, b, g->dApk64, g->dCpk64, st_lo, st_hi, nullptr, rng_off, plan);
     return launch_mfma_t<float>(ctx, g, b, g->dApk32, g->dCpk32, st_lo, st_hi, g->dCen32, rng_off, plan);
 }

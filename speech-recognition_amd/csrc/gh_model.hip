@@ -1,8 +1,14 @@
 // C ABI: packed emission model (gh_gmm), resident utterance batches (gh_batch), gh_loglik entry.
 #include "gh_internal.h"
+#include <atomic>
 #include "gh_host.h"
 
 // -------------------------------------------------------------------- model
+uint64_t gh_next_serial() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
 extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mean, const double* var,
                              const double* weight, gh_gmm** out) {
     GH_REQUIRE(ctx && out && mean && var && weight, "gh_gmm_create: NULL argument");
@@ -106,6 +112,7 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
         gh_gmm_destroy(g);
         return rc;
     }
+    g->serial = gh_next_serial();
     *out = g;
     return GH_OK;
 }
@@ -214,6 +221,7 @@ int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double
     hipLaunchKernelGGL(gmm_pack_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v);
     GH_HIP(hipGetLastError());
     g->host_stale = true;
+    g->serial = gh_next_serial();      // likelihood matrices computed before this point belong to an older model
     return GH_OK;
 }
 

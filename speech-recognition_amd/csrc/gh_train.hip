@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void bw_stats_kernel(const double* __restrict_
             __syncthreads();
             if (tid == 0) {
                 int c = 0;
-                for (int j = 0; j < 8; ++j) { const int s = utt_states[u * 8 + j]; if (s >= 0) s_list[c++] = s; }
+                for (int j = 0; j < GH_FBCHAIN_MAX; ++j) { const int s = utt_states[u * GH_FBCHAIN_MAX + j]; if (s >= 0) s_list[c++] = s; }
                 s_count = c;
             }
             __syncthreads();

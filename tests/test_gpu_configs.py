@@ -158,11 +158,13 @@ def test_c3_em_statistics_of_sampled_states_vs_numpy():
     tr.close()
 
 
-def test_c4_shape_em_statistics_generic_kernels_vs_numpy():
-    """EM at the configs[3] shape -- 64 words x 16 states x 32 mixtures, ~100 k frames: M = 32 and n = 16 are outside
-    the fused matrix-core statistics kernel and the chain forward-backward, so this is the GENERIC route (fb_kernel,
-    bw_stats_kernel<false, ...>: densities on the VALU) that round 2 never ran at this shape.  Statistics of sampled
-    states against numpy on the same occupancies; one full iteration raises the likelihood."""
+def test_c4_shape_em_statistics_vs_numpy_and_generic_kernels(monkeypatch):
+    """EM at the configs[3] shape -- 64 words x 16 states x 32 mixtures, ~100 k frames.  Three routes to the same
+    statistics: (a) the matrix-core route -- chain forward-backward with 16 lanes per utterance, statistics kernel with a
+    wave per 16 components of a state, normalised by the likelihood kernel's own per-state sums (M > 8); (b) the GENERIC
+    route (fb_kernel, bw_stats_kernel<false, ...>: densities on the VALU) that was the only one until round 3;
+    (c) numpy on the occupancies.  Then the device-resident session: its first E-step equals (a), iterations raise the
+    likelihood, and it equals the call-by-call trainer."""
     import bench
     from sr.recognition.train import BaumWelchTrainer
     from sr.recognition import _hip
@@ -173,9 +175,18 @@ def test_c4_shape_em_statistics_generic_kernels_vs_numpy():
     labels = [[int(w)] for w in wl["words"]]
     means0 = wl["means"] + 0.3 * np.random.default_rng(0).normal(size=wl["means"].shape)
     tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels)
-    assert tr.session is None and tr.batch.N >= 95000            # (the device-resident session does not cover M = 32)
-    stats, xi, ll = tr.e_step()
+    assert tr.session is not None and tr.batch.N >= 95000        # (round 3: the session covers n = 16, M = 32)
+    stats, xi, ll = tr.e_step()                                  # (a), call by call
+    assert "fb_chain" in tr.lat.forms()                          # 16-row chains: 16 lanes per utterance
     assert stats.shape == (1024, 32, 79) and np.isfinite(ll) and ll < 0
+    monkeypatch.setenv("GMMHMM_FB", "generic")
+    monkeypatch.setenv("GMMHMM_BW", "generic")
+    stats_g, xi_g, ll_g = tr.e_step()                            # (b)
+    monkeypatch.delenv("GMMHMM_FB")
+    monkeypatch.delenv("GMMHMM_BW")
+    np.testing.assert_allclose(ll, ll_g, rtol=1e-12)
+    np.testing.assert_allclose(xi, xi_g, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(stats, stats_g, rtol=1e-8, atol=1e-9)
     gmm = _hip.PackedGMM(tr.ctx, tr.means, tr.vars, tr.weights)
     tr.batch.loglik(gmm, fetch=False, state_sets=tr.state_sets)
     occ = tr.lat.forward_backward(tr.batch, utt_lattice=tr.utt_graph, want_occ=True)["occ"]
@@ -200,9 +211,68 @@ def test_c4_shape_em_statistics_generic_kernels_vs_numpy():
             ref[m, 1 + D:] = (r[:, [m]] * d * d).sum(axis=0)
         np.testing.assert_allclose(stats[s], ref, rtol=1e-8, atol=1e-9)
     del occ
-    h = tr.fit(2)
-    assert h[1] > h[0] and np.all(tr.vars > 0)
+    # the device-resident iteration: its E-step is (a)'s, and it walks with the call-by-call trainer
+    ref_tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device_resident=False)
+    h = [tr.iteration()]
+    packed = tr.session.packed()
+    np.testing.assert_allclose(packed[:tr.n_stats].reshape(stats.shape), stats, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(packed[tr.n_stats:tr.n_stats + tr.S], xi, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(packed[tr.n_stats + tr.S], ll, rtol=1e-11)
+    h_ref = [ref_tr.iteration()]
+    for _ in range(2):
+        h.append(tr.iteration())
+        h_ref.append(ref_tr.iteration())
+    np.testing.assert_allclose(h, h_ref, rtol=1e-10)
+    np.testing.assert_allclose(tr.means, ref_tr.means, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(tr.vars, ref_tr.vars, rtol=1e-6)
+    np.testing.assert_allclose(tr.weights, ref_tr.weights, rtol=1e-7, atol=1e-11)
+    assert h[1] > h[0] and h[2] >= h[1] - 1e-9 * abs(h[1]) and np.all(tr.vars > 0)
     tr.close()
+    ref_tr.close()
+
+
+def test_wide_mixture_statistics_need_the_models_own_likelihoods():
+    """M > 8: gh_bw_accumulate normalises with the batch's likelihood matrix.  When that matrix was computed with ANOTHER
+    model (or the model was updated in place since), the library notices (model / matrix serial numbers) and takes the
+    generic kernel, which computes its own densities: same statistics either way."""
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(3)
+    W, n, M, D = 3, 9, 12, 13
+    means = rng.normal(size=(W * n, M, D)) * 2
+    vars_ = rng.uniform(0.5, 1.5, size=(W * n, M, D))
+    w = rng.dirichlet(np.ones(M), size=W * n)
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = -np.log(0.8)
+        if i:
+            trans[i, i - 1] = -np.log(0.2)
+    words = rng.integers(0, W, size=40)
+    xs = []
+    for wd in words:
+        T = int(rng.integers(2 * n, 5 * n))
+        st = wd * n + np.minimum(np.arange(T) * n // T, n - 1)
+        xs.append(means[st, rng.integers(0, M, size=T)] + rng.normal(size=(T, D)))
+    graphs = [packed_lattice([trans] * W, n, [[k]])[0] for k in range(W)]
+    lat = _hip.Lattices(ctx, graphs)
+    b = _hip.Batch(ctx, xs)
+    g = _hip.PackedGMM(ctx, means, vars_, w)
+    other = _hip.PackedGMM(ctx, means + 0.5, vars_, w)
+
+    def stats_after(loglik_model):
+        b.loglik(g, fetch=False)
+        lat.forward_backward(b, utt_lattice=words.astype(np.int32), want_occ=True, fetch_occ=False)
+        if loglik_model is not g:
+            b.loglik(loglik_model, fetch=False)          # the matrix now belongs to another model; gamma is still g's
+        return b.bw_accumulate(g)
+
+    own = stats_after(g)
+    stale = stats_after(other)
+    np.testing.assert_allclose(stale, own, rtol=1e-9, atol=1e-11)
+    assert np.isclose(own[:, :, 0].sum(), b.N, rtol=1e-9)
+    for h in (b, lat, g, other):
+        h.close()
 
 
 def test_c3_em_likelihood_is_monotone_and_recovers_the_model():
