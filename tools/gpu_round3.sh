@@ -18,6 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ctrain -o ct -- 
 CTRAIN_PROFILE=0 python3 tools/time_ctrain.py 2000 7 8 > $O/ctrain.log 2>&1; echo "ctrain exit $?"
 python3 tools/time_ctrain.py 2000 7 4 > $O/ctrain_host_profile.log 2>&1; echo "ctrain host profile exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o c5 -- python3 tools/time_c5.py 125000 > $O/c5.json 2> $O/c5.err; echo "c5 prof exit $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4em -o c4em -- python3 tools/time_c4_em.py 50000 > $O/c4em.json 2> $O/c4em.err; echo "c4 em prof exit $?"
 python3 tools/comm_probe.py --world 2 --same-gpu > $O/comm_probe_2ranks.log 2>&1; echo "comm probe exit $?"
 python3 bench.py --gpus 2 --same-gpu --steps 20 --warmup 5 --no-cpu-baseline --c5-utts 20000 --c4-utts 2000 > $O/bench_2ranks_same_gpu.json 2> $O/bench_2ranks_same_gpu.err; echo "2-rank bench exit $?"
 ls $O
