@@ -252,3 +252,52 @@ def test_a_rank_without_utterances_still_joins_every_collective(tmp_path):
     _close(r0["hist"], hist, 1e-12)
     _close(r0["means"], tr.means, 1e-12, 1e-13)
     tr.close()
+
+
+@pytest.mark.parametrize("W,n,M,D,skip", [(4, 12, 4, 13, False),     # 6 state pairs per word: 8 waves per workgroup
+                                          (3, 9, 12, 13, True),      # M > 8 in one 16-column piece, odd chain length, skip arcs
+                                          (2, 16, 33, 23, False),    # three pieces per state, the last one 1 component wide
+                                          (5, 8, 16, 39, True),      # a full 16-component piece, 8-lane chains
+                                          (3, 7, 64, 5, False)])     # 4 pieces, 28 column groups
+def test_session_shapes_between_the_named_configs(W, n, M, D, skip):
+    """The device-resident iteration on shapes between configs[2] (5 states x 8 mixtures) and configs[3] (16 x 32): chains
+    of 9-16 rows run with 16 lanes per utterance, mixtures of more than 8 components with one wave per 16 components
+    (normalised by the likelihood matrix), up to 64 column groups per word.  Statistics, log P, models and the stop rule
+    == the call-by-call trainer forced onto the generic kernels."""
+    import bench
+    from sr.recognition.train import BaumWelchTrainer
+    U = 120
+    wl = bench.synth_workload(77 + n + M, U, W=W, n=n, M=M, D=D, tmin=2 * n, tmax=5 * n)
+    trans = wl["trans"].copy()
+    if skip:
+        for i in range(n - 2):
+            trans[i + 2, i] = -np.log(0.02)
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    labels = [[int(w)] for w in wl["words"]]
+    means0 = wl["means"] + 0.3 * np.random.default_rng(1).normal(size=wl["means"].shape)
+    a = BaumWelchTrainer(means0, wl["vars"], wl["w"], [trans] * W, data, labels)
+    assert a.session is not None
+    b = BaumWelchTrainer(means0, wl["vars"], wl["w"], [trans] * W, data, labels, device_resident=False)
+    os.environ["GMMHMM_FB"] = "generic"
+    os.environ["GMMHMM_BW"] = "generic"
+    try:
+        stats, xi, ll = b.e_step()
+        hb = [b.iteration() for _ in range(3)]
+    finally:
+        del os.environ["GMMHMM_FB"], os.environ["GMMHMM_BW"]
+    ha = [a.iteration()]
+    packed = a.session.packed()
+    _close(packed[:a.n_stats].reshape(stats.shape), stats, 1e-8, 1e-9)
+    _close(packed[a.n_stats:a.n_stats + a.S], xi, 1e-8, 1e-9)
+    _close(packed[a.n_stats + a.S], ll, 1e-11)
+    ha += [a.iteration() for _ in range(2)]
+    _close(ha, hb, 1e-10)
+    _close(a.means, b.means, 1e-7, 1e-9)
+    _close(a.vars, b.vars, 1e-6)
+    _close(a.weights, b.weights, 1e-7, 1e-11)
+    for ta, tb in zip(a.transitions, b.transitions):
+        fin = np.isfinite(tb)
+        np.testing.assert_array_equal(np.isfinite(ta), fin)
+        _close(ta[fin], tb[fin], 1e-7, 1e-9)
+    a.close()
+    b.close()
