@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                      const int32_t* __restrict__ ulist, const bwf_wg* __restrict__ wgs,
                                                      const gh_fbchain* __restrict__ chains, const double* __restrict__ tables,
                                                      double* __restrict__ partial, int slot_shift,
-                                                     const double* __restrict__ nll, int nll_S) {
+                                                     const double* __restrict__ nll, int nll_S, const int32_t* __restrict__ rng) {
     constexpr int KP = 2 * KS;            // padded feature length
     constexpr int TF = 16;                // frames per block
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -169,6 +169,156 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int gcol_b = (row_b >= 0) ? (gam_by_state ? sb : row_b) : -1;
     __syncthreads();
     double px[PX], pg = 0.0, pn = 0.0;                         // the staged-ahead block: frames, gamma (and likelihoods) in registers
+    // block [bf, bf + 16) of the segment (f0, T) -> registers (its X rows, the pair's gamma, WIDE: the state's likelihoods)
+    auto fetch = [&](int64_t f0, int T, int bf) {
+        const int nf_ = (T - bf < TF) ? T - bf : TF;
+        const double* src = X + (f0 + bf) * D;
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int i = lane + 64 * e;
+#ifdef BWF_NOSTAGE   // diagnostic builds (tools/bwf_variants.sh): timing without HBM reads / MFMAs / responsibilities
+            px[e] = (i < nf_ * D) ? 0.25 * (double)(i & 15) : 0.0;
+#else
+            px[e] = (i < nf_ * D) ? src[i] : 0.0;
+#endif
+        }
+#ifdef BWF_NOSTAGE
+        pg = (j < nf_ && gcol >= 0) ? 0.125 : 0.0;
+#else
+        pg = (j < nf_ && gcol >= 0) ? gam[(f0 + bf + j) * gam_stride + gcol] : 0.0;
+#endif
+        if (WIDE) pn = (lane < nf_) ? nll[(f0 + bf + lane) * (int64_t)nll_S + sa] : 0.0;
+    };
+    // the fetched block -> LDS [16][DP] (rows >= nf zero) + gamma [16][2] (+ likelihoods [16])
+    auto park = [&]() {
+#pragma unroll
+        for (int e = 0; e < PX; ++e) {
+            const int i = lane + 64 * e;
+            if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = px[e]; }
+        }
+        if (lane < 32) gt[j * 2 + st] = pg;
+        if (WIDE && lane < TF) nt[lane] = pn * GH_LSE_SCALE64;
+    };
+    // densities, responsibilities and accumulation of the parked block (nf frames)
+    auto compute = [&](int nf) {
+        // ---- component log-densities of 16 frames x 16 components (scaled log domain) ----
+        v4d da = (v4d){Cj, Cj, Cj, Cj};
+        const double* xr = xt + j * DP + q;              // A operand: row = frame j, columns q, q + 4, ...
+        double xa[KS / 2];
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) xa[ks] = xr[4 * ks];             // (KS is even: k < KP <=> ks < KS / 2)
+#ifdef BWF_NODENS
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) da[ks & 3] += xa[ks] * P[ks];
+#else
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks] * xa[ks], P[ks], da, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], P[KS / 2 + ks], da, 0, 0, 0);
+#endif
+        // ---- responsibilities: lane = component j, register r = frame q + 4 r ----
+        double R[4];
+#ifdef BWF_NOEPI
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[r] = da[r];
+#else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int fr = q + 4 * r;
+            const double y = da[r];
+            if (WIDE) {
+                // log(w pdf) - log sum_m' w pdf = y + K nll: the likelihood kernel's own normaliser
+                const double e = bwf_exp2s(y + nt[fr], tab);
+                const double g = gt[fr * 2];
+                const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
+                R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? e * wgt : 0.0;
+            } else {
+                const double mx = max8(y);
+                const double e = bwf_exp2s(y - mx, tab);
+                const double s8 = sum8(e);
+                const double g = gt[fr * 2 + (j >> 3)];
+                const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
+                double inv = __builtin_amdgcn_rcp(s8);
+                inv = fma(fma(-s8, inv, 1.0), inv, inv);      // two Newton steps: full double accuracy
+                inv = fma(fma(-s8, inv, 1.0), inv, inv);
+                const double rv = e * (wgt * inv);
+                R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? rv : 0.0;   // (every component off: s8 = 8, e = 1 -- killed by `valid`)
+            }
+        }
+#endif
+        // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames {0..3} + 4 r ----
+        double zx[4][LT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < LT; ++t) zx[r][t] = xt[(q + 4 * r) * DP + dd[t]];   // all reads in flight
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < LT; ++t) {
+                const double xv = zx[r][t] - cs[t];
+#ifdef BWF_NOACC
+                acc[t][r] += xv * R[r];
+#else
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, R[r], acc[t], 0, 0, 0);
+                // (the ones column squares to 1 as well: row D of the squared half holds sum r, unused)
+                acc[LT + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv * xv, R[r], acc[LT + t], 0, 0, 0);
+#endif
+            }
+    };
+    if (rng) {
+        // ---- block lists from the forward-backward's occupancy ranges: 64 utterances at a time, lane = utterance ----
+        // (rng[u][row] = first / last frame of the row with gamma above the floor: no pass over gamma, and the block that
+        //  travels from HBM while the current one is computed may belong to the NEXT utterance -- with the gamma scan below a
+        //  wave pays two memory round trips per utterance before its first MFMA)
+        for (int ui0 = wg.u_begin; ui0 < wg.u_end; ui0 += 64) {
+            const bool have = ui0 + lane < wg.u_end;
+            const int32_t u_l = have ? ulist[ui0 + lane] : 0;
+            const int64_t f0_l = have ? seg_first[u_l] : 0;
+            const int T_l = have ? seg_len[u_l] : 0;
+            int lo_l = 0x7fffffff, hi_l = -1;
+            if (have) {
+                const int32_t* ra = rng + ((int64_t)u_l * GH_FBCHAIN_MAX + row_a) * 2;
+                lo_l = ra[0]; hi_l = ra[1];
+                if (row_b >= 0) {
+                    const int32_t* rb = rng + ((int64_t)u_l * GH_FBCHAIN_MAX + row_b) * 2;
+                    const int lb = rb[0], hb = rb[1];
+                    if (hb >= lb) { lo_l = (hi_l >= lo_l && lo_l < lb) ? lo_l : lb; hi_l = (hi_l > hb) ? hi_l : hb; }
+                }
+                if (hi_l >= T_l) hi_l = T_l - 1;
+                if (lo_l < 0) lo_l = 0;
+            }
+            unsigned long long mask = __ballot(have && hi_l >= lo_l);
+            const int f0lo_l = (int)(f0_l & 0xffffffffll), f0hi_l = (int)(f0_l >> 32);
+            // the item being computed (c*) and the one in flight (n*): segment, block, last block of the segment
+            int64_t cf0 = 0, nf0 = 0;
+            int cT = 0, cb = 0, clast = -1, nT = 0, nb = 0, nlast = -1;
+            bool cvalid = false, nvalid = false;
+            auto open_next_utt = [&]() {       // next utterance of the batch with a non-empty range -> (n*)
+                if (!mask) { nvalid = false; return; }
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int sl = __builtin_amdgcn_readfirstlane(l);
+                nf0 = ((int64_t)__builtin_amdgcn_readlane(f0hi_l, sl) << 32) | (uint32_t)__builtin_amdgcn_readlane(f0lo_l, sl);
+                nT = __builtin_amdgcn_readlane(T_l, sl);
+                nb = __builtin_amdgcn_readlane(lo_l, sl) / TF;
+                nlast = __builtin_amdgcn_readlane(hi_l, sl) / TF;
+                nvalid = true;
+            };
+            open_next_utt();
+            if (nvalid) fetch(nf0, nT, nb * TF);
+            while (nvalid) {
+                cf0 = nf0; cT = nT; cb = nb; clast = nlast; cvalid = true;
+                park();
+                if (cb < clast) nb = cb + 1; else open_next_utt();
+                if (nvalid) fetch(nf0, nT, nb * TF);     // travels from HBM while this block is computed
+                __syncthreads();                         // (one wave: orders the LDS stores above before the operand reads below)
+                compute((cT - cb * TF < TF) ? cT - cb * TF : TF);
+                __syncthreads();                         // (the next block's stores come after these reads)
+            }
+            (void)cf0; (void)cvalid;
+        }
+    } else
     for (int ui = wg.u_begin; ui < wg.u_end; ++ui) {
         const int32_t u = ulist[ui];
         const int64_t f0 = seg_first[u];
@@ -180,7 +330,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             {
                 const int fb = c0 + lane * TF;
                 bool nz = false;
-#ifdef BWF_NOSTAGE   // diagnostic builds (tools/bwf_variants.sh): timing without HBM reads / MFMAs / responsibilities
+#ifdef BWF_NOSTAGE
                 nz = fb < T;
 #else
                 double ga[TF], gb[TF];
@@ -196,111 +346,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #ifdef BWF_NOSKIP
                 nz = fb < T;
 #endif
-                todo = __ballot(nz);     // same test as `wgt` below: a block without occupancy adds exact zeros -- not a pruning
+                todo = __ballot(nz);     // same test as `wgt` in compute: a block without occupancy adds exact zeros -- not a pruning
             }
-            auto fetch = [&](int blk) {   // block blk of this chunk -> registers (its X rows and the pair's gamma)
-                const int bf = c0 + blk * TF;
-                const int nf_ = (T - bf < TF) ? T - bf : TF;
-                const double* src = X + (f0 + bf) * D;
-#pragma unroll
-                for (int e = 0; e < PX; ++e) {
-                    const int i = lane + 64 * e;
-#ifdef BWF_NOSTAGE
-                    px[e] = (i < nf_ * D) ? 0.25 * (double)(i & 15) : 0.0;
-#else
-                    px[e] = (i < nf_ * D) ? src[i] : 0.0;
-#endif
-                }
-#ifdef BWF_NOSTAGE
-                pg = (j < nf_ && gcol >= 0) ? 0.125 : 0.0;
-#else
-                pg = (j < nf_ && gcol >= 0) ? gam[(f0 + bf + j) * gam_stride + gcol] : 0.0;
-#endif
-                if (WIDE) pn = (lane < nf_) ? nll[(f0 + bf + lane) * (int64_t)nll_S + sa] : 0.0;
-            };
             int blk = todo ? __builtin_ctzll(todo) : -1;
-            if (blk >= 0) fetch(blk);
+            if (blk >= 0) fetch(f0, T, c0 + blk * TF);
             while (blk >= 0) {
                 const int bf = c0 + blk * TF;
-                const int nf = (T - bf < TF) ? T - bf : TF;
-                // ---- park the fetched block in LDS [16][DP] (rows >= nf zero) + gamma [16][2] ----
-#pragma unroll
-                for (int e = 0; e < PX; ++e) {
-                    const int i = lane + 64 * e;
-                    if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = px[e]; }
-                }
-                if (lane < 32) gt[j * 2 + st] = pg;
-                if (WIDE && lane < TF) nt[lane] = pn * GH_LSE_SCALE64;
+                park();
                 todo &= todo - 1;
                 const int nxt = todo ? __builtin_ctzll(todo) : -1;
-                if (nxt >= 0) fetch(nxt);      // travels from HBM while this block is computed
+                if (nxt >= 0) fetch(f0, T, c0 + nxt * TF);      // travels from HBM while this block is computed
                 __syncthreads();               // (one wave: orders the LDS stores above before the operand reads below)
-            {
-                // ---- component log-densities of 16 frames x 16 components (scaled log domain) ----
-                v4d da = (v4d){Cj, Cj, Cj, Cj};
-                const double* xr = xt + j * DP + q;              // A operand: row = frame j, columns q, q + 4, ...
-                double xa[KS / 2];
-#pragma unroll
-                for (int ks = 0; ks < KS / 2; ++ks) xa[ks] = xr[4 * ks];             // (KS is even: k < KP <=> ks < KS / 2)
-#ifdef BWF_NODENS
-#pragma unroll
-                for (int ks = 0; ks < KS / 2; ++ks) da[ks & 3] += xa[ks] * P[ks];
-#else
-#pragma unroll
-                for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks] * xa[ks], P[ks], da, 0, 0, 0);
-#pragma unroll
-                for (int ks = 0; ks < KS / 2; ++ks) da = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], P[KS / 2 + ks], da, 0, 0, 0);
-#endif
-                // ---- responsibilities: lane = component j, register r = frame q + 4 r ----
-                double R[4];
-#ifdef BWF_NOEPI
-#pragma unroll
-                for (int r = 0; r < 4; ++r) R[r] = da[r];
-#else
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int fr = q + 4 * r;
-                    const double y = da[r];
-                    if (WIDE) {
-                        // log(w pdf) - log sum_m' w pdf = y + K nll: the likelihood kernel's own normaliser
-                        const double e = bwf_exp2s(y + nt[fr], tab);
-                        const double g = gt[fr * 2];
-                        const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
-                        R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? e * wgt : 0.0;
-                    } else {
-                    const double mx = max8(y);
-                    const double e = bwf_exp2s(y - mx, tab);
-                    const double s8 = sum8(e);
-                    const double g = gt[fr * 2 + (j >> 3)];
-                    const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
-                    double inv = __builtin_amdgcn_rcp(s8);
-                    inv = fma(fma(-s8, inv, 1.0), inv, inv);      // two Newton steps: full double accuracy
-                    inv = fma(fma(-s8, inv, 1.0), inv, inv);
-                    const double rv = e * (wgt * inv);
-                    R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? rv : 0.0;   // (every component off: s8 = 8, e = 1 -- killed by `valid`)
-                    }
-                }
-#endif
-                // ---- accumulate: G^T[Zcol, comp] += Z[frame, Zcol] r[frame, comp], k-step r = frames {0..3} + 4 r ----
-                double zx[4][LT];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < LT; ++t) zx[r][t] = xt[(q + 4 * r) * DP + dd[t]];   // all reads in flight
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < LT; ++t) {
-                        const double xv = zx[r][t] - cs[t];
-#ifdef BWF_NOACC
-                        acc[t][r] += xv * R[r];
-#else
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, R[r], acc[t], 0, 0, 0);
-                        // (the ones column squares to 1 as well: row D of the squared half holds sum r, unused)
-                        acc[LT + t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv * xv, R[r], acc[LT + t], 0, 0, 0);
-#endif
-                    }
-            }
+                compute((T - bf < TF) ? T - bf : TF);
                 __syncthreads();               // (the next block's stores come after these reads)
                 blk = nxt;
             }
@@ -578,7 +635,9 @@ void gh_bwf_plan_free(gh_bwf_plan* p) {
 // enqueue the fused statistics kernel + its two reduction kernels on the context's stream (no host sync).
 // d_chains: the chains (n, state[]) on the device, or null for the copy the plan was built with.
 int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
-                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out, const double* nll, int nll_S) {
+                  int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out, const double* nll, int nll_S,
+                  const int32_t* rng) {
+    if (rng && gam_by_state) { gh_set_error("gh_bwf_launch: internal: occupancy ranges belong to the compact gamma"); return GH_ERR_INVALID; }
     hipStream_t st = ctx->stream;
     const int S = pl.S, M = pl.M, D = pl.D, KS = pl.KS, lt = pl.lt;
     const int W = 1 + 2 * D;
@@ -594,7 +653,7 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
 #define GH_BWF_W(ks, nc, wd)                                                                                             \
     hipLaunchKernelGGL((bw_fused_kernel<ks, nc, wd>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,               \
                        g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
-                       ctx->d_fp64_tables, pl.d_part, pl.slot_shift, nll, nll_S)
+                       ctx->d_fp64_tables, pl.d_part, pl.slot_shift, nll, nll_S, rng)
 #define GH_BWF(ks, nc) do { if (wide) GH_BWF_W(ks, nc, true); else GH_BWF_W(ks, nc, false); } while (0)
 #define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {

@@ -40,6 +40,7 @@ struct gh_em {
     int32_t *d_utt_word, *d_word_utts, *d_word_off;
     int64_t* d_coff;
     double *d_alpha, *d_logp, *d_xi_utt, *d_gam;
+    int32_t* d_rng;        // [U, GH_FBCHAIN_MAX, 2] frames of every chain row with gamma above the floor (fb_chain_kernel -> bw_fused_kernel)
     double* d_packed;
     int64_t n_stats, n_packed;
     int* d_flags;          // [0] entries not allclose to the previous iteration, [1] error bits (16: zero variance)
@@ -50,6 +51,7 @@ struct gh_em {
     // other half's likelihood / statistics kernels.  Half 0 on the context's stream, half 1 on `s2`; they join before the
     // tail kernel.  Same results; measured no faster (see gh_em_create), so one half is the default.
     int n_half;
+    bool use_rng;          // block lists from occupancy ranges (default) or from a pass over gamma (GMMHMM_BWF_RANGES=0)
     int lanes;             // lanes per utterance of the chain forward-backward = columns of d_gam (8, or 16 when n > 8)
     gh_loglik_plan ll_plan[2];
     bool ll_subset;
@@ -238,6 +240,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     memset((void*)e, 0, sizeof *e);
     e->ctx = ctx; e->b = b; e->W = W; e->n = n; e->M = M; e->D = D; e->S = S; e->U = U; e->N = b->N;
     e->lanes = n > 8 ? 16 : 8;
+    e->use_rng = !(getenv("GMMHMM_BWF_RANGES") && !atoi(getenv("GMMHMM_BWF_RANGES")));
     e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
     int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
     if (rc) { gh_em_destroy(e); return rc; }
@@ -335,6 +338,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     lay.add((void**)&e->d_logp, std::max<size_t>(1, U) * 8, nullptr);
     lay.add((void**)&e->d_xi_utt, std::max<size_t>(1, U) * GH_FBCHAIN_MAX * 8, nullptr);
     lay.add((void**)&e->d_gam, std::max<size_t>(1, (size_t)b->N) * e->lanes * 8, nullptr);
+    lay.add((void**)&e->d_rng, std::max<size_t>(1, U) * GH_FBCHAIN_MAX * 2 * 4, nullptr);
     lay.add((void**)&e->d_packed, (size_t)e->n_packed * 8, nullptr);
     lay.add((void**)&e->d_flags, 64, nullptr);
     lay.add((void**)&e->d_hist, (size_t)e->hist_cap * 4 * 8, nullptr);
@@ -383,12 +387,14 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
                 ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
                 ca.perm = e->d_perm_h[h]; ca.U = e->Uh[h]; ca.alpha_scratch = e->d_alpha; ca.scratch_off = e->d_coff_h[h];
                 ca.logp = e->d_logp; ca.gam = e->d_gam; ca.self_xi_utt = e->d_xi_utt; ca.lanes = e->lanes;
+                ca.occ_rng = e->use_rng ? e->d_rng : nullptr; ca.rng_floor = e->occ_floor;
                 r = gh_launch_fb_chain(ctx, ca, true);
             }
         }
         // (M > 8: the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
         if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
-                                  e->d_chains, stats_out, e->M > 8 ? (const double*)b->nll : nullptr, e->S);
+                                  e->d_chains, stats_out, e->M > 8 ? (const double*)b->nll : nullptr, e->S,
+                                  e->use_rng ? e->d_rng : nullptr);
         ctx->stream = keep;
         return r;
     };

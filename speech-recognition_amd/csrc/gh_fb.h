@@ -54,6 +54,9 @@ struct gh_fbchain_args {
     double* self_xi_utt;         // optional [U, GH_FBCHAIN_MAX]: expected self transitions of every chain row of every utterance
                                  //   (entries behind the utterance's chain length are not written)
     int lanes;                   // 8 or 16 lanes per utterance (gh_fbchain_lanes): >= the longest chain
+    int32_t* occ_rng;            // optional [U, GH_FBCHAIN_MAX, 2] (with gam): first / last frame (utterance-local) of every chain
+    double rng_floor;            //   row whose gamma exceeds rng_floor (or is NaN); none: (T, -1) -- the block lists of the
+                                 //   fused statistics kernel (gh_bw_fused.hip) without a pass over gamma
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);
 

@@ -357,6 +357,8 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     auto load_ae = [&](int t) -> int { return (act && t >= 0 && t < T) ? ale[(int64_t)t * n + j] : XN_ZERO_E; };
     xnum be = (act && j == n - 1) ? xn_one() : xn_zero();
     double xi_acc = 0.0;                      // expected self transitions of this row (when asked for)
+    int r_lo = T, r_hi = -1;                  // frames of this row with gamma above the floor (when asked for)
+    const bool want_rng = a.occ_rng != nullptr;
     const bool want_xi = a.self_xi_utt != nullptr;
     xnum ap = xnum{load_af(T - 1), load_ae(T - 1)};
     double e = (double)load_e(T - 1);
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
                 const double g = (act && reach) ? xn_ratio(ap, be, inv_pf, P.e) : 0.0;
                 if (a.gam) a.gam[(f0 + t) * NL + j] = g;              // all NL columns (rows >= n: 0): one 64- / 128-byte line per frame
                 else if (act) a.occ[(f0 + t) * a.S + st] = g;
+                if (want_rng && ((g > a.rng_floor) | (g != g))) { r_lo = t; if (r_hi < 0) r_hi = t; }   // (t runs downwards)
             }
             // beta_{t-1}(j) = sum over successors s = j, j+1, j+2 of beta_t(s) b_s(x_t) a_{j -> s}
             const xnum w = (act && t >= 0) ? xn_mul(be, xn_exp_neg(e)) : xn_zero();
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
         }
     }
     if (want_xi && has_utt) a.self_xi_utt[u * NMAX + j] = act ? xi_acc : 0.0;
+    if (want_rng && has_utt) { a.occ_rng[(u * NMAX + j) * 2] = r_lo; a.occ_rng[(u * NMAX + j) * 2 + 1] = r_hi; }
 }
 
 }  // namespace

@@ -291,7 +291,8 @@ int gh_bwf_plan_build(gh_ctx* ctx, int S, int M, int D, int KP, const std::vecto
 void gh_bwf_plan_free(gh_bwf_plan* p);
 int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
                   int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out,
-                  const double* nll = nullptr, int nll_S = 0);   // nll: the batch's likelihoods under g (needed when M > 8)
+                  const double* nll = nullptr, int nll_S = 0,   // nll: the batch's likelihoods under g (needed when M > 8)
+                  const int32_t* rng = nullptr);               // [U, GH_FBCHAIN_MAX, 2] occupancy ranges of fb_chain_kernel (same floor)
 // lanes per utterance of the chain forward-backward (= columns of the compact gamma matrix): 8, or 16 when a chain is longer
 inline int gh_fbchain_lanes(const std::vector<gh_fbchain>& chains) {
     for (const gh_fbchain& c : chains) if (c.n > 8) return 16;

@@ -301,3 +301,31 @@ def test_session_shapes_between_the_named_configs(W, n, M, D, skip):
         _close(ta[fin], tb[fin], 1e-7, 1e-9)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("shape", ["c2", "wide"])
+def test_block_lists_from_occupancy_ranges_equal_the_gamma_scan(shape, monkeypatch):
+    """The statistics kernel of the session takes its list of 16-frame blocks from the per-(utterance, chain row) occupancy
+    ranges the forward-backward writes (first / last frame with gamma above the floor); GMMHMM_BWF_RANGES=0 makes it scan
+    gamma instead, as the call-by-call path does.  A range may include blocks the scan skips -- they add exact zeros --
+    so the packed statistics agree BIT FOR BIT."""
+    import bench
+    from sr.recognition.train import BaumWelchTrainer
+    if shape == "c2":
+        means, vars_, w, trans, data, labels = c3_problem(900)
+    else:
+        wl = bench.synth_workload(5, 300, W=6, n=11, M=20, D=13, tmin=25, tmax=70)
+        means, vars_, w, trans = wl["means"] + 0.2, wl["vars"], wl["w"], [wl["trans"]] * 6
+        data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(300)]
+        labels = [[int(x)] for x in wl["words"]]
+    for floor in (1e-30, 0.0, 1e-3):
+        a = BaumWelchTrainer(means, vars_, w, trans, data, labels, occ_floor=floor)
+        monkeypatch.setenv("GMMHMM_BWF_RANGES", "0")
+        b = BaumWelchTrainer(means, vars_, w, trans, data, labels, occ_floor=floor)
+        monkeypatch.delenv("GMMHMM_BWF_RANGES")
+        for _ in range(2):
+            la, lb = a.iteration(), b.iteration()
+            assert la == lb
+            np.testing.assert_array_equal(a.session.packed(), b.session.packed())
+        a.close()
+        b.close()
