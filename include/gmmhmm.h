@@ -63,12 +63,14 @@ int gh_device_sync(gh_ctx* ctx);
  * (back-pointers, alpha columns) of one launch is bounded by a quarter of the free HBM (<= 24 GiB), or by
  * GMMHMM_SCRATCH_BUDGET=<bytes>[K|M|G]; larger batches run as several launches with identical results. */
 int gh_ctx_last_chunks(const gh_ctx* ctx);
-/* Compatibility switches of a context (default 0; GMMHMM_COMPAT=underflow sets bit 0 at creation).
+/* Compatibility switches of a context (default 1 = bit 0 set; GMMHMM_COMPAT=0 clears it at creation).
  *   bit 0  gh_loglik* return +inf for a state whose every weighted density is below 2^-1075: GMM.evaluate sums w pdf in
  *          the LINEAR domain (hmm_state.py:114-120), where such terms round to 0 and -log 0 = inf -- a decode through
  *          these frames is then unreachable exactly where it is in the reference.  Without it the kernels stay in the
- *          log domain and return the (large, finite) cost.  The test is made on the term's total logarithm; the
- *          reference can also lose a term earlier, in exp(-q/2) before the normalisation (not reproduced). */
+ *          log domain and return the (large, finite) cost -- the numerically kinder choice for un-normalised features,
+ *          but not what the reference computes.  The test is made on the term's total logarithm (one compare against a
+ *          runtime threshold in the kernels' epilogues: no cost); the reference can also lose a term earlier, in
+ *          exp(-q/2) before the normalisation (not reproduced). */
 int gh_ctx_set_compat(gh_ctx* ctx, int flags);
 /* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);

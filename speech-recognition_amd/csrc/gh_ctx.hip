@@ -36,7 +36,7 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     c->pinned = nullptr;
     c->pinned_bytes = 0;
     c->last_chunks = 0;
-    c->compat = 0;
+    c->compat = 1;     // the reference's linear-domain underflow rule (gh_ctx_set_compat); GMMHMM_COMPAT=0: log domain throughout
     if (const char* e = getenv("GMMHMM_COMPAT")) c->compat = strstr(e, "underflow") ? 1 : atoi(e);
     hipDeviceProp_t prop;
     GH_HIP(hipGetDeviceProperties(&prop, device));

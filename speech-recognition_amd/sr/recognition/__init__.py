@@ -17,10 +17,12 @@ from .hmm_state import *  # noqa: F401,F403
 
 
 def set_compat(underflow=True, device=None):
-    """Reference-compatible corner cases that the kernels do not reproduce by default (extension; see
-    `gh_ctx_set_compat` in include/gmmhmm.h).  underflow=True: a state whose every weighted density underflows fp64
-    costs +inf -- the reference's `GMM.evaluate` sums in the linear domain (hmm_state.py:114-120) -- instead of the
-    finite log-domain cost, so `decode_hmm_states` / `HMM.evaluate` / the batch decoders treat such frames as
-    unreachable exactly where the reference does.  Applies to the default context of `device`."""
+    """Reference-compatible corner cases of the kernels (extension; see `gh_ctx_set_compat` in include/gmmhmm.h).
+    underflow=True (the default of every context): a state whose every weighted density underflows fp64 costs +inf -- the
+    reference's `GMM.evaluate` sums in the linear domain (hmm_state.py:114-120) -- so `decode_hmm_states` / `HMM.evaluate` /
+    the batch decoders treat such frames as unreachable exactly where the reference does.  underflow=False keeps the
+    likelihoods in the log domain: finite costs however far a frame lies from every mean (useful for features that were
+    not standardised; not what the reference computes).  Applies to the default context of `device`;
+    GMMHMM_COMPAT=0 in the environment switches it off for every new context."""
     from . import _hip
     _hip.default_context(device).set_compat(underflow=underflow)

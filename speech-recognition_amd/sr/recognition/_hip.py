@@ -201,9 +201,10 @@ class Context:
     def sync(self):
         _check(self.lib, self.lib.gh_ctx_sync(self.h))
 
-    def set_compat(self, underflow=False):
-        """underflow=True: likelihoods of states whose every weighted density underflows fp64 come back as +inf, like the
-        reference's linear-domain GMM.evaluate (hmm_state.py:114-120); see gh_ctx_set_compat."""
+    def set_compat(self, underflow=True):
+        """underflow=True (a context's default): likelihoods of states whose every weighted density underflows fp64 come
+        back as +inf, like the reference's linear-domain GMM.evaluate (hmm_state.py:114-120); False: log domain throughout,
+        finite costs.  See gh_ctx_set_compat."""
         _check(self.lib, self.lib.gh_ctx_set_compat(self.h, 1 if underflow else 0))
 
     @property

@@ -729,7 +729,9 @@ def test_loglik_subset_equals_full_on_the_ranges(hip, ctx, S, M, D):
 
 def test_loglik_extreme_parameter_ranges(hip, ctx):
     """Tiny and huge variances, offsets far from zero, weights spanning 12 decades, far-away frames: the scaled-log-domain
-    epilogue of the MFMA kernel against the oracle's log-domain arithmetic (fp64)."""
+    epilogue of the MFMA kernel against the oracle's log-domain arithmetic (fp64).  With the log domain kept throughout
+    (set_compat(underflow=False)) every cost is finite; with the reference's rule (a context's default) exactly the costs
+    beyond -ln 2^-1075 = 745.13 are +inf and the others are the same numbers."""
     rng = np.random.default_rng(77)
     S, M, D, N = 6, 8, 13, 200
     means = rng.normal(size=(S, M, D)) * np.array([1e-3, 1.0, 30.0, 1e3, 1.0, 1.0])[:, None, None]
@@ -742,11 +744,25 @@ def test_loglik_extreme_parameter_ranges(hip, ctx):
     ref = O.gmm_neg_loglik_batch(X, means, vars_, w)
     gmm = hip.PackedGMM(ctx, means, vars_, w)
     b = hip.Batch(ctx, feats=X, offsets=[0, N])
-    got = b.loglik(gmm)
+    ruled = b.loglik(gmm).copy()
+    ctx.set_compat(underflow=False)
+    try:
+        got = b.loglik(gmm).copy()
+    finally:
+        ctx.set_compat(underflow=True)
     assert np.all(np.isfinite(got))
     # the contraction sum_k P_k z_k cancels terms of size ~max|x^2/var|: compare to that scale
     scale = np.maximum(np.abs(ref), ((X[:, None, None, :] ** 2 + means[None] ** 2) / vars_[None]).sum(axis=3).max(axis=2))
     assert np.max(np.abs(got - ref) / scale) < 1e-12
+    # the reference's rule: +inf where the LARGEST weighted density of the state is below 2^-1075 (the sum's other terms are
+    # smaller still), the log-domain number elsewhere; costs within rounding of the threshold may fall on either side
+    logc = np.log(w) - 0.5 * (D * np.log(2 * np.pi) + np.log(vars_).sum(axis=2))
+    best = (logc[None] - 0.5 * (((X[:, None, None, :] - means[None]) ** 2) / vars_[None]).sum(axis=3)).max(axis=2)
+    thr = 1075 * np.log(2.0)
+    clear = np.abs(best + thr) > 1e-6 * scale
+    np.testing.assert_array_equal(np.isinf(ruled)[clear], (best < -thr)[clear])
+    np.testing.assert_array_equal(ruled[np.isfinite(ruled)], got[np.isfinite(ruled)])
+    assert np.isinf(ruled).any() and np.isfinite(ruled).any()
     b.close()
     gmm.close()
 
@@ -935,9 +951,9 @@ def test_dtw_long_templates(n, beam):
 @pytest.mark.parametrize("M,D", [(4, 5), (1, 13), (8, 39), (32, 39)])
 def test_compat_linear_domain_underflow(hip, dtype, M, D):
     """GMM.evaluate sums w pdf in the LINEAR domain (hmm_state.py:114-120): once every term underflows fp64 the state
-    costs -log 0 = +inf.  Default: the kernels stay in the log domain and return the finite cost (documented deviation);
-    gh_ctx_set_compat bit 0 reproduces the +inf (VERDICT r2 'missing' 5) -- checked against the oracle's linear-domain
-    evaluate frame by frame, together with the frames that do not underflow."""
+    costs -log 0 = +inf.  A context reproduces the +inf by default (gh_ctx_set_compat bit 0; VERDICT r2 'missing' 5) --
+    checked against the oracle's linear-domain evaluate frame by frame, together with the frames that do not underflow;
+    set_compat(underflow=False) keeps the kernels in the log domain: the finite cost everywhere."""
     ctx = hip.Context(0)                        # a context of its own: the switch is a property of the context
     rng = np.random.default_rng(M * 100 + D)
     S, N = 6, 96
@@ -952,12 +968,12 @@ def test_compat_linear_domain_underflow(hip, dtype, M, D):
     gmm = hip.PackedGMM(ctx, means, vars_, w)
     b = hip.Batch(ctx, feats=X, offsets=[0, N], dtype=dtype)
     rtol = 1e-10 if dtype == np.float64 else 1e-3
-    np.testing.assert_allclose(b.loglik(gmm), logdom, rtol=rtol)             # default: finite everywhere
-    ctx.set_compat(underflow=True)
-    got = b.loglik(gmm)
+    got = b.loglik(gmm).copy()                                               # default: the reference's rule
     np.testing.assert_array_equal(np.isinf(got), np.isinf(lin))
     fin = np.isfinite(lin)
     np.testing.assert_allclose(got[fin], lin[fin], rtol=rtol)
     ctx.set_compat(underflow=False)
-    np.testing.assert_allclose(b.loglik(gmm), logdom, rtol=rtol)
+    np.testing.assert_allclose(b.loglik(gmm), logdom, rtol=rtol)             # log domain: finite everywhere
+    ctx.set_compat(underflow=True)
+    np.testing.assert_array_equal(b.loglik(gmm), got)
     b.close(); gmm.close(); ctx.close()
