@@ -644,7 +644,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
                 const int64_t u = b->perm[k];
                 coff[k] = (int64_t)cacc;
                 const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * lat->h_fbchain[utt_lattice ? utt_lattice[u] : 0].n;
-                cacc += cells + (cells + 1) / 2;   // [T, n] mantissas (double) followed by as many exponents (int32)
+                cacc += gh_fbchain_scratch(cells, gh_fbchain_two_way(ctx, compact_gam, want_occ && !compact_gam, U, chain_lanes));
             }
             int64_t* d_coff;
             int32_t* d_ul = nullptr;

@@ -308,7 +308,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
         for (int64_t u : perm_h[h]) {
             coff_h[h].push_back((int64_t)cacc);
             const size_t cells = (size_t)(b->offsets[u + 1] - b->offsets[u]) * n;
-            cacc += cells + (cells + 1) / 2;            // [T, n] mantissas (double) followed by as many exponents (int32)
+            cacc += gh_fbchain_scratch(cells, true) ;   // (sized for the two-way form: alpha and beta columns)
         }
     std::vector<int32_t> word_utts, word_off(W + 1, 0);
     for (int w = 0; w < W; ++w) {

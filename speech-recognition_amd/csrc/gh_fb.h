@@ -59,6 +59,15 @@ struct gh_fbchain_args {
                                  //   fused statistics kernel (gh_bw_fused.hip) without a pass over gamma
 };
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64);
+// Two-way form (fb_chain2_kernel): compact gamma only (a.gam), forward and backward recursions side by side in one wave.
+// Scratch per utterance in doubles, T x n cells (both forms keep an utterance's piece on cache lines of its own):
+// the form gh_launch_fb_chain takes: two-way for compact gamma on batches too small to fill the chip with one-way waves
+bool gh_fbchain_two_way(const gh_ctx* ctx, bool compact_gamma, bool occupancy_matrix, int64_t U, int lanes);
+inline size_t gh_fbchain_scratch(size_t cells, bool two_way) {
+    const size_t need = two_way ? 3 * cells + 2       // alpha, beta mantissas [T, n] each + both exponent arrays (int32) + P
+                                : cells + (cells + 1) / 2;   // alpha mantissas + exponents
+    return (need + 15) & ~size_t(15);
+}
 
 // forced-alignment graphs in sequence form (gh_seqgraph): four utterances per wave, lane = layer (fb_seq_kernel, gh_seq.hip)
 #define GH_FBSEQ_XI_PARTS 256

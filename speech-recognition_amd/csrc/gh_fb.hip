@@ -396,6 +396,181 @@ __global__ __launch_bounds__(64) void fb_chain_kernel(gh_fbchain_args a) {
     if (want_rng && has_utt) { a.occ_rng[(u * NMAX + j) * 2] = r_lo; a.occ_rng[(u * NMAX + j) * 2 + 1] = r_hi; }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-way form.  fb_chain_kernel is latency bound on small batches: a wave walks its utterances' columns twice (forward,
+// then backward: ~300 dependent steps of ~2 000 cycles for a 150-frame utterance), and 12 500 utterances are only 1.5 waves
+// per SIMD.  The backward recursion on w_t(j) = beta_t(j) b_j(x_t),
+//     w_{t-1}(j) = b_j(x_{t-1}) [ w_t(j) a_jj + w_t(j+1) a_{j,j+1} + w_t(j+2) a_{j,j+2} ],
+// is the forward recursion with time and chain reversed, and the bracket is beta_{t-1}(j).  So an utterance gets 2 NL
+// lanes: the first NL run alpha over rows 0 .. n-1 from the first frame, the other NL run w over rows n-1 .. 0 from the
+// last frame -- the SAME instructions, half the dependent steps, twice the waves.  Both store their column (alpha_t, resp.
+// the bracket beta_t) to scratch; once both are through, the group's lanes sweep the (t, row) cells in parallel:
+// gamma = alpha beta / P (compact, all NL columns), xi_t(j -> j) = alpha_{t-1}(j) a_jj b_j(x_t) beta_t(j) / P summed per
+// row, the rows' occupancy ranges, log P.  Same definitions as fb_chain_kernel; results agree to rounding (beta_t is kept
+// as the unnormalised bracket, gamma is formed in a different order).
+template <typename ET, int NL>
+__global__ __launch_bounds__(64) void fb_chain2_kernel(gh_fbchain_args a) {
+    constexpr int G = 2 * NL;              // lanes per utterance
+    constexpr int NMAX = GH_FBCHAIN_MAX;
+    constexpr int PD = 4;                  // columns of emission loads in flight per lane
+    const int lane = threadIdx.x;
+    const int k = lane & (NL - 1);         // position inside the direction's lane group
+    const int dir = (lane / NL) & 1;       // 0: forward (alpha), 1: backward (w)
+    const int64_t slot = (int64_t)blockIdx.x * (64 / G) + lane / G;
+    const bool has_utt = slot < a.U;
+    const int64_t u = has_utt ? (a.perm ? a.perm[slot] : slot) : 0;
+    const gh_fbchain* chp = a.chains + ((has_utt && a.utt_lat) ? a.utt_lat[u] : 0);
+    const int n = chp->n;
+    const bool act = has_utt && k < n;
+    const bool skip = chp->pad != 0;
+    const int j = act ? (dir ? n - 1 - k : k) : 0;            // chain row of this lane in the recursion
+    const int st = act ? chp->state[j] : 0;
+    const double INF = INFINITY;
+    // arc probabilities into this lane's cell from lane k (same row), k - 1, k - 2 of its direction:
+    //   forward: rows j, j-1, j-2 -> j;  backward: successors j, j+1, j+2 of row j (arcs are stored at their destination)
+    const xnum p_a = xn_exp_neg(act ? chp->self_c[j] : INF);
+    const xnum p_b = xn_exp_neg((act && k >= 1) ? (dir ? chp->next_c[j + 1] : chp->next_c[j]) : INF);
+    const xnum p_c = xn_exp_neg((act && k >= 2 && skip) ? (dir ? chp->skip_c[j + 2] : chp->skip_c[j]) : INF);
+    const int64_t f0 = has_utt ? a.utt_off[u] : 0;
+    const int T = has_utt ? (int)(a.utt_off[u + 1] - f0) : 0;
+    int Tmax = T;
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
+    if (has_utt && lane % G == 0 && T <= 0 && a.logp) a.logp[u] = -INF;
+    const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
+    const int64_t cells = (int64_t)T * n;
+    double* base = a.alpha_scratch + (has_utt ? a.scratch_off[slot] : 0);
+    double* af = base;                                         // alpha mantissas [T, n]
+    double* bf = base + cells;                                 // beta mantissas
+    int* ae = reinterpret_cast<int*>(base + 2 * cells);        // alpha exponents, then beta exponents
+    int* be = ae + cells;
+    double* myf = dir ? bf : af;
+    int* mye = dir ? be : ae;
+    auto col = [&](int i) -> int { return dir ? T - 1 - i : i; };   // frame of this direction's step i
+    auto load_e = [&](int i) -> ET { return (act && i >= 0 && i < T) ? nll[(int64_t)col(i) * a.S + st] : ET(0); };
+    ET ering[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) ering[q] = load_e(1 + q);
+    // step 0: alpha_0 = [row 0] exp(-c0) b(x_0);   w_{T-1} = [row n-1] b(x_{T-1}), beta_{T-1} = [row n-1]
+    xnum v = xn_zero(), sv = xn_zero();
+    if (act && k == 0 && T > 0) {
+        v = xn_norm(xn_mul(dir ? xn_one() : xn_exp_neg(chp->c0), xn_exp_neg((double)load_e(0))));
+        sv = dir ? xn_one() : v;
+    }
+    xnum v_last = xn_zero();
+    for (int i0 = 0; i0 < Tmax; i0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int i = i0 + q;
+            if (i >= Tmax) break;
+            if (act && i < T) { const int64_t at = (int64_t)col(i) * n + j; myf[at] = sv.f; mye[at] = sv.e; }
+            if (i == T - 1) v_last = v;
+            xnum up1 = fbc_dpp<0x111>(v), up2 = fbc_dpp<0x112>(v);              // lanes k - 1, k - 2 (row_shr)
+            if (k < 1) up1 = xn_zero();                                          // (what came from the neighbouring group)
+            if (k < 2) up2 = xn_zero();
+            const xnum bn = xn_exp_neg((double)ering[q]);                        // emission probability of step i + 1
+            const xnum s = skip ? xn_add3(xn_mul(v, p_a), xn_mul(up1, p_b), xn_mul(up2, p_c))
+                                : xn_add(xn_mul(v, p_a), xn_mul(up1, p_b));
+            const xnum nx = xn_norm(xn_mul(s, bn));
+            if (act && i + 1 < T) { v = nx; sv = dir ? s : nx; }                 // backward: the bracket is beta of step i + 1
+            ering[q] = load_e(i + 1 + PD);
+        }
+    }
+    // P = alpha_{T-1}(n - 1): forward lane n - 1 of the group; left behind the columns for the cell kernel
+    xnum P;
+    P.f = __shfl(v_last.f, (n > 0 ? n - 1 : 0), G);
+    P.e = __shfl(v_last.e, (n > 0 ? n - 1 : 0), G);
+    if (has_utt && lane % G == 0 && T > 0) {
+        base[3 * cells] = P.f;
+        base[3 * cells + 1] = (double)P.e;
+        if (a.logp) a.logp[u] = xn_log(P);
+    }
+}
+
+// The cells of the two-way form, one wave per utterance, lane = (frame mod 64 / NL, row): gamma = alpha beta / P written
+// as whole lines of the compact matrix, xi_t(j -> j) = alpha_{t-1}(j) a_jj b_j(x_t) beta_t(j) / P summed per row, the rows'
+// occupancy ranges.  (Inside the recursion kernel -- the group's lanes sweeping their utterance after the last column --
+// this cost as much as the recursion had saved: a latency-bound loop of T / 2 dependent round trips per lane.)
+template <typename ET, int NL>
+__global__ __launch_bounds__(64) void fb_chain2_cells_kernel(gh_fbchain_args a) {
+    constexpr int NMAX = GH_FBCHAIN_MAX;
+    constexpr int FPI = 64 / NL;           // frames per sweep of the wave
+    constexpr int UN = 4;
+    const int64_t slot = blockIdx.x;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const gh_fbchain* chp = a.chains + (a.utt_lat ? a.utt_lat[u] : 0);
+    const int n = chp->n;
+    const int64_t f0 = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - f0);
+    const int k = threadIdx.x & (NL - 1), tl = threadIdx.x / NL;
+    const bool want_xi = a.self_xi_utt != nullptr;
+    const bool want_rng = a.occ_rng != nullptr;
+    if (T <= 0) {
+        if (tl == 0) {
+            if (want_xi) a.self_xi_utt[u * NMAX + k] = 0.0;
+            if (want_rng) { a.occ_rng[(u * NMAX + k) * 2] = 0; a.occ_rng[(u * NMAX + k) * 2 + 1] = -1; }
+        }
+        return;
+    }
+    const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S;
+    const int64_t cells = (int64_t)T * n;
+    const double* base = a.alpha_scratch + a.scratch_off[slot];
+    const double* af = base;
+    const double* bf = base + cells;
+    const int* ae = reinterpret_cast<const int*>(base + 2 * cells);
+    const int* be = ae + cells;
+    xnum P;
+    P.f = base[3 * cells];
+    P.e = (int)base[3 * cells + 1];
+    const bool reach = P.f > 0.0;
+    const double inv_pf = 1.0 / P.f;
+    const bool row = k < n;
+    const int st = row ? chp->state[k] : 0;
+    const xnum p_self = xn_exp_neg(row ? chp->self_c[k] : INFINITY);
+    double xi_acc = 0.0;
+    int r_lo = T, r_hi = -1;
+    for (int t0 = tl; t0 < T; t0 += FPI * UN) {
+        double xaf[UN], xbf[UN], xpf[UN];
+        int xae[UN], xbe[UN], xpe[UN];
+        ET xe[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int t = t0 + FPI * q;
+            const bool in = row && t < T;
+            const int64_t at = (int64_t)t * n + k;
+            xaf[q] = in ? af[at] : 0.0; xae[q] = in ? ae[at] : XN_ZERO_E;
+            xbf[q] = in ? bf[at] : 0.0; xbe[q] = in ? be[at] : XN_ZERO_E;
+            const bool inp = in && t >= 1 && want_xi;
+            xpf[q] = inp ? af[at - n] : 0.0; xpe[q] = inp ? ae[at - n] : XN_ZERO_E;
+            xe[q] = inp ? nll[(int64_t)t * a.S + st] : ET(0);
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int t = t0 + FPI * q;
+            if (t >= T) break;
+            const xnum A = xnum{xaf[q], xae[q]}, B = xnum{xbf[q], xbe[q]};
+            const double g = (row && reach) ? xn_ratio(A, B, inv_pf, P.e) : 0.0;
+            a.gam[(f0 + t) * NL + k] = g;                     // all NL columns (rows >= n: 0): whole lines per sweep
+            if (want_rng && ((g > a.rng_floor) | (g != g))) { r_hi = t; if (r_lo > t) r_lo = t; }   // (t runs upwards)
+            if (want_xi && row && reach && t >= 1) {
+                const xnum wt = xn_mul(B, xn_exp_neg((double)xe[q]));
+                xi_acc += xn_ratio(xnum{xpf[q], xpe[q]}, xn_mul(wt, p_self), inv_pf, P.e);
+            }
+        }
+    }
+    // a row's lanes: k, k + NL, k + 2 NL, ...
+#pragma unroll
+    for (int o = NL; o < 64; o <<= 1) {
+        xi_acc += __shfl_xor(xi_acc, o);
+        r_lo = min(r_lo, __shfl_xor(r_lo, o));
+        r_hi = max(r_hi, __shfl_xor(r_hi, o));
+    }
+    if (tl == 0) {
+        if (want_xi) a.self_xi_utt[u * NMAX + k] = row ? xi_acc : 0.0;
+        if (want_rng) { a.occ_rng[(u * NMAX + k) * 2] = r_lo; a.occ_rng[(u * NMAX + k) * 2 + 1] = r_hi; }
+    }
+}
+
 }  // namespace
 
 int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, size_t lds_bytes, bool f64) {
@@ -406,9 +581,43 @@ int gh_launch_fb(gh_ctx* ctx, const gh_fb_args& a, int64_t n_utts, int block, si
     return GH_OK;
 }
 
+// compact gamma and nothing per state: the two-way form (GMMHMM_FBCHAIN=1 keeps the one-way kernel)
+// The two-way form halves the dependent steps of a wave and doubles the waves, at the price of a second pass over the
+// columns (beta is stored too; gamma / xi come from a separate kernel): it pays while the one-way waves are too few to hide
+// their own latency -- 12 500 five-state utterances = 1.5 waves per SIMD: 0.257 -> 0.129 + 0.072 ms -- and costs a little once
+// the one-way kernel is throughput bound (50 000 sixteen-state utterances = 12 waves per SIMD: 0.87 -> 1.2 ms).
+// GMMHMM_FBCHAIN=1 / 2 forces the one-way / two-way form.
+bool gh_fbchain_two_way(const gh_ctx* ctx, bool compact_gamma, bool occupancy_matrix, int64_t U, int lanes) {
+    if (!compact_gamma || occupancy_matrix) return false;
+    if (const char* e = getenv("GMMHMM_FBCHAIN")) { if (atoi(e) == 1) return false; if (atoi(e) == 2) return true; }
+    const int64_t one_way_waves = (U * lanes + 63) / 64;
+    return one_way_waves < (int64_t)4 * 4 * ctx->n_cu;        // fewer than 4 waves per SIMD
+}
+
 int gh_launch_fb_chain(gh_ctx* ctx, const gh_fbchain_args& a, bool f64) {
     if (a.U <= 0) return GH_OK;
     if (a.lanes != 8 && a.lanes != 16) { gh_set_error("gh_launch_fb_chain: internal: %d lanes per utterance", a.lanes); return GH_ERR_INVALID; }
+    if (gh_fbchain_two_way(ctx, a.gam != nullptr, a.occ != nullptr, a.U, a.lanes)) {
+        const int per_wave2 = 32 / a.lanes;                // 4 (or 2) utterances per wave, 2 x 8 (or 2 x 16) lanes each
+        const dim3 grid2((unsigned)((a.U + per_wave2 - 1) / per_wave2)), blk2(64);
+        if (a.lanes == 8) {
+            if (f64) hipLaunchKernelGGL((fb_chain2_kernel<double, 8>), grid2, blk2, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((fb_chain2_kernel<float, 8>), grid2, blk2, 0, ctx->stream, a);
+        } else {
+            if (f64) hipLaunchKernelGGL((fb_chain2_kernel<double, 16>), grid2, blk2, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((fb_chain2_kernel<float, 16>), grid2, blk2, 0, ctx->stream, a);
+        }
+        const dim3 grid3((unsigned)a.U);
+        if (a.lanes == 8) {
+            if (f64) hipLaunchKernelGGL((fb_chain2_cells_kernel<double, 8>), grid3, blk2, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((fb_chain2_cells_kernel<float, 8>), grid3, blk2, 0, ctx->stream, a);
+        } else {
+            if (f64) hipLaunchKernelGGL((fb_chain2_cells_kernel<double, 16>), grid3, blk2, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((fb_chain2_cells_kernel<float, 16>), grid3, blk2, 0, ctx->stream, a);
+        }
+        GH_HIP(hipGetLastError());
+        return GH_OK;
+    }
     const int per_wave = 64 / a.lanes;                     // 8 (or 4) utterances per wave, 8 (or 16) lanes each
     const dim3 grid((unsigned)((a.U + per_wave - 1) / per_wave)), blk(64);
     if (a.lanes == 8) {

@@ -329,3 +329,64 @@ def test_block_lists_from_occupancy_ranges_equal_the_gamma_scan(shape, monkeypat
             np.testing.assert_array_equal(a.session.packed(), b.session.packed())
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("n,M,skip", [(5, 8, False), (7, 3, True), (13, 4, True), (16, 20, False)])
+def test_two_way_chain_forward_backward_equals_the_one_way_kernel(n, M, skip, monkeypatch):
+    """The chain forward-backward has two forms: one lane group per utterance walking forward, then backward
+    (fb_chain_kernel), and -- for batches too small to fill the chip -- forward and backward side by side in two lane groups
+    plus a cell kernel (fb_chain2_kernel, fb_chain2_cells_kernel).  Same log P, compact gamma, self transitions and occupancy
+    ranges (hence the same statistics through the session) to rounding; both against the generic kernel's occupancies."""
+    import bench
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice
+    from sr.recognition.train import BaumWelchTrainer
+    W, D, U = 4, 13, 150
+    wl = bench.synth_workload(31 + n, U, W=W, n=n, M=M, D=D, tmin=n + 1, tmax=6 * n)
+    trans = wl["trans"].copy()
+    if skip:
+        for i in range(n - 2):
+            trans[i + 2, i] = -np.log(0.03)
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    data[3] = data[3][:1]                     # a one-frame utterance: no path through n > 1 states
+    data[4] = data[4][:n]                     # exactly one frame per state
+    labels = [[int(w)] for w in wl["words"]]
+    out = {}
+    for form in ("1", "2"):
+        monkeypatch.setenv("GMMHMM_FBCHAIN", form)
+        tr = BaumWelchTrainer(wl["means"] + 0.2, wl["vars"], wl["w"], [trans] * W, data, labels)
+        assert tr.session is not None
+        ll = tr.iteration()
+        packed = tr.session.packed()
+        stats, xi, ll2 = tr.e_step()          # call by call (compact gamma: the same form)
+        out[form] = (ll, packed, stats, xi, ll2)
+        tr.close()
+    monkeypatch.delenv("GMMHMM_FBCHAIN")
+    a, b = out["1"], out["2"]
+    _close(a[0], b[0], 1e-12)
+    _close(a[1], b[1], 1e-9, 1e-11)
+    _close(a[2], b[2], 1e-9, 1e-11)
+    _close(a[3], b[3], 1e-9, 1e-11)
+    _close(a[4], b[4], 1e-12)
+    # against the any-graph kernel
+    ctx = _hip.default_context()
+    gmm = _hip.PackedGMM(ctx, (wl["means"] + 0.2).reshape(W * n, M, D), wl["vars"].reshape(W * n, M, D), wl["w"].reshape(W * n, M))
+    bt = _hip.Batch(ctx, data)
+    bt.loglik(gmm, fetch=False)
+    lat = _hip.Lattices(ctx, [packed_lattice([trans] * W, n, [[k]])[0] for k in range(W)])
+    ul = np.asarray(wl["words"], dtype=np.int32)
+    monkeypatch.setenv("GMMHMM_FB", "generic")
+    ref = lat.forward_backward(bt, utt_lattice=ul, want_occ=True, want_self_xi=True)
+    monkeypatch.delenv("GMMHMM_FB")
+    for form in ("1", "2"):
+        monkeypatch.setenv("GMMHMM_FBCHAIN", form)
+        got = lat.forward_backward(bt, utt_lattice=ul, want_occ=True, want_self_xi=True, fetch_occ=False)
+        st = bt.bw_accumulate(gmm)
+        monkeypatch.delenv("GMMHMM_FBCHAIN")
+        fin = np.isfinite(ref["logp"])
+        np.testing.assert_array_equal(np.isfinite(got["logp"]), fin)
+        _close(got["logp"][fin], ref["logp"][fin], 1e-11)
+        _close(got["self_xi"], ref["self_xi"], 1e-9, 1e-11)
+        assert np.isclose(st[:, :, 0].sum(), ref["occ"].sum(), rtol=1e-9)
+    for h in (bt, lat, gmm):
+        h.close()
