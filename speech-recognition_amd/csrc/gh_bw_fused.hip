@@ -291,9 +291,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             unsigned long long mask = __ballot(have && hi_l >= lo_l);
             const int f0lo_l = (int)(f0_l & 0xffffffffll), f0hi_l = (int)(f0_l >> 32);
             // the item being computed (c*) and the one in flight (n*): segment, block, last block of the segment
-            int64_t cf0 = 0, nf0 = 0;
+            int64_t nf0 = 0;
             int cT = 0, cb = 0, clast = -1, nT = 0, nb = 0, nlast = -1;
-            bool cvalid = false, nvalid = false;
+            bool nvalid = false;
             auto open_next_utt = [&]() {       // next utterance of the batch with a non-empty range -> (n*)
                 if (!mask) { nvalid = false; return; }
                 const int l = __builtin_ctzll(mask);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             open_next_utt();
             if (nvalid) fetch(nf0, nT, nb * TF);
             while (nvalid) {
-                cf0 = nf0; cT = nT; cb = nb; clast = nlast; cvalid = true;
+                cT = nT; cb = nb; clast = nlast;
                 park();
                 if (cb < clast) nb = cb + 1; else open_next_utt();
                 if (nvalid) fetch(nf0, nT, nb * TF);     // travels from HBM while this block is computed
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 compute((cT - cb * TF < TF) ? cT - cb * TF : TF);
                 __syncthreads();                         // (the next block's stores come after these reads)
             }
-            (void)cf0; (void)cvalid;
         }
     } else
     for (int ui = wg.u_begin; ui < wg.u_end; ++ui) {
