@@ -603,7 +603,7 @@ def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D
         row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
         ml = max_labels if max_labels is not None else b.lengths // (n - 1) + 2
         group.barrier()
-        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False), reps=5, ramp=0.25)   # (the first calls grow the scratch arenas)
+        t_dec, r = _timeit(lambda: lat.viterbi_labels(b, row_word, max_labels=ml, as_lists=False, want_end_cost=False), reps=5, ramp=0.25)   # (the first calls grow the scratch arenas)
         lf, lo, ln = r["labels_flat"], r["label_off"], r["n_labels"]
         acc = float(np.mean([[int(v) for v in lf[lo[u]:lo[u] + ln[u]]] == truth[u % U_base] for u in range(0, U, max(1, U // 4000))]))
         # fp32-likelihood decode against the fp64 one, on the distinct utterances: state paths and label sequences
@@ -681,7 +681,7 @@ def _pipelined_decode(dev, base, reps, gmm_arrays, graphs, n, npdt, group, piece
                     st["ctx"].record(ev)
                     chain["last"] = ev
                 ml = max_labels if max_labels is not None else bb.lengths // (n - 1) + 2
-                st["lat"].viterbi_labels(bb, row_word, max_labels=ml, as_lists=False)
+                st["lat"].viterbi_labels(bb, row_word, max_labels=ml, as_lists=False, want_end_cost=False)
 
         def step():
             chain["last"] = None

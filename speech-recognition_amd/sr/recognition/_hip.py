@@ -961,14 +961,16 @@ class Lattices:
                             for u in range(U)]
         return out
 
-    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True):
+    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True, want_end_cost=True):
         """A6 + A12 in one call: decode, keep the path on the device, return the decoded label sequences
         (main.py:59-67: first row of every emitting run between non-emitting rows).  row_label: one int32 array per
         graph (label per row, < 0 on non-emitting rows) or a single array when there is one graph.
         max_labels (scalar or [U]): upper bound on the labels per utterance; exceeding it raises BackendError.
         Returns dict(labels [list of int32 arrays], best_end [U], end_cost_flat, end_off, labels_flat, label_off,
         n_labels); as_lists=False leaves out the per-utterance list (at 10^5 utterances building it costs more host
-        time than the decode takes on the GPU): utterance u is labels_flat[label_off[u] : label_off[u] + n_labels[u]]."""
+        time than the decode takes on the GPU): utterance u is labels_flat[label_off[u] : label_off[u] + n_labels[u]].
+        want_end_cost=False: the costs of the end rows stay on the device (best_end, the chosen end row, still comes back) --
+        for a 10-word grammar that is 80 bytes per utterance of copy-back a label decode has no use for."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
         lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
@@ -977,9 +979,11 @@ class Lattices:
         rl = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.int32).reshape(-1) for r in row_label]))
         assert len(rl) == int(np.sum(self.R)), "row_label must give one label per graph row"
         T = batch.lengths
-        n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
-        end_off = np.concatenate([[0], np.cumsum(n_end)])
-        end_cost = np.empty(int(end_off[-1]), dtype=np.float64)
+        end_off = end_cost = None
+        if want_end_cost:
+            n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
+            end_off = np.concatenate([[0], np.cumsum(n_end)])
+            end_cost = np.empty(int(end_off[-1]), dtype=np.float64)
         best_end = np.empty(U, dtype=np.int32)
         nlev = np.array([self.path_cap(l, 1) for l in range(self.L)], dtype=np.int64)[lidx]
         cap = np.where(T > 1, T * nlev // 2 + 1, 0)

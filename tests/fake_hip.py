@@ -306,7 +306,7 @@ class Lattices:
         out["end_cost_flat"] = np.concatenate(out["end_cost"]) if out["end_cost"] else np.zeros(0)
         return out
 
-    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True):
+    def viterbi_labels(self, batch, row_label, utt_lattice=None, max_labels=None, as_lists=True, want_end_cost=True):
         if isinstance(row_label, np.ndarray) and row_label.ndim == 1 and self.L == 1:
             row_label = [row_label]
         r = self.viterbi(batch, utt_lattice=utt_lattice, want_path=True)

@@ -292,3 +292,31 @@ def test_layers_kernel_is_not_taken_for_other_graphs(hip, ctx):
         lat.close()
     b.close()
     gmm.close()
+
+
+def test_label_decode_without_the_end_costs():
+    """viterbi_labels(want_end_cost=False): same labels and chosen end rows, nothing but them comes back (packed and
+    per-utterance form, layer form and loop form)."""
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(21)
+    W, n, M, D, K = 5, 4, 2, 6, 3
+    means = rng.normal(size=(W * n, M, D)) * 2
+    gmm = _hip.PackedGMM(ctx, means, rng.uniform(0.5, 1.5, size=(W * n, M, D)), rng.dirichlet(np.ones(M), size=W * n))
+    wt = [word_trans(rng, n) for _ in range(W)]
+    xs = [means[rng.integers(0, W * n, size=int(rng.integers(n * K, 5 * n * K))), 0] + rng.normal(size=(1, D)) for _ in range(40)]
+    b = _hip.Batch(ctx, xs)
+    b.loglik(gmm, fetch=False)
+    for graph in (packed_lattice(wt, n, [list(range(W))] * K)[0], packed_loop_lattice(wt, n)[0]):
+        lat = _hip.Lattices(ctx, [graph])
+        row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+        for as_lists in (True, False):
+            full = lat.viterbi_labels(b, row_word, as_lists=as_lists)
+            lean = lat.viterbi_labels(b, row_word, as_lists=as_lists, want_end_cost=False)
+            assert lean["end_cost_flat"] is None and full["end_cost_flat"] is not None
+            np.testing.assert_array_equal(lean["best_end"], full["best_end"])
+            np.testing.assert_array_equal(lean["n_labels"], full["n_labels"])
+            np.testing.assert_array_equal(lean["labels_flat"], full["labels_flat"])
+        lat.close()
+    b.close(); gmm.close()
