@@ -88,7 +88,10 @@ __device__ __forceinline__ double bwf_exp2s(double y, const double* __restrict__
 // density MFMAs 28 %, accumulation MFMAs 32 %, responsibilities 19 %, HBM 5 %, barriers 1.5 % of its 0.72 ms -- so the way
 // down was less work, not fewer stalls; skipping zero blocks inside that structure only gained 14 % because the waves of a
 // workgroup still met at every tile.)
-template <int KS, int LT, bool WIDE>
+// NORM: the mixture normaliser comes from the batch's likelihood matrix (always with WIDE; with state pairs when the caller
+// vouches for the matrix -- the device-resident session, or matching model / matrix stamps): r = gamma 2^((y + K nll) / 128),
+// no maximum, no sum across the 8 lanes, no reciprocal (~24 of the ~45 VALU instructions per frame register).
+template <int KS, int LT, bool WIDE, bool NORM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bw_fused_kernel(const double* __restrict__ X, int D, int M,
                                                      const double* __restrict__ mean, const double* __restrict__ ivar,
                                                      const double* __restrict__ logc, const double* __restrict__ gam,
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                           // below need no bounds test
     double* xt = sm;                      // [TF][DP]
     double* gt = xt + TF * DP;            // [TF][2]  gamma of the block's frames for the pair's two states
-    double* nt = gt + TF * 2;             // [TF]     WIDE: K x the state's negative log-likelihood of the block's frames
-    double* tab = nt + (WIDE ? TF : 0);   // [128]    2^(j/128)
+    double* nt = gt + TF * 2;             // [TF][2]  NORM: K x the states' negative log-likelihoods of the block's frames
+    double* tab = nt + (NORM ? TF * 2 : 0);   // [128]    2^(j/128)
     const int lane = threadIdx.x;
     const int j = lane & 15, q = lane >> 4;
     const int p = blockIdx.x & ((1 << slot_shift) - 1);   // column group (slots beyond the word's groups leave)
@@ -187,7 +190,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #else
         pg = (j < nf_ && gcol >= 0) ? gam[(f0 + bf + j) * gam_stride + gcol] : 0.0;
 #endif
-        if (WIDE) pn = (lane < nf_) ? nll[(f0 + bf + lane) * (int64_t)nll_S + sa] : 0.0;
+        if (NORM) {   // lanes (frame j, state st) like gamma
+            const int s_n = st ? sb : sa;
+            pn = (lane < 32 && j < nf_ && s_n >= 0) ? nll[(f0 + bf + j) * (int64_t)nll_S + s_n] : 0.0;
+        }
     };
     // the fetched block -> LDS [16][DP] (rows >= nf zero) + gamma [16][2] (+ likelihoods [16])
     auto park = [&]() {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (i < TF * D) { const int f = i / D, d = i - f * D; xt[f * DP + d] = px[e]; }
         }
         if (lane < 32) gt[j * 2 + st] = pg;
-        if (WIDE && lane < TF) nt[lane] = pn * GH_LSE_SCALE64;
+        if (NORM && lane < 32) nt[j * 2 + st] = pn * GH_LSE_SCALE64;
     };
     // densities, responsibilities and accumulation of the parked block (nf frames)
     auto compute = [&](int nf) {
@@ -226,10 +232,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int r = 0; r < 4; ++r) {
             const int fr = q + 4 * r;
             const double y = da[r];
-            if (WIDE) {
+            if (NORM) {
                 // log(w pdf) - log sum_m' w pdf = y + K nll: the likelihood kernel's own normaliser
-                const double e = bwf_exp2s(y + nt[fr], tab);
-                const double g = gt[fr * 2];
+                const int hs = WIDE ? 0 : (j >> 3);
+                const double e = bwf_exp2s(y + nt[fr * 2 + hs], tab);
+                const double g = gt[fr * 2 + hs];
                 const double wgt = ((g > occ_floor) | (g != g)) ? g : 0.0;
                 R[r] = (valid & (fr < nf) & (wgt != 0.0)) ? e * wgt : 0.0;
             } else {
@@ -464,7 +471,8 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
     // M > 8: the mixture normalisers are the batch's likelihoods -- they must be this model's (else: generic kernel)
     const bool wide = M > 8;
-    if (wide && !(b->nll && b->nll_S == S && b->dtype == GH_F64 && b->nll_serial == g->serial && g->serial != 0)) return 1;
+    const bool own_nll = b->nll && b->nll_S == S && b->dtype == GH_F64 && b->nll_serial == g->serial && g->serial != 0;
+    if (wide && !own_nll) return 1;
     const int L = (int)chains.size();
     // a state may only sit in one place of one graph (the re-centring kernel writes every state once)
     std::vector<int> owner(S, -1);
@@ -534,7 +542,7 @@ int gh_bw_accumulate_fused(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, doub
     double* d_out = stats_dev ? stats_dev : plan.d_own;
     *d_result = d_out;
     rc = gh_bwf_launch(ctx, plan, g, (const double*)b->feats, seq ? b->occ : b->gam, seq ? S : b->gam_lanes, seq ? 1 : 0, occ_floor, nullptr,
-                       d_out, wide ? (const double*)b->nll : nullptr, S);
+                       d_out, own_nll ? (const double*)b->nll : nullptr, S);
     if (rc) return rc;
     GH_HIP(hipStreamSynchronize(ctx->stream));   // the plan lives in the context's scratch: the next call may overwrite it
     return GH_OK;
@@ -644,16 +652,17 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
     if (pl.n_wgs == 0) return GH_OK;
     const bool wide = M > 8;
     if (wide && !nll) { gh_set_error("gh_bwf_launch: internal: M = %d needs the batch's likelihoods", M); return GH_ERR_INVALID; }
-    const size_t lds = ((size_t)16 * ((2 * KS) | 1) + 16 * 2 + (wide ? 16 : 0) + 128) * 8;
+    const bool norm = nll != nullptr;     // (state pairs: the kernel's own log-sum-exp when the caller has no likelihoods to vouch for)
+    const size_t lds = ((size_t)16 * ((2 * KS) | 1) + 16 * 2 + (norm ? 32 : 0) + 128) * 8;
     const dim3 grid((unsigned)pl.n_wgs << pl.slot_shift), blk(64);   // one wave per (utterance group, column group slot)
     const gh_fbchain* chains = d_chains ? d_chains : pl.d_chains;
     const bwf_wg* d_wgs = (const bwf_wg*)pl.d_wgs;
     const bwf_pair* d_pairs = (const bwf_pair*)pl.d_pairs;
-#define GH_BWF_W(ks, nc, wd)                                                                                             \
-    hipLaunchKernelGGL((bw_fused_kernel<ks, nc, wd>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,               \
+#define GH_BWF_W(ks, nc, wd, nm)                                                                                         \
+    hipLaunchKernelGGL((bw_fused_kernel<ks, nc, wd, nm>), grid, blk, lds, st, feats, D, M, g->dMean, g->dIvar,           \
                        g->dLogc, gam, occ_floor, gam_stride, gam_by_state, pl.d_segfirst, pl.d_seglen, pl.d_ulist, d_wgs, chains, \
                        ctx->d_fp64_tables, pl.d_part, pl.slot_shift, nll, nll_S, rng)
-#define GH_BWF(ks, nc) do { if (wide) GH_BWF_W(ks, nc, true); else GH_BWF_W(ks, nc, false); } while (0)
+#define GH_BWF(ks, nc) do { if (wide) GH_BWF_W(ks, nc, true, true); else if (norm) GH_BWF_W(ks, nc, false, true); else GH_BWF_W(ks, nc, false, false); } while (0)
 #define GH_BWF_N(ks) switch (lt) { case 1: GH_BWF(ks, 1); break; case 2: GH_BWF(ks, 2); break; default: GH_BWF(ks, 3); break; }
     switch (KS) {
         case 2: GH_BWF_N(2) break;

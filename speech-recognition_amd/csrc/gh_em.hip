@@ -51,6 +51,7 @@ struct gh_em {
     // other half's likelihood / statistics kernels.  Half 0 on the context's stream, half 1 on `s2`; they join before the
     // tail kernel.  Same results; measured no faster (see gh_em_create), so one half is the default.
     int n_half;
+    bool norm_nll;         // mixture normalisers from the likelihood matrix (always for M > 8; GMMHMM_BWF_NORM=0: own log-sum-exp for M <= 8)
     bool use_rng;          // block lists from occupancy ranges (default) or from a pass over gamma (GMMHMM_BWF_RANGES=0)
     int lanes;             // lanes per utterance of the chain forward-backward = columns of d_gam (8, or 16 when n > 8)
     gh_loglik_plan ll_plan[2];
@@ -241,6 +242,7 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     e->ctx = ctx; e->b = b; e->W = W; e->n = n; e->M = M; e->D = D; e->S = S; e->U = U; e->N = b->N;
     e->lanes = n > 8 ? 16 : 8;
     e->use_rng = !(getenv("GMMHMM_BWF_RANGES") && !atoi(getenv("GMMHMM_BWF_RANGES")));
+    e->norm_nll = M > 8 || !(getenv("GMMHMM_BWF_NORM") && !atoi(getenv("GMMHMM_BWF_NORM")));
     e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
     int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
     if (rc) { gh_em_destroy(e); return rc; }
@@ -391,9 +393,9 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
                 r = gh_launch_fb_chain(ctx, ca, true);
             }
         }
-        // (M > 8: the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
+        // (the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
         if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
-                                  e->d_chains, stats_out, e->M > 8 ? (const double*)b->nll : nullptr, e->S,
+                                  e->d_chains, stats_out, e->norm_nll ? (const double*)b->nll : nullptr, e->S,
                                   e->use_rng ? e->d_rng : nullptr);
         ctx->stream = keep;
         return r;
