@@ -136,7 +136,7 @@ extern "C" int gh_event_elapsed_ms(void* start, void* stop, float* out_ms) {
 // GMMHMM_SCRATCH_BUDGET=<bytes>[K|M|G] (read at every call: the tests force several chunks with it); else a quarter of
 // what is free on the device (counting the arena this context already holds, which is reused), within [256 MiB, 24 GiB]:
 // several contexts or several ranks on one GPU each take their share instead of a fixed 24 GiB.
-size_t gh_scratch_budget(gh_ctx* ctx) {
+size_t gh_scratch_budget(gh_ctx* ctx, bool fresh) {
     if (const char* e = getenv("GMMHMM_SCRATCH_BUDGET")) {
         char* end = nullptr;
         double v = strtod(e, &end);
@@ -145,10 +145,13 @@ size_t gh_scratch_budget(gh_ctx* ctx) {
         else if (end && (*end == 'G' || *end == 'g')) v *= 1073741824.0;
         if (v >= 1.0) return (size_t)v;
     }
+    if (!fresh && ctx->budget_cache && ++ctx->budget_age < 64) return ctx->budget_cache;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4 << 30;
     const size_t avail = free_b + ctx->scratch_bytes;
-    return std::min((size_t)24 << 30, std::max((size_t)256 << 20, avail / 4));
+    ctx->budget_cache = std::min((size_t)24 << 30, std::max((size_t)256 << 20, avail / 4));
+    ctx->budget_age = 0;
+    return ctx->budget_cache;
 }
 
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
@@ -158,6 +161,7 @@ int gh_scratch(gh_ctx* ctx, size_t bytes, void** out) {
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
         size_t want = bytes + bytes / 8 + (1u << 20);
+        ctx->budget_cache = 0;                     // (the arena changes size: the next budget comes from the driver again)
         GH_HIP(hipMalloc(&ctx->scratch, want));
         ctx->scratch_bytes = want;
     }

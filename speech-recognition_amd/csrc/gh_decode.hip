@@ -1,5 +1,7 @@
 // C ABI: launch orchestration of the dynamic programs (gh_viterbi, gh_dtw, gh_forward_backward).
 #include "gh_internal.h"
+#include <chrono>
+#include <string>
 #include "gh_host.h"
 #include "gh_viterbi.h"
 #include "gh_dtw.h"
@@ -106,6 +108,22 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
     GH_REQUIRE(!out_costs || costs_off, "gh_viterbi: out_costs needs costs_off");
     GH_HIP(hipSetDevice(ctx->device));
+    // GMMHMM_HOST_TRACE=1: wall-clock phases of the call's host side on stderr (diagnostic)
+    struct HostTrace {
+        bool on; std::chrono::steady_clock::time_point t0, last; std::string line;
+        HostTrace() : on(getenv("GMMHMM_HOST_TRACE") && atoi(getenv("GMMHMM_HOST_TRACE"))) { t0 = last = std::chrono::steady_clock::now(); }
+        void mark(const char* what) {
+            if (!on) return;
+            const auto now = std::chrono::steady_clock::now();
+            char buf[96];
+            snprintf(buf, sizeof buf, " %s %.0f us |", what, std::chrono::duration<double, std::micro>(now - last).count());
+            line += buf; last = now;
+        }
+        ~HostTrace() {
+            if (on) fprintf(stderr, "[gh_viterbi host]%s total %.0f us\n", line.c_str(),
+                            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } trace;
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
     const int S = b->nll_S;
@@ -218,6 +236,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         }
         chunk_begin.push_back(U);
     };
+    trace.mark("checks");
     const int64_t n_path = (want_path && !labels_direct) ? path_off[U] : 0;
     const int64_t n_costs = out_costs ? costs_off[U] : 0;
 
@@ -261,11 +280,12 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         rc = carve();
         const size_t floor_b = (size_t)64 << 20;
         if (rc == GH_ERR_NOMEM && want_bp && bp_max * 2 > floor_b && budget > floor_b) {   // smaller chunks, same result
-            budget = std::min(budget, bp_max * 2) / 2;
+            budget = std::min(std::min(budget, gh_scratch_budget(ctx, /*fresh=*/true)), bp_max * 2) / 2;
             continue;
         }
         break;
     }
+    trace.mark("plan+carve");
     if (rc) return rc;
     ctx->last_chunks = (int)chunk_begin.size() - 1;
     hipStream_t st = ctx->stream;
@@ -280,6 +300,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         GH_HIP(hipMemcpyAsync(d_labeloff, label_off, (U + 1) * 8, hipMemcpyHostToDevice, st));
     }
 
+    trace.mark("uploads");
     a.descs = lat->d_desc; a.row_state = lat->d_row_state; a.row_start = lat->d_row_start;
     a.pred_ptr = lat->d_pred_ptr; a.pred_row = lat->d_pred_row; a.pred_cost = lat->d_pred_cost;
     a.order = lat->d_order; a.level_ptr = lat->d_level_ptr; a.end_rows = lat->d_end_rows;
@@ -404,6 +425,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
                          : gh_launch_viterbi(ctx, a, nu, block, lds, b->dtype == GH_F64, want_path);
         if (rc) return rc;
     }
+    trace.mark("launches");
     char* pin;
     rc = gh_pinned(ctx, small_bytes, (void**)&pin);
     if (rc) return rc;
@@ -437,6 +459,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         GH_HIP(hipGetLastError());
         GH_HIP(hipMemcpyAsync(out_frame_state, d_framestate, (size_t)b->N * 4, hipMemcpyDeviceToHost, st));
     }
+    trace.mark("labels");
     GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
     if (out_path) {
         GH_HIP(hipMemcpyAsync(out_path, d_path, 2 * n_path * 4, hipMemcpyDeviceToHost, st));
@@ -444,6 +467,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     }
     if (out_costs) GH_HIP(hipMemcpyAsync(out_costs, d_costs, n_costs * 8, hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));
+    trace.mark("final sync");
     const int flag = *reinterpret_cast<int*>(pin);
     if (out_best_end) memcpy(out_best_end, pin + ((char*)d_bestend - (char*)d_flag2), U * 4);
     if (out_end_cost) memcpy(out_end_cost, pin + ((char*)d_endcost - (char*)d_flag2), n_end_total * 8);
