@@ -7,6 +7,7 @@ exceptions).  Every density evaluation runs in HIP through libgmmhmm
 (`_hip.py`); this file only holds parameters and the O(M) / O(k*D) host glue
 (exp/sum of M component values, the M-step division, convergence tests).
 """
+import copy
 import uuid
 
 import numpy as np
@@ -21,6 +22,27 @@ def _ctx():
     return _hip.default_context()
 
 
+def _deepcopy_arrays_directly(self, memo):
+    """copy.deepcopy of a parameter object without the generic walk: numpy arrays are copied with .copy() (what
+    ndarray.__deepcopy__ does, aliasing between objects kept through `memo` as deepcopy keeps it), everything else goes
+    through copy.deepcopy with the same memo.  continuous_train deep-copies every model once per outer iteration
+    (continuous_speech.py:62,101): 400 MultivariateNormal objects for ten 5-state 8-mixture words -- 10 ms of generic
+    deepcopy, 2 ms like this; same result, same `id` (so the copies still hash like the originals)."""
+    new = self.__class__.__new__(self.__class__)
+    memo[id(self)] = new
+    d = new.__dict__
+    for k, v in self.__dict__.items():
+        if type(v) is np.ndarray and v.dtype != object:
+            y = memo.get(id(v))
+            if y is None:
+                y = v.copy()
+                memo[id(v)] = y
+            d[k] = y
+        else:
+            d[k] = copy.deepcopy(v, memo)
+    return new
+
+
 class MultivariateNormal:
     """Diagonal-covariance Gaussian (reference: hmm_state.py:5-45).
 
@@ -32,6 +54,8 @@ class MultivariateNormal:
     def __init__(self, mean, cov):
         self.mean = mean
         self.cov = cov
+
+    __deepcopy__ = _deepcopy_arrays_directly
 
     @property
     def cov(self):
@@ -91,6 +115,8 @@ class HMMState:
     def __init__(self):
         self.id = uuid.uuid4().int
         self.parent = None
+
+    __deepcopy__ = _deepcopy_arrays_directly
 
     def evaluate(self, x):
         raise NotImplemented()

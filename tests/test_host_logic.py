@@ -267,3 +267,39 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_deepcopy_of_models_equals_the_generic_deepcopy():
+    """MultivariateNormal / HMMState.__deepcopy__ copy their arrays directly (continuous_train copies every model once
+    per outer iteration): same values, same ids and hashes, fresh arrays, aliasing between objects preserved, parent
+    cycles survive -- as with the generic copy.deepcopy the reference relies on (continuous_speech.py:62,101)."""
+    import copy
+    import pickle
+    from sr.recognition.hmm_state import GMM, NES, MultivariateNormal
+    rng = np.random.default_rng(0)
+    mu, sigma = rng.normal(size=5), rng.uniform(0.5, 2, size=5)
+    g = GMM(mu, sigma, 4)                      # all four components share the SAME mean / cov arrays (hmm_state.py:110)
+    g.update_models(rng.normal(size=(2, 5)), rng.uniform(0.5, 2, size=(2, 5)), np.array([0.3, 0.7]))
+    g.parent = [g]                             # a cycle through a non-array attribute
+    nes = NES()
+    models = [g, nes, g]
+    c = copy.deepcopy(models)
+    assert c[0] is c[2] and c[0] is not g and c[0].parent[0] is c[0]
+    assert c[0].id == g.id and hash(c[0]) == hash(g) and c[1].id == nes.id and c[1] == nes
+    assert c[0] == g
+    for a, b in zip(c[0].dists, g.dists):
+        assert a is not b and a.mean is not b.mean
+        np.testing.assert_array_equal(a.mean, b.mean)
+        np.testing.assert_array_equal(a.cov, b.cov)
+        np.testing.assert_array_equal(a.inv_cov, b.inv_cov)
+    assert c[0].dists[2].mean is c[0].dists[3].mean            # untouched components still share one array
+    assert c[0].dists[0].mean is not c[0].dists[1].mean
+    assert set(vars(c[0])) == set(vars(g)) and set(vars(c[0].dists[0])) == set(vars(g.dists[0]))
+    c[0].dists[0].mean[0] = 99.0
+    assert g.dists[0].mean[0] != 99.0
+    r = pickle.loads(pickle.dumps(c[0]))
+    assert r == g or r.dists[0].mean[0] == 99.0
+    m = MultivariateNormal(mu, np.diag(sigma))
+    mc = copy.deepcopy(m)
+    np.testing.assert_array_equal(mc.inv_cov, m.inv_cov)
+    assert mc.inv_cov is not m.inv_cov
