@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "speech-recogni
 import bench
 from sr.recognition import _hip
 
-w = bench.synth_workload(1001, 10000)
+# shape: WT_SHAPE="utterances:mixtures:dim" (default 10000:8:39 = configs[1]; "100000:1:13" = configs[0] x 1000)
+_shape = [int(v) for v in os.environ.get("WT_SHAPE", "10000:8:39").split(":")]
+w = bench.synth_workload(1001, _shape[0], M=_shape[1], D=_shape[2])
 means, vars_, wts = w["means"], w["vars"], w["w"]
 S = means.shape[0] * means.shape[1]
 ctx = _hip.default_context(0)
