@@ -977,3 +977,45 @@ def test_compat_linear_domain_underflow(hip, dtype, M, D):
     ctx.set_compat(underflow=True)
     np.testing.assert_array_equal(b.loglik(gmm), got)
     b.close(); gmm.close(); ctx.close()
+
+
+@pytest.mark.parametrize("n", [9, 12, 16])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chain_forward_backward_with_16_lanes_equals_generic(hip, ctx, n, dtype, monkeypatch):
+    """Chains of 9-16 rows (configs[3]: 16 states per word) run the chain forward-backward with 16 lanes per utterance;
+    log P, the [N, S] occupancy matrix and the expected self transitions == the any-graph kernel, skip arcs included,
+    on fp64 and fp32 likelihoods."""
+    from sr.recognition.continuous_speech import packed_lattice
+    rng = np.random.default_rng(40 + n)
+    W, M, D, U = 3, 4, 13, 40
+    means = rng.normal(size=(W * n, M, D)) * 2
+    vars_ = rng.uniform(0.5, 1.5, size=(W * n, M, D))
+    w = rng.dirichlet(np.ones(M), size=W * n)
+    trans = np.full((n, n), np.inf)
+    for i in range(n):
+        trans[i, i] = 0.3
+        if i:
+            trans[i, i - 1] = 1.2
+        if i > 1:
+            trans[i, i - 2] = 3.0
+    words = rng.integers(0, W, size=U)
+    xs = []
+    for wd in words:
+        T = int(rng.integers(n, 5 * n))
+        st = wd * n + np.minimum(np.arange(T) * n // T, n - 1)
+        xs.append(means[st, rng.integers(0, M, size=T)] + rng.normal(size=(T, D)))
+    lat = hip.Lattices(ctx, [packed_lattice([trans] * W, n, [[k]])[0] for k in range(W)])
+    assert "fb_chain" in lat.forms()
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, xs, dtype=dtype)
+    b.loglik(gmm, fetch=False)
+    ul = words.astype(np.int32)
+    got = lat.forward_backward(b, utt_lattice=ul, want_occ=True, want_self_xi=True)
+    monkeypatch.setenv("GMMHMM_FB", "generic")
+    ref = lat.forward_backward(b, utt_lattice=ul, want_occ=True, want_self_xi=True)
+    monkeypatch.delenv("GMMHMM_FB")
+    np.testing.assert_allclose(got["logp"], ref["logp"], rtol=1e-10)
+    np.testing.assert_allclose(got["occ"], ref["occ"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(got["self_xi"], ref["self_xi"], rtol=1e-8, atol=1e-10)
+    for h in (b, lat, gmm):
+        h.close()
