@@ -121,20 +121,28 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
 // born in HBM (M-step kernel); packing them on the host meant a D2H, ~0.2 ms of host arithmetic, an allocation and an
 // H2D per EM iteration.  One thread per Gaussian writes the plain arrays, one thread per operand element the MFMA
 // fragments; mixture / tile padding keeps what gh_gmm_create put there (P = 0, C = OFF).
-// one block per dimension: the finite means of the G Gaussians summed by 64 lanes (strided, then a shuffle tree)
-__global__ __launch_bounds__(64) void gmm_centre_kernel(const double* __restrict__ mean, int G, int D, int KP, float* __restrict__ cen32) {
-    const int d = blockIdx.x, lane = threadIdx.x;
+// one block per dimension: the finite means of the G Gaussians summed by 1024 threads (strided, a shuffle tree per wave,
+// the 16 wave sums in order) -- with 64 lanes the 32 768 Gaussians of the configs[3] model took 0.18 ms per model update
+__global__ __launch_bounds__(1024) void gmm_centre_kernel(const double* __restrict__ mean, int G, int D, int KP, float* __restrict__ cen32) {
+    __shared__ double s_acc[16];
+    __shared__ int s_cnt[16];
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc = 0;
     int cnt = 0;
     if (d < D)
-        for (int i = lane; i < G; i += 64) {
+        for (int i = tid; i < G; i += 1024) {
             const double mu = mean[(size_t)i * D + d];
             if (mu - mu == 0.0) { acc += mu; ++cnt; }   // finite
         }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o); cnt += __shfl_xor(cnt, o); }
-    if (lane == 0) {
-        float c = cnt ? (float)(acc / cnt) : 0.f;
+    if (lane == 0) { s_acc[wave] = acc; s_cnt[wave] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0;
+        int n = 0;
+        for (int w = 0; w < 16; ++w) { a += s_acc[w]; n += s_cnt[w]; }
+        float c = n ? (float)(a / n) : 0.f;
         if (!(c - c == 0.f)) c = 0.f;
         cen32[d] = c;
     }
@@ -215,7 +223,7 @@ int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double
     v.A64 = g->dA64; v.B64 = g->dB64; v.C64 = g->dC64; v.Mean = g->dMean; v.Ivar = g->dIvar; v.Logc = g->dLogc;
     v.Apk64 = g->dApk64; v.Cpk64 = g->dCpk64; v.A32 = g->dA32; v.B32 = g->dB32; v.C32 = g->dC32;
     v.Apk32 = g->dApk32; v.Cpk32 = g->dCpk32; v.cen32 = g->dCen32;
-    hipLaunchKernelGGL(gmm_centre_kernel, dim3(g->KP), dim3(64), 0, st, d_mean, G, g->D, g->KP, g->dCen32);
+    hipLaunchKernelGGL(gmm_centre_kernel, dim3(g->KP), dim3(1024), 0, st, d_mean, G, g->D, g->KP, g->dCen32);
     hipLaunchKernelGGL(gmm_pack_plain_kernel, dim3((G + 63) / 64), dim3(64), 0, st, v, d_mean, d_var, d_weight, d_flag);
     const int64_t total = (int64_t)g->n_tiles * 16 * 2 * g->KP;
     hipLaunchKernelGGL(gmm_pack_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v);
