@@ -246,6 +246,25 @@ int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
                double* out_end_cost, int32_t* out_best_end,
                int32_t* out_path, const int64_t* path_off /*[U+1]*/, int32_t* out_path_len,
                double* out_costs, const int64_t* costs_off /*[U+1]*/);
+/* A5 + A2 (and A6 + A3 with one component) in ONE sweep: HMM.evaluate for word models with a single Gaussian per state,
+ * hmm.py:131-135 -- `dtw(x, self.mu, mahalanobis, self.transitions, self.sigma)` (use_gmm=False; hmm_state.py:48-58,
+ * decode.py:7-77) or `decode_hmm_states(x, [GMM(mu, sigma, 1)...], self.transitions)` (hmm_state.py:114-120) -- which both
+ * score a cell while they fill the cost matrix.  Same graphs, outputs and conventions as gh_viterbi (one graph for the
+ * whole batch), but every lane evaluates its own state's Gaussian against the frame: no [N, S] likelihood matrix is
+ * written or read (8 D + 4 bytes of HBM traffic per frame instead of 8 D + 16 S + 4).
+ *   g           model with ONE component per state (its weight enters as -log w, 1.0 for a plain Gaussian)
+ *   log_domain  1: the distance is mahalanobis() -- a log-domain quantity that never underflows (use_gmm=False models);
+ *               0: the cell is GMM.evaluate: with compat bit 0 of the context, +inf where exp(-q/2) or the weighted
+ *               density rounds to 0 in the reference's linear domain
+ * The fused kernel takes left-to-right chains (any number of word models side by side), D <= 40, no beam, no
+ * single-frame utterance; anything else runs as gh_loglik + gh_viterbi inside the call with identical results
+ * (gh_ctx_last_fused tells which; GMMHMM_FUSED=0 forces the two-kernel form). */
+int gh_viterbi_fused(gh_ctx* ctx, const gh_gmm* g, const gh_lattices* lat, gh_batch* b, int log_domain,
+                     double* out_end_cost, int32_t* out_best_end,
+                     int32_t* out_path, const int64_t* path_off /*[U+1]*/, int32_t* out_path_len,
+                     double* out_costs, const int64_t* costs_off /*[U+1]*/);
+/* 1: the last gh_viterbi_fused call on this context ran the fused kernel; 0: gh_loglik + gh_viterbi */
+int gh_ctx_last_fused(const gh_ctx* ctx);
 /* upper bound on the number of path cells of an utterance of T frames on graph l */
 int64_t gh_viterbi_path_cap(const gh_lattices* lat, int l, int64_t T);
 /* A6 + A12 in one call: the same decode, but the path stays on the device and only the DECODED LABEL

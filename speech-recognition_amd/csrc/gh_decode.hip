@@ -102,9 +102,9 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
                         const int64_t* path_off, int32_t* out_path_len, double* out_costs,
                         const int64_t* costs_off, const int32_t* row_label, int32_t* out_labels,
                         const int64_t* label_off, int32_t* out_n_labels, int64_t packed_cap = -1,
-                        int32_t* out_frame_state = nullptr) {
+                        int32_t* out_frame_state = nullptr, const gh_gmm* fused = nullptr, int fused_log_domain = 0) {
     GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
-    GH_REQUIRE(b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
+    GH_REQUIRE(fused || b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
     GH_REQUIRE(!out_costs || costs_off, "gh_viterbi: out_costs needs costs_off");
     GH_HIP(hipSetDevice(ctx->device));
@@ -126,7 +126,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     } trace;
     const int64_t U = b->U;
     if (U == 0) return GH_OK;
-    const int S = b->nll_S;
+    const int S = fused ? fused->S : b->nll_S;
     if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernels runs on its expanded twin
         bool seq_fit = forced_kernel() == 0 && lat->beam <= 0 && !out_costs;
         for (int64_t u = 0; seq_fit && u < U; ++u)
@@ -148,6 +148,9 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         for (int64_t u = 0; use_chain && u < U; ++u)
             if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
     }
+    // fused single-Gaussian decode (gh_viterbi_fused.hip): the chain form without the [N, S] matrix
+    const int fused_dv = (fused && use_chain) ? gh_fused_dv(fused->D) : 0;
+    const bool use_fused = fused_dv > 0;
     // layer-form kernels: one K-layer word lattice / word-loop grammar for the whole batch (GMMHMM_VITERBI=lean /
     // generic force the others)
     bool use_layers = !use_chain && lat->layers_ok && uniform && !out_costs && lat->beam <= 0;
@@ -249,6 +252,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     int* d_flag2;  // [flag | best_end | end_cost] are carved back to back: ONE D2H copy into pinned memory
     size_t small_bytes = 0;
     int32_t* d_framestate = nullptr;
+    double* d_fpar = nullptr;
+    const int fused_rp = (lat->max_R + 63) & ~63;
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
     int64_t *d_labeloff = nullptr, *d_poff = nullptr;
     int32_t* d_packed = nullptr;
@@ -257,6 +262,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     auto carve = [&]() -> int {
         Carver cv;
         cv.add(&d_flag2, 64); cv.add(&d_bestend, U);
+        if (use_fused) cv.add(&d_fpar, (size_t)(2 * fused_dv + 2) * fused_rp);
         if (!out_end_cost) small_bytes = cv.total;       // (nobody wants the end costs: they stay on the device -- 8 MB of
         cv.add(&d_endcost, n_end_total);                 //  copy-back for 100 000 utterances x 10 word ends otherwise)
         if (out_end_cost) small_bytes = cv.total;
@@ -312,8 +318,9 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     a.flag = d_flag2;
 
     if (use_chain) {
-        gh_chain_args c;
-        memset(&c, 0, sizeof c);
+        gh_fused_args fa;
+        memset(&fa, 0, sizeof fa);
+        gh_chain_args& c = fa.c;
         c.cost0 = lat->d_ch_cost0; c.cost1 = lat->d_ch_cost1; c.cost2 = lat->d_ch_cost2; c.row_info = lat->d_ch_info;
         c.row_state = lat->d_row_state; c.end_slot = lat->d_ch_end_slot; c.end_rows = lat->d_end_rows;
         c.group_row0 = lat->d_ch_group_row0; c.n_groups = lat->chain_groups; c.R = lat->lat[0].R; c.S = S;
@@ -321,9 +328,18 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         c.bp = reinterpret_cast<uint8_t*>(d_bp); c.bp_off = d_bpoff; c.end_cost = d_endcost; c.best_end = d_bestend;
         c.path = d_path; c.path_off = d_pathoff; c.path_len = d_pathlen; c.costs = d_costs; c.costs_off = d_costsoff;
         c.flag = d_flag2;
+        if (use_fused) {
+            // ln 2^-1075: below it np.exp() and the weighted density round to +0 in the reference's linear domain
+            const double thr = (!fused_log_domain && (ctx->compat & 1)) ? 745.1332191019412 : INFINITY;
+            rc = gh_launch_fused_params(ctx, fused, lat->d_row_state, c.R, fused_rp, fused_dv, thr, d_fpar);
+            if (rc) return rc;
+            fa.feats = b->feats; fa.par = d_fpar; fa.D = fused->D; fa.Rp = fused_rp; fa.skip = lat->chain_skip ? 1 : 0;
+        }
+        ctx->last_fused = use_fused ? 1 : 0;
         for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
             const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
-            rc = gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
+            rc = use_fused ? gh_launch_viterbi_fused(ctx, fa, fused_dv, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr)
+                           : gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
             if (!rc) rc = gh_launch_chain_backtrace(ctx, c, u0, nu);  // end selection (+ path when requested)
             if (rc) return rc;
         }
@@ -497,6 +513,32 @@ extern "C" int gh_viterbi(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b
     return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, out_path, path_off, out_path_len, out_costs,
                         costs_off, nullptr, nullptr, nullptr, nullptr);
 }
+
+// A5 + A2 / A6 + A3 in one sweep for models with ONE Gaussian per state (HMM.evaluate, hmm.py:131-135).  Shapes the fused
+// kernel does not take (several components, graphs that are not left-to-right chains, single-frame utterances, a beam,
+// D > 40) run as gh_loglik followed by gh_viterbi: same results, two kernels.
+extern "C" int gh_viterbi_fused(gh_ctx* ctx, const gh_gmm* g, const gh_lattices* lat, gh_batch* b, int log_domain,
+                                double* out_end_cost, int32_t* out_best_end, int32_t* out_path, const int64_t* path_off,
+                                int32_t* out_path_len, double* out_costs, const int64_t* costs_off) {
+    GH_REQUIRE(ctx && g && lat && b, "gh_viterbi_fused: NULL argument");
+    GH_REQUIRE(g->D == b->D || b->N == 0, "gh_viterbi_fused: model has %d dimensions, batch %d", g->D, b->D);
+    ctx->last_fused = 0;
+    bool can = g->M == 1 && lat->chain_ok && lat->beam <= 0 && forced_kernel() == 0 && gh_fused_dv(g->D) > 0 && !lat->deferred_src;
+    if (const char* e = getenv("GMMHMM_FUSED")) can = can && atoi(e) != 0;
+    for (int64_t u = 0; can && u < b->U; ++u)
+        if (b->offsets[u + 1] - b->offsets[u] == 1) can = false;   // T == 1: the reference's column wrap (other kernels)
+    if (!can) {
+        const int compat = ctx->compat;
+        if (log_domain) ctx->compat &= ~1;     // mahalanobis() is a log-domain distance: it never underflows
+        const int rc = gh_loglik(ctx, g, b, nullptr);
+        ctx->compat = compat;
+        if (rc) return rc;
+    }
+    return viterbi_impl(ctx, lat, b, nullptr, out_end_cost, out_best_end, out_path, path_off, out_path_len, out_costs, costs_off,
+                        nullptr, nullptr, nullptr, nullptr, -1, nullptr, can ? g : nullptr, log_domain);
+}
+
+extern "C" int gh_ctx_last_fused(const gh_ctx* ctx) { return ctx ? ctx->last_fused : -1; }
 
 extern "C" int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
                                  const int32_t* row_label, double* out_end_cost, int32_t* out_best_end,

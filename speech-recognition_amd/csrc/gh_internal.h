@@ -51,6 +51,7 @@ struct gh_ctx {
     size_t pinned_bytes;
     double* d_fp64_tables;  // [384] exp2 / inv / -log tables of the fp64 log-sum-exp (gh_loglik_mfma.hip)
     int compat;             // gh_ctx_set_compat: bit 0 = linear-domain underflow of the reference's GMM.evaluate (+inf)
+    int last_fused = 0;     // 1: the last gh_viterbi_fused call on this context ran the fused kernel (0: gh_loglik + gh_viterbi)
     int last_chunks;        // launches the last gh_viterbi* / gh_forward_backward call on this context was cut into (scratch budget)
     size_t budget_cache = 0;     // gh_scratch_budget's last answer (hipMemGetInfo is ~0.2 ms: asked again only when the arena
     int budget_age = 0;          //   changes size, an allocation fails, or after 64 calls)

@@ -76,6 +76,9 @@ SIGNATURES = {
     "gh_lattices_forms": (C.c_int, [C.c_void_p]),
     "gh_viterbi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
                              _c_i32p, _c_f64p, _c_i64p]),
+    "gh_viterbi_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_i32p, _c_i32p, _c_i64p,
+                                   _c_i32p, _c_f64p, _c_i64p]),
+    "gh_ctx_last_fused": (C.c_int, [C.c_void_p]),
     "gh_viterbi_path_cap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
     "gh_viterbi_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, _c_f64p, _c_i32p, _c_i32p,
                                     _c_i64p, _c_i32p]),
@@ -206,6 +209,11 @@ class Context:
         back as +inf, like the reference's linear-domain GMM.evaluate (hmm_state.py:114-120); False: log domain throughout,
         finite costs.  See gh_ctx_set_compat."""
         _check(self.lib, self.lib.gh_ctx_set_compat(self.h, 1 if underflow else 0))
+
+    @property
+    def last_fused(self):
+        """True when the last fused decode on this context ran the fused kernel (False: gh_loglik + gh_viterbi)."""
+        return int(self.lib.gh_ctx_last_fused(self.h)) == 1
 
     @property
     def last_chunks(self):
@@ -927,10 +935,13 @@ class Lattices:
     def path_cap(self, l, T):
         return int(self.ctx.lib.gh_viterbi_path_cap(self.h, int(l), int(T)))
 
-    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True):
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True, fused_gmm=None,
+                log_domain=False):
         """A6 for every utterance.  Returns dict(end_cost [list per utt], best_end [U],
         paths [list of int64 [K,2]], costs [list of [R,T]]).  want_end_cost=False: only best_end (the cheapest end
-        row, last minimum on ties: decode.py:129-134) comes back, the end costs stay on the device."""
+        row, last minimum on ties: decode.py:129-134) comes back, the end costs stay on the device.
+        fused_gmm: a one-component `PackedGMM` -- the cells are scored inside the sweep (gh_viterbi_fused; the batch
+        needs no likelihood matrix); log_domain=True scores with mahalanobis() (no linear-domain underflow)."""
         lib, U = self.ctx.lib, batch.U
         lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
         lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
@@ -949,9 +960,16 @@ class Lattices:
             Rs = np.asarray(self.R, dtype=np.int64)[lidx]
             costs_off = np.concatenate([[0], np.cumsum(Rs * T)]).astype(np.int64)
             costs = np.empty(int(costs_off[-1]), dtype=np.float64)
-        _check(lib, lib.gh_viterbi(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(end_cost, _c_f64p),
-                                   _ptr(best_end, _c_i32p), _ptr(path, _c_i32p), _ptr(path_off, _c_i64p),
-                                   _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p), _ptr(costs_off, _c_i64p)))
+        if fused_gmm is not None:
+            assert lat is None, "the fused decode takes one graph for the whole batch"
+            _check(lib, lib.gh_viterbi_fused(self.ctx.h, fused_gmm.h, self.h, batch.h, int(bool(log_domain)),
+                                             _ptr(end_cost, _c_f64p), _ptr(best_end, _c_i32p), _ptr(path, _c_i32p),
+                                             _ptr(path_off, _c_i64p), _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p),
+                                             _ptr(costs_off, _c_i64p)))
+        else:
+            _check(lib, lib.gh_viterbi(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(end_cost, _c_f64p),
+                                       _ptr(best_end, _c_i32p), _ptr(path, _c_i32p), _ptr(path_off, _c_i64p),
+                                       _ptr(path_len, _c_i32p), _ptr(costs, _c_f64p), _ptr(costs_off, _c_i64p)))
         out = dict(best_end=best_end, end_off=end_off, end_cost_flat=end_cost,
                    end_cost=[end_cost[end_off[u]:end_off[u + 1]] for u in range(U)] if (U <= 2048 and want_end_cost) else None)
         if want_path:

@@ -17,10 +17,23 @@ __all__ = ["IsolatedWordRecognizer", "ContinuousDecoder", "InFlight", "path_to_w
 
 
 def _stack_models(ctx, models):
+    """(states per word, packed Gaussians of all words, single-Gaussian flag).  A model trained with use_gmm=False has no
+    `gmm_states` (hmm.py:57-76): its states are the rows of `mu` / `sigma`, scored by mahalanobis() (hmm.py:133-134)."""
+    single = [not getattr(m, "use_gmm", True) or m.gmm_states is None for m in models]
+    assert all(single) or not any(single), "word models with and without mixtures cannot share one recogniser"
+    if single[0]:
+        n = len(models[0].mu)
+        for m in models:
+            assert len(m.mu) == n
+        mean = np.concatenate([np.asarray(m.mu, dtype=np.float64) for m in models])[:, None, :]
+        var = np.concatenate([np.asarray(m.sigma, dtype=np.float64) for m in models])[:, None, :]
+        key = (id(ctx), _pack._digest(mean, var, np.zeros(1)))
+        gmm = _pack._gmm_cache.lookup(key, lambda: _hip.PackedGMM(ctx, mean, var, np.ones((len(mean), 1))))
+        return n, gmm, True
     n = len(models[0].gmm_states)
     for m in models:
         assert len(m.gmm_states) == n
-    return n, _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states])
+    return n, _pack.device_gmm(ctx, [s for m in models for s in m.gmm_states]), False
 
 
 def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_em=True):
@@ -107,7 +120,7 @@ class IsolatedWordRecognizer:
         self.ctx = ctx if ctx is not None else _hip.default_context(device)
         self.dtype = dtype
         self.W = len(models)
-        self.n, self.gmm = _stack_models(self.ctx, models)
+        self.n, self.gmm, self.single = _stack_models(self.ctx, models)
         n, W = self.n, self.W
         to, frm, cost = [], [], []
         for i, m in enumerate(models):
@@ -122,9 +135,15 @@ class IsolatedWordRecognizer:
         self.lat = _hip.Lattices(self.ctx, [graph])
 
     def costs(self, batch):
-        """[U, W] matrix of HMM.evaluate values for a resident `_hip.Batch`."""
-        batch.loglik(self.gmm, fetch=False)
-        r = self.lat.viterbi(batch, want_path=False)
+        """[U, W] matrix of HMM.evaluate values for a resident `_hip.Batch`.  Models with ONE Gaussian per state
+        (use_gmm=False, or one-component mixtures) are scored inside the dynamic program -- the reference's own
+        single-Gaussian path, hmm.py:133-134 (`dtw` with `mahalanobis`): no [N, S] likelihood matrix exists
+        (gh_viterbi_fused); mixtures run gh_loglik + gh_viterbi."""
+        if self.gmm.M == 1:
+            r = self.lat.viterbi(batch, want_path=False, fused_gmm=self.gmm, log_domain=self.single)
+        else:
+            batch.loglik(self.gmm, fetch=False)
+            r = self.lat.viterbi(batch, want_path=False)
         return r["end_cost_flat"].reshape(batch.U, self.W)
 
     def recognize(self, xs):
@@ -206,7 +225,9 @@ class ContinuousDecoder:
     def __init__(self, models, n_layers=7, device=None, dtype=np.float64, grammar="layers", word_penalty=0.0, ctx=None):
         self.ctx = ctx if ctx is not None else _hip.default_context(device)
         self.dtype = dtype
-        self.n, self.gmm = _stack_models(self.ctx, models)
+        # (single-Gaussian word models decode through the likelihood kernel here: mahalanobis() is the one-component
+        #  GMM.evaluate with weight 1, the same number up to rounding)
+        self.n, self.gmm, _ = _stack_models(self.ctx, models)
         W = len(models)
         wt = [m.transitions for m in models]
         if grammar == "layers":
