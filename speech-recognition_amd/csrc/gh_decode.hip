@@ -333,14 +333,15 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             const double thr = (!fused_log_domain && (ctx->compat & 1)) ? 745.1332191019412 : INFINITY;
             rc = gh_launch_fused_params(ctx, fused, lat->d_row_state, c.R, fused_rp, fused_dv, thr, d_fpar);
             if (rc) return rc;
-            fa.feats = b->feats; fa.par = d_fpar; fa.D = fused->D; fa.Rp = fused_rp; fa.skip = lat->chain_skip ? 1 : 0;
+            fa.feats = b->feats; fa.par = d_fpar; fa.D = fused->D; fa.Rp = fused_rp; fa.skip = lat->chain_skip ? 1 : 0; fa.DVp = fused_dv; fa.lin = std::isfinite(thr) ? 1 : 0;
+            fa.select_end = (c.n_groups == 1 && !want_path && !out_costs) ? 1 : 0;
         }
         ctx->last_fused = use_fused ? 1 : 0;
         for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
             const int64_t u0 = chunk_begin[k], nu = chunk_begin[k + 1] - u0;
-            rc = use_fused ? gh_launch_viterbi_fused(ctx, fa, fused_dv, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr)
+            rc = use_fused ? gh_launch_viterbi_fused(ctx, fa, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr)
                            : gh_launch_viterbi_chain(ctx, c, u0, nu, b->dtype == GH_F64, want_bp, out_costs != nullptr, lat->chain_skip);
-            if (!rc) rc = gh_launch_chain_backtrace(ctx, c, u0, nu);  // end selection (+ path when requested)
+            if (!rc && !(use_fused && fa.select_end)) rc = gh_launch_chain_backtrace(ctx, c, u0, nu);  // end selection (+ path when requested)
             if (rc) return rc;
         }
     }

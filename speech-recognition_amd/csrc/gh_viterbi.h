@@ -80,14 +80,17 @@ int gh_launch_chain_backtrace(gh_ctx* ctx, const gh_chain_args& a, int64_t u_beg
 struct gh_fused_args {
     gh_chain_args c;
     const void* feats;   // [N, D] features of the batch's dtype
-    const double* par;   // [2 DV + 2][Rp]: sqrt(1/(2 var)) rows, -mean sqrt(1/(2 var)) rows, -logc, underflow threshold
-    int D, Rp, skip;     // feature dimension (<= DV), padded row count, any r-2 -> r arc
+    const double* par;   // [2 DVp + 2][Rp]: sqrt(1/(2 var)) rows, -mean sqrt(1/(2 var)) rows, -logc, underflow threshold
+    int D, Rp, skip;     // feature dimension, padded row count, any r-2 -> r arc
+    int DVp;             // rows per half of the constants table (gh_fused_dv(D))
+    int select_end;      // 1: the sweep also picks the best end row (one lane group, no path wanted): no back-trace launch
+    int lin;             // 1: the linear-domain underflow rule of GMM.evaluate is on (finite threshold in the table)
     int64_t n_items;     // (utterance, row group) pairs of the launch
 };
-int gh_fused_dv(int D);  // register-resident dimensions of the instantiation that takes D (0: none)
+int gh_fused_dv(int D);  // rows per half of the constants table for D dimensions (0: D not covered)
 int gh_launch_fused_params(gh_ctx* ctx, const gh_gmm* g, const int32_t* d_row_state, int R, int Rp, int DV, double thr,
                            double* d_par);
-int gh_launch_viterbi_fused(gh_ctx* ctx, const gh_fused_args& fa, int DV, int64_t u_begin, int64_t n_utts, bool f64,
+int gh_launch_viterbi_fused(gh_ctx* ctx, const gh_fused_args& fa, int64_t u_begin, int64_t n_utts, bool f64,
                             bool want_bp, bool want_costs);
 
 // Layer-form kernel (gh_viterbi_layers.hip): K identical layers of W words x N states (gh_layerform), one graph for
