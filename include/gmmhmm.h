@@ -70,7 +70,9 @@ int gh_ctx_last_chunks(const gh_ctx* ctx);
  *          log domain and return the (large, finite) cost -- the numerically kinder choice for un-normalised features,
  *          but not what the reference computes.  The test is made on the term's total logarithm (one compare against a
  *          runtime threshold in the kernels' epilogues: no cost); the reference can also lose a term earlier, in
- *          exp(-q/2) before the normalisation (not reproduced). */
+ *          exp(-q/2) before the normalisation, when w * norm > 1 (variances below ~1/2pi): models with such a component
+ *          get a second pass over the few entries whose cost lies within log(w norm) of the threshold, which re-tests
+ *          them per component (round 4; a no-op launch for ordinary models). */
 int gh_ctx_set_compat(gh_ctx* ctx, int flags);
 /* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);

@@ -80,6 +80,10 @@ struct gh_gmm {
     float* dCen32;                   // [KP]
     // plain parameters (fp64) for the training kernels: mean, inv_var [G,D], logc [G]
     double *dMean, *dIvar, *dLogc;
+    // 1 when some component's log(w * normaliser) is positive (tight variances): the linear-domain underflow rule of
+    // GMM.evaluate then needs the per-component test of gh_loglik_underflow_fix (written by gh_gmm_create and by
+    // every device-side re-pack)
+    int* dAnyPos = nullptr;
     // MFMA operand packing (gh_loglik_mfma.hip): mixtures padded to M_pad components,
     // Gaussians to n_tiles*16 rows; Apk[tile][kstep][lane] fragments, Cpk[tile*16 + j]
     int M_pad, n_tiles;
@@ -263,6 +267,9 @@ struct gh_lattices {
 
 int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double* d_var, const double* d_weight, int* d_flag);
 int gh_batch_ensure_nll(gh_ctx* ctx, gh_batch* b, int S, bool zero);
+// compat bit 0, second half: +inf where EVERY component's exp(-q/2) or weighted density rounds to 0 although the largest
+// total logarithm is still above ln 2^-1075 (components with w * norm > 1); a no-op launch for ordinary models
+int gh_loglik_underflow_fix(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
 struct gh_comm;
 int gh_comm_allreduce_enqueue(gh_comm* c, double* dev, int64_t n);
 gh_ctx* gh_comm_context(const gh_comm* c);

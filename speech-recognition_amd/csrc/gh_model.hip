@@ -102,10 +102,12 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
                 }
         }
     std::vector<double> vmean(mean, mean + (size_t)G * D);
+    std::vector<int> anypos(1, 0);
+    for (int i = 0; i < G; ++i) if (logc[i] > 0) anypos[0] = 1;
     UploadArena ar;
     ar.add(&g->dA64, g->hA); ar.add(&g->dB64, g->hB); ar.add(&g->dC64, g->hC);
     ar.add(&g->dA32, fA); ar.add(&g->dB32, fB); ar.add(&g->dC32, fC); ar.add(&g->dCen32, cen32);
-    ar.add(&g->dMean, vmean); ar.add(&g->dIvar, ivar); ar.add(&g->dLogc, logc);
+    ar.add(&g->dMean, vmean); ar.add(&g->dIvar, ivar); ar.add(&g->dLogc, logc); ar.add(&g->dAnyPos, anypos);
     ar.add(&g->dApk64, apk64); ar.add(&g->dCpk64, cpk64); ar.add(&g->dApk32, apk32); ar.add(&g->dCpk32, cpk32);
     const int rc = ar.commit(&g->d_arena);
     if (rc) {
@@ -123,10 +125,12 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
 // fragments; mixture / tile padding keeps what gh_gmm_create put there (P = 0, C = OFF).
 // one block per dimension: the finite means of the G Gaussians summed by 1024 threads (strided, a shuffle tree per wave,
 // the 16 wave sums in order) -- with 64 lanes the 32 768 Gaussians of the configs[3] model took 0.18 ms per model update
-__global__ __launch_bounds__(1024) void gmm_centre_kernel(const double* __restrict__ mean, int G, int D, int KP, float* __restrict__ cen32) {
+__global__ __launch_bounds__(1024) void gmm_centre_kernel(const double* __restrict__ mean, int G, int D, int KP, float* __restrict__ cen32,
+                                                          int* __restrict__ any_pos) {
     __shared__ double s_acc[16];
     __shared__ int s_cnt[16];
     const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (d == 0 && tid == 0) *any_pos = 0;      // (raised again by gmm_pack_plain_kernel, next on the stream)
     double acc = 0;
     int cnt = 0;
     if (d < D)
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(1024) void gmm_centre_kernel(const double* __restri
 }
 
 struct gmm_dev_view {
+    int* any_pos;
     int S, M, D, KP, M_pad, n_tiles;
     double *A64, *B64, *C64, *Mean, *Ivar, *Logc, *Apk64, *Cpk64;
     float *A32, *B32, *C32, *Apk32, *Cpk32;
@@ -180,6 +185,7 @@ __global__ void gmm_pack_plain_kernel(gmm_dev_view v, const double* __restrict__
     }
     const double logc = log(weight[i]) - 0.5 * (D * log2pi + sum_logv);
     v.Logc[i] = logc;
+    if (logc > 0) atomicOr(v.any_pos, 1);
     const double c = logc - 0.5 * sum_m2, c32 = logc - 0.5 * sum_m2c;
     v.C64[i] = c;
     v.C32[i] = (float)c32;
@@ -222,8 +228,8 @@ int gh_gmm_update_dev(gh_ctx* ctx, gh_gmm* g, const double* d_mean, const double
     v.S = g->S; v.M = g->M; v.D = g->D; v.KP = g->KP; v.M_pad = g->M_pad; v.n_tiles = g->n_tiles;
     v.A64 = g->dA64; v.B64 = g->dB64; v.C64 = g->dC64; v.Mean = g->dMean; v.Ivar = g->dIvar; v.Logc = g->dLogc;
     v.Apk64 = g->dApk64; v.Cpk64 = g->dCpk64; v.A32 = g->dA32; v.B32 = g->dB32; v.C32 = g->dC32;
-    v.Apk32 = g->dApk32; v.Cpk32 = g->dCpk32; v.cen32 = g->dCen32;
-    hipLaunchKernelGGL(gmm_centre_kernel, dim3(g->KP), dim3(1024), 0, st, d_mean, G, g->D, g->KP, g->dCen32);
+    v.Apk32 = g->dApk32; v.Cpk32 = g->dCpk32; v.cen32 = g->dCen32; v.any_pos = g->dAnyPos;
+    hipLaunchKernelGGL(gmm_centre_kernel, dim3(g->KP), dim3(1024), 0, st, d_mean, G, g->D, g->KP, g->dCen32, g->dAnyPos);
     hipLaunchKernelGGL(gmm_pack_plain_kernel, dim3((G + 63) / 64), dim3(64), 0, st, v, d_mean, d_var, d_weight, d_flag);
     const int64_t total = (int64_t)g->n_tiles * 16 * 2 * g->KP;
     hipLaunchKernelGGL(gmm_pack_operands_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v);
@@ -409,6 +415,54 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
 }
 
 // ------------------------------------------------------------------- loglik
+// ---- the linear-domain underflow rule, exactly (gh_ctx_set_compat bit 0).  GMM.evaluate sums w * pdf with
+// pdf = norm * np.exp(-q/2) (hmm_state.py:36-45,114-120): a term is 0 once exp(-q/2) is -- below ln 2^-1075, WHATEVER the
+// normaliser -- or once the product is.  The likelihood kernels test the largest total logarithm a = log(w norm) - q/2
+// against ln 2^-1075, which is the whole rule while every log(w norm) <= 0 (ordinary variances).  With a component whose
+// w * norm > 1 (variances below ~1/2pi on average) a frame can have a > ln 2^-1075 and -q/2 below it: this pass finds the
+// entries in that band (cost within max(log(w norm), 0) of the threshold: next to none) and re-tests them per component.
+template <typename T>
+__global__ void loglik_underflow_fix_kernel(const T* __restrict__ X, int64_t N, int S, int M, int D, const double* __restrict__ mean,
+                                            const double* __restrict__ ivar, const double* __restrict__ logc,
+                                            const float* __restrict__ cen32, const int* __restrict__ any_pos, T* __restrict__ nll) {
+    if (*any_pos == 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * S) return;
+    const int64_t t = idx / S;
+    const int s = (int)(idx - t * S);
+    double P = 0.0;
+    for (int m = 0; m < M; ++m) P = fmax(P, logc[s * M + m]);     // (-inf for a switched-off component)
+    if (!(P > 0.0)) return;
+    const double thr = 745.1332191019412;
+    const double v = (double)nll[idx];
+    if (!(v > thr - P) || v == INFINITY) return;
+    for (int m = 0; m < M; ++m) {
+        const double lc = logc[s * M + m];
+        double q2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dx = (double)X[t * D + d] - mean[(size_t)(s * M + m) * D + d];
+            q2 += dx * dx * ivar[(size_t)(s * M + m) * D + d];
+        }
+        q2 *= 0.5;
+        if (!(q2 > thr) && !(q2 - lc > thr)) return;              // this term survives in the reference: the cost is finite
+    }
+    nll[idx] = (T)INFINITY;
+}
+
+int gh_loglik_underflow_fix(gh_ctx* ctx, const gh_gmm* g, gh_batch* b) {
+    if (!(ctx->compat & 1) || b->N == 0 || !b->nll || !g->dAnyPos) return GH_OK;
+    const int64_t total = b->N * (int64_t)g->S;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (b->dtype == GH_F64)
+        hipLaunchKernelGGL(loglik_underflow_fix_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)b->feats, b->N, g->S,
+                           g->M, g->D, g->dMean, g->dIvar, g->dLogc, g->dCen32, g->dAnyPos, (double*)b->nll);
+    else
+        hipLaunchKernelGGL(loglik_underflow_fix_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)b->feats, b->N, g->S,
+                           g->M, g->D, g->dMean, g->dIvar, g->dLogc, g->dCen32, g->dAnyPos, (float*)b->nll);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
+
 extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_host) {
     GH_REQUIRE(ctx && g && b, "gh_loglik: NULL argument");
     GH_REQUIRE(g->D == b->D, "gh_loglik: feature dim %d != model dim %d (hmm_state.py:45)", b->D, g->D);
@@ -427,6 +481,7 @@ extern "C" int gh_loglik(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, void* out_ho
     static const bool force_valu = [] { const char* e = getenv("GMMHMM_LOGLIK"); return e && !strcmp(e, "valu"); }();
     int rc = force_valu ? 1 : gh_launch_loglik_mfma(ctx, g, b);
     if (rc == 1) rc = gh_launch_loglik(ctx, g, b);
+    if (!rc) rc = gh_loglik_underflow_fix(ctx, g, b);
     if (rc) return rc;
     if (out_host && b->N > 0) {
         GH_HIP(hipMemcpyAsync(out_host, b->nll, (size_t)b->N * g->S * esz, hipMemcpyDeviceToHost, ctx->stream));
@@ -473,6 +528,7 @@ static int loglik_subset_impl(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const i
     }
     int rc = gh_launch_loglik_mfma(ctx, g, b, state_lo, state_hi, range_off);
     if (rc == 1) return gh_loglik(ctx, g, b, nullptr);   // shape / range not covered: the full matrix is a superset
+    if (!rc) rc = gh_loglik_underflow_fix(ctx, g, b);    // (entries outside the ranges: zeros / stale values, nobody reads them)
     return rc;
 }
 

@@ -979,6 +979,51 @@ def test_compat_linear_domain_underflow(hip, dtype, M, D):
     b.close(); gmm.close(); ctx.close()
 
 
+@pytest.mark.parametrize("M,D", [(1, 13), (4, 13), (8, 39)])
+def test_compat_underflow_with_normalisers_above_one(hip, M, D):
+    """the reference loses a term already in np.exp(-q/2) -- below ln 2^-1075 WHATEVER the normaliser is
+    (hmm_state.py:36-45) -- so with tight variances (log(w norm) > 0) a frame costs +inf although the total logarithm of
+    its largest term is still representable.  Frames with -q/2 in (-790, -746), variances of 0.01: +inf exactly where the
+    oracle's linear-domain evaluate says so (the band the test on the total logarithm alone would miss), finite elsewhere."""
+    ctx = hip.Context(0)
+    rng = np.random.default_rng(7 * M + D)
+    S, N = 5, 120
+    means = rng.normal(size=(S, M, D)) * 0.002
+    vars_ = np.full((S, M, D), 0.01) * rng.uniform(0.9, 1.1, size=(S, M, D))
+    w = rng.dirichlet(np.ones(M), size=S)
+    X = rng.normal(size=(N, D)) * 0.1
+    for i in range(0, N, 2):                                    # every other frame: -q/2 between -700 and -790
+        d = rng.normal(size=D)
+        X[i] = d / np.linalg.norm(d) * np.sqrt(2 * (700.0 + 90.0 * i / N) * 0.01)
+    with np.errstate(divide="ignore"):
+        lin = np.array([[O.gmm_evaluate(x, means[s], vars_[s], w[s]) for s in range(S)] for x in X])
+    logdom = O.gmm_neg_loglik_batch(X, means, vars_, w)
+    lognorm = -0.5 * (D * np.log(2 * np.pi) + np.sum(np.log(vars_), axis=2)) + np.log(w)
+    assert (lognorm > 5).all()
+    band = np.isinf(lin) & (logdom < 745.0)                     # +inf in the reference, total logarithm above the threshold
+    assert band.sum() >= 20 and np.isfinite(lin).sum() >= N * S // 2
+    gmm = hip.PackedGMM(ctx, means, vars_, w)
+    b = hip.Batch(ctx, feats=X, offsets=[0, 40, N])
+    got = b.loglik(gmm)
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(lin))
+    # (values: where the reference's exp(-q/2) is a normal number -- beyond ~708 it works on denormals, whose few bits
+    #  show in the cost; the +inf pattern above is exact everywhere)
+    q2min = np.array([[0.5 * np.min(np.sum((x - means[s]) ** 2 / vars_[s], axis=1)) for s in range(S)] for x in X])
+    fin = np.isfinite(lin) & (q2min < 700)
+    assert fin.sum() >= N * S // 3
+    np.testing.assert_allclose(got[fin], lin[fin], rtol=1e-10)
+    # the same entries through a subset launch and after an in-place parameter update (device-side re-pack)
+    lo, hi = np.zeros(2, dtype=np.int32), np.full(2, S, dtype=np.int32)
+    got2 = b.loglik(gmm, state_ranges=(lo, hi))
+    np.testing.assert_array_equal(np.isinf(got2), np.isinf(lin))
+    gmm.update(means, vars_ * 100.0, w)                         # ordinary variances: nothing underflows early any more
+    got3 = b.loglik(gmm)
+    assert np.isfinite(got3).all()
+    gmm.update(means, vars_, w)
+    np.testing.assert_array_equal(np.isinf(b.loglik(gmm)), np.isinf(lin))
+    b.close(); gmm.close(); ctx.close()
+
+
 @pytest.mark.parametrize("n", [9, 12, 16])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_chain_forward_backward_with_16_lanes_equals_generic(hip, ctx, n, dtype, monkeypatch):
