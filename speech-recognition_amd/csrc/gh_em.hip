@@ -366,7 +366,6 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
 
 extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out_tail) {
     GH_REQUIRE(ctx && e && e->ctx == ctx, "gh_em_iteration: NULL argument / foreign context");
-    GH_REQUIRE(e->it < e->hist_cap, "gh_em_iteration: more than %d iterations in one session", e->hist_cap);
     GH_REQUIRE(!comm || gh_comm_context(comm) == ctx, "gh_em_iteration: the communicator belongs to another context (its "
                "collective must sit on the stream of the kernels around it)");
     GH_HIP(hipSetDevice(ctx->device));
@@ -427,7 +426,7 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
     GH_HIP(hipGetLastError());
     rc = gh_gmm_update_dev(ctx, e->gmm, e->d_mean, e->d_var, e->d_weight, e->d_flags + 1);
     if (rc) return rc;
-    double* row = e->d_hist + (size_t)e->it * 4;
+    double* row = e->d_hist + (size_t)(e->it % e->hist_cap) * 4;   // a ring: the last hist_cap iterations stay readable
     hipLaunchKernelGGL(em_finish_kernel, dim3(1), dim3(1), 0, st, tail + e->S, e->d_flags, row);
     GH_HIP(hipGetLastError());
     e->it += 1;
@@ -448,9 +447,13 @@ extern "C" int gh_em_iterations_done(const gh_em* e) { return e ? e->it : 0; }
 extern "C" int gh_em_history(gh_ctx* ctx, gh_em* e, int first, int count, double* out) {
     GH_REQUIRE(ctx && e && out && first >= 0 && count >= 0 && first + count <= e->it, "gh_em_history: range [%d, %d) of %d",
                first, first + count, e ? e->it : 0);
+    GH_REQUIRE(first >= e->it - e->hist_cap, "gh_em_history: iteration %d has left the history (the last %d of %d are kept)", first,
+               e->hist_cap, e->it);
     if (count == 0) return GH_OK;
     GH_HIP(hipSetDevice(ctx->device));
-    GH_HIP(hipMemcpyAsync(out, e->d_hist + (size_t)first * 4, (size_t)count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    const int r0 = first % e->hist_cap, n0 = std::min(count, e->hist_cap - r0);      // (the range may wrap around the ring)
+    GH_HIP(hipMemcpyAsync(out, e->d_hist + (size_t)r0 * 4, (size_t)n0 * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (count > n0) GH_HIP(hipMemcpyAsync(out + (size_t)n0 * 4, e->d_hist, (size_t)(count - n0) * 32, hipMemcpyDeviceToHost, ctx->stream));
     GH_HIP(hipStreamSynchronize(ctx->stream));
     return GH_OK;
 }

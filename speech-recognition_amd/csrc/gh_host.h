@@ -66,6 +66,13 @@ struct UploadLayout {
             *it.dst = static_cast<char*>(base) + it.off;
             if (it.src_bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.src_bytes); }
         }
+        // (the one copy below covers [lo, hi): a piece that is "left as it is" must not lie inside it -- it would be
+        //  overwritten with the staging buffer's zeros; every current user adds its host pieces back to back)
+        for (auto& it : items)
+            if (!it.src_bytes && it.off >= lo && it.off < hi) {
+                gh_set_error("UploadLayout: a piece without host data lies between two host pieces");
+                return GH_ERR_INVALID;
+            }
         if (hi > lo) {
             std::vector<char> stage(hi - lo, 0);
             for (auto& it : items) if (it.src_bytes) memcpy(stage.data() + (it.off - lo), it.src, it.src_bytes);

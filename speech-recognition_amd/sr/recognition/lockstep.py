@@ -53,7 +53,9 @@ class LockstepFitter:
             dim = self.segs[0].shape[1] if self.segs else 0
         else:
             assert source is not None and lengths is not None and dim is not None
-            self.segs = None
+            # (no state at all -- empty data, or every alignment failed: the empty fitter must still build, the callers'
+            #  S == 0 early returns then do what the reference does: warn 'No MFCC data', keep the models)
+            self.segs = None if len(lengths) else []
         self.S = len(lengths)
         self.D = int(dim) if self.S else 0
         self.seg_off = np.zeros(self.S + 1, dtype=np.int64)

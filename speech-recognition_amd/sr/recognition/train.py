@@ -86,7 +86,15 @@ class BaumWelchTrainer:
         red = self.reducer
         native = getattr(red, "native", False)
         alone = not getattr(red, "enabled", False) or red.world_size == 1
-        if device_resident and all(len(l) == 1 for l in label_seqs) and (native or alone) and self.batch.np_dtype == np.float64:
+        possible = bool(device_resident and all(len(l) == 1 for l in label_seqs) and (native or alone)
+                        and self.batch.np_dtype == np.float64)
+        if not alone and native:      # (another kind of reducer rules the session out on every rank alike)
+            # the choice is COLLECTIVE: a rank with a multi-word transcript (or another dtype) takes the
+            # call-by-call path, and then every rank must -- M-step and stop test on the device here and in numpy there
+            # would let the replicated models drift apart bit by bit, and with them the number of collectives per fit()
+            n_no = red(np.array([0.0 if possible else 1.0]))
+            possible = possible and float(np.asarray(n_no).ravel()[0]) == 0.0
+        if possible:
             try:
                 self.session = _hip.EMSession(self.ctx, self.batch, self._means, self._vars, self._weights,
                                               np.asarray(self._transitions), [int(l[0]) for l in label_seqs], self.var_floor,
@@ -170,6 +178,9 @@ class BaumWelchTrainer:
             out = self.session.iteration(comm=self._comm(), sync=sync)
             self._stale = True
             if not sync:
+                # (the session keeps the last 4096 history rows: unread ones are collected before the ring wraps)
+                if self.session.iterations_done - len(self.history) >= 4000:
+                    self._drain_to(self.session.iterations_done)
                 return None
             self._drain_to(self.session.iterations_done - 1)
             ll, _, self.converged = out

@@ -253,9 +253,19 @@ class Lattices:
     def path_cap(self, l, T):
         return 3 * T
 
-    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True):
+    def viterbi(self, batch, utt_lattice=None, want_path=True, want_costs=False, want_end_cost=True, fused_gmm=None,
+                log_domain=False):
         """Each start row is decoded as its own reference problem (the reference has ONE start cell,
-        row 0; a stacked graph is W independent chains), then merged."""
+        row 0; a stacked graph is W independent chains), then merged.  fused_gmm: the double of gh_viterbi_fused --
+        the oracle scores the cells first (mahalanobis for log_domain, the linear-domain GMM.evaluate otherwise)."""
+        if fused_gmm is not None:
+            g = fused_gmm
+            if log_domain:
+                batch.nll = np.array([[O.mahalanobis(x, g.mean[s, 0], g.var[s, 0]) - np.log(g.w[s, 0]) for s in range(g.S)]
+                                      for x in batch.feats]).reshape(batch.N, g.S)
+                batch.S = g.S
+            else:
+                batch.loglik(g, fetch=False)
         U = batch.U
         lidx = np.zeros(U, dtype=int) if utt_lattice is None else np.asarray(utt_lattice, dtype=int)
         out = dict(best_end=np.zeros(U, dtype=np.int32), end_cost=[], paths=[], costs=[])
