@@ -308,6 +308,7 @@ class Group:
                                    % self.ctx.lib.gh_last_error().decode())
             with native_stdout_to_stderr():
                 self.native = NativeReducer(self.ctx, rank, world)
+                Group.active_native = self.native      # (what a failing rank aborts on its way out)
                 self.native.barrier()
             self.kind = "native"
 
@@ -1197,4 +1198,21 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # a rank that fails aborts its communicator and exits 1 on the spot (its peers get an error from the library's
+    # deadline / RCCL's asynchronous error instead of hanging in a collective; the spawner relays the status)
+    # (sr.recognition.parallel.exit_rank_on_failure, spelled out: nothing of the package is imported before the spawner runs)
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        try:
+            if getattr(Group, "active_native", None) is not None:
+                Group.active_native.abort()
+        except BaseException:
+            traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)

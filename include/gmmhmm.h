@@ -39,7 +39,8 @@ typedef enum {
     GH_ERR_NOMEM = -3,       /* device or host allocation failed                        */
     GH_ERR_NODEVICE = -4,    /* no usable GPU                                           */
     GH_ERR_SELF_POINTER = -5,/* a DP cell chose itself as origin: decode.py:120-121     */
-    GH_ERR_UNSUPPORTED = -6  /* shape outside what the kernels are built for            */
+    GH_ERR_UNSUPPORTED = -6, /* shape outside what the kernels are built for            */
+    GH_ERR_COMM = -7         /* a collective failed or timed out; the communicator has been aborted */
 } gh_status;
 
 typedef enum { GH_F32 = 0, GH_F64 = 1 } gh_dtype;
@@ -422,6 +423,12 @@ typedef struct gh_comm gh_comm;
 int gh_comm_unique_id(char* out_id /*[GH_COMM_ID_BYTES]*/);
 int gh_comm_create(gh_ctx* ctx, int rank, int world, const char* unique_id /*[GH_COMM_ID_BYTES]*/, gh_comm** out);
 void gh_comm_destroy(gh_comm* comm);
+/* Failure path: ncclCommAbort -- the collectives in flight on this rank leave, the stream drains, every later call on the
+ * handle returns GH_ERR_COMM (gh_comm_destroy still frees it).  A rank that fails calls it before it exits, so that its
+ * peers' connections close; the peers themselves never hang either: every wait behind a collective (gh_comm_barrier,
+ * gh_comm_allreduce_host, the read-back of gh_em_iteration, the polls of gh_fit_kmeans / gh_fit_em) watches RCCL's
+ * asynchronous errors and a deadline of GMMHMM_COMM_TIMEOUT seconds (default 300), aborts and returns GH_ERR_COMM. */
+int gh_comm_abort(gh_comm* comm);
 int gh_comm_count(const gh_comm* comm);
 int gh_comm_rank(const gh_comm* comm);
 int gh_comm_version(void);            /* ncclGetVersion, 0 when librccl cannot be opened */

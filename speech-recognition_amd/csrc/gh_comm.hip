@@ -9,7 +9,9 @@
 #include "gh_internal.h"
 #include "gh_host.h"
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 struct gh_comm {
@@ -17,6 +19,7 @@ struct gh_comm {
     ncclComm_t comm;
     int rank, world;
     double* d_one;      // one double on the device: the barrier's payload
+    bool aborted = false;   // ncclCommAbort has run (failure path): every later call on the handle returns GH_ERR_COMM
 };
 
 namespace {
@@ -99,6 +102,81 @@ int need_rccl(const char* who) {
 
 }  // namespace
 
+// ---- failure path ("Failure detection": the C ABI returns error codes).  A rank that dies before
+// or inside a collective leaves its peers inside ncclAllReduce: a bare hipStreamSynchronize behind it never returns.
+// Every wait behind a collective therefore polls the stream, asks RCCL for asynchronous errors (a closed peer connection
+// shows up there) and gives up at a deadline -- GMMHMM_COMM_TIMEOUT seconds, default 300 -- by aborting the communicator
+// (ncclCommAbort: the collective's kernels leave, the stream drains) and returning GH_ERR_COMM.
+static double comm_timeout_s() {
+    if (const char* e = getenv("GMMHMM_COMM_TIMEOUT")) {
+        const double v = atof(e);
+        if (v > 0) return v;
+    }
+    return 300.0;
+}
+
+static void comm_abort_now(gh_comm* c) {
+    if (c->aborted) return;
+    c->aborted = true;
+    if (c->comm) {
+        if (g_rccl.CommAbort) g_rccl.CommAbort(c->comm);
+        else if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    // the aborted collective's kernels leave on their own; give the stream a bounded time to drain
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(c->ctx->stream) == hipErrorNotReady &&
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 10.0)
+        usleep(1000);
+}
+
+extern "C" int gh_comm_abort(gh_comm* c) {
+    GH_REQUIRE(c, "gh_comm_abort: NULL argument");
+    hipSetDevice(c->ctx->device);
+    comm_abort_now(c);
+    return GH_OK;
+}
+
+// wait for the context's stream; with a communicator: deadline + RCCL's asynchronous errors (see above)
+int gh_stream_wait(gh_ctx* ctx, gh_comm* c, const char* who) {
+    if (!c) {
+        GH_HIP(hipStreamSynchronize(ctx->stream));
+        return GH_OK;
+    }
+    if (c->aborted) {
+        gh_set_error("%s: the communicator has been aborted", who);
+        return GH_ERR_COMM;
+    }
+    const double limit = comm_timeout_s();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int polls = 0;; ++polls) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return GH_OK;
+        if (q != hipErrorNotReady) {
+            gh_set_error("%s: hipStreamQuery -> %s", who, hipGetErrorString(q));
+            return GH_ERR_HIP;
+        }
+        if ((polls & 63) == 63 || polls > 4096) {
+            ncclResult_t ar = ncclSuccess;
+            if (g_rccl.CommGetAsyncError && g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess &&
+                ar != ncclInProgress) {
+                gh_set_error("%s: RCCL reports an asynchronous error (%s) -- a peer rank is gone; communicator aborted", who,
+                             g_rccl.GetErrorString(ar));
+                comm_abort_now(c);
+                return GH_ERR_COMM;
+            }
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > limit) {
+                gh_set_error("%s: rank %d of %d waited %.0f s behind a collective (GMMHMM_COMM_TIMEOUT) -- a peer rank never "
+                             "arrived; communicator aborted", who, c->rank, c->world, el);
+                comm_abort_now(c);
+                return GH_ERR_COMM;
+            }
+        }
+        if (polls > 4096) usleep(50);      // (the first polls spin: a collective of this path takes tens of microseconds)
+    }
+}
+
 extern "C" int gh_comm_unique_id(char* out_id /*[128]*/) {
     GH_REQUIRE(out_id, "gh_comm_unique_id: NULL argument");
     static_assert(sizeof(ncclUniqueId) == GH_COMM_ID_BYTES, "ncclUniqueId size");
@@ -136,14 +214,14 @@ extern "C" int gh_comm_create(gh_ctx* ctx, int rank, int world, const char* uniq
 extern "C" void gh_comm_destroy(gh_comm* c) {
     if (!c) return;
     hipSetDevice(c->ctx->device);
-    hipStreamSynchronize(c->ctx->stream);
+    if (!c->aborted) gh_stream_wait(c->ctx, c, "gh_comm_destroy");     // (a hung collective aborts the communicator here)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->d_one) hipFree(c->d_one);
     delete c;
 }
 
 extern "C" int gh_comm_count(const gh_comm* c) {
-    if (!c || !g_rccl.CommCount) return 0;
+    if (!c || !g_rccl.CommCount || c->aborted) return 0;
     int n = 0;
     return g_rccl.CommCount(c->comm, &n) == ncclSuccess ? n : 0;
 }
@@ -166,6 +244,10 @@ extern "C" int gh_comm_version(void) {
 
 // internal: the collective every trainer path uses (gh_em.hip enqueues it between the statistics and the M-step)
 int gh_comm_allreduce_enqueue(gh_comm* c, double* dev, int64_t n) {
+    if (c->aborted) {
+        gh_set_error("gh_stats_allreduce: the communicator has been aborted");
+        return GH_ERR_COMM;
+    }
     if (n <= 0) return GH_OK;
     GH_RCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, c->comm, c->ctx->stream), "gh_stats_allreduce");
     return GH_OK;
@@ -185,8 +267,7 @@ extern "C" int gh_comm_barrier(gh_ctx* ctx, gh_comm* c) {
     GH_HIP(hipMemsetAsync(c->d_one, 0, 8, ctx->stream));
     int rc = gh_comm_allreduce_enqueue(c, c->d_one, 1);
     if (rc) return rc;
-    GH_HIP(hipStreamSynchronize(ctx->stream));
-    return GH_OK;
+    return gh_stream_wait(ctx, c, "gh_comm_barrier");
 }
 
 // host buffer in, reduced host buffer out (staged through the context's scratch): the lock-step trainer's cluster sums
@@ -198,10 +279,13 @@ extern "C" int gh_comm_allreduce_host(gh_ctx* ctx, gh_comm* c, double* host_io, 
     void* base;
     int rc = gh_scratch(ctx, (size_t)n * 8, &base);
     if (rc) return rc;
+    if (c->aborted) {
+        gh_set_error("gh_comm_allreduce_host: the communicator has been aborted");
+        return GH_ERR_COMM;
+    }
     GH_HIP(hipMemcpyAsync(base, host_io, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     GH_RCCL(g_rccl.AllReduce(base, base, (size_t)n, ncclDouble, op_max ? ncclMax : ncclSum, c->comm, ctx->stream),
             "gh_comm_allreduce_host");
     GH_HIP(hipMemcpyAsync(host_io, base, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GH_HIP(hipStreamSynchronize(ctx->stream));
-    return GH_OK;
+    return gh_stream_wait(ctx, c, "gh_comm_allreduce_host");
 }

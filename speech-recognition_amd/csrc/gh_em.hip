@@ -432,7 +432,8 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
     e->it += 1;
     if (out_tail) {
         GH_HIP(hipMemcpyAsync(e->h_tail, row, 32, hipMemcpyDeviceToHost, st));
-        GH_HIP(hipStreamSynchronize(st));
+        rc = gh_stream_wait(ctx, comm, "gh_em_iteration");     // (behind the all-reduce: a lost peer is an error, not a hang)
+        if (rc) return rc;
         memcpy(out_tail, e->h_tail, 32);
         if ((int)e->h_tail[3] & 16) {
             gh_set_error("gh_em_iteration: a re-estimated variance is 0 (singular covariance); raise var_floor");

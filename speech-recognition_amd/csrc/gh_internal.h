@@ -273,6 +273,9 @@ int gh_loglik_underflow_fix(gh_ctx* ctx, const gh_gmm* g, gh_batch* b);
 struct gh_comm;
 int gh_comm_allreduce_enqueue(gh_comm* c, double* dev, int64_t n);
 gh_ctx* gh_comm_context(const gh_comm* c);
+// hipStreamSynchronize of the context's stream -- behind a collective (c != NULL) with RCCL's asynchronous errors and the
+// GMMHMM_COMM_TIMEOUT deadline: GH_ERR_COMM (communicator aborted) instead of a hang when a peer rank is gone
+int gh_stream_wait(gh_ctx* ctx, gh_comm* c, const char* who);
 
 // the handle whose row-per-lane arrays are valid: `l` itself, or the lazily expanded twin of a transcripts handle
 int gh_lattices_full(const gh_lattices* l, const gh_lattices** out);

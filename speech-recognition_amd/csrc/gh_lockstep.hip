@@ -910,10 +910,11 @@ static int fit_build_lists(gh_fit* f, int k, bool from_assign_counts, const uint
     return GH_OK;
 }
 
-static int fit_poll(gh_fit* f, int* n_active, int* flags) {
+static int fit_poll(gh_fit* f, gh_comm* comm, int* n_active, int* flags) {
     hipStream_t st = f->ctx->stream;
     GH_HIP(hipMemcpyAsync(f->h_pin, f->d_counter, 8, hipMemcpyDeviceToHost, st));
-    GH_HIP(hipStreamSynchronize(st));
+    const int rc_ = gh_stream_wait(f->ctx, comm, "gh_fit");
+    if (rc_) return rc_;
     *n_active = f->h_pin[0];
     *flags = f->h_pin[1];
     return GH_OK;
@@ -1020,7 +1021,7 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         }
         it += blkn;
         int n_active = 0, flags = 0;
-        rc = fit_poll(f, &n_active, &flags);
+        rc = fit_poll(f, comm, &n_active, &flags);
         if (rc) return rc;
         if (n_active == 0) break;
     }
@@ -1041,8 +1042,7 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     if (out_cov) GH_HIP(hipMemcpyAsync(out_cov, f->d_cov, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
     if (out_counts) GH_HIP(hipMemcpyAsync(out_counts, f->d_sq, (size_t)S * k * 8, hipMemcpyDeviceToHost, st));
     if (out_iters) GH_HIP(hipMemcpyAsync(out_iters, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-    GH_HIP(hipStreamSynchronize(st));
-    return GH_OK;
+    return gh_stream_wait(ctx, comm, "gh_fit_kmeans");
 }
 
 extern "C" int gh_fit_clusters(gh_ctx* ctx, gh_fit* f, int32_t* out /*[N]*/) {
@@ -1108,7 +1108,7 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
         }
         it += blkn;
         int n_active = 0, flags = 0;
-        rc = fit_poll(f, &n_active, &flags);
+        rc = fit_poll(f, comm, &n_active, &flags);
         if (rc) return rc;
         if (flags & 16) {
             gh_set_error("gh_fit_em: a variance is 0 (singular covariance)");
@@ -1123,8 +1123,7 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
     GH_HIP(hipMemcpyAsync(sigma_old_io, f->d_old_sigma, skd, hipMemcpyDeviceToHost, st));
     GH_HIP(hipMemcpyAsync(w_old_io, f->d_old_w, sk, hipMemcpyDeviceToHost, st));
     if (out_converged_at) GH_HIP(hipMemcpyAsync(out_converged_at, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-    GH_HIP(hipStreamSynchronize(st));
-    return GH_OK;
+    return gh_stream_wait(ctx, comm, "gh_fit_em");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("GMMHMM_LIB") or os.path.normpath(
 GH_F32, GH_F64 = 0, 1
 GH_ERR_SELF_POINTER = -5
 GH_ERR_UNSUPPORTED = -6
+GH_ERR_COMM = -7
 
 _c_i32p = C.POINTER(C.c_int32)
 _c_i64p = C.POINTER(C.c_int64)
@@ -122,6 +123,7 @@ SIGNATURES = {
     "gh_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gh_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "gh_comm_destroy": (None, [C.c_void_p]),
+    "gh_comm_abort": (C.c_int, [C.c_void_p]),
     "gh_comm_count": (C.c_int, [C.c_void_p]),
     "gh_comm_rank": (C.c_int, [C.c_void_p]),
     "gh_comm_version": (C.c_int, []),
@@ -137,6 +139,10 @@ RESIDENT = object()   # kmeans_assign_multi(clusters=RESIDENT): assignments stay
 
 class BackendError(RuntimeError):
     """The HIP backend is unavailable or a library call failed."""
+
+
+class CommError(BackendError):
+    """A collective failed or ran into its deadline (GH_ERR_COMM): a peer rank is gone; the communicator has been aborted."""
 
 
 _lib = None
@@ -180,6 +186,8 @@ def _check(lib, rc):
         msg = lib.gh_last_error().decode("utf-8", "replace")
         if rc == GH_ERR_SELF_POINTER:
             raise NameError("FUCKED")  # the reference's own exception (decode.py:120-121)
+        if rc == GH_ERR_COMM:
+            raise CommError("libgmmhmm error %d: %s" % (rc, msg))
         raise BackendError("libgmmhmm error %d: %s" % (rc, msg))
 
 
@@ -309,6 +317,12 @@ class Comm:
 
     def barrier(self):
         _check(self.ctx.lib, self.ctx.lib.gh_comm_barrier(self.ctx.h, self.h))
+
+    def abort(self):
+        """Failure path (gh_comm_abort): this rank leaves its collectives; what a rank does before it exits on an error,
+        so that its peers' connections close instead of waiting for it."""
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.gh_comm_abort(self.h)
 
     def close(self):
         if getattr(self, "h", None):

@@ -240,8 +240,38 @@ class NativeReducer:
     def barrier(self):
         self.comm.barrier()
 
+    def abort(self):
+        """This rank leaves its collectives for good (gh_comm_abort): called on the way out after a failure, so that the
+        peers' waits end in `_hip.CommError` (connection closed / deadline) instead of a hang."""
+        self.comm.abort()
+
     def close(self):
         self.comm.close()
+
+
+def exit_rank_on_failure(fn, reducer_of=lambda: None):
+    """Run `fn()`; on ANY exception print it, abort the communicator `reducer_of()` returns (if any) and leave the process
+    with status 1 -- from where it stands (os._exit: no interpreter teardown that could wait on a collective, and never a
+    re-exec of a process that has touched the GPU).  A launcher that sees the status takes the other ranks down; ranks
+    that are already inside a collective with this one get GH_ERR_COMM from the library (GMMHMM_COMM_TIMEOUT)."""
+    import os
+    import sys
+    import traceback
+    try:
+        return fn()
+    except SystemExit:
+        raise
+    except BaseException:
+        traceback.print_exc()
+        try:
+            red = reducer_of()
+            if red is not None and hasattr(red, "abort"):
+                red.abort()
+        except BaseException:
+            traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
 
 
 def m_step(stats, counts, means):

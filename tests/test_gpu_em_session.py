@@ -192,11 +192,11 @@ red.close()
 '''
 
 
-def _spawn_ranks(tmp_path, world, extra_env=None):
+def _spawn_ranks(tmp_path, world, extra_env=None, script_text=None, expect_status=None):
     two = _n_gpus() >= world
     port = _free_port()
     script = tmp_path / "rank.py"
-    script.write_text(_RANK_SCRIPT)
+    script.write_text(script_text or _RANK_SCRIPT)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
@@ -216,8 +216,87 @@ def _spawn_ranks(tmp_path, world, extra_env=None):
                 q.kill()
             raise
         outs.append(out)
-    for p, out in zip(procs, outs):
-        assert p.returncode == 0, out[-3000:]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == (expect_status[r] if expect_status else 0), "rank %d: %s" % (r, out[-3000:])
+    return outs
+
+
+# A rank dies: before its first collective (FAIL_AT=0) or between two EM iterations (FAIL_AT=2).  It leaves through
+# parallel.exit_rank_on_failure (communicator aborted, status 1).  The surviving rank must come back from its collective
+# with _hip.CommError within the deadline -- RCCL's asynchronous error (the closed connection) or GMMHMM_COMM_TIMEOUT --
+# and every later call on the communicator must fail at once instead of hanging.
+_FAIL_SCRIPT = r'''
+import os, sys, time
+import numpy as np
+root = sys.argv[1]
+for p in (root, os.path.join(root, "speech-recognition_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+from sr.recognition import _hip
+from sr.recognition.parallel import NativeReducer, shard_utterances, exit_rank_on_failure
+from sr.recognition.train import BaumWelchTrainer
+from test_gpu_configs import c3_problem
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+fail_at = int(os.environ["FAIL_AT"])
+ctx = _hip.default_context(int(os.environ["GMMHMM_DEVICE"]))
+red = NativeReducer(ctx, timeout=120)
+state = {}
+
+def work():
+    if fail_at == 0 and rank == 1:
+        raise RuntimeError("rank 1 fails before its first collective")
+    if fail_at == 0:
+        t0 = time.perf_counter()
+        try:
+            red.barrier()
+            state["outcome"] = "barrier returned"
+        except _hip.CommError as e:
+            state["outcome"], state["message"] = "CommError", str(e)
+        state["seconds"] = time.perf_counter() - t0
+    else:
+        means, vars_, w, trans, data, labels = c3_problem(600)
+        mine = shard_utterances([len(x) for x in data], world)[rank]
+        tr = BaumWelchTrainer(means, vars_, w, trans, [data[i] for i in mine], [labels[i] for i in mine], reducer=red)
+        assert tr.session is not None
+        tr.iteration()
+        tr.iteration()
+        if rank == 1:
+            raise RuntimeError("rank 1 fails between two EM iterations")
+        t0 = time.perf_counter()
+        try:
+            tr.iteration()
+            state["outcome"] = "iteration returned"
+        except _hip.CommError as e:
+            state["outcome"], state["message"] = "CommError", str(e)
+        state["seconds"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    try:
+        red(np.ones(3))
+        state["after"] = "returned"
+    except _hip.CommError:
+        state["after"] = "CommError"
+    state["after_seconds"] = time.perf_counter() - t0
+    state["count"] = red.comm.count
+
+exit_rank_on_failure(work, lambda: red)
+np.savez(os.path.join(sys.argv[2], "fail%d.npz" % rank), **{k: np.array(v) for k, v in state.items()})
+red.close()
+os._exit(0)      # (nothing of the interpreter's teardown may wait on the GPU after an aborted collective)
+'''
+
+
+@pytest.mark.parametrize("fail_at", [0, 2])
+def test_a_failing_rank_is_an_error_on_its_peers_not_a_hang(tmp_path, fail_at):
+    import time
+    t0 = time.perf_counter()
+    outs = _spawn_ranks(tmp_path, 2, {"FAIL_AT": str(fail_at), "GMMHMM_COMM_TIMEOUT": "20"}, script_text=_FAIL_SCRIPT,
+                        expect_status=[0, 1])
+    assert time.perf_counter() - t0 < 240
+    assert "rank 1 fails" in outs[1]
+    r0 = np.load(tmp_path / "fail0.npz")
+    assert str(r0["outcome"]) == "CommError", (str(r0["outcome"]), outs[0][-2000:])
+    assert float(r0["seconds"]) < 40.0                     # the deadline (20 s) or RCCL's asynchronous error, whichever first
+    assert str(r0["after"]) == "CommError" and float(r0["after_seconds"]) < 1.0 and int(r0["count"]) == 0
+    assert not os.path.exists(tmp_path / "fail1.npz")
 
 
 def test_two_native_rccl_ranks_equal_one_rank(tmp_path):
