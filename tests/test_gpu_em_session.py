@@ -163,6 +163,79 @@ def test_native_one_rank_communicator_in_the_iteration():
     red.close()
 
 
+def test_session_iteration_against_the_oracle_directly():
+    """ONE gh_em_iteration against the CPU oracle with nothing of this repo's GPU code in between (parity hole
+    2): the oracle's likelihoods (`gmm_neg_loglik_batch`) and its forward-backward (`O.forward_backward`, the brute-force
+    pinned sum-product twin of decode.py:80-146) give gamma, log P and the expected self transitions of every utterance;
+    numpy turns them into the sufficient statistics of hmm_state.py:134-148 and into the M-step.  The session's packed
+    buffer [statistics | self transitions | log P | utterances] and its re-estimated model must agree."""
+    import bench
+    from oracle import ref_numpy as O
+    from sr.recognition.train import BaumWelchTrainer
+    W, n, M, D, U = 4, 5, 4, 13, 60
+    wl = bench.synth_workload(4242, U, W=W, n=n, M=M, D=D, tmin=12, tmax=40)
+    data = [wl["X"][wl["off"][u]:wl["off"][u + 1]] for u in range(U)]
+    labels = [[int(w)] for w in wl["words"]]
+    S = W * n
+    means0 = (wl["means"] + 0.3 * np.random.default_rng(3).normal(size=wl["means"].shape)).reshape(S, M, D)
+    vars0, w0, trans = wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M), wl["trans"]
+    tr = BaumWelchTrainer(means0.reshape(W, n, M, D), wl["vars"], wl["w"], [trans] * W, data, labels, occ_floor=0.0)
+    assert tr.session is not None
+    ll = tr.iteration()
+    packed = tr.session.packed()
+    n_stats = S * M * (1 + 2 * D)
+    # ---- the oracle's E-step ----
+    stats = np.zeros((S, M, 1 + 2 * D))
+    xi = np.zeros(S)
+    logp_total = 0.0
+    logc = np.log(w0) - 0.5 * (D * np.log(2 * np.pi) + np.log(vars0).sum(axis=2))
+    for x, lab in zip(data, labels):
+        sts = np.arange(n) + lab[0] * n
+        nll = O.gmm_neg_loglik_batch(x, means0[sts], vars0[sts], w0[sts])          # [T, n]
+        la, lb, gamma, logp = O.forward_backward(nll.T, np.zeros(n, dtype=bool), trans, [n - 1])
+        logp_total += logp
+        for j, s in enumerate(sts):
+            with np.errstate(over="ignore", invalid="ignore"):
+                xi[s] += np.exp(la[j, :-1] - trans[j, j] - nll[1:, j] + lb[j, 1:] - logp).sum()
+            ll_c = logc[s][None, :] - 0.5 * (((x[:, None, :] - means0[s][None]) ** 2) / vars0[s][None]).sum(axis=2)
+            r = np.exp(ll_c - ll_c.max(axis=1, keepdims=True))
+            r = gamma[j][:, None] * r / r.sum(axis=1, keepdims=True)
+            for m in range(M):
+                d = x - means0[s, m]
+                stats[s, m, 0] += r[:, m].sum()
+                stats[s, m, 1:1 + D] += (r[:, [m]] * d).sum(axis=0)
+                stats[s, m, 1 + D:] += (r[:, [m]] * d * d).sum(axis=0)
+    _close(packed[:n_stats].reshape(S, M, 1 + 2 * D), stats, 1e-8, 1e-10)
+    _close(packed[n_stats:n_stats + S], xi, 1e-8, 1e-10)
+    _close(packed[n_stats + S], logp_total, 1e-10)
+    _close(ll, logp_total, 1e-10)
+    assert packed[n_stats + S + 1] == U
+    # ---- the M-step of hmm_state.py:134-148 from those statistics (soft counts; the trainer's variance floor) ----
+    s0 = stats[:, :, 0]
+    mu = means0 + stats[:, :, 1:1 + D] / s0[:, :, None]
+    delta = mu - means0
+    sigma = np.maximum((stats[:, :, 1 + D:] - delta * (2.0 * stats[:, :, 1:1 + D] - delta * s0[:, :, None])) / s0[:, :, None],
+                       tr.var_floor)
+    wgt = s0 / s0.sum(axis=1, keepdims=True)
+    seen = s0.sum(axis=1) > 0
+    _close(tr.means[seen], mu[seen], 1e-8, 1e-10)
+    _close(tr.vars[seen], sigma[seen], 1e-7, 1e-10)
+    _close(tr.weights[seen], wgt[seen], 1e-8, 1e-12)
+    # transition costs from the expected self transitions (continuous_speech.py:146-164 with soft counts)
+    counts = s0.sum(axis=1)
+    for wi in range(W):
+        t = tr.transitions[wi]
+        for si in range(n):
+            s = wi * n + si
+            if counts[s] > 0:
+                p_stay = min(max(xi[s] / counts[s], 0.0), 1.0)
+                with np.errstate(divide="ignore"):
+                    _close(t[si, si], -np.log(p_stay), 1e-8, 1e-10)
+                    if si < n - 1:
+                        _close(t[si + 1, si], -np.log(1.0 - p_stay), 1e-8, 1e-10)
+    tr.close()
+
+
 _RANK_SCRIPT = r'''
 import os, sys
 import numpy as np
