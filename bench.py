@@ -577,6 +577,82 @@ def fp32_mismatch_c2(ctx, wl):
             "fp32_path_mismatch_rate": float(np.mean([not np.array_equal(x, y) for x, y in zip(p64, p32)]))}
 
 
+def lse_f32exp_leg(dev, wl, c5_distinct=2000, K=7):
+    """The fp64 likelihood kernel with the exponentials of its log-sum-exp in FP32 (gh_ctx_set_compat bit 1; OFF by
+    default) next to the all-fp64 epilogue: kernel time from HIP events on the launch stream and the fraction of the fp64
+    matrix peak both ways, the largest |delta nll| over configs[1]'s 50 M likelihoods, and how many decodes change: the
+    recognised word and the whole state path of every configs[1] utterance, the state paths of `c5_distinct` distinct
+    configs[4] utterances through the K-layer lattice and the loop grammar (the tiled copies decode like the originals)."""
+    from sr.recognition import _hip
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    W, n, M, D = wl["W"], wl["n"], wl["M"], wl["D"]
+    S = W * n
+    ctx = _hip.Context(dev)          # a context of its own: the switch is a property of the context
+    gmm = _hip.PackedGMM(ctx, wl["means"].reshape(S, M, D), wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M))
+    b = _hip.Batch(ctx, feats=wl["X"], offsets=wl["off"])
+    lat = _hip.Lattices(ctx, [stacked_graph(W, n, wl["trans"])])
+
+    def kernel_ms(reps=20, ramp=0.4):
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < ramp:
+            b.loglik(gmm, fetch=False)
+        ctx.sync()
+        e0, e1 = ctx.new_event(), ctx.new_event()
+        ctx.record(e0)
+        for _ in range(reps):
+            b.loglik(gmm, fetch=False)
+        ctx.record(e1)
+        ctx.sync()
+        return ctx.elapsed_ms(e0, e1) / reps
+
+    res = {}
+    for name, fe in (("fp64", False), ("f32exp", True)):
+        ctx.set_compat(underflow=True, lse_f32=fe)
+        ms = kernel_ms()
+        nll = b.loglik(gmm)
+        r = lat.viterbi(b, want_path=True)
+        res[name] = (ms, nll.copy(), r["best_end"].copy(), r["paths"])
+    flops = 2.0 * 2 * D * S * M * b.N
+    d = np.abs(res["fp64"][1] - res["f32exp"][1])
+    out = {"kernel": "loglik_mfma_kernel<double, 20, 8>", "kernel_ms_fp64_epilogue": res["fp64"][0], "kernel_ms_f32exp": res["f32exp"][0],
+           "frac_fp64_epilogue": flops / (res["fp64"][0] * 1e-3) / PEAK_F64, "frac_f32exp": flops / (res["f32exp"][0] * 1e-3) / PEAK_F64,
+           "max_abs_delta_nll": float(d.max()), "max_rel_delta_nll": float((d / np.abs(res["fp64"][1])).max()),
+           "C2_utterances": int(b.U), "C2_word_mismatch_rate": float(np.mean(res["fp64"][2] != res["f32exp"][2])),
+           "C2_path_mismatch_rate": float(np.mean([not np.array_equal(x, y) for x, y in zip(res["fp64"][3], res["f32exp"][3])])),
+           "default": "off (gh_ctx_set_compat bit 1 / GMMHMM_LSE=f32exp turns it on)"}
+    del res
+    b.close(); lat.close(); gmm.close()
+    # configs[4]: distinct K-word utterances of the configs[4] model
+    rng = np.random.default_rng(1005)
+    wl5 = synth_workload(1005, 1, W=W, n=n, M=M, D=D)
+    means, vars_, trans = wl5["means"], wl5["vars"], wl5["trans"]
+    words = rng.integers(0, W, size=(c5_distinct, K))
+    Tw = rng.integers(30, 61, size=(c5_distinct, K))
+    seg_len = Tw.reshape(-1)
+    seg_off = np.concatenate([[0], np.cumsum(seg_len)])
+    seg = np.repeat(np.arange(len(seg_len)), seg_len)
+    t = np.arange(int(seg_off[-1])) - seg_off[seg]
+    st = np.minimum(t * n // seg_len[seg], n - 1)
+    idx = (words.reshape(-1)[seg] * n + st) * M + rng.integers(0, M, size=len(seg))
+    X = means.reshape(-1, D)[idx] + np.sqrt(vars_).reshape(-1, D)[idx] * rng.standard_normal((len(seg), D))
+    off = np.concatenate([[0], np.cumsum(Tw.sum(axis=1))]).astype(np.int64)
+    gmm5 = _hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), wl5["w"].reshape(S, M))
+    b5 = _hip.Batch(ctx, feats=X, offsets=off)
+    for key, graph in (("C5_K7_lattice", packed_lattice([trans] * W, n, [list(range(W))] * K)[0]),
+                       ("C5_loop_grammar", packed_loop_lattice([trans] * W, n)[0])):
+        lat5 = _hip.Lattices(ctx, [graph])
+        got = {}
+        for name, fe in (("fp64", False), ("f32exp", True)):
+            ctx.set_compat(underflow=True, lse_f32=fe)
+            b5.loglik(gmm5, fetch=False)
+            got[name] = lat5.viterbi(b5, want_path=True)["paths"]
+        out[key + "_path_mismatch_rate"] = float(np.mean([not np.array_equal(x, y) for x, y in zip(got["fp64"], got["f32exp"])]))
+        lat5.close()
+    out["C5_distinct_utterances"] = int(c5_distinct)
+    b5.close(); gmm5.close(); ctx.close()
+    return out
+
+
 def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D=39):
     """configs[4] at its per-GPU size (1 M utterances / 8 GPUs): `U_base` distinct synthetic K-word utterances per
     rank, tiled on the device to `U_total` (synthesising 39 M distinct frames costs ~12 GB of host memory and ~1 min
@@ -902,6 +978,8 @@ def extra_configs(args, group, npdt, peak_flops, wl):
         legs.append(("C3_word_strings", lambda: _training_config(ctx, args.c3_utts)))
         legs.append(("C3_continuous_train", lambda: _ctrain_config(ctx, args.c3_utts)))
         legs.append(("C2_fp32_decode", lambda: fp32_mismatch_c2(ctx, wl)))
+        if npdt == np.float64:
+            legs.append(("C2_lse_f32exp", lambda: lse_f32exp_leg(ctx.device, wl)))
         legs.append(("C2_train_words", lambda: _train_words_config(ctx)))
     legs.append(("C5", lambda: _continuous_config(ctx, group, args.c5_utts, min(args.c5_utts, 5000), npdt)))
     for key, fn in legs:

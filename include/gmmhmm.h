@@ -73,7 +73,11 @@ int gh_ctx_last_chunks(const gh_ctx* ctx);
  *          runtime threshold in the kernels' epilogues: no cost); the reference can also lose a term earlier, in
  *          exp(-q/2) before the normalisation, when w * norm > 1 (variances below ~1/2pi): models with such a component
  *          get a second pass over the few entries whose cost lies within log(w norm) of the threshold, which re-tests
- *          them per component (round 4; a no-op launch for ordinary models). */
+ *          them per component (round 4; a no-op launch for ordinary models).
+ *   bit 1  (off by default; GMMHMM_LSE=f32exp sets it at creation) the fp64 likelihood kernel takes the exponentials of its
+ *          log-sum-exp in FP32: maximum, differences and the final max + log(sum) stay fp64, the terms 2^(a - max) <= 1
+ *          and their sum are fp32.  |delta nll| <= ~2.4e-7 absolute; bench.py reports the kernel both ways with the
+ *          measured difference and path mismatch rates.  Mixtures of >= 4 components, fp64 batches. */
 int gh_ctx_set_compat(gh_ctx* ctx, int flags);
 /* raw hipStream_t of the context (for torch interop) */
 void* gh_ctx_stream(gh_ctx* ctx);

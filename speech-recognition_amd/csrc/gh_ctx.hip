@@ -38,6 +38,7 @@ extern "C" int gh_ctx_create(int device, gh_ctx** out) {
     c->last_chunks = 0;
     c->compat = 1;     // the reference's linear-domain underflow rule (gh_ctx_set_compat); GMMHMM_COMPAT=0: log domain throughout
     if (const char* e = getenv("GMMHMM_COMPAT")) c->compat = strstr(e, "underflow") ? 1 : atoi(e);
+    if (const char* e = getenv("GMMHMM_LSE")) if (!strcmp(e, "f32exp")) c->compat |= 2;   // fp32 exponentials in the fp64 log-sum-exp
     hipDeviceProp_t prop;
     GH_HIP(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;

@@ -177,6 +177,30 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, co
     sm = e;
 }
 
+// ---- opt-in epilogue with the exponentials in FP32 (gh_ctx_set_compat bit 1 / GMMHMM_LSE=f32exp; fp64 batches only).
+// The maximum, `a - max` and the final `max + log(sum)` stay fp64; the terms 2^((a - max)/128) <= 1 go through
+// v_cvt_f32_f64 + v_exp_f32, their sum and its v_log_f32 stay fp32: 2 instructions on the shared fp64 pipe per term
+// instead of ~10.  A term carries v_exp_f32's relative error (~1.2e-7), so the log-sum-exp -- and with it the
+// negative log-likelihood -- moves by at most ~2.4e-7 ABSOLUTE (on costs of ~60: 4e-9 relative, north star 1e-5).
+// Off by default: bench.py reports the kernel both ways together with max |delta nll| and the path mismatch rates.
+__device__ __forceinline__ float exp2s_fe(double y) { return __builtin_amdgcn_exp2f((float)y * 0.0078125f); }
+template <int W> __device__ __forceinline__ float pair_sum_f(float v) { float a, b; pair_of<W>(v, a, b); return a + b; }
+template <typename V>
+__device__ __forceinline__ void tile_lse_fe(const V& a, int width, double& mx, float& sm) {
+    double m = vmax(vmax(a[0], a[1]), vmax(a[2], a[3]));
+    if (width >= 2) m = pair_max<double, 16>(m);
+    if (width >= 4) m = pair_max<double, 32>(m);
+    float e = (exp2s_fe(a[0] - m) + exp2s_fe(a[1] - m)) + (exp2s_fe(a[2] - m) + exp2s_fe(a[3] - m));
+    if (width >= 2) e = pair_sum_f<16>(e);
+    if (width >= 4) e = pair_sum_f<32>(e);
+    mx = m;
+    sm = e;
+}
+__device__ __forceinline__ double nll_of_fe(double mx, float sm, double inf_below) {
+    const double v = (mx + (double)(128.0f * __builtin_amdgcn_logf(sm))) * -Dom<double>::inv_k;     // v_log_f32 = log2
+    return (mx < inf_below) ? (double)INFINITY : v;
+}
+
 // One tile's epilogue: log-sum-exp over the mixture components held in the accumulators of
 // both column tiles, written into the LDS output tile.  MP = padded mixture size (compile
 // time); MP == 32 stands for "several tiles per state" (M_pad = 16 * tiles_per_state, run
@@ -184,7 +208,7 @@ __device__ __forceinline__ void tile_lse(const V& a, int width, T& mx, T& sm, co
 // write to a per-lane dummy slot behind the tile.  When a state spans two or four lane groups
 // every group ends up with the same (max, sum) pair, so the even group finishes column tile 0
 // and the odd group column tile 1: ONE logarithm per lane instead of two.
-template <typename T, typename V, int MP>
+template <typename T, typename V, int MP, bool FE = false>
 __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int t, int f, int q, int S, int RS,
                                               int chunk_s0, int tiles_per_state, T* lds, T* dummy,
                                               const double* tab, T (&run_mx)[2], T (&run_sm)[2], T inf_below) {
@@ -220,6 +244,49 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
         *(((q & (MP / 4 - 1)) == 0 && s < S) ? orow0 + s : dummy) = -((acc0[0] + acc0[1]) + (acc0[2] + acc0[3]));
         *(((q & (MP / 4 - 1)) == 0 && s < S) ? orow1 + s : dummy) = -((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
 #endif
+    } else if (FE && MP == 4) {
+        if constexpr (FE) {
+            double mx; float sm;
+            const int s = 4 * t + q;
+            tile_lse_fe<V>(acc0, 1, mx, sm);
+            *((s < S) ? orow0 + s : dummy) = nll_of_fe(mx, sm, inf_below);
+            tile_lse_fe<V>(acc1, 1, mx, sm);
+            *((s < S) ? orow1 + s : dummy) = nll_of_fe(mx, sm, inf_below);
+        }
+    } else if (FE && MP <= 16) {
+        if constexpr (FE) {
+            constexpr int width = MP / 4;
+            double mx0, mx1; float sm0, sm1;
+            tile_lse_fe<V>(acc0, width, mx0, sm0);
+            tile_lse_fe<V>(acc1, width, mx1, sm1);
+            const bool odd = q & 1;
+            const int s = (16 / MP) * t + q / width;
+            const double v = nll_of_fe(odd ? mx1 : mx0, odd ? sm1 : sm0, inf_below);
+            *(((q & (width - 1)) < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
+        }
+    } else if (FE) {
+        if constexpr (FE) {
+            const bool last = (t + 1) % tiles_per_state == 0;
+            const int s = t / tiles_per_state;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double mx; float smf;
+                tile_lse_fe<V>(c ? acc1 : acc0, 4, mx, smf);
+                const double d = run_mx[c] - mx;
+                const float e = exp2s_fe((d > 0.0) ? -d : d);
+                const float rs = (float)run_sm[c];              // (the running sum is an fp32 value kept in the fp64 slot)
+                run_sm[c] = (double)((d > 0.0) ? fmaf(smf, e, rs) : fmaf(rs, e, smf));
+                run_mx[c] = (d > 0.0) ? run_mx[c] : mx;
+            }
+            const bool odd = q & 1;
+            const double v = nll_of_fe(odd ? run_mx[1] : run_mx[0], (float)(odd ? run_sm[1] : run_sm[0]), inf_below);
+            *((last && q < 2 && s < S) ? (odd ? orow1 : orow0) + s : dummy) = v;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                run_mx[c] = last ? Dom<T>::off : run_mx[c];
+                run_sm[c] = last ? T(0) : run_sm[c];
+            }
+        }
     } else if (MP == 4) {
         T mx, sm;
         const int s = 4 * t + q;
@@ -272,7 +339,7 @@ __device__ __forceinline__ void tile_epilogue(const V& acc0, const V& acc1, int 
 #define GH_MF_SGB 0
 #endif
 // MULTI: the wave walks `bpw` blocks (light models); false = one block per wave, the block loop folds away.
-template <typename T, int KS, int MP, bool MULTI>
+template <typename T, int KS, int MP, bool MULTI, bool FE = false>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kernel(const T* __restrict__ X, int64_t N, int D,
                                                          const T* __restrict__ Apk, const T* __restrict__ Cpk,
                                                          int n_tiles, int S, int M_pad, int chunk_tiles,
@@ -454,7 +521,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
         // Two tiles per iteration with the accumulator pairs swapping roles: the epilogue of tile t-1 is scheduled
         // with the MFMAs of tile t without copying accumulators (16 v_mov per tile otherwise).
         auto epi = [&](const V& e0, const V& e1, int t) {
-            tile_epilogue<T, V, MP>(e0, e1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm, inf_below);
+            tile_epilogue<T, V, MP, FE>(e0, e1, t, f, q, S, RS, chunk_s0, tiles_per_state, lds, dummy, tab, run_mx, run_sm, inf_below);
 #pragma unroll
             for (int i = 0; i < (GH_MF_SGB ? 2 * KS : 0); ++i) {   // (forced MFMA / VALU interleave: measured slower)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -617,9 +684,18 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     const unsigned grid = (unsigned)((n_blocks + bpw - 1) / bpw);
     const T* X = static_cast<const T*>(b->feats);
     T* out = static_cast<T*>(b->nll);
+    // fp32 exponentials in the fp64 epilogue (opt-in, see tile_lse_fe): mixtures of >= 4 components
+    const bool fe = sizeof(T) == 8 && (ctx->compat & 2) && M_pad >= 4;
 #define GH_MF_LAUNCH(ks, mp)                                                                                             \
     do {                                                                                                                 \
-        if (bpw > 1)                                                                                                     \
+        if (fe && sizeof(T) == 8 && mp >= 4) {                                                                           \
+            if (bpw > 1)                                                                                                 \
+                hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true, (sizeof(T) == 8 && mp >= 4)>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
+                                   Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen, inf_below); \
+            else                                                                                                         \
+                hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, false, (sizeof(T) == 8 && mp >= 4)>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
+                                   Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen, inf_below); \
+        } else if (bpw > 1)                                                                                                     \
             hipLaunchKernelGGL((loglik_mfma_kernel<T, ks, mp, true>), dim3(grid), dim3(64), lds, ctx->stream, X, N, g->D, \
                                Apk, Cpk, n_tiles, S, M_pad, chunk_tiles, tables, tab_off, out, bpw, d_blk, n_blk, cen, inf_below); \
         else                                                                                                             \

@@ -212,11 +212,12 @@ class Context:
     def sync(self):
         _check(self.lib, self.lib.gh_ctx_sync(self.h))
 
-    def set_compat(self, underflow=True):
+    def set_compat(self, underflow=True, lse_f32=False):
         """underflow=True (a context's default): likelihoods of states whose every weighted density underflows fp64 come
         back as +inf, like the reference's linear-domain GMM.evaluate (hmm_state.py:114-120); False: log domain throughout,
-        finite costs.  See gh_ctx_set_compat."""
-        _check(self.lib, self.lib.gh_ctx_set_compat(self.h, 1 if underflow else 0))
+        finite costs.  lse_f32=True: the fp64 likelihood kernel takes the exponentials of its log-sum-exp in fp32
+        (|delta nll| <= ~2.4e-7 absolute; faster).  See gh_ctx_set_compat."""
+        _check(self.lib, self.lib.gh_ctx_set_compat(self.h, (1 if underflow else 0) | (2 if lse_f32 else 0)))
 
     @property
     def last_fused(self):
