@@ -505,8 +505,20 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 1)) void loglik_mfma_kern
             nrows = (int)((N - n0 < 32) ? (N - n0) : 32);
         }
         if (!(subset && ib > 0 && n0 == staged_n0)) {   // (block table: the previous entry may cover the same frames)
+            // (Round 4, measured and NOT kept: this prologue at raised priority, s_setprio 3 ... 0.  A wave that has just
+            //  started is the youngest on its SIMD and the issue arbiter -- priority, then age -- serves the older waves'
+            //  MFMAs first: 45 k of an fp32 wave's 191 k cycles pass in a prologue of ~300 instructions, 16 k of 171 k in
+            //  fp64.  With the priority the prologues shrink to 27 k / 11 k cycles and the tile loops grow by as much:
+            //  the pipe is shared, the waves' totals do not move -- fp64 1.24 -> 1.27 ms, fp32 0.69 -> 0.77 ms per launch.
+            //  -DGH_MF_PRIO brings it back.)
+#ifdef GH_MF_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             stage_frames();
             build_b();
+#ifdef GH_MF_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             staged_n0 = n0;
         }
         chunk_s0 = (MP <= 16) ? t_lo * (16 / (MP <= 16 ? MP : 16)) : t_lo / tiles_per_state;   // 0 without a block table

@@ -15,7 +15,8 @@ means, vars_, wts = w["means"], w["vars"], w["w"]
 S = means.shape[0] * means.shape[1]
 ctx = _hip.default_context(0)
 gmm = _hip.PackedGMM(ctx, means.reshape(S, *means.shape[2:]), vars_.reshape(S, *vars_.shape[2:]), wts.reshape(S, -1))
-b = _hip.Batch(ctx, feats=w["X"], offsets=w["off"])
+_dt = np.float32 if os.environ.get("WT_DTYPE", "f64") == "f32" else np.float64   # WT_DTYPE=f32: the fp32 kernel
+b = _hip.Batch(ctx, feats=w["X"], offsets=w["off"], dtype=_dt)
 for _ in range(int(os.environ.get('WARM', 3))):
     b.loglik(gmm, fetch=False)
 nll = b.loglik(gmm, fetch=True)
