@@ -441,6 +441,36 @@ def em_leg(args, group):
         dt_q = group.max(time.perf_counter() - t0)
         hist = list(tr.history)
     frames = float(tr.batch.N)
+    # (c) the phases of an iteration from HIP events on the kernels' stream (gh_em_profile): rooflines of the E-step kernels
+    phase_roofline = None
+    if tr.session is not None:
+        try:
+            tr.session.profile(True)
+            ph = np.zeros(4)
+            for _ in range(10):
+                tr.iteration(sync=False)
+                ph += tr.session.phase_ms()
+            tr.drain()
+            tr.session.profile(False)
+            ph /= 10.0
+            n_, M_, D_ = tr.n, tr.M, tr.D
+            fl_ll = 2.0 * 2 * D_ * n_ * M_ * frames                       # the utterance's own word: n states x M components
+            fl_bw = (2.0 * 2 * D_ + 2.0 * (2 * D_ + 1)) * n_ * M_ * frames  # densities again + the statistics GEMM
+            by_fb = (8.0 * n_ + 8.0 * tr.session_lanes()) * frames if hasattr(tr, "session_lanes") else (8.0 * n_ + 64.0) * frames
+            phase_roofline = [
+                {"kernel": "loglik_mfma_kernel (own-state subset)", "ms": ph[0], "bound": "mfma", "achieved": fl_ll / (ph[0] * 1e-3) / 1e12,
+                 "peak": PEAK_F64 / 1e12, "unit": "TFLOP/s", "frac": fl_ll / (ph[0] * 1e-3) / PEAK_F64},
+                {"kernel": "fb_chain2_kernel + fb_chain2_cells_kernel", "ms": ph[1], "bound": "hbm (latency bound at this size)",
+                 "achieved": by_fb / (ph[1] * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by_fb / (ph[1] * 1e-3) / PEAK_HBM,
+                 "bytes_per_frame": by_fb / frames,
+                 "note": "algorithmic bytes: the n own-state likelihoods read + one 64-byte line of compact gamma written per frame; "
+                         "12 500 utterances are 1.5 waves per SIMD walking ~150 dependent columns each: the recursion waits, HBM idles"},
+                {"kernel": "bw_fused_kernel + bw_fused_reduce_kernel", "ms": ph[2], "bound": "mfma", "achieved": fl_bw / (ph[2] * 1e-3) / 1e12,
+                 "peak": PEAK_F64 / 1e12, "unit": "TFLOP/s", "frac": fl_bw / (ph[2] * 1e-3) / PEAK_F64,
+                 "note": "nominal flops (every frame x every own state); blocks without occupancy above occ_floor are skipped"},
+                {"kernel": "em_tail + all-reduce + em_mstep + gmm re-pack + em_finish", "ms": ph[3]}]
+        except Exception as e:     # (a library without gh_em_profile, two streams: the line goes out without the entry)
+            phase_roofline = {"error": repr(e)[:200]}
     tot = group.sum([float(U), frames])
     all_utts, all_frames = float(tot[0]), float(tot[1])
     # the collective by itself: the packed buffer's size through the same communicator, stream-synchronised
@@ -468,6 +498,7 @@ def em_leg(args, group):
         "ms_per_iteration_enqueued": None if dt_q is None else dt_q / args.em_iters * 1e3,
         "em_utterances_per_s": all_utts / per_it, "em_frames_per_s": all_frames / per_it,
         "occ_floor": tr.occ_floor, "ms_per_iteration_occ_floor_0": None if dt_exact is None else dt_exact * 1e3,
+        "roofline": phase_roofline,
         "device_resident_iteration": tr.session is not None,
         "host_syncs_per_iteration": 1 if tr.session is not None else 3,
         "allreduce_ms": ar_ms, "allreduce_bytes": tr._packed_len() * 8,
@@ -577,6 +608,25 @@ def fp32_mismatch_c2(ctx, wl):
             "fp32_path_mismatch_rate": float(np.mean([not np.array_equal(x, y) for x, y in zip(p64, p32)]))}
 
 
+def _lattice_roofline(key, bytes_dp, t_dec, N, K, W, n):
+    """The bound that binds.  K-layer lattice (viterbi_layers_kernel): 114 vector instructions per column and wave for all
+    K x W x n cell slots at ~4 cycles each on one of 1024 SIMDs -- the sweep is VALU-issue bound, its HBM
+    fraction says how far the likelihood stream is from mattering.  Loop grammar (viterbi_loop_kernel): four utterances
+    per wave, the sweep runs at the rate HBM delivers the likelihood matrix."""
+    hbm = {"hbm_achieved": bytes_dp / t_dec / 1e9, "hbm_frac": bytes_dp / t_dec / PEAK_HBM}
+    if key == "C5_K7_lattice":
+        issue_s = 114.0 * 4.0 * N / (1024 * 2.4e9)        # instructions x cycles x columns / (SIMDs x clock)
+        return dict({"kernel": "viterbi_layers_kernel + lattice_backtrace_kernel", "bound": "valu", "achieved": issue_s / t_dec,
+                     "peak": 1.0, "unit": "fraction of the VALU issue rate", "frac": issue_s / t_dec,
+                     "instructions_per_column": 114,
+                     "note": "rank 0: 114 VALU instructions x 4 cycles per column and wave over 1024 SIMDs at 2.4 GHz against the "
+                             "wall time of gh_viterbi_labels (kernels + label copy-back + host slicing)"}, **hbm)
+    return dict({"kernel": "viterbi_loop_kernel + lattice_backtrace_kernel", "bound": "hbm", "achieved": bytes_dp / t_dec / 1e9,
+                 "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_dp / t_dec / PEAK_HBM,
+                 "note": "rank 0: algorithmic bytes (esz*S + 4) per frame over the wall time of gh_viterbi_labels "
+                         "(kernels + label copy-back + host slicing)"}, **hbm)
+
+
 def lse_f32exp_leg(dev, wl, c5_distinct=2000, K=7):
     """The fp64 likelihood kernel with the exponentials of its log-sum-exp in FP32 (gh_ctx_set_compat bit 1; OFF by
     default) next to the all-fp64 epilogue: kernel time from HIP events on the launch stream and the fraction of the fp64
@@ -595,7 +645,7 @@ def lse_f32exp_leg(dev, wl, c5_distinct=2000, K=7):
     def kernel_ms(reps=20, ramp=0.4):
         t_r = time.perf_counter()
         while time.perf_counter() - t_r < ramp:
-            b.loglik(gmm, fetch=False)
+            b.loglik(gmm, fetch=False); ctx.sync()      # (launches are asynchronous: without the sync the ramp queues seconds of work)
         ctx.sync()
         e0, e1 = ctx.new_event(), ctx.new_event()
         ctx.record(e0)
@@ -727,10 +777,7 @@ def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D
                     "sequence_accuracy_sampled": tot[2] / group.world,
                     "fp32_path_mismatch_rate": tot[3] / group.world, "fp32_label_mismatch_rate": tot[4] / group.world,
                     "fp32_mismatch_sample": "%d distinct utterances per rank, fp32 vs fp64 likelihoods, fp64 DP" % U_base,
-                    "roofline": {"kernel": "viterbi (lattice)", "bound": "hbm", "achieved": bytes_dp / t_dec / 1e9,
-                                 "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_dp / t_dec / PEAK_HBM,
-                                 "note": "rank 0: algorithmic bytes (esz*S + 4) per frame over the wall time of gh_viterbi_labels "
-                                         "(kernels + label copy-back + host slicing)"}}
+                    "roofline": _lattice_roofline(key, bytes_dp, t_dec, N, K, W, n)}
         lat.close()
     b.close(); base_o.close()
     # ---- the same decode PIPELINED: the batch in 4 pieces over two contexts (HIP stream + host thread each), so that a

@@ -476,6 +476,11 @@ int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* me
 void gh_em_destroy(gh_em* em);
 int gh_em_iteration(gh_ctx* ctx, gh_em* em, gh_comm* comm /*or NULL*/, double* out_tail /*[4] or NULL*/);
 int gh_em_iterations_done(const gh_em* em);
+/* Measurement aid: gh_em_profile(on) makes every following iteration record HIP events between its phases, on the stream
+ * its kernels run on; gh_em_phase_ms waits for the last iteration and returns four spans in milliseconds: own-state
+ * likelihoods | chain forward-backward | statistics kernel + its reduction | tail + collective + M-step + model re-pack. */
+int gh_em_profile(gh_ctx* ctx, gh_em* em, int on);
+int gh_em_phase_ms(gh_ctx* ctx, gh_em* em, double* out /*[4]*/);
 /* rows [first, first + count) of the iteration history; the session keeps the last 4096 rows (a ring: older ones are gone) */
 int gh_em_history(gh_ctx* ctx, gh_em* em, int first, int count, double* out /*[count,4]*/);
 int gh_em_get_model(gh_ctx* ctx, gh_em* em, double* mean, double* var, double* weight, double* word_trans /*any may be NULL*/);

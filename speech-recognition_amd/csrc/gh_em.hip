@@ -63,6 +63,10 @@ struct gh_em {
     hipStream_t s2;
     hipEvent_t ev_start, ev_half;
     double* h_tail;        // pinned [4]
+    // gh_em_profile: HIP events between the phases of an iteration (likelihoods | forward-backward | statistics | tail +
+    // collective + M-step + re-pack), on the stream the kernels run on; one half only
+    bool prof = false;
+    hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -190,6 +194,7 @@ extern "C" void gh_em_destroy(gh_em* e) {
     hipSetDevice(e->ctx->device);
     hipStreamSynchronize(e->ctx->stream);
     if (e->s2) hipStreamSynchronize(e->s2);
+    for (auto& ev : e->pe) if (ev) { hipEventDestroy(ev); ev = nullptr; }
     if (e->gmm) gh_gmm_destroy(e->gmm);
     for (int h = 0; h < 2; ++h) { gh_loglik_plan_free(&e->ll_plan[h]); gh_bwf_plan_free(&e->bw_plan[h]); }
     if (e->ev_start) hipEventDestroy(e->ev_start);
@@ -379,8 +384,11 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
         hipStream_t keep = ctx->stream;
         ctx->stream = on;                      // (the launch helpers enqueue on the context's stream)
         int r = GH_OK;
+        const bool pf = e->prof && e->n_half == 1;
+        if (pf) hipEventRecord(e->pe[0], on);
         if (e->N > 0 && e->Uh[h] > 0) {
             r = gh_launch_loglik_mfma(ctx, e->gmm, b, nullptr, nullptr, nullptr, e->ll_subset ? &e->ll_plan[h] : nullptr);
+            if (pf) hipEventRecord(e->pe[1], on);
             if (r == 1) { gh_set_error("gh_em_iteration: likelihood shape not covered"); r = GH_ERR_UNSUPPORTED; }
             if (!r) {
                 gh_fbchain_args ca;
@@ -391,11 +399,13 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
                 ca.occ_rng = e->use_rng ? e->d_rng : nullptr; ca.rng_floor = e->occ_floor;
                 r = gh_launch_fb_chain(ctx, ca, true);
             }
-        }
+        } else if (pf) hipEventRecord(e->pe[1], on);
+        if (pf) hipEventRecord(e->pe[2], on);
         // (the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
         if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
                                   e->d_chains, stats_out, e->norm_nll ? (const double*)b->nll : nullptr, e->S,
                                   e->use_rng ? e->d_rng : nullptr);
+        if (pf) hipEventRecord(e->pe[3], on);
         ctx->stream = keep;
         return r;
     };
@@ -429,6 +439,7 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
     double* row = e->d_hist + (size_t)(e->it % e->hist_cap) * 4;   // a ring: the last hist_cap iterations stay readable
     hipLaunchKernelGGL(em_finish_kernel, dim3(1), dim3(1), 0, st, tail + e->S, e->d_flags, row);
     GH_HIP(hipGetLastError());
+    if (e->prof && e->n_half == 1) hipEventRecord(e->pe[4], st);
     e->it += 1;
     if (out_tail) {
         GH_HIP(hipMemcpyAsync(e->h_tail, row, 32, hipMemcpyDeviceToHost, st));
@@ -444,6 +455,31 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
 }
 
 extern "C" int gh_em_iterations_done(const gh_em* e) { return e ? e->it : 0; }
+
+// Measurement aid: with on != 0 every following iteration records HIP events between its phases (on the stream the
+// kernels are launched on); gh_em_phase_ms waits for the last iteration and returns the four spans in milliseconds:
+// own-state likelihoods | chain forward-backward | statistics (+ its reduction) | tail + collective + M-step + re-pack.
+extern "C" int gh_em_profile(gh_ctx* ctx, gh_em* e, int on) {
+    GH_REQUIRE(ctx && e && e->ctx == ctx, "gh_em_profile: NULL argument / foreign context");
+    GH_HIP(hipSetDevice(ctx->device));
+    if (on && !e->pe[0])
+        for (auto& ev : e->pe) GH_HIP(hipEventCreate(&ev));
+    e->prof = on != 0;
+    return GH_OK;
+}
+
+extern "C" int gh_em_phase_ms(gh_ctx* ctx, gh_em* e, double* out /*[4]*/) {
+    GH_REQUIRE(ctx && e && out && e->ctx == ctx, "gh_em_phase_ms: NULL argument / foreign context");
+    GH_REQUIRE(e->prof && e->pe[0] && e->it > 0 && e->n_half == 1, "gh_em_phase_ms: no profiled iteration (gh_em_profile, one stream)");
+    GH_HIP(hipSetDevice(ctx->device));
+    GH_HIP(hipEventSynchronize(e->pe[4]));
+    for (int k = 0; k < 4; ++k) {
+        float ms = 0.f;
+        GH_HIP(hipEventElapsedTime(&ms, e->pe[k], e->pe[k + 1]));
+        out[k] = ms;
+    }
+    return GH_OK;
+}
 
 extern "C" int gh_em_history(gh_ctx* ctx, gh_em* e, int first, int count, double* out) {
     GH_REQUIRE(ctx && e && out && first >= 0 && count >= 0 && first + count <= e->it, "gh_em_history: range [%d, %d) of %d",

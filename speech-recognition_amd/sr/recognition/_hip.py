@@ -106,6 +106,8 @@ SIGNATURES = {
     "gh_em_destroy": (None, [C.c_void_p]),
     "gh_em_iteration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_f64p]),
     "gh_em_iterations_done": (C.c_int, [C.c_void_p]),
+    "gh_em_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "gh_em_phase_ms": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p]),
     "gh_em_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_f64p]),
     "gh_em_get_model": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_f64p, _c_f64p, _c_f64p]),
     "gh_em_packed": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_i64p]),
@@ -422,6 +424,17 @@ class EMSession:
             raise np.linalg.LinAlgError("Singular matrix")
         _check(self.ctx.lib, rc)
         return None if tail is None else (float(tail[0]), float(tail[1]), bool(tail[2]))
+
+    def profile(self, on=True):
+        """HIP events between the phases of every following iteration (gh_em_profile)."""
+        _check(self.ctx.lib, self.ctx.lib.gh_em_profile(self.ctx.h, self.h, 1 if on else 0))
+
+    def phase_ms(self):
+        """[likelihoods, forward-backward, statistics, tail + collective + M-step + re-pack] of the last profiled
+        iteration, in milliseconds (gh_em_phase_ms; waits for it)."""
+        out = np.zeros(4)
+        _check(self.ctx.lib, self.ctx.lib.gh_em_phase_ms(self.ctx.h, self.h, _ptr(out, _c_f64p)))
+        return out
 
     @property
     def iterations_done(self):

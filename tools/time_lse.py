@@ -23,7 +23,7 @@ def kernel_ms(b, gmm, reps=20, ramp=0.5):
     b.loglik(gmm, fetch=False); ctx.sync()
     t_r = time.perf_counter()
     while time.perf_counter() - t_r < ramp:
-        b.loglik(gmm, fetch=False)
+        b.loglik(gmm, fetch=False); ctx.sync()      # (launches are asynchronous: without the sync the ramp queues seconds of work)
     ctx.sync()
     e0, e1 = ctx.new_event(), ctx.new_event()
     ctx.record(e0)
