@@ -129,8 +129,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     const int S = fused ? fused->S : b->nll_S;
     if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernels runs on its expanded twin
         bool seq_fit = forced_kernel() == 0 && lat->beam <= 0 && !out_costs;
-        for (int64_t u = 0; seq_fit && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) seq_fit = false;
+        if (b->any_T1) seq_fit = false;
         if (!seq_fit) {
             const int rc0 = gh_lattices_full(lat, &lat);
             if (rc0) return rc0;
@@ -145,8 +144,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     {
         const bool no_chain = forced_kernel() != 0;
         if (no_chain) use_chain = false;
-        for (int64_t u = 0; use_chain && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) use_chain = false;
+        if (b->any_T1) use_chain = false;
     }
     // fused single-Gaussian decode (gh_viterbi_fused.hip): the chain form without the [N, S] matrix
     const int fused_dv = (fused && use_chain) ? gh_fused_dv(fused->D) : 0;
@@ -157,16 +155,14 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     {
         const bool no_layers = forced_kernel() != 0;
         if (no_layers) use_layers = false;
-        for (int64_t u = 0; use_layers && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
+        if (b->any_T1) use_layers = false;   // T == 1: the reference's column wrap (lean kernel)
     }
     // sequence form (forced-alignment graphs, one per distinct transcript; gh_seq.hip)
     bool use_seq = !use_chain && !use_layers && lat->seq_ok && !out_costs && lat->beam <= 0;
     {
         const bool no_seq = forced_kernel() != 0;
         if (no_seq) use_seq = false;
-        for (int64_t u = 0; use_seq && u < U; ++u)
-            if (b->offsets[u + 1] - b->offsets[u] == 1) use_seq = false;
+        if (b->any_T1) use_seq = false;
     }
     GH_REQUIRE(!lat->deferred_src || use_seq, "gh_viterbi: internal: a transcripts handle left the sequence-form path unexpanded");
     // layer-form kernels in label mode: the back-trace writes the label sequences itself, no path is materialised
@@ -335,6 +331,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
             if (rc) return rc;
             fa.feats = b->feats; fa.par = d_fpar; fa.D = fused->D; fa.Rp = fused_rp; fa.skip = lat->chain_skip ? 1 : 0; fa.DVp = fused_dv; fa.lin = std::isfinite(thr) ? 1 : 0;
             fa.select_end = (c.n_groups == 1 && !want_path && !out_costs) ? 1 : 0;
+            fa.pw = c.n_groups == 1 ? gh_fused_window(c.R, lat->chain_unit, &fa.period) : 0;
         }
         ctx->last_fused = use_fused ? 1 : 0;
         for (size_t k = 0; k + 1 < chunk_begin.size(); ++k) {
@@ -526,8 +523,7 @@ extern "C" int gh_viterbi_fused(gh_ctx* ctx, const gh_gmm* g, const gh_lattices*
     ctx->last_fused = 0;
     bool can = g->M == 1 && lat->chain_ok && lat->beam <= 0 && forced_kernel() == 0 && gh_fused_dv(g->D) > 0 && !lat->deferred_src;
     if (const char* e = getenv("GMMHMM_FUSED")) can = can && atoi(e) != 0;
-    for (int64_t u = 0; can && u < b->U; ++u)
-        if (b->offsets[u + 1] - b->offsets[u] == 1) can = false;   // T == 1: the reference's column wrap (other kernels)
+    if (b->any_T1) can = false;   // T == 1: the reference's column wrap (other kernels)
     if (!can) {
         const int compat = ctx->compat;
         if (log_domain) ctx->compat &= ~1;     // mahalanobis() is a log-domain distance: it never underflows

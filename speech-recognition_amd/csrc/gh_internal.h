@@ -118,6 +118,7 @@ struct gh_batch {
     std::vector<int64_t> offsets;  // host [U+1]
     int64_t* d_offsets;            // device [U+1]
     int64_t max_T;
+    bool any_T1 = false;           // some utterance has exactly one frame (the reference's column wrap: special kernels)
     void* nll;  // device [N,S] (dtype) after gh_loglik
     int nll_S;
     uint64_t nll_serial = 0;   // gh_gmm::serial of the model whose likelihoods `nll` holds (0: none yet)
@@ -243,6 +244,7 @@ struct gh_lattices {
     // chain form (gh_viterbi_chain.hip), only for L == 1 graphs whose arcs all come from r, r-1, r-2
     bool chain_ok, chain_skip;
     int chain_groups;
+    int chain_unit = 0;              // all chains of the chain form have this many rows (0: lengths differ)
     double *d_ch_cost0, *d_ch_cost1, *d_ch_cost2;
     uint8_t* d_ch_info;
     int32_t *d_ch_end_slot, *d_ch_group_row0;

@@ -295,16 +295,19 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         }
         if (ok) {  // 64-lane groups made of whole chains (a chain starts where no arc arrives from r-1 / r-2)
             chgroups.push_back(0);
-            int gs = 0, cs = 0;
+            int gs = 0, cs = 0, unit = 0;       // unit: the common length of all chains (0: they differ)
+            bool uniform = true;
             for (int r = 1; r <= R && ok; ++r) {
                 const bool chain_start = r == R || (std::isinf(ch1[r]) && std::isinf(ch2[r]) &&
                                                     (r + 1 >= R || std::isinf(ch2[r + 1])));
                 if (!chain_start) continue;
                 if (r - cs > 64) { ok = false; break; }     // one chain longer than a wave
                 if (r - gs > 64) { chgroups.push_back(cs); gs = cs; }
+                if (unit == 0) unit = r - cs; else if (r - cs != unit) uniform = false;
                 cs = r;
             }
             chgroups.push_back(R);
+            lt->chain_unit = (ok && uniform) ? unit : 0;
         }
         if (ok) { lt->chain_ok = true; lt->chain_skip = skip; lt->chain_groups = (int)chgroups.size() - 1; }
     }

@@ -182,7 +182,12 @@ __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restr
     if (live) out[d] = acc;
 }
 
-template <int DR>
+// RECIP: (t * (1/var)) * t instead of the reference's t / var * t (mahalanobis, hmm_state.py:58: `m / variance * m`).  The
+// division is ~25 fp64 instructions per (cluster, dimension) -- 8 x 39 of them per frame made this kernel the longest of
+// the refit (437 us per sweep of 1.4 M frames).  The two forms differ in the last bit of a term; an assignment changes
+// only where two centroids tie to ~1e-16 relative.  The device-resident refit takes RECIP (goldens G8 / G10 / G11 / G17:
+// identical cluster ids); GMMHMM_KMEANS_EXACT=1 and the call-by-call gh_kmeans_assign_multi keep the division.
+template <int DR, bool RECIP = false>
 __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
                                                           const double* __restrict__ cent /*[S,k,D]*/,
                                                           const double* __restrict__ var /*[S,D] or null*/,
@@ -200,7 +205,10 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
     const int lane = threadIdx.x;
     const double* c0 = cent + (int64_t)tl.state * k * D;
     for (int i = lane; i < k * D; i += 64) sc[i] = c0[i];
-    if (var) for (int i = lane; i < D; i += 64) sv[i] = var[(int64_t)tl.state * (vstride ? vstride : D) + i];   // (vstride: [S,k,D] variances, cluster 0's row)
+    if (var) for (int i = lane; i < D; i += 64) {     // (vstride: [S,k,D] variances, cluster 0's row)
+        const double v = var[(int64_t)tl.state * (vstride ? vstride : D) + i];
+        sv[i] = RECIP ? 1.0 / v : v;
+    }
     double x[DR];
     stage_tile<DR>(X, tl.first, tl.count, D, tile, x);
     double best = 0;
@@ -210,7 +218,10 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
         double q = 0, dist;
         if (var) {
 #pragma unroll
-            for (int d = 0; d < DR; ++d) if (d < D) { const double t = sc[c * D + d] - x[d]; q += t / sv[d] * t; }
+            for (int d = 0; d < DR; ++d) if (d < D) {
+                const double t = sc[c * D + d] - x[d];
+                if (RECIP) q += t * sv[d] * t; else q += t / sv[d] * t;
+            }
             dist = ld + 0.5 * q;                                   // mahalanobis(centroid, x, cov[0]), kmeans.py:183
         } else {
 #pragma unroll
@@ -975,7 +986,9 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     // frame-order pass over the final assignment produces the centroids, which are then numpy's bit for bit.  What can
     // differ: a frame whose two nearest centroids tie to within an ulp might be assigned differently in an intermediate
     // iteration.  GMMHMM_KMEANS_EXACT=1 keeps the frame-order sums and the np.array_equal rule in every iteration.
-    const bool exact_order = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }() && !comm;
+    const bool exact_env = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }();
+    const bool exact_order = exact_env && !comm;
+    const bool exact_div = exact_env;          // the reference's division in the distance (see kmeans_multi_kernel)
     GH_HIP(hipMemcpyAsync(f->d_cent, centroids_in, (size_t)S * k * D * 8, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
     GH_HIP(hipMemsetAsync(f->d_iters, 0, (size_t)S * 4, st));
@@ -989,9 +1002,10 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         for (int j = 0; j < blkn; ++j) {
             if (f->n_tiles > 0) {
                 const dim3 grid((unsigned)f->n_tiles), blk(64);
-#define GH_KM(DR) hipLaunchKernelGGL((kmeans_multi_kernel<DR>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_cent, \
+#define GH_KM(DR, RC) hipLaunchKernelGGL((kmeans_multi_kernel<DR, RC>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_cent, \
                                      (const double*)f->d_cov, (const double*)f->d_logdet, f->d_ids, f->d_changed, f->d_tilecnt, (const uint8_t*)f->d_active, k * D)
-                if (D <= 16) GH_KM(16); else if (D <= 40) GH_KM(40); else GH_KM(64);
+                if (exact_div) { if (D <= 16) GH_KM(16, false); else if (D <= 40) GH_KM(40, false); else GH_KM(64, false); }
+                else { if (D <= 16) GH_KM(16, true); else if (D <= 40) GH_KM(40, true); else GH_KM(64, true); }
 #undef GH_KM
             }
             rc = fit_build_lists(f, k, true, f->d_active);

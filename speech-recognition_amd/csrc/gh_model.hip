@@ -285,7 +285,10 @@ static int batch_common(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U
     b->d_occ_states = nullptr;
     b->offsets.assign(off, off + U + 1);
     b->max_T = 0;
-    for (int64_t u = 0; u < U; ++u) b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
+    for (int64_t u = 0; u < U; ++u) {
+        b->max_T = std::max(b->max_T, off[u + 1] - off[u]);
+        if (off[u + 1] - off[u] == 1) b->any_T1 = true;
+    }
     b->perm.resize(U);
     std::iota(b->perm.begin(), b->perm.end(), (int64_t)0);
     std::stable_sort(b->perm.begin(), b->perm.end(), [&](int64_t x, int64_t y) {

@@ -86,7 +86,10 @@ struct gh_fused_args {
     int select_end;      // 1: the sweep also picks the best end row (one lane group, no path wanted): no back-trace launch
     int lin;             // 1: the linear-domain underflow rule of GMM.evaluate is on (finite threshold in the table)
     int64_t n_items;     // (utterance, row group) pairs of the launch
+    int pw, period;      // packed form: rows per wave window (0: one utterance per wave), windows per repeat of the row pattern
+    int64_t n_windows;
 };
+int gh_fused_window(int R, int unit, int* period_out);   // rows per packed window (0: one utterance per wave)
 int gh_fused_dv(int D);  // rows per half of the constants table for D dimensions (0: D not covered)
 int gh_launch_fused_params(gh_ctx* ctx, const gh_gmm* g, const int32_t* d_row_state, int R, int Rp, int DV, double thr,
                            double* d_par);

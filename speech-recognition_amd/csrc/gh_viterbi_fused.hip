@@ -260,9 +260,226 @@ __global__ __launch_bounds__(64) void viterbi_fused_kernel(gh_fused_args fa) {
     }
 }
 
+// ---- PACKED form: a wave's 64 lanes are a WINDOW of `pw` consecutive rows of the endless sequence
+//   [rows of launch slot 0 | rows of launch slot 1 | ...]          (R rows each, pw a multiple of the chains' length)
+// so that a model of R = 50 rows (configs[0]: 10 words x 5 states) fills 60 of 64 lanes -- 12 whole chains, the last two of
+// them the next utterance's -- instead of 50.  A window holds rows of at most TWO utterances (the host picks pw so); each
+// has its own tile in LDS, a lane reads the frame of ITS utterance (two distinct addresses per broadcast read).  Both
+// utterances advance together, column by column; the shorter one's lanes run on past its end on stale frames -- a chain
+// never reads across a chain boundary (arc costs +inf there), so nothing of it reaches the longer one's rows -- and its
+// final costs are taken when it ends.  Waves stride over the windows by a multiple of the pattern's period, so a lane keeps
+// the same model row and loads its constants once.  End costs go to memory; the best end per utterance is a kernel of
+// its own (an utterance's chains may sit in two waves).
+constexpr int FT2 = 16;   // frames per tile and utterance in the packed form
+
+template <typename ET, int DV, int DX, bool WANT_BP, bool WANT_COSTS, bool SKIP, bool LIN>
+__global__ __launch_bounds__(64) void viterbi_fused_packed_kernel(gh_fused_args fa) {
+    constexpr int NLD = (FT2 * DV + 63) / 64;
+    constexpr int VW = 16 / sizeof(ET);
+    constexpr int TILE = (FT2 + 1) * DV;       // elements of one utterance's tile (+1 row: read-ahead of the last column)
+    static_assert(DV % VW == 0 && DX <= DV, "LDS rows are 16-byte multiples");
+    typedef ET vec_t __attribute__((ext_vector_type(VW)));
+    __shared__ __attribute__((aligned(16))) ET tile[2 * TILE];
+    __shared__ uint16_t slot_of[NLD * 64];
+    const gh_chain_args& a = fa.c;
+    const int lane = threadIdx.x;
+    const int D = fa.D, Rp = fa.Rp, R = a.R, PW = fa.pw;
+    const int64_t n_utts = fa.n_items;          // (one lane group: items are utterances)
+    const double INF = INFINITY;
+
+    for (int e = lane; e < NLD * 64; e += 64) {
+        const int fr = e / D;
+        slot_of[e] = (uint16_t)(fr * DV + (e - fr * D));
+    }
+    for (int i = lane; i < 2 * TILE; i += 64) tile[i] = ET(0);
+
+    ET s[DX], ms[DX];
+    double konst = 0, cthr = 0, c0 = INF, c1 = INF, c2 = INF;
+    uint8_t first_code = 3;
+    bool is_start = false;
+    int cur_row = -1, es = -1;
+
+    for (int64_t w = blockIdx.x; w < fa.n_windows; w += gridDim.x) {
+        const int64_t v0 = w * PW;
+        const int64_t sA = v0 / R;
+        const int o = (int)(v0 - sA * R);                  // first row of the window inside utterance A
+        const bool inwin = lane < PW && (sA * R + o + lane) < n_utts * R;
+        const bool isB = o + lane >= R;
+        const int row = inwin ? (isB ? o + lane - R : o + lane) : 0;
+        if (row != cur_row) {                              // (the stride keeps the pattern: true once per wave)
+            cur_row = row;
+            const double* p = fa.par + row;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                s[d] = (ET)p[(size_t)d * Rp];
+                ms[d] = (ET)p[(size_t)(fa.DVp + d) * Rp];
+            }
+            konst = p[(size_t)(2 * fa.DVp) * Rp];
+            cthr = p[(size_t)(2 * fa.DVp + 1) * Rp];
+            c0 = a.cost0[row];
+            c1 = a.cost1[row];
+            c2 = SKIP ? a.cost2[row] : INF;
+            const uint8_t info = a.row_info[row];
+            first_code = info & 3;
+            is_start = (info & 4) != 0;
+            es = a.end_slot[row];
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        const bool hasB = (o + PW > R) && (sA + 1 < n_utts);        // wave-uniform
+        const int64_t slotA = a.slot0 + sA, slotB = slotA + (hasB ? 1 : 0);
+        const int64_t uA = a.perm ? a.perm[slotA] : slotA, uB = a.perm ? a.perm[slotB] : slotB;
+        const int64_t fA = a.utt_off[uA], fB = a.utt_off[uB];
+        const int TA = (int)(a.utt_off[uA + 1] - fA), TB = hasB ? (int)(a.utt_off[uB + 1] - fB) : 0;
+        const int T1 = hasB ? (TA < TB ? TA : TB) : TA, T2 = TA > TB ? TA : TB;     // both run to T1, the longer one to T2
+        if (T2 <= 0) continue;
+        const ET* srcA = static_cast<const ET*>(fa.feats) + fA * D;
+        const ET* srcB = static_cast<const ET*>(fa.feats) + fB * D;
+        const int T_mine = isB ? TB : TA;
+        const int64_t u_mine = isB ? uB : uA, slot_mine = isB ? slotB : slotA;
+        const bool act = inwin && (!isB || hasB) && T_mine > 0;
+        const int xbase = isB ? TILE : 0;
+
+        ET pre[2][NLD];
+        auto issue = [&](int t0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int Tj = j ? TB : TA;
+                int nF = Tj - t0;
+                nF = nF < 0 ? 0 : (nF > FT2 ? FT2 : nF);
+                const int nE = nF * D;
+                const ET* p = (j ? srcB : srcA) + (int64_t)t0 * D;
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = lane + 64 * i;
+                    pre[j][i] = e < nE ? p[e] : ET(0);
+                }
+            }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = lane + 64 * i;
+                    if (e < FT2 * D) tile[j * TILE + slot_of[e]] = pre[j][i];
+                }
+        };
+        constexpr int NV = DX / VW, NT = DX % VW;
+        vec_t xv[NV > 0 ? NV : 1];
+        ET xt[NT > 0 ? NT : 1];
+        auto fetch = [&](int k) {
+            const ET* base = tile + xbase + k * DV;
+            const vec_t* xr = reinterpret_cast<const vec_t*>(base);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) xv[j] = xr[j];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xt[j] = base[NV * VW + j];
+        };
+        issue(0);
+        commit();
+        fetch(0);
+
+        double prev = INF, fin = INF;
+        uint8_t* bp = WANT_BP ? a.bp + a.bp_off[slot_mine] + row : nullptr;
+        double* co = WANT_COSTS ? a.costs + a.costs_off[u_mine] + (int64_t)row * T_mine : nullptr;
+
+        auto column = [&](int k, int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            ET q0 = sizeof(ET) == 8 ? (ET)konst : ET(0);
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                const ET e0 = fma_(d < NV * VW ? xv[d / VW][d % VW] : xt[d % VW], s[d], ms[d]);
+                q0 = fma_(e0, e0, q0);
+            }
+            asm volatile("" : "+v"(q0) :: "memory");
+            fetch(k + 1);
+            const double q = sizeof(ET) == 8 ? (double)q0 : konst + (double)q0;
+            double c;
+            uint8_t code = 3;
+            if (FIRST) {
+                const double e = (LIN && q > cthr) ? INF : q;
+                c = is_start ? e : INF;
+            } else {
+                const double e = LIN ? __hiloint2double((q > cthr) ? 0x7FF00000 : __double2hiint(q), __double2loint(q)) : q;
+                const double p1 = wave_shr1z(prev);
+                if (!WANT_BP) {
+                    double best = vmin(c1 + p1, c0 + prev);
+                    if (SKIP) best = vmin(best, c2 + wave_shr1z(p1));
+                    c = vmin(best + e, INF);
+                } else {
+                    double best = INF;
+                    code = first_code;
+                    if (SKIP) {
+                        const double v2 = c2 + wave_shr1z(p1);
+                        if (v2 < best) { best = v2; code = 2; }
+                    }
+                    const double v1 = c1 + p1;
+                    if (v1 < best) { best = v1; code = 1; }
+                    const double v0 = c0 + prev;
+                    if (v0 < best) { best = v0; code = 0; }
+                    c = best + e;
+                    c = (c != c) ? INF : c;
+                    if (first_code == 3) c = INF;
+                }
+            }
+            prev = c;
+            if ((WANT_BP || WANT_COSTS) && act && t < T_mine) {
+                if (WANT_BP) { *bp = code; bp += R; }
+                if (WANT_COSTS) { *co = c; co += 1; }
+            }
+        };
+
+        for (int t0 = 0; t0 < T2; t0 += FT2) {
+            const bool more = t0 + FT2 < T2;
+            if (more) issue(t0 + FT2);
+            const int nF = (T2 - t0 < FT2) ? T2 - t0 : FT2;
+            int k = 0;
+            if (t0 == 0) { column(0, 0, std::true_type()); k = 1; if (T1 == 1) fin = prev; }
+            for (; k < nF; ++k) {
+                column(k, t0 + k, std::false_type());
+                if (t0 + k + 1 == T1) fin = prev;           // (wave-uniform test: the shorter utterance ends here)
+            }
+            if (more) { commit(); fetch(0); }
+        }
+        if (es >= 0 && act) a.end_cost[u_mine * a.n_end + es] = (T_mine == T2) ? prev : fin;
+    }
+}
+
+// the cheapest end row per utterance, the LAST of equal minima (decode.py:129-134 keeps an end when `best >= cost`): one
+// lane per utterance -- what chain_backtrace_kernel does with a wave per utterance when no path is wanted
+__global__ void end_select_kernel(gh_chain_args a, int64_t u_begin, int64_t n_utts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_utts) return;
+    const int64_t slot = u_begin + i;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const int T = (int)(a.utt_off[u + 1] - a.utt_off[u]);
+    double best = INFINITY;
+    int bi = -1;
+    for (int k = 0; k < a.n_end; ++k) {
+        const double c = a.end_cost[u * a.n_end + k];
+        if (best >= c) { best = c; bi = k; }
+    }
+    a.best_end[u] = T <= 0 ? -1 : bi;
+}
+
 template <typename ET, int DV, int DX, bool BP, bool CO, bool SK, bool LIN>
 int launch_one(gh_ctx* ctx, const gh_fused_args& fa) {
     int occ = 0;
+    if (fa.pw > 0) {       // packed windows (one lane group, uniform chains)
+        GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)viterbi_fused_packed_kernel<ET, DV, DX, BP, CO, SK, LIN>, 64, 0));
+        if (occ < 1) occ = 1;
+        int64_t grid = (int64_t)ctx->n_cu * occ;
+        if (const char* e = getenv("GMMHMM_FUSED_WAVES")) grid = (int64_t)ctx->n_cu * std::max(1, atoi(e));
+        grid = std::min<int64_t>(grid, fa.n_windows);
+        if (grid > fa.period) grid -= grid % fa.period;        // (a lane keeps its model row from window to window)
+        hipLaunchKernelGGL((viterbi_fused_packed_kernel<ET, DV, DX, BP, CO, SK, LIN>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, fa);
+        GH_HIP(hipGetLastError());
+        if (fa.select_end) {
+            hipLaunchKernelGGL(end_select_kernel, dim3((unsigned)((fa.n_items + 255) / 256)), dim3(256), 0, ctx->stream, fa.c, fa.c.slot0, fa.n_items);
+            GH_HIP(hipGetLastError());
+        }
+        return GH_OK;
+    }
     GH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)viterbi_fused_kernel<ET, DV, DX, BP, CO, SK, LIN>, 64, 0));
     if (occ < 1) occ = 1;
     int64_t grid = (int64_t)ctx->n_cu * occ;
@@ -306,6 +523,22 @@ int launch_et(gh_ctx* ctx, const gh_fused_args& fa, bool want_bp, bool want_cost
 
 }  // namespace
 
+// Window width of the packed form for a graph of R rows in chains of `unit` rows: the widest multiple of `unit` <= 64 whose
+// windows never hold rows of more than two utterances (with g = gcd(pw, R): R - g + pw <= 2 R), provided it beats one
+// utterance per wave; 0: keep the one-utterance form.  *period_out: windows after which the lane -> row map repeats.
+int gh_fused_window(int R, int unit, int* period_out) {
+    if (const char* e = getenv("GMMHMM_FUSED_PACK")) if (atoi(e) == 0) return 0;
+    if (R <= 0 || unit <= 0 || R > 64 || R % unit) return 0;
+    auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+    int best = 0;
+    for (int pw = (64 / unit) * unit; pw > R; pw -= unit)
+        if (R - gcd(pw, R) + pw <= 2 * R) { best = pw; break; }
+    if (best == 0 && 2 * R <= 64) best = 2 * R;          // small models: two whole utterances per wave
+    if (best <= R) return 0;
+    *period_out = R / gcd(best, R);
+    return best;
+}
+
 // rows of the constants table per half (>= the dimensions any instantiation that takes D computes); 0: D not covered
 int gh_fused_dv(int D) { return D <= 8 ? 8 : D <= 16 ? 16 : D <= 28 ? 28 : D <= 40 ? 40 : 0; }
 
@@ -323,5 +556,6 @@ int gh_launch_viterbi_fused(gh_ctx* ctx, const gh_fused_args& fa, int64_t u_begi
     gh_fused_args b = fa;
     b.c.slot0 = u_begin;
     b.n_items = n_utts * fa.c.n_groups;
+    if (b.pw > 0) b.n_windows = (n_utts * (int64_t)fa.c.R + b.pw - 1) / b.pw;
     return f64 ? launch_et<double>(ctx, b, want_bp, want_costs) : launch_et<float>(ctx, b, want_bp, want_costs);
 }

@@ -202,6 +202,7 @@ class AlignmentPlan:
             self.utt_graph[u] = keys[key]
         self.flat = _hip.Lattices.flatten_transcripts(self.transcripts) if hasattr(_hip.Lattices, "flatten_transcripts") else None
         self.gmm = None
+        self.frame_state_buf = None       # int32 [N]: the alignment's result lands in the same pages every iteration
 
     def packed_model(self, ctx, models):
         states = [s for m in models for s in m.gmm_states]
@@ -267,7 +268,15 @@ def aligned_frame_states(frames, models, label_seqs, plan=None):
     segment_start bool [N]: first frame of a segment).  Equals `cut_segments` applied to `forced_alignments`."""
     lat, _, utt_graph = _alignment_lattices(frames, models, label_seqs, plan)
     try:
-        res = lat.align_segments(frames, utt_lattice=utt_graph)
+        if plan is not None:
+            if plan.frame_state_buf is None or plan.frame_state_buf.shape != (frames.N,):
+                plan.frame_state_buf = np.empty(frames.N, dtype=np.int32)
+            try:
+                res = lat.align_segments(frames, utt_lattice=utt_graph, out=plan.frame_state_buf)
+            except TypeError:          # (a test double of the binding without `out`)
+                res = lat.align_segments(frames, utt_lattice=utt_graph)
+        else:
+            res = lat.align_segments(frames, utt_lattice=utt_graph)
     finally:
         lat.close()
     return res["frame_state"], res["segment_start"]
