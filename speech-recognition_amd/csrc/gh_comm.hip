@@ -286,6 +286,11 @@ extern "C" int gh_comm_allreduce_host(gh_ctx* ctx, gh_comm* c, double* host_io, 
     GH_HIP(hipMemcpyAsync(base, host_io, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     GH_RCCL(g_rccl.AllReduce(base, base, (size_t)n, ncclDouble, op_max ? ncclMax : ncclSum, c->comm, ctx->stream),
             "gh_comm_allreduce_host");
+    // (the wait BEFORE the copy back: a device-to-host copy into pageable memory blocks inside hipMemcpyAsync until the
+    //  stream gets there -- behind a collective a lost peer would turn that into a hang no deadline can end)
+    const int rcw = gh_stream_wait(ctx, c, "gh_comm_allreduce_host");
+    if (rcw) return rcw;
     GH_HIP(hipMemcpyAsync(host_io, base, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    return gh_stream_wait(ctx, c, "gh_comm_allreduce_host");
+    GH_HIP(hipStreamSynchronize(ctx->stream));
+    return GH_OK;
 }

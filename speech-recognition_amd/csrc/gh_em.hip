@@ -65,6 +65,7 @@ struct gh_em {
     double* h_tail;        // pinned [4]
     // gh_em_profile: HIP events between the phases of an iteration (likelihoods | forward-backward | statistics | tail +
     // collective + M-step + re-pack), on the stream the kernels run on; one half only
+    gh_comm* last_comm = nullptr;   // the communicator of the last iteration: every later wait on the stream is behind its collective
     bool prof = false;
     hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -427,6 +428,7 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
     hipLaunchKernelGGL(em_tail_kernel, dim3(e->W + 1), dim3(256), 0, st, e->d_xi_utt, e->d_logp, e->d_word_utts, e->d_word_off,
                        e->W, e->n, e->U, tail, e->d_flags);
     GH_HIP(hipGetLastError());
+    e->last_comm = comm;
     if (comm) {
         rc = gh_comm_allreduce_enqueue(comm, e->d_packed, e->n_packed);   // the ONE collective of the iteration
         if (rc) return rc;
@@ -488,6 +490,10 @@ extern "C" int gh_em_history(gh_ctx* ctx, gh_em* e, int first, int count, double
                e->hist_cap, e->it);
     if (count == 0) return GH_OK;
     GH_HIP(hipSetDevice(ctx->device));
+    // iterations enqueued without a read-back wait HERE for their collectives -- BEFORE the copies: a device-to-host copy
+    // into pageable memory blocks inside hipMemcpyAsync until the stream gets there, deadline or not
+    const int rcw = gh_stream_wait(ctx, e->last_comm, "gh_em_history");
+    if (rcw) return rcw;
     const int r0 = first % e->hist_cap, n0 = std::min(count, e->hist_cap - r0);      // (the range may wrap around the ring)
     GH_HIP(hipMemcpyAsync(out, e->d_hist + (size_t)r0 * 4, (size_t)n0 * 32, hipMemcpyDeviceToHost, ctx->stream));
     if (count > n0) GH_HIP(hipMemcpyAsync(out + (size_t)n0 * 4, e->d_hist, (size_t)(count - n0) * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -500,6 +506,8 @@ extern "C" int gh_em_get_model(gh_ctx* ctx, gh_em* e, double* mean, double* var,
     GH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t nd = (size_t)e->S * e->M * e->D;
+    const int rcw = gh_stream_wait(ctx, e->last_comm, "gh_em_get_model");     // (before the pageable copies: see gh_em_history)
+    if (rcw) return rcw;
     if (mean) GH_HIP(hipMemcpyAsync(mean, e->d_mean, nd * 8, hipMemcpyDeviceToHost, st));
     if (var) GH_HIP(hipMemcpyAsync(var, e->d_var, nd * 8, hipMemcpyDeviceToHost, st));
     if (weight) GH_HIP(hipMemcpyAsync(weight, e->d_weight, (size_t)e->S * e->M * 8, hipMemcpyDeviceToHost, st));
@@ -515,6 +523,8 @@ extern "C" int gh_em_packed(gh_ctx* ctx, gh_em* e, double* out /*[n] or NULL*/, 
     if (out_n) *out_n = e->n_packed;
     if (out) {
         GH_HIP(hipSetDevice(ctx->device));
+        const int rcw = gh_stream_wait(ctx, e->last_comm, "gh_em_packed");
+        if (rcw) return rcw;
         GH_HIP(hipMemcpyAsync(out, e->d_packed, (size_t)e->n_packed * 8, hipMemcpyDeviceToHost, ctx->stream));
         GH_HIP(hipStreamSynchronize(ctx->stream));
     }

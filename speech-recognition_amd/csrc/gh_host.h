@@ -61,26 +61,25 @@ struct UploadLayout {
         total += (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
     }
     int commit(void* base, hipStream_t st, bool sync) {
-        size_t lo = total, hi = 0;
-        for (auto& it : items) {
-            *it.dst = static_cast<char*>(base) + it.off;
-            if (it.src_bytes) { lo = std::min(lo, it.off); hi = std::max(hi, it.off + it.src_bytes); }
-        }
-        // (the one copy below covers [lo, hi): a piece that is "left as it is" must not lie inside it -- it would be
-        //  overwritten with the staging buffer's zeros; every current user adds its host pieces back to back)
-        for (auto& it : items)
-            if (!it.src_bytes && it.off >= lo && it.off < hi) {
-                gh_set_error("UploadLayout: a piece without host data lies between two host pieces");
-                return GH_ERR_INVALID;
+        for (auto& it : items) *it.dst = static_cast<char*>(base) + it.off;
+        // every maximal run of consecutive pieces WITH host data travels as one copy; a piece that is "left as it is"
+        // (no source) between two runs is not touched (one copy over [first, last) would have zeroed it)
+        std::vector<char> stage(total, 0);
+        bool any = false;
+        size_t i = 0;
+        while (i < items.size()) {
+            if (!items[i].src_bytes) { ++i; continue; }
+            size_t j = i, lo = items[i].off, hi = lo;
+            while (j < items.size() && items[j].src_bytes) {
+                memcpy(stage.data() + items[j].off, items[j].src, items[j].src_bytes);
+                hi = items[j].off + items[j].src_bytes;
+                ++j;
             }
-        if (hi > lo) {
-            std::vector<char> stage(hi - lo, 0);
-            for (auto& it : items) if (it.src_bytes) memcpy(stage.data() + (it.off - lo), it.src, it.src_bytes);
-            GH_HIP(hipMemcpyAsync(static_cast<char*>(base) + lo, stage.data(), hi - lo, hipMemcpyHostToDevice, st));
-            GH_HIP(hipStreamSynchronize(st));    // `stage` is pageable host memory of this call
-        } else if (sync) {
-            GH_HIP(hipStreamSynchronize(st));
+            GH_HIP(hipMemcpyAsync(static_cast<char*>(base) + lo, stage.data() + lo, hi - lo, hipMemcpyHostToDevice, st));
+            any = true;
+            i = j;
         }
+        if (any || sync) GH_HIP(hipStreamSynchronize(st));    // (`stage` is pageable host memory of this call)
         return GH_OK;
     }
 };

@@ -1052,11 +1052,14 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     hipLaunchKernelGGL(fit_counts_kernel, dim3((unsigned)((S * k + 255) / 256)), dim3(256), 0, st, S * k, (const int32_t*)f->d_counts, f->d_sq);
     GH_HIP(hipGetLastError());
     if (comm) { rc = gh_comm_allreduce_enqueue(comm, f->d_sq, (int64_t)S * k); if (rc) return rc; }
+    rc = gh_stream_wait(ctx, comm, "gh_fit_kmeans");      // (before the copies into pageable memory, which block on the stream)
+    if (rc) return rc;
     if (out_centroids) GH_HIP(hipMemcpyAsync(out_centroids, f->d_cent, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
     if (out_cov) GH_HIP(hipMemcpyAsync(out_cov, f->d_cov, (size_t)S * k * D * 8, hipMemcpyDeviceToHost, st));
     if (out_counts) GH_HIP(hipMemcpyAsync(out_counts, f->d_sq, (size_t)S * k * 8, hipMemcpyDeviceToHost, st));
     if (out_iters) GH_HIP(hipMemcpyAsync(out_iters, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-    return gh_stream_wait(ctx, comm, "gh_fit_kmeans");
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
 }
 
 extern "C" int gh_fit_clusters(gh_ctx* ctx, gh_fit* f, int32_t* out /*[N]*/) {
@@ -1130,6 +1133,8 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
         }
         if (n_active == 0) break;
     }
+    rc = gh_stream_wait(ctx, comm, "gh_fit_em");          // (before the copies into pageable memory, which block on the stream)
+    if (rc) return rc;
     GH_HIP(hipMemcpyAsync(mean_io, f->d_mean, skd, hipMemcpyDeviceToHost, st));
     GH_HIP(hipMemcpyAsync(var_io, f->d_var, skd, hipMemcpyDeviceToHost, st));
     GH_HIP(hipMemcpyAsync(weight_io, f->d_weight, sk, hipMemcpyDeviceToHost, st));
@@ -1137,7 +1142,8 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
     GH_HIP(hipMemcpyAsync(sigma_old_io, f->d_old_sigma, skd, hipMemcpyDeviceToHost, st));
     GH_HIP(hipMemcpyAsync(w_old_io, f->d_old_w, sk, hipMemcpyDeviceToHost, st));
     if (out_converged_at) GH_HIP(hipMemcpyAsync(out_converged_at, f->d_iters, (size_t)S * 4, hipMemcpyDeviceToHost, st));
-    return gh_stream_wait(ctx, comm, "gh_fit_em");
+    GH_HIP(hipStreamSynchronize(st));
+    return GH_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -336,7 +336,12 @@ def work():
             raise RuntimeError("rank 1 fails between two EM iterations")
         t0 = time.perf_counter()
         try:
-            tr.iteration()
+            if fail_at == 3:            # iterations ENQUEUED without a read-back: the wait is in the history read
+                for _ in range(3):
+                    tr.iteration(sync=False)
+                tr.drain()
+            else:
+                tr.iteration()
             state["outcome"] = "iteration returned"
         except _hip.CommError as e:
             state["outcome"], state["message"] = "CommError", str(e)
@@ -357,7 +362,7 @@ os._exit(0)      # (nothing of the interpreter's teardown may wait on the GPU af
 '''
 
 
-@pytest.mark.parametrize("fail_at", [0, 2])
+@pytest.mark.parametrize("fail_at", [0, 2, 3])
 def test_a_failing_rank_is_an_error_on_its_peers_not_a_hang(tmp_path, fail_at):
     import time
     t0 = time.perf_counter()
