@@ -428,34 +428,36 @@ template <typename T>
 __global__ void loglik_underflow_fix_kernel(const T* __restrict__ X, int64_t N, int S, int M, int D, const double* __restrict__ mean,
                                             const double* __restrict__ ivar, const double* __restrict__ logc,
                                             const float* __restrict__ cen32, const int* __restrict__ any_pos, T* __restrict__ nll) {
-    if (*any_pos == 0) return;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * S) return;
-    const int64_t t = idx / S;
-    const int s = (int)(idx - t * S);
-    double P = 0.0;
-    for (int m = 0; m < M; ++m) P = fmax(P, logc[s * M + m]);     // (-inf for a switched-off component)
-    if (!(P > 0.0)) return;
+    if (*any_pos == 0) return;     // ordinary models: a few thousand threads read one word and leave (a fixed, small grid:
+                                   // one thread per entry made the launch itself cost 0.4 ms at 5e8 entries)
     const double thr = 745.1332191019412;
-    const double v = (double)nll[idx];
-    if (!(v > thr - P) || v == INFINITY) return;
-    for (int m = 0; m < M; ++m) {
-        const double lc = logc[s * M + m];
-        double q2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double dx = (double)X[t * D + d] - mean[(size_t)(s * M + m) * D + d];
-            q2 += dx * dx * ivar[(size_t)(s * M + m) * D + d];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < N * S; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = idx / S;
+        const int s = (int)(idx - t * S);
+        double P = 0.0;
+        for (int m = 0; m < M; ++m) P = fmax(P, logc[s * M + m]);     // (-inf for a switched-off component)
+        if (!(P > 0.0)) continue;
+        const double v = (double)nll[idx];
+        if (!(v > thr - P) || v == INFINITY) continue;
+        bool survives = false;
+        for (int m = 0; m < M && !survives; ++m) {
+            const double lc = logc[s * M + m];
+            double q2 = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double dx = (double)X[t * D + d] - mean[(size_t)(s * M + m) * D + d];
+                q2 += dx * dx * ivar[(size_t)(s * M + m) * D + d];
+            }
+            q2 *= 0.5;
+            if (!(q2 > thr) && !(q2 - lc > thr)) survives = true;     // this term survives in the reference: the cost is finite
         }
-        q2 *= 0.5;
-        if (!(q2 > thr) && !(q2 - lc > thr)) return;              // this term survives in the reference: the cost is finite
+        if (!survives) nll[idx] = (T)INFINITY;
     }
-    nll[idx] = (T)INFINITY;
 }
 
 int gh_loglik_underflow_fix(gh_ctx* ctx, const gh_gmm* g, gh_batch* b) {
     if (!(ctx->compat & 1) || b->N == 0 || !b->nll || !g->dAnyPos) return GH_OK;
     const int64_t total = b->N * (int64_t)g->S;
-    const unsigned grid = (unsigned)((total + 255) / 256);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)ctx->n_cu * 16);     // grid-stride loop
     if (b->dtype == GH_F64)
         hipLaunchKernelGGL(loglik_underflow_fix_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)b->feats, b->N, g->S,
                            g->M, g->D, g->dMean, g->dIvar, g->dLogc, g->dCen32, g->dAnyPos, (double*)b->nll);
