@@ -731,6 +731,8 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
         GH_MF_CASE(8)
         GH_MF_CASE(12)
         GH_MF_CASE(20)
+        GH_MF_CASE(24)
+        GH_MF_CASE(32)
         default:
             return 1;  // not an MFMA shape: caller falls back to the vector kernel
     }
@@ -760,7 +762,7 @@ int gh_loglik_plan_build(gh_ctx* ctx, const gh_gmm* g, const gh_batch* b, const 
     out->d_blk = nullptr; out->n_blk = 0; out->max_tiles = 1;
     if (!g->dApk64) return 1;
     const int KS = g->KP / 2;
-    if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) return 1;
+    if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20 && KS != 24 && KS != 32) return 1;
     int chunk_tiles, SC;
     chunk_shape(g, &chunk_tiles, &SC);
     std::vector<gh_loglik_blk> tabv;

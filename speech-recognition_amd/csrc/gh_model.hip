@@ -16,7 +16,12 @@ extern "C" int gh_gmm_create(gh_ctx* ctx, int S, int M, int D, const double* mea
     *out = nullptr;
     GH_HIP(hipSetDevice(ctx->device));
     const int G = S * M;
-    const int KP = (D + 3) & ~3;
+    // feature length padded to what the matrix-core kernels are instantiated for (k-steps KS = KP / 2 in {2, 4, 8, 12, 20,
+    // 24, 32}: gh_loglik_mfma.hip; the pad columns are zero operands): every D <= 64 runs on the matrix cores -- until round
+    // 4 only D with (D + 3) & ~3 in that list did, the rest (9-12, 17-20, 25-36, > 40) fell to the vector kernel
+    int KP = (D + 3) & ~3;
+    for (const int kp : {4, 8, 16, 24, 40, 48, 64})
+        if (KP <= kp) { KP = kp; break; }
     gh_gmm* g = new gh_gmm();
     g->ctx = ctx;
     g->d_arena = nullptr;

@@ -53,7 +53,10 @@ def test_loglik_golden(hip, ctx, tag, dtype, rtol):
 
 
 @pytest.mark.parametrize("S,M,D,N", [(3, 1, 6, 130), (50, 8, 39, 1000), (7, 5, 13, 257), (4, 3, 50, 64), (2, 9, 24, 63),
-                                     (5, 32, 39, 100), (3, 20, 13, 70), (70, 2, 13, 300), (130, 4, 39, 65), (9, 48, 7, 33)])
+                                     (5, 32, 39, 100), (3, 20, 13, 70), (70, 2, 13, 300), (130, 4, 39, 65), (9, 48, 7, 33),
+                                     # round 4: every D <= 64 on the matrix cores (operands zero-padded to the next
+                                     # instantiated length: 10 -> 16, 18 -> 24, 30 -> 40, 45 -> 48, 64), D = 70 on the vector kernel
+                                     (6, 8, 10, 200), (5, 4, 18, 97), (11, 8, 30, 130), (4, 8, 45, 96), (3, 16, 64, 70), (3, 2, 70, 40)])
 def test_loglik_vs_oracle_shapes(hip, ctx, S, M, D, N):
     rng = np.random.default_rng(S * 100 + M)
     means = rng.normal(size=(S, M, D))
