@@ -1091,7 +1091,27 @@ def pcie_inclusive(dev, wl, npdt, steps=6):
             l.close()
         return dt
     dt1, dt2 = timed(1), timed(2)
-    return {"ms_per_step": dt1 * 1e3, "value": X.shape[0] * S / dt1, "unit": "frame-state loglik/s",
+    # fp32 on the wire, fp64 in HBM and in every kernel (gh_batch_create_wire: half the bytes over the link, widened on the
+    # device, host buffer page-locked for the copy); the features are fp32-rounded before the call -- a caller's choice
+    wire = {}
+    if npdt == np.float64:
+        X32 = np.ascontiguousarray(wl["X"], dtype=np.float32)
+        step64 = Lane.step
+
+        def step_wire(self):
+            b = _hip.Batch(self.ctx, feats=X32, offsets=wl["off"], dtype=np.float64, wire=np.float32, pin="keep")
+            b.loglik(self.gmm, fetch=False)
+            self.lat.viterbi(b, want_path=False)
+            b.close()
+        Lane.step = step_wire
+        try:
+            w1, w2 = timed(1), timed(2)
+            wire = {"ms_per_step_f32_wire": w1 * 1e3, "ms_per_step_f32_wire_two_lanes": w2 * 1e3, "h2d_bytes_per_step_f32_wire": int(X32.nbytes),
+                    "h2d_GBps_f32_wire_two_lanes": X32.nbytes / w2 / 1e9}
+        finally:
+            Lane.step = step64
+            _hip.host_unpin(X32)
+    return {**wire, "ms_per_step": dt1 * 1e3, "value": X.shape[0] * S / dt1, "unit": "frame-state loglik/s",
             "ms_per_step_two_lanes": dt2 * 1e3, "value_two_lanes": X.shape[0] * S / dt2,
             "h2d_bytes_per_step": int(X.nbytes), "h2d_GBps_two_lanes": X.nbytes / dt2 / 1e9,
             "note": "upload + likelihoods + Viterbi per step from pageable host memory; one context / two contexts on two host threads"}

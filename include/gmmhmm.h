@@ -111,6 +111,15 @@ void gh_gmm_destroy(gh_gmm* g);
 int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
                     const void* feats_host, const int64_t* utt_offsets, gh_batch** out);
 /* same, features already in HBM (e.g. a torch tensor's data_ptr); not copied, not freed */
+/* gh_batch_create with a choice of wire format: wire_dtype == dtype, or GH_F32 for a GH_F64 batch -- half the bytes over
+ * the host link, widened on the device (the caller's features are then fp32-rounded BEFORE the call; the arithmetic stays
+ * fp64).  pin != 0: the host buffer is page-locked for the duration of the copy (hipHostRegister) so that the copy runs at
+ * the link's rate; pin == 2: it STAYS page-locked after the call (registering costs about what one faster copy saves: a
+ * caller that uploads from the same buffer repeatedly pays it once) until gh_host_unpin(feats_host), which must come
+ * before the buffer is freed.  For callers that hand over host buffers every time (bench.py's `pcie_inclusive` leg). */
+int gh_host_unpin(const void* host_ptr);
+int gh_batch_create_wire(gh_ctx* ctx, gh_dtype dtype, gh_dtype wire_dtype, int pin, int D, int64_t N, int64_t U,
+                         const void* feats_host, const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
 int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
                   void* feats_dev, const int64_t* utt_offsets, gh_batch** out);
 /* Rows idx[0..n) of a resident batch as a new resident batch of U utterances (utt_offsets as in gh_batch_create), copied

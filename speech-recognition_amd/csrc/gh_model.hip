@@ -328,6 +328,91 @@ extern "C" int gh_batch_create(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, in
     return GH_OK;
 }
 
+// fp32 on the wire, the batch's dtype in HBM: the upload is half the bytes of an fp64 one and a kernel widens it on the
+// device (every value exactly: fp32 -> fp64 is lossless; what the caller gives up is the fp64 features' low 29 bits BEFORE
+// the call).  pin != 0: the host buffer is page-locked for the copy (hipHostRegister): the copy then runs at the link's
+// rate instead of through the runtime's pageable staging.
+// page-locking of caller buffers, counted per base address: two host threads may upload from the same array at once
+// (bench.py's two lanes), and registering a range twice -- or unregistering it under the other thread's copy -- is an error
+#include <map>
+#include <mutex>
+static std::mutex g_pin_mutex;
+static std::map<const void*, std::pair<size_t, int>> g_pinned;
+static bool pin_acquire(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    auto it = g_pinned.find(p);
+    if (it != g_pinned.end()) {
+        if (it->second.first < bytes) return false;      // (a longer range at the same base: leave it pageable)
+        ++it->second.second;
+        return true;
+    }
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    g_pinned[p] = {bytes, 1};
+    return true;
+}
+static void pin_release(const void* p, bool keep) {
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    auto it = g_pinned.find(p);
+    if (it == g_pinned.end()) return;
+    if (--it->second.second == 0 && !keep) {
+        hipHostUnregister(const_cast<void*>(p));
+        g_pinned.erase(it);
+    }
+}
+
+// pin == 2 leaves the caller's buffer page-locked after the call (registering 150 MB costs about what the faster copy
+// saves: a caller that uploads from the same buffer again and again pays it once); gh_host_unpin ends that -- before the
+// buffer is freed
+extern "C" int gh_host_unpin(const void* host_ptr) {
+    std::lock_guard<std::mutex> lk(g_pin_mutex);
+    auto it = g_pinned.find(host_ptr);
+    if (it == g_pinned.end() || it->second.second > 0) return GH_OK;
+    hipHostUnregister(const_cast<void*>(host_ptr));
+    g_pinned.erase(it);
+    return GH_OK;
+}
+
+__global__ void widen_f32_kernel(const float* __restrict__ src, int64_t n, double* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+
+extern "C" int gh_batch_create_wire(gh_ctx* ctx, gh_dtype dtype, gh_dtype wire_dtype, int pin, int D, int64_t N, int64_t U,
+                                    const void* feats, const int64_t* off, gh_batch** out) {
+    GH_REQUIRE(feats || N == 0, "gh_batch_create_wire: feats is NULL");
+    GH_REQUIRE(wire_dtype == dtype || (wire_dtype == GH_F32 && dtype == GH_F64),
+               "gh_batch_create_wire: the wire format is the batch's dtype, or fp32 for an fp64 batch");
+    int rc = batch_common(ctx, dtype, D, N, U, off, out);
+    if (rc) return rc;
+    gh_batch* b = *out;
+    const size_t n = (size_t)N * D, wire_bytes = n * (wire_dtype == GH_F64 ? 8 : 4), bytes = n * (dtype == GH_F64 ? 8 : 4);
+    b->owns_feats = true;
+    if (!n) return GH_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        gh_set_error("gh_batch_create_wire: %s -> %s", what, hipGetErrorString(e));
+        gh_batch_destroy(b);
+        *out = nullptr;
+        return e == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+    };
+    hipError_t e = hipMalloc(&b->feats, bytes);
+    if (e != hipSuccess) return fail(e, "hipMalloc");
+    void* dst = b->feats;
+    if (wire_dtype != dtype) {
+        rc = gh_scratch(ctx, wire_bytes, &dst);
+        if (rc) { gh_batch_destroy(b); *out = nullptr; return rc; }
+    }
+    const bool pinned = pin && pin_acquire(feats, wire_bytes);
+    e = hipMemcpyAsync(dst, feats, wire_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && wire_dtype != dtype) {
+        hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->n_cu * 32)), dim3(256), 0, ctx->stream,
+                           (const float*)dst, (int64_t)n, (double*)b->feats);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (pinned) pin_release(feats, pin == 2);
+    if (e != hipSuccess) return fail(e, "upload");
+    return GH_OK;
+}
+
 extern "C" int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U, void* feats_dev,
                              const int64_t* off, gh_batch** out) {
     GH_REQUIRE(feats_dev || N == 0, "gh_batch_wrap: feats_dev is NULL");

@@ -43,6 +43,9 @@ SIGNATURES = {
     "gh_gmm_destroy": (None, [C.c_void_p]),
     "gh_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
                                   C.POINTER(C.c_void_p)]),
+    "gh_batch_create_wire": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, _c_i64p,
+                                       C.POINTER(C.c_void_p)]),
+    "gh_host_unpin": (C.c_int, [C.c_void_p]),
     "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
     "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gh_device_sync": (C.c_int, [C.c_void_p]),
@@ -173,6 +176,11 @@ def load_library(path=None):
         if path is None:
             _lib = lib
         return lib
+
+
+def host_unpin(array):
+    """End the page-locking a `Batch(..., pin="keep")` upload left on `array` (gh_host_unpin) -- before the array is freed."""
+    load_library().gh_host_unpin(array.ctypes.data_as(C.c_void_p))
 
 
 def device_count():
@@ -609,7 +617,10 @@ class Batch:
     """Ragged batch of utterances resident in HBM (gh_batch)."""
 
     def __init__(self, ctx, utterances=None, dtype=np.float64, feats=None, offsets=None, cepstra=None, frontend_mode=0,
-                 pcm=None, sample_rate=16000, mfcc_params=None, feats_dev=None, dim=None):
+                 pcm=None, sample_rate=16000, mfcc_params=None, feats_dev=None, dim=None, wire=None, pin=False):
+        """wire=np.float32 with dtype float64: `feats` cross the host link as fp32 and are widened on the device
+        (gh_batch_create_wire); pin=True page-locks the host buffer for the copy, pin="keep" leaves it page-locked for
+        the next upload from the same array (`host_unpin(array)` ends that, before the array is freed)."""
         self.ctx = ctx
         self.np_dtype = np.dtype(dtype)
         assert self.np_dtype in (np.dtype(np.float32), np.dtype(np.float64))
@@ -664,14 +675,21 @@ class Batch:
             D = np.asarray(utterances[0]).shape[1] if lens else 1
             feats = (np.concatenate([np.asarray(u, dtype=self.np_dtype).reshape(-1, D) for u in utterances])
                      if lens else np.zeros((0, D), dtype=self.np_dtype))
-        feats = np.ascontiguousarray(feats, dtype=self.np_dtype)
+        wire_dt = self.np_dtype if wire is None else np.dtype(wire)
+        feats = np.ascontiguousarray(feats, dtype=wire_dt)
         self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self.N, self.D = feats.shape
         self.U = len(self.offsets) - 1
         h = C.c_void_p()
-        _check(ctx.lib, ctx.lib.gh_batch_create(ctx.h, GH_F64 if self.np_dtype == np.float64 else GH_F32, self.D,
-                                                self.N, self.U, feats.ctypes.data_as(C.c_void_p),
-                                                _ptr(self.offsets, _c_i64p), C.byref(h)))
+        code = lambda dt: GH_F64 if dt == np.float64 else GH_F32
+        if wire is None and not pin:
+            _check(ctx.lib, ctx.lib.gh_batch_create(ctx.h, code(self.np_dtype), self.D,
+                                                    self.N, self.U, feats.ctypes.data_as(C.c_void_p),
+                                                    _ptr(self.offsets, _c_i64p), C.byref(h)))
+        else:
+            _check(ctx.lib, ctx.lib.gh_batch_create_wire(ctx.h, code(self.np_dtype), code(wire_dt), 2 if pin == "keep" else (1 if pin else 0), self.D, self.N,
+                                                         self.U, feats.ctypes.data_as(C.c_void_p), _ptr(self.offsets, _c_i64p),
+                                                         C.byref(h)))
         self.h = h
         self.S = None
 
