@@ -482,6 +482,18 @@ int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* me
                  const double* var /*[W*n,M,D]*/, const double* weight /*[W*n,M]*/, const double* word_trans /*[W,n,n]*/,
                  const int32_t* utt_word /*[U]*/, double var_floor, double occ_floor, double min_occupancy,
                  int update_transitions, gh_em** out);
+/* The same session over WORD STRINGS (continuous_train's transcripts, continuous_speech.py:80-82: one word per layer of
+ * the forced-alignment graph): L distinct transcripts as in gh_lattices_create_transcripts (label_off [L+1], labels),
+ * utt_graph [U] = the transcript of every utterance.  Words of 2 <= n <= 8 states, transcripts of <= 16 words, at least
+ * one of them longer than one word (else GH_ERR_UNSUPPORTED: gh_em_create is the form for isolated words).  The
+ * forward-backward in the middle is the sequence-form kernel, the occupancies stay a [frames, states] matrix in HBM, the
+ * M-step writes the new transition costs into the word templates of the graphs; everything else -- the packed buffer
+ * that crosses the ranks included -- is as above, and ranks of either kind of session may share a communicator. */
+int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* mean /*[W*n,M,D]*/,
+                             const double* var /*[W*n,M,D]*/, const double* weight /*[W*n,M]*/,
+                             const double* word_trans /*[W,n,n]*/, int64_t L, const int64_t* label_off /*[L+1]*/,
+                             const int32_t* labels, const int32_t* utt_graph /*[U]*/, double var_floor, double occ_floor,
+                             double min_occupancy, int update_transitions, gh_em** out);
 void gh_em_destroy(gh_em* em);
 int gh_em_iteration(gh_ctx* ctx, gh_em* em, gh_comm* comm /*or NULL*/, double* out_tail /*[4] or NULL*/);
 int gh_em_iterations_done(const gh_em* em);

@@ -433,7 +433,65 @@ __global__ void expand_gam_kernel(const double* __restrict__ gam, int lanes, con
     }
 }
 
+// Sequence-form forward-backward -> occupancy ranges of the fused statistics kernel, on the device (the EM session over
+// word strings, gh_em_create_transcripts).  The occupancy matrix is per STATE: a word that stands in several layers of a
+// transcript has their occupancies added up in its columns, so the frames of the word's layers must be walked ONCE -- the
+// layers of a word are merged wherever their ranges share a 16-frame block (the kernel computes whole blocks); the j-th
+// merged range goes to the word's j-th layer slot, the other slots of the word stay empty.  One thread per utterance,
+// slot = slot_off[u] + layer; every chain row of the slot gets the layer's range.
+__global__ __launch_bounds__(64) void bw_seq_ranges_kernel(const gh_seqgraph* __restrict__ graphs, const int32_t* __restrict__ utt_graph,
+                                                           const int64_t* __restrict__ slot_off, const int32_t* __restrict__ seg_lo,
+                                                           const int32_t* __restrict__ seg_hi, int64_t U, int n, int32_t* __restrict__ rng) {
+    constexpr int TF = 16;                // frames per block of bw_fused_kernel
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const gh_seqgraph* g = graphs + (utt_graph ? utt_graph[u] : 0);
+    const int K = g->K < GH_SEQ_MAXK ? g->K : GH_SEQ_MAXK;
+    int lo[GH_SEQ_MAXK], hi[GH_SEQ_MAXK], olo[GH_SEQ_MAXK], ohi[GH_SEQ_MAXK];
+    for (int k = 0; k < K; ++k) {
+        lo[k] = seg_lo[u * GH_SEQ_MAXK + k]; hi[k] = seg_hi[u * GH_SEQ_MAXK + k];
+        olo[k] = 0x7fffffff; ohi[k] = -1;
+    }
+    unsigned done = 0;
+    for (int k = 0; k < K; ++k) {
+        if (done >> k & 1) continue;
+        const int w = g->word[k];
+        int idx[GH_SEQ_MAXK], ord[GH_SEQ_MAXK], ni = 0, no = 0;
+        for (int k2 = k; k2 < K; ++k2)
+            if (g->word[k2] == w) {
+                done |= 1u << k2;
+                idx[ni++] = k2;
+                if (hi[k2] >= lo[k2]) {          // insertion by first frame
+                    int p = no++;
+                    while (p > 0 && lo[ord[p - 1]] > lo[k2]) { ord[p] = ord[p - 1]; --p; }
+                    ord[p] = k2;
+                }
+            }
+        int out = 0, clo = 0, chi = -1;
+        for (int i = 0; i < no; ++i) {
+            const int a = lo[ord[i]], b = hi[ord[i]];
+            if (chi >= clo && a / TF <= chi / TF) { chi = b > chi ? b : chi; continue; }
+            if (chi >= clo) { olo[idx[out]] = clo; ohi[idx[out]] = chi; ++out; }
+            clo = a; chi = b;
+        }
+        if (chi >= clo) { olo[idx[out]] = clo; ohi[idx[out]] = chi; }
+    }
+    for (int k = 0; k < K; ++k) {
+        int32_t* r = rng + (slot_off[u] + k) * GH_FBCHAIN_MAX * 2;
+        for (int j = 0; j < n; ++j) { r[2 * j] = olo[k]; r[2 * j + 1] = ohi[k]; }
+    }
+}
+
 }  // namespace
+
+int gh_bwf_seq_ranges_launch(gh_ctx* ctx, const gh_seqgraph* graphs, const int32_t* utt_graph, const int64_t* slot_off,
+                             const int32_t* seg_lo, const int32_t* seg_hi, int64_t U, int n, int32_t* rng) {
+    if (U <= 0) return GH_OK;
+    hipLaunchKernelGGL(bw_seq_ranges_kernel, dim3((unsigned)((U + 63) / 64)), dim3(64), 0, ctx->stream, graphs, utt_graph, slot_off,
+                       seg_lo, seg_hi, U, n, rng);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
 
 // shapes the fused kernel does not cover: the compact gamma becomes the full occupancy matrix for the generic kernel
 int gh_bw_expand_gamma(gh_ctx* ctx, gh_batch* b, int S) {
@@ -644,7 +702,7 @@ void gh_bwf_plan_free(gh_bwf_plan* p) {
 int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const double* feats, const double* gam, int gam_stride,
                   int gam_by_state, double occ_floor, const gh_fbchain* d_chains, double* d_out, const double* nll, int nll_S,
                   const int32_t* rng) {
-    if (rng && gam_by_state) { gh_set_error("gh_bwf_launch: internal: occupancy ranges belong to the compact gamma"); return GH_ERR_INVALID; }
+    // (rng with gam_by_state: ranges per SEGMENT of the plan -- gh_bwf_seq_ranges_launch, the EM session over word strings)
     hipStream_t st = ctx->stream;
     const int S = pl.S, M = pl.M, D = pl.D, KS = pl.KS, lt = pl.lt;
     const int W = 1 + 2 * D;

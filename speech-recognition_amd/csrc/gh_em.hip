@@ -22,6 +22,17 @@
 // too) on an fp64 batch, word models of n <= 16 states with arcs from s, s-1, s-2 only, M <= 64 mixtures, D <= 47 --
 // what fb_chain_kernel / bw_fused_kernel cover; anything else returns GH_ERR_UNSUPPORTED and the caller keeps the
 // call-by-call path.
+//
+// WORD STRINGS (gh_em_create_transcripts; continuous_train's transcripts, continuous_speech.py:80-82, in soft form): the
+// same iteration with the sequence-form forward-backward in the middle --
+//
+//     loglik (states of the utterance's words) -> fb_seq (occupancy matrix [N, S], self transitions, log P, frame range of
+//       every layer) -> ranges per (utterance, word) (bw_seq_ranges_kernel) -> bw_fused (columns by state)
+//       -> tail (self transitions summed, total log P) -> all-reduce -> M-step (transition costs -> word templates) -> ...
+//
+// with words of n <= 8 states and transcripts of <= 16 words (what fb_seq_kernel covers).  The call-by-call form of the
+// same iteration paid a graph rebuild, three synchronous calls, a host pass over 10^5 segments and a numpy M-step per
+// iteration: 5.6 ms of wall time around 2.8 ms of kernels on the configs[2] shard with 7-word strings.
 #include "gh_internal.h"
 #include "gh_host.h"
 #include "gh_fb.h"
@@ -65,6 +76,14 @@ struct gh_em {
     double* h_tail;        // pinned [4]
     // gh_em_profile: HIP events between the phases of an iteration (likelihoods | forward-backward | statistics | tail +
     // collective + M-step + re-pack), on the stream the kernels run on; one half only
+    // word strings (gh_em_create_transcripts): the session's own transcripts handle and the buffers of the sequence form
+    bool seq = false;
+    gh_lattices* lat = nullptr;
+    int32_t* d_utt_graph = nullptr;
+    int64_t *d_soff = nullptr, *d_slot_off = nullptr;
+    double *d_scratch = nullptr, *d_occ = nullptr, *d_xiparts = nullptr;
+    int32_t *d_seglo = nullptr, *d_seghi = nullptr;
+    bool occ_lds = false;
     gh_comm* last_comm = nullptr;   // the communicator of the last iteration: every later wait on the stream is behind its collective
     bool prof = false;
     hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -114,6 +133,35 @@ __global__ __launch_bounds__(256) void em_tail_kernel(const double* __restrict__
     }
 }
 
+// word strings: the self transitions arrive as GH_FBSEQ_XI_PARTS partial rows (summed here in a fixed order); block 1 is
+// the total log-likelihood as above
+__global__ __launch_bounds__(256) void em_tail_seq_kernel(const double* __restrict__ xi_parts, const double* __restrict__ logp,
+                                                          int S, int64_t U, double* __restrict__ tail, int* __restrict__ flags) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int s = tid; s < S; s += 256) {
+            double a = 0.0;
+            for (int p = 0; p < GH_FBSEQ_XI_PARTS; ++p) a += xi_parts[(size_t)p * S + s];
+            tail[s] = a;
+        }
+        return;
+    }
+    double acc = 0.0;
+    for (int64_t u = tid; u < U; u += 256) {
+        const double l = logp[u];
+        if (l - l == 0.0) acc += l;
+    }
+    if (tid == 0) flags[0] = 0;
+    red[tid] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) { tail[S] = red[0]; tail[S + 1] = (double)U; }
+}
+
 __device__ __forceinline__ bool em_close(double a, double b) {   // np.isclose(a, b) with numpy's default tolerances
     if (a == b) return true;
     if (!(a - a == 0.0) || !(b - b == 0.0)) return false;
@@ -125,7 +173,8 @@ __device__ __forceinline__ bool em_close(double a, double b) {   // np.isclose(a
 __global__ __launch_bounds__(256) void em_mstep_kernel(const double* __restrict__ packed, int64_t n_stats, int n, int M, int D,
                                                        double var_floor, double min_occ, int update_trans,
                                                        double* __restrict__ mean, double* __restrict__ var, double* __restrict__ weight,
-                                                       double* __restrict__ trans, gh_fbchain* __restrict__ chains, int* __restrict__ flags) {
+                                                       double* __restrict__ trans, gh_fbchain* __restrict__ chains,
+                                                       gh_seqword* __restrict__ seqwords, int* __restrict__ flags) {
     const int s = blockIdx.x, tid = threadIdx.x;
     const int W1 = 1 + 2 * D;
     const double* st = packed + (int64_t)s * M * W1;
@@ -167,10 +216,12 @@ __global__ __launch_bounds__(256) void em_mstep_kernel(const double* __restrict_
             const double c = -log(1.0 - p);
             t[(si + 1) * n + si] = c;
             ch->next_c[si + 1] = c;
+            if (seqwords) seqwords[wi].c1[si + 1] = c;
         }
         const double c = -log(p);
         t[si * n + si] = c;
         ch->self_c[si] = c;
+        if (seqwords) seqwords[wi].c0[si] = c;
     }
     if (bad) atomicAdd(&flags[0], bad);
 }
@@ -197,6 +248,7 @@ extern "C" void gh_em_destroy(gh_em* e) {
     if (e->s2) hipStreamSynchronize(e->s2);
     for (auto& ev : e->pe) if (ev) { hipEventDestroy(ev); ev = nullptr; }
     if (e->gmm) gh_gmm_destroy(e->gmm);
+    if (e->lat) gh_lattices_destroy(e->lat);
     for (int h = 0; h < 2; ++h) { gh_loglik_plan_free(&e->ll_plan[h]); gh_bwf_plan_free(&e->bw_plan[h]); }
     if (e->ev_start) hipEventDestroy(e->ev_start);
     if (e->ev_half) hipEventDestroy(e->ev_half);
@@ -370,6 +422,158 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     return GH_OK;
 }
 
+// The session over WORD STRINGS: L distinct transcripts (label_off / labels as in gh_lattices_create_transcripts),
+// utt_graph [U] the transcript of every utterance of the batch.  Everything else as gh_em_create; the handle goes through
+// the same gh_em_iteration / gh_em_history / gh_em_get_model / gh_em_packed / gh_em_destroy.
+extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const double* mean, const double* var,
+                                        const double* weight, const double* word_trans, int64_t L, const int64_t* label_off,
+                                        const int32_t* labels, const int32_t* utt_graph, double var_floor, double occ_floor,
+                                        double min_occupancy, int update_transitions, gh_em** out) {
+    GH_REQUIRE(ctx && b && mean && var && weight && word_trans && out, "gh_em_create_transcripts: NULL argument");
+    GH_REQUIRE(W > 0 && n > 0 && M > 0 && L >= 0, "gh_em_create_transcripts: W=%d n=%d M=%d L=%lld", W, n, M, (long long)L);
+    GH_REQUIRE(b->U == 0 || (L > 0 && label_off && labels && utt_graph), "gh_em_create_transcripts: utterances without transcripts");
+    *out = nullptr;
+    const int D = b->D, S = W * n;
+    const int64_t U = b->U;
+    if (b->dtype != GH_F64 || n < 2 || n > GH_LAYERS_MAXN || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
+        gh_set_error("gh_em_create_transcripts: shape outside the device-resident path (fp64 batch, 2 <= n <= %d, M <= 64, D <= 47)",
+                     GH_LAYERS_MAXN);
+        return GH_ERR_UNSUPPORTED;
+    }
+    for (int64_t u = 0; u < U; ++u)
+        GH_REQUIRE(utt_graph[u] >= 0 && utt_graph[u] < L, "gh_em_create_transcripts: utt_graph[%lld]=%d", (long long)u, utt_graph[u]);
+    GH_HIP(hipSetDevice(ctx->device));
+    gh_em* e = new gh_em();
+    memset((void*)e, 0, sizeof *e);
+    e->ctx = ctx; e->b = b; e->W = W; e->n = n; e->M = M; e->D = D; e->S = S; e->U = U; e->N = b->N;
+    e->seq = true;
+    e->lanes = 8; e->use_rng = true; e->norm_nll = true; e->n_half = 1; e->ll_subset = false;
+    e->Uh[0] = U; e->Uh[1] = 0;
+    e->var_floor = var_floor; e->occ_floor = occ_floor; e->min_occ = min_occupancy; e->update_trans = update_transitions ? 1 : 0;
+    e->occ_lds = S <= 256;
+    int rc = gh_gmm_create(ctx, S, M, D, mean, var, weight, &e->gmm);
+    if (rc) { gh_em_destroy(e); return rc; }
+    // ---- the graphs: the sequence form written down from the label strings (a rank without utterances has none) ----
+    if (U > 0) {
+        rc = gh_lattices_create_transcripts(ctx, W, n, word_trans, nullptr, L, label_off, labels, &e->lat);
+        if (rc) { gh_em_destroy(e); return rc; }
+        if (!e->lat->seq_ok || !e->lat->deferred_src) {
+            gh_em_destroy(e);
+            gh_set_error("gh_em_create_transcripts: transcripts outside the sequence form (one-word transcripts: gh_em_create; "
+                         "<= %d words, arcs from s, s-1, s-2 only)", GH_SEQ_MAXK);
+            return GH_ERR_UNSUPPORTED;
+        }
+    }
+    // word -> states of the statistics kernel (the M-step keeps its transition costs in step, unused here)
+    std::vector<gh_fbchain> chains(W);
+    for (int w = 0; w < W; ++w) {
+        gh_fbchain& fc = chains[w];
+        memset(&fc, 0, sizeof fc);
+        fc.n = n;
+        for (int i = 0; i < GH_FBCHAIN_MAX; ++i) fc.self_c[i] = fc.next_c[i] = fc.skip_c[i] = INFINITY;
+        for (int i = 0; i < n; ++i) fc.state[i] = w * n + i;
+    }
+    // ---- likelihoods: the states of every utterance's words (persistent block table), else the whole matrix ----
+    if (U > 0) {
+        std::vector<int64_t> rng_off(U + 1, 0);
+        std::vector<int32_t> lo, hi;
+        for (int64_t u = 0; u < U; ++u) {
+            const gh_seqgraph& sg = e->lat->h_seqgraphs[utt_graph[u]];
+            uint64_t seen[4] = {0, 0, 0, 0};
+            for (int k = 0; k < sg.K; ++k) {
+                const int w = sg.word[k];
+                if (w < 256 && (seen[w >> 6] >> (w & 63) & 1)) continue;
+                if (w < 256) seen[w >> 6] |= 1ull << (w & 63);
+                lo.push_back(w * n); hi.push_back(w * n + n);
+            }
+            rng_off[u + 1] = (int64_t)lo.size();
+        }
+        rc = gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), rng_off.data(), &e->ll_plan[0]);
+        if (rc < 0) { gh_em_destroy(e); return rc; }
+        e->ll_subset = rc == 0;
+        if (!e->ll_subset) {
+            const int KS = e->gmm->KP / 2;
+            if (KS != 2 && KS != 4 && KS != 8 && KS != 12 && KS != 20) {
+                gh_em_destroy(e);
+                gh_set_error("gh_em_create_transcripts: D=%d is not a matrix-core likelihood shape", D);
+                return GH_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    // ---- statistics kernel: one segment slot per (utterance, layer), grouped by the layer's word, longest first ----
+    std::vector<int64_t> slot_off(U + 1, 0), soff(U, 0);
+    size_t sacc = 0;
+    {
+        for (int64_t u = 0; u < U; ++u) slot_off[u + 1] = slot_off[u] + e->lat->h_seqgraphs[utt_graph[u]].K;
+        const int64_t n_slots = slot_off[U];
+        std::vector<int64_t> seg_first(n_slots);
+        std::vector<int32_t> seg_len(n_slots);
+        std::vector<std::vector<int32_t>> by_graph(W);
+        if (n_slots > 0x7fffffff) { gh_em_destroy(e); gh_set_error("gh_em_create_transcripts: too many layers"); return GH_ERR_UNSUPPORTED; }
+        for (int64_t kk = 0; kk < U; ++kk) {
+            const int64_t u = b->perm[kk];
+            const gh_seqgraph& sg = e->lat->h_seqgraphs[utt_graph[u]];
+            const int64_t T = b->offsets[u + 1] - b->offsets[u];
+            for (int k = 0; k < sg.K; ++k) {
+                const int64_t sl = slot_off[u] + k;
+                seg_first[sl] = b->offsets[u]; seg_len[sl] = (int32_t)T;
+                if (T > 0) by_graph[sg.word[k]].push_back((int32_t)sl);
+            }
+            // forward-backward scratch in launch order: [T, K, n] mantissas followed by as many int32 exponents
+            soff[kk] = (int64_t)sacc;
+            const size_t cells = (size_t)T * sg.K * n;
+            sacc += cells + (cells + 1) / 2;
+        }
+        rc = gh_bwf_plan_build(ctx, S, M, D, e->gmm->KP, chains, seg_first, seg_len, by_graph, /*persistent=*/true, &e->bw_plan[0]);
+        if (rc) {
+            gh_em_destroy(e);
+            if (rc == 1) { gh_set_error("gh_em_create_transcripts: shape outside the fused statistics kernel"); return GH_ERR_UNSUPPORTED; }
+            return rc;
+        }
+    }
+    std::vector<double> trans(word_trans, word_trans + (size_t)W * n * n);
+    e->n_stats = (int64_t)S * M * (1 + 2 * D);
+    e->n_packed = e->n_stats + S + 2;
+    e->hist_cap = 4096;
+    const size_t nd = (size_t)S * M * D;
+    const size_t n_slots = (size_t)slot_off[U];
+    UploadLayout lay;
+    lay.add((void**)&e->d_mean, nd * 8, mean, nd * 8);
+    lay.add((void**)&e->d_var, nd * 8, var, nd * 8);
+    lay.add((void**)&e->d_weight, (size_t)S * M * 8, weight, (size_t)S * M * 8);
+    lay.add((void**)&e->d_trans, trans.size() * 8, trans.data(), trans.size() * 8);
+    lay.add((void**)&e->d_chains, (size_t)W * sizeof(gh_fbchain), chains.data(), (size_t)W * sizeof(gh_fbchain));
+    lay.add((void**)&e->d_utt_graph, std::max<size_t>(1, U) * 4, utt_graph, (size_t)U * 4);
+    lay.add((void**)&e->d_soff, std::max<size_t>(1, U) * 8, soff.data(), (size_t)U * 8);
+    lay.add((void**)&e->d_slot_off, slot_off.size() * 8, slot_off.data(), slot_off.size() * 8);
+    lay.add((void**)&e->d_scratch, std::max<size_t>(1, sacc) * 8, nullptr);
+    lay.add((void**)&e->d_logp, std::max<size_t>(1, U) * 8, nullptr);
+    lay.add((void**)&e->d_xiparts, (size_t)GH_FBSEQ_XI_PARTS * S * 8, nullptr);
+    lay.add((void**)&e->d_occ, std::max<size_t>(1, (size_t)b->N) * S * 8, nullptr);
+    lay.add((void**)&e->d_seglo, std::max<size_t>(1, U) * GH_SEQ_MAXK * 4, nullptr);
+    lay.add((void**)&e->d_seghi, std::max<size_t>(1, U) * GH_SEQ_MAXK * 4, nullptr);
+    lay.add((void**)&e->d_rng, std::max<size_t>(1, n_slots) * GH_FBCHAIN_MAX * 2 * 4, nullptr);
+    lay.add((void**)&e->d_packed, (size_t)e->n_packed * 8, nullptr);
+    lay.add((void**)&e->d_flags, 64, nullptr);
+    lay.add((void**)&e->d_hist, (size_t)e->hist_cap * 4 * 8, nullptr);
+    hipError_t he = hipMalloc(&e->d_arena, lay.total);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&e->h_tail, 64, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        gh_set_error("gh_em_create_transcripts: %s (%zu bytes)", hipGetErrorString(he), lay.total);
+        gh_em_destroy(e);
+        return he == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+    }
+    rc = lay.commit(e->d_arena, ctx->stream, true);
+    if (!rc && hipMemsetAsync(e->d_flags, 0, 64, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc && hipMemsetAsync(e->d_packed, 0, (size_t)e->n_packed * 8, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc && hipMemsetAsync(e->d_xiparts, 0, (size_t)GH_FBSEQ_XI_PARTS * S * 8, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;   // (a rank without utterances never runs the forward-backward)
+    if (!rc) rc = gh_batch_ensure_nll(ctx, b, S, /*zero=*/true);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (rc) { gh_em_destroy(e); return rc; }
+    *out = e;
+    return GH_OK;
+}
+
 extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out_tail) {
     GH_REQUIRE(ctx && e && e->ctx == ctx, "gh_em_iteration: NULL argument / foreign context");
     GH_REQUIRE(!comm || gh_comm_context(comm) == ctx, "gh_em_iteration: the communicator belongs to another context (its "
@@ -391,7 +595,22 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
             r = gh_launch_loglik_mfma(ctx, e->gmm, b, nullptr, nullptr, nullptr, e->ll_subset ? &e->ll_plan[h] : nullptr);
             if (pf) hipEventRecord(e->pe[1], on);
             if (r == 1) { gh_set_error("gh_em_iteration: likelihood shape not covered"); r = GH_ERR_UNSUPPORTED; }
-            if (!r) {
+            if (!r && e->seq) {
+                // word strings: four utterances per wave, lane = layer (gh_seq.hip); every frame's row of the occupancy
+                // matrix is written whole when the S columns fit in LDS, else it is cleared and added to
+                if (hipMemsetAsync(e->d_xiparts, 0, (size_t)GH_FBSEQ_XI_PARTS * e->S * 8, on) != hipSuccess) r = GH_ERR_HIP;
+                if (!r && !e->occ_lds && hipMemsetAsync(e->d_occ, 0, (size_t)e->N * e->S * 8, on) != hipSuccess) r = GH_ERR_HIP;
+                gh_fbseq_args q;
+                memset(&q, 0, sizeof q);
+                q.occ_in_lds = e->occ_lds;
+                q.graphs = e->lat->d_seqgraphs; q.words = e->lat->d_seqwords; q.end_slot = e->lat->d_seq_end_slot;
+                q.nll = b->nll; q.S = e->S; q.utt_off = b->d_offsets; q.utt_lat = e->d_utt_graph; q.perm = b->d_perm;
+                q.alpha_scratch = e->d_scratch; q.scratch_off = e->d_soff; q.logp = e->d_logp; q.occ = e->d_occ;
+                q.self_xi_parts = e->d_xiparts; q.seg_lo = e->d_seglo; q.seg_hi = e->d_seghi; q.occ_floor = e->occ_floor;
+                if (!r) r = gh_launch_fb_seq(ctx, q, e->lat->seq_N, e->lat->seq_skip, 0, e->U, true);
+                if (!r) r = gh_bwf_seq_ranges_launch(ctx, e->lat->d_seqgraphs, e->d_utt_graph, e->d_slot_off, e->d_seglo, e->d_seghi,
+                                                     e->U, e->n, e->d_rng);
+            } else if (!r) {
                 gh_fbchain_args ca;
                 memset(&ca, 0, sizeof ca);
                 ca.chains = e->d_chains; ca.nll = b->nll; ca.S = e->S; ca.utt_off = b->d_offsets; ca.utt_lat = e->d_utt_word;
@@ -403,9 +622,13 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
         } else if (pf) hipEventRecord(e->pe[1], on);
         if (pf) hipEventRecord(e->pe[2], on);
         // (the statistics kernel normalises with the likelihoods written a few lines up -- same model, same stream)
-        if (!r) r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
-                                  e->d_chains, stats_out, e->norm_nll ? (const double*)b->nll : nullptr, e->S,
-                                  e->use_rng ? e->d_rng : nullptr);
+        if (!r && e->seq)
+            r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_occ, e->S, 1, e->occ_floor, e->d_chains,
+                              stats_out, e->norm_nll ? (const double*)b->nll : nullptr, e->S, e->d_rng);
+        else if (!r)
+            r = gh_bwf_launch(ctx, e->bw_plan[h], e->gmm, (const double*)b->feats, e->d_gam, e->lanes, 0, e->occ_floor,
+                              e->d_chains, stats_out, e->norm_nll ? (const double*)b->nll : nullptr, e->S,
+                              e->use_rng ? e->d_rng : nullptr);
         if (pf) hipEventRecord(e->pe[3], on);
         ctx->stream = keep;
         return r;
@@ -425,8 +648,11 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
         GH_HIP(hipGetLastError());
     }
     double* tail = e->d_packed + e->n_stats;
-    hipLaunchKernelGGL(em_tail_kernel, dim3(e->W + 1), dim3(256), 0, st, e->d_xi_utt, e->d_logp, e->d_word_utts, e->d_word_off,
-                       e->W, e->n, e->U, tail, e->d_flags);
+    if (e->seq)
+        hipLaunchKernelGGL(em_tail_seq_kernel, dim3(2), dim3(256), 0, st, e->d_xiparts, e->d_logp, e->S, e->U, tail, e->d_flags);
+    else
+        hipLaunchKernelGGL(em_tail_kernel, dim3(e->W + 1), dim3(256), 0, st, e->d_xi_utt, e->d_logp, e->d_word_utts, e->d_word_off,
+                           e->W, e->n, e->U, tail, e->d_flags);
     GH_HIP(hipGetLastError());
     e->last_comm = comm;
     if (comm) {
@@ -434,7 +660,8 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
         if (rc) return rc;
     }
     hipLaunchKernelGGL(em_mstep_kernel, dim3(e->S), dim3(256), 0, st, e->d_packed, e->n_stats, e->n, e->M, e->D, e->var_floor,
-                       e->min_occ, e->update_trans, e->d_mean, e->d_var, e->d_weight, e->d_trans, e->d_chains, e->d_flags);
+                       e->min_occ, e->update_trans, e->d_mean, e->d_var, e->d_weight, e->d_trans, e->d_chains,
+                       (e->seq && e->lat) ? e->lat->d_seqwords : nullptr, e->d_flags);
     GH_HIP(hipGetLastError());
     rc = gh_gmm_update_dev(ctx, e->gmm, e->d_mean, e->d_var, e->d_weight, e->d_flags + 1);
     if (rc) return rc;

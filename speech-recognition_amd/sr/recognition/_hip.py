@@ -106,6 +106,9 @@ SIGNATURES = {
     "gh_gmm_update": (C.c_int, [C.c_void_p, C.c_void_p, _c_f64p, _c_f64p, _c_f64p]),
     "gh_em_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p, _c_i32p,
                                C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "gh_em_create_transcripts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_f64p, _c_f64p, _c_f64p, _c_f64p,
+                                           C.c_int64, _c_i64p, _c_i32p, _c_i32p, C.c_double, C.c_double, C.c_double, C.c_int,
+                                           C.POINTER(C.c_void_p)]),
     "gh_em_destroy": (None, [C.c_void_p]),
     "gh_em_iteration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_f64p]),
     "gh_em_iterations_done": (C.c_int, [C.c_void_p]),
@@ -398,11 +401,13 @@ class Unsupported(BackendError):
 
 
 class EMSession:
-    """Device-resident soft-EM over one-word transcripts (gh_em): `iteration()` enqueues likelihoods -> forward-backward
-    -> statistics -> [all-reduce] -> M-step -> model re-pack on the context's stream."""
+    """Device-resident soft-EM (gh_em): `iteration()` enqueues likelihoods -> forward-backward -> statistics ->
+    [all-reduce] -> M-step -> model re-pack on the context's stream.  utt_word: the word of every utterance (one-word
+    transcripts, gh_em_create) -- or, with `transcripts` (a list of distinct label strings), the index of every
+    utterance's transcript in that list (word strings, gh_em_create_transcripts)."""
 
     def __init__(self, ctx, batch, means, vars_, weights, word_trans, utt_word, var_floor, occ_floor=0.0,
-                 min_occupancy=1e-8, update_transitions=True):
+                 min_occupancy=1e-8, update_transitions=True, transcripts=None):
         means, vars_, weights = _f64(means), _f64(vars_), _f64(weights)
         wt = _f64(word_trans)
         W, n = wt.shape[0], wt.shape[1]
@@ -412,9 +417,19 @@ class EMSession:
         assert len(uw) == batch.U
         self.ctx, self.batch, self.W, self.n, self.S, self.M, self.D = ctx, batch, W, n, S, M, D
         h = C.c_void_p()
-        rc = ctx.lib.gh_em_create(ctx.h, batch.h, W, n, M, _ptr(means, _c_f64p), _ptr(vars_, _c_f64p), _ptr(weights, _c_f64p),
-                                  _ptr(wt, _c_f64p), _ptr(uw, _c_i32p), float(var_floor), float(occ_floor),
-                                  float(min_occupancy), int(bool(update_transitions)), C.byref(h))
+        self.word_strings = transcripts is not None
+        if transcripts is not None:
+            label_off, labels = Lattices.flatten_transcripts(transcripts)
+            assert len(labels) == 0 or (labels.min() >= 0 and labels.max() < W), "transcripts: word index out of range"
+            rc = ctx.lib.gh_em_create_transcripts(ctx.h, batch.h, W, n, M, _ptr(means, _c_f64p), _ptr(vars_, _c_f64p),
+                                                  _ptr(weights, _c_f64p), _ptr(wt, _c_f64p), len(transcripts),
+                                                  _ptr(label_off, _c_i64p), _ptr(labels, _c_i32p), _ptr(uw, _c_i32p),
+                                                  float(var_floor), float(occ_floor), float(min_occupancy),
+                                                  int(bool(update_transitions)), C.byref(h))
+        else:
+            rc = ctx.lib.gh_em_create(ctx.h, batch.h, W, n, M, _ptr(means, _c_f64p), _ptr(vars_, _c_f64p), _ptr(weights, _c_f64p),
+                                      _ptr(wt, _c_f64p), _ptr(uw, _c_i32p), float(var_floor), float(occ_floor),
+                                      float(min_occupancy), int(bool(update_transitions)), C.byref(h))
         if rc == GH_ERR_UNSUPPORTED:
             raise Unsupported(ctx.lib.gh_last_error().decode("utf-8", "replace"))
         if rc == -1 and b"singular" in ctx.lib.gh_last_error():

@@ -86,8 +86,9 @@ class BaumWelchTrainer:
         red = self.reducer
         native = getattr(red, "native", False)
         alone = not getattr(red, "enabled", False) or red.world_size == 1
-        possible = bool(device_resident and all(len(l) == 1 for l in label_seqs) and (native or alone)
-                        and self.batch.np_dtype == np.float64)
+        single = all(len(l) == 1 for l in label_seqs)
+        possible = bool(device_resident and (native or alone) and self.batch.np_dtype == np.float64
+                        and all(len(l) >= 1 for l in label_seqs))
         if not alone and native:      # (another kind of reducer rules the session out on every rank alike)
             # the choice is COLLECTIVE: a rank with a multi-word transcript (or another dtype) takes the
             # call-by-call path, and then every rank must -- M-step and stop test on the device here and in numpy there
@@ -95,12 +96,26 @@ class BaumWelchTrainer:
             n_no = red(np.array([0.0 if possible else 1.0]))
             possible = possible and float(np.asarray(n_no).ravel()[0]) == 0.0
         if possible:
+            # one-word transcripts: the chain-form session; word strings: the sequence-form one (either may decline a
+            # shape -- the call-by-call path stays; ranks of the two kinds share the packed buffer and the M-step kernel)
             try:
-                self.session = _hip.EMSession(self.ctx, self.batch, self._means, self._vars, self._weights,
-                                              np.asarray(self._transitions), [int(l[0]) for l in label_seqs], self.var_floor,
-                                              occ_floor=self.occ_floor, min_occupancy=self.min_occupancy,
-                                              update_transitions=self.update_transitions)
+                if single:
+                    self.session = _hip.EMSession(self.ctx, self.batch, self._means, self._vars, self._weights,
+                                                  np.asarray(self._transitions), [int(l[0]) for l in label_seqs], self.var_floor,
+                                                  occ_floor=self.occ_floor, min_occupancy=self.min_occupancy,
+                                                  update_transitions=self.update_transitions)
+                else:
+                    self.session = _hip.EMSession(self.ctx, self.batch, self._means, self._vars, self._weights,
+                                                  np.asarray(self._transitions), self.utt_graph, self.var_floor,
+                                                  occ_floor=self.occ_floor, min_occupancy=self.min_occupancy,
+                                                  update_transitions=self.update_transitions, transcripts=self.graph_labels)
             except _hip.Unsupported:
+                self.session = None
+        if not alone and native:
+            # ... and so is the outcome: a rank whose shapes the session declined takes every rank to the call-by-call path
+            n_no = red(np.array([0.0 if (self.session is not None or not possible) else 1.0]))
+            if possible and float(np.asarray(n_no).ravel()[0]) != 0.0 and self.session is not None:
+                self.session.close()
                 self.session = None
         self._label_seqs = label_seqs
         self.state_sets = None

@@ -135,9 +135,9 @@ def test_session_rejects_what_it_does_not_cover():
         _hip.EMSession(ctx, b, means.reshape(-1, 8, 39), vars_.reshape(-1, 8, 39), w.reshape(-1, 8), t,
                        [l[0] for l in labels], 1e-6)
     b.close()
-    two_words = [[l[0], l[0]] for l in labels]         # multi-word transcripts: the call-by-call path
+    two_words = [[l[0], l[0]] for l in labels]         # multi-word transcripts: the sequence-form session (test_gpu_em_strings.py)
     tr = BaumWelchTrainer(means, vars_, w, trans, [np.concatenate([x, x]) for x in data], two_words)
-    assert tr.session is None
+    assert tr.session is not None and tr.session.word_strings
     tr.iteration()
     tr.close()
 
