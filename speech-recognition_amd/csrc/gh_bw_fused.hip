@@ -439,18 +439,23 @@ __global__ void expand_gam_kernel(const double* __restrict__ gam, int lanes, con
 // layers of a word are merged wherever their ranges share a 16-frame block (the kernel computes whole blocks); the j-th
 // merged range goes to the word's j-th layer slot, the other slots of the word stay empty.  One thread per utterance,
 // slot = slot_off[u] + layer; every chain row of the slot gets the layer's range.
+// row_lo / row_hi [U, GH_SEQ_MAXK, GH_LAYERS_MAXN] (optional; the lane = cell forward-backward writes them): the range of
+// every chain row of a layer instead of the layer's -- a state pair then walks its own ~40 % of the layer's blocks.
 __global__ __launch_bounds__(64) void bw_seq_ranges_kernel(const gh_seqgraph* __restrict__ graphs, const int32_t* __restrict__ utt_graph,
                                                            const int64_t* __restrict__ slot_off, const int32_t* __restrict__ seg_lo,
-                                                           const int32_t* __restrict__ seg_hi, int64_t U, int n, int32_t* __restrict__ rng) {
+                                                           const int32_t* __restrict__ seg_hi, const int32_t* __restrict__ row_lo,
+                                                           const int32_t* __restrict__ row_hi, int64_t U, int n,
+                                                           int32_t* __restrict__ rng) {
     constexpr int TF = 16;                // frames per block of bw_fused_kernel
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
     const gh_seqgraph* g = graphs + (utt_graph ? utt_graph[u] : 0);
     const int K = g->K < GH_SEQ_MAXK ? g->K : GH_SEQ_MAXK;
     int lo[GH_SEQ_MAXK], hi[GH_SEQ_MAXK], olo[GH_SEQ_MAXK], ohi[GH_SEQ_MAXK];
+    int8_t into[GH_SEQ_MAXK];             // the slot a layer's frames are walked by (-1: none)
     for (int k = 0; k < K; ++k) {
         lo[k] = seg_lo[u * GH_SEQ_MAXK + k]; hi[k] = seg_hi[u * GH_SEQ_MAXK + k];
-        olo[k] = 0x7fffffff; ohi[k] = -1;
+        olo[k] = 0x7fffffff; ohi[k] = -1; into[k] = -1;
     }
     unsigned done = 0;
     for (int k = 0; k < K; ++k) {
@@ -470,25 +475,41 @@ __global__ __launch_bounds__(64) void bw_seq_ranges_kernel(const gh_seqgraph* __
         int out = 0, clo = 0, chi = -1;
         for (int i = 0; i < no; ++i) {
             const int a = lo[ord[i]], b = hi[ord[i]];
-            if (chi >= clo && a / TF <= chi / TF) { chi = b > chi ? b : chi; continue; }
+            if (chi >= clo && a / TF <= chi / TF) { chi = b > chi ? b : chi; into[ord[i]] = (int8_t)idx[out]; continue; }
             if (chi >= clo) { olo[idx[out]] = clo; ohi[idx[out]] = chi; ++out; }
             clo = a; chi = b;
+            into[ord[i]] = (int8_t)idx[out];
         }
         if (chi >= clo) { olo[idx[out]] = clo; ohi[idx[out]] = chi; }
     }
     for (int k = 0; k < K; ++k) {
         int32_t* r = rng + (slot_off[u] + k) * GH_FBCHAIN_MAX * 2;
-        for (int j = 0; j < n; ++j) { r[2 * j] = olo[k]; r[2 * j + 1] = ohi[k]; }
+        if (!row_lo) {
+            for (int j = 0; j < n; ++j) { r[2 * j] = olo[k]; r[2 * j + 1] = ohi[k]; }
+            continue;
+        }
+        // per chain row: the hull of the row's ranges over the layers this slot walks (all inside [olo, ohi], whose blocks
+        // no other slot of the word touches)
+        for (int j = 0; j < n; ++j) {
+            int a = 0x7fffffff, b = -1;
+            for (int k2 = 0; k2 < K; ++k2)
+                if (into[k2] == k) {
+                    const int l2 = row_lo[(u * GH_SEQ_MAXK + k2) * GH_LAYERS_MAXN + j], h2 = row_hi[(u * GH_SEQ_MAXK + k2) * GH_LAYERS_MAXN + j];
+                    if (h2 >= l2) { a = l2 < a ? l2 : a; b = h2 > b ? h2 : b; }
+                }
+            r[2 * j] = a; r[2 * j + 1] = b;
+        }
     }
 }
 
 }  // namespace
 
 int gh_bwf_seq_ranges_launch(gh_ctx* ctx, const gh_seqgraph* graphs, const int32_t* utt_graph, const int64_t* slot_off,
-                             const int32_t* seg_lo, const int32_t* seg_hi, int64_t U, int n, int32_t* rng) {
+                             const int32_t* seg_lo, const int32_t* seg_hi, const int32_t* row_lo, const int32_t* row_hi,
+                             int64_t U, int n, int32_t* rng) {
     if (U <= 0) return GH_OK;
     hipLaunchKernelGGL(bw_seq_ranges_kernel, dim3((unsigned)((U + 63) / 64)), dim3(64), 0, ctx->stream, graphs, utt_graph, slot_off,
-                       seg_lo, seg_hi, U, n, rng);
+                       seg_lo, seg_hi, row_lo, row_hi, U, n, rng);
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

@@ -811,6 +811,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
             q.utt_off = b->d_offsets; q.utt_lat = d_uttlat; q.perm = b->d_perm; q.alpha_scratch = d_scratch; q.scratch_off = d_soff;
             q.logp = d_logp; q.occ = want_occ ? b->occ : nullptr; q.self_xi_parts = d_xiparts;
             q.seg_lo = d_seglo; q.seg_hi = d_seghi; q.occ_floor = 0.0;
+            for (const gh_seqgraph& sg : lat->h_seqgraphs) q.max_cells = std::max(q.max_cells, sg.K * lat->seq_N);
             for (size_t c = 0; c + 1 < chunk_begin.size(); ++c) {
                 rc = gh_launch_fb_seq(ctx, q, lat->seq_N, lat->seq_skip, chunk_begin[c], chunk_begin[c + 1] - chunk_begin[c], b->dtype == GH_F64);
                 if (rc) return rc;

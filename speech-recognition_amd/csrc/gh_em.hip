@@ -82,8 +82,9 @@ struct gh_em {
     int32_t* d_utt_graph = nullptr;
     int64_t *d_soff = nullptr, *d_slot_off = nullptr;
     double *d_scratch = nullptr, *d_occ = nullptr, *d_xiparts = nullptr;
-    int32_t *d_seglo = nullptr, *d_seghi = nullptr;
+    int32_t *d_seglo = nullptr, *d_seghi = nullptr, *d_rowlo = nullptr, *d_rowhi = nullptr;
     bool occ_lds = false;
+    int max_cells = 0;
     gh_comm* last_comm = nullptr;   // the communicator of the last iteration: every later wait on the stream is behind its collective
     bool prof = false;
     hipEvent_t pe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -488,7 +489,17 @@ extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, 
             }
             rng_off[u + 1] = (int64_t)lo.size();
         }
-        rc = gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), rng_off.data(), &e->ll_plan[0]);
+        // the table-driven kernel pays ~1.3x per tile (short runs of tiles per 32-frame block, the table itself): it wins
+        // while the transcripts' words cover less than ~0.75 of the model (10 % for isolated words; 7 of 10 digits cover
+        // 52 %: 1.24 ms against 1.75 ms for the whole matrix on the configs[2] shard).  GMMHMM_EM_LL=subset|full decides.
+        double covered = 0.0;
+        for (int64_t u = 0; u < U; ++u) covered += (double)(b->offsets[u + 1] - b->offsets[u]) * (double)(rng_off[u + 1] - rng_off[u]) * n;
+        const char* ev = getenv("GMMHMM_EM_LL");
+        const int KSf = e->gmm->KP / 2;
+        const bool full_ok = KSf == 2 || KSf == 4 || KSf == 8 || KSf == 12 || KSf == 20;
+        const bool want_full = ev ? !strcmp(ev, "full") : covered > 0.75 * (double)b->N * S;
+        rc = 1;
+        if (!(want_full && full_ok)) rc = gh_loglik_plan_build(ctx, e->gmm, b, lo.data(), hi.data(), rng_off.data(), &e->ll_plan[0]);
         if (rc < 0) { gh_em_destroy(e); return rc; }
         e->ll_subset = rc == 0;
         if (!e->ll_subset) {
@@ -504,7 +515,11 @@ extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, 
     std::vector<int64_t> slot_off(U + 1, 0), soff(U, 0);
     size_t sacc = 0;
     {
-        for (int64_t u = 0; u < U; ++u) slot_off[u + 1] = slot_off[u] + e->lat->h_seqgraphs[utt_graph[u]].K;
+        for (int64_t u = 0; u < U; ++u) {
+            const int K = e->lat->h_seqgraphs[utt_graph[u]].K;
+            slot_off[u + 1] = slot_off[u] + K;
+            e->max_cells = std::max(e->max_cells, K * n);
+        }
         const int64_t n_slots = slot_off[U];
         std::vector<int64_t> seg_first(n_slots);
         std::vector<int32_t> seg_len(n_slots);
@@ -552,6 +567,8 @@ extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, 
     lay.add((void**)&e->d_occ, std::max<size_t>(1, (size_t)b->N) * S * 8, nullptr);
     lay.add((void**)&e->d_seglo, std::max<size_t>(1, U) * GH_SEQ_MAXK * 4, nullptr);
     lay.add((void**)&e->d_seghi, std::max<size_t>(1, U) * GH_SEQ_MAXK * 4, nullptr);
+    lay.add((void**)&e->d_rowlo, std::max<size_t>(1, U) * GH_SEQ_MAXK * GH_LAYERS_MAXN * 4, nullptr);
+    lay.add((void**)&e->d_rowhi, std::max<size_t>(1, U) * GH_SEQ_MAXK * GH_LAYERS_MAXN * 4, nullptr);
     lay.add((void**)&e->d_rng, std::max<size_t>(1, n_slots) * GH_FBCHAIN_MAX * 2 * 4, nullptr);
     lay.add((void**)&e->d_packed, (size_t)e->n_packed * 8, nullptr);
     lay.add((void**)&e->d_flags, 64, nullptr);
@@ -607,9 +624,11 @@ extern "C" int gh_em_iteration(gh_ctx* ctx, gh_em* e, gh_comm* comm, double* out
                 q.nll = b->nll; q.S = e->S; q.utt_off = b->d_offsets; q.utt_lat = e->d_utt_graph; q.perm = b->d_perm;
                 q.alpha_scratch = e->d_scratch; q.scratch_off = e->d_soff; q.logp = e->d_logp; q.occ = e->d_occ;
                 q.self_xi_parts = e->d_xiparts; q.seg_lo = e->d_seglo; q.seg_hi = e->d_seghi; q.occ_floor = e->occ_floor;
+                q.max_cells = e->max_cells; q.row_lo = e->d_rowlo; q.row_hi = e->d_rowhi;
+                const bool rows = gh_fb_seq_by_cell(q, e->lat->seq_N) != 0;     // (the lane = cell kernel knows every chain row's range)
                 if (!r) r = gh_launch_fb_seq(ctx, q, e->lat->seq_N, e->lat->seq_skip, 0, e->U, true);
                 if (!r) r = gh_bwf_seq_ranges_launch(ctx, e->lat->d_seqgraphs, e->d_utt_graph, e->d_slot_off, e->d_seglo, e->d_seghi,
-                                                     e->U, e->n, e->d_rng);
+                                                     rows ? e->d_rowlo : nullptr, rows ? e->d_rowhi : nullptr, e->U, e->n, e->d_rng);
             } else if (!r) {
                 gh_fbchain_args ca;
                 memset(&ca, 0, sizeof ca);

@@ -91,5 +91,10 @@ struct gh_fbseq_args {
     int32_t* seg_lo;             // optional [U, GH_SEQ_MAXK] (with occ): first / last frame of every layer whose occupancy
     int32_t* seg_hi;             //   exceeds occ_floor (hi < lo: none) -- the segments of the fused statistics kernel
     double occ_floor;
+    int max_cells;               // most cells (layers x states) any graph of the launch has; 0 = not known.  <= 64: one
+                                 //   utterance per wave, lane = cell (fb_seq_cell_kernel) instead of four with lane = layer
+    int32_t* row_lo;             // optional [U, GH_SEQ_MAXK, GH_LAYERS_MAXN] (lane = cell kernel only): frame range of every
+    int32_t* row_hi;             //   cell with occupancy above occ_floor
 };
+int gh_fb_seq_by_cell(const gh_fbseq_args& a, int N);
 int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64);

@@ -310,7 +310,8 @@ int gh_bwf_launch(gh_ctx* ctx, const gh_bwf_plan& pl, const gh_gmm* g, const dou
                   const int32_t* rng = nullptr);               // [U, GH_FBCHAIN_MAX, 2] occupancy ranges of fb_chain_kernel (same floor)
 // occupancy ranges of a sequence-form forward-backward (seg_lo / seg_hi [U, GH_SEQ_MAXK]) -> rng [slots, GH_FBCHAIN_MAX, 2]
 int gh_bwf_seq_ranges_launch(gh_ctx* ctx, const struct gh_seqgraph* graphs, const int32_t* utt_graph, const int64_t* slot_off,
-                             const int32_t* seg_lo, const int32_t* seg_hi, int64_t U, int n, int32_t* rng);
+                             const int32_t* seg_lo, const int32_t* seg_hi, const int32_t* row_lo /*or null*/,
+                             const int32_t* row_hi, int64_t U, int n, int32_t* rng);
 // lanes per utterance of the chain forward-backward (= columns of the compact gamma matrix): 8, or 16 when a chain is longer
 inline int gh_fbchain_lanes(const std::vector<gh_fbchain>& chains) {
     for (const gh_fbchain& c : chains) if (c.n > 8) return 16;

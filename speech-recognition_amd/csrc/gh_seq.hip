@@ -14,6 +14,7 @@
 #include "gh_viterbi.h"
 #include "gh_fb.h"
 #include "gh_xnum.h"
+#include <cstring>
 
 namespace {
 
@@ -249,7 +250,10 @@ __device__ __forceinline__ xnum xn_row_shl1(xnum v, xnum fill) {
 
 template <typename ET, int N, bool SKIP, bool OCC_LDS>
 __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slot_end) {
-    constexpr int PF = 2;
+#ifndef GH_FBSEQ_PF
+#define GH_FBSEQ_PF 2
+#endif
+    constexpr int PF = GH_FBSEQ_PF;                           // columns whose loads are in flight ahead of the recursion
     extern __shared__ __attribute__((aligned(16))) double seq_lds[];   // OCC_LDS: [4 utterances][S] occupancies of a frame
     const int lane = threadIdx.x, kk = lane >> 4, k = lane & 15;
     double* occ_row = seq_lds + (OCC_LDS ? kk * a.S : 0);
@@ -436,6 +440,194 @@ __global__ __launch_bounds__(64) void fb_seq_kernel(gh_fbseq_args a, int64_t slo
     }
 }
 
+// The same forward-backward with ONE UTTERANCE PER WAVE and lane = CELL (layer k, state s; lane = k N + s, K N <= 64).
+// With the lane = layer mapping above a lane walks the N states of its word one after the other -- N split exponentials
+// and N sums per column on a dependent chain, ~250 fp64 instructions per column forward and ~350 backward -- and a batch
+// of 2 000 seven-word utterances is 500 waves: one wave on every other SIMD, nothing to hide the latency of the chain
+// behind (2.1 ms for 1.4 M frames, no faster with deeper read-ahead).  Here a column is ONE exponential, one sum and one
+// normalisation per lane; the neighbours are wave_shr:1 / wave_shl:1 away (a word's first state has no arc from the cell
+// below it -- its p1 is 0 -- so the shift may cross the word boundary), and the same-column hand-over through the
+// non-emitting row is a second, short step for the first (forward) / last (backward) state of every layer.  Same
+// arithmetic in the same order per cell: the alpha columns ([T, K N] mantissas + exponents, the layout of the kernel
+// above), log P, gamma and xi are bit-identical to the lane = layer kernel's whenever a graph has one end row.
+// Also written: the frame range of every CELL with occupancy above the floor (row_lo / row_hi), which lets the fused
+// statistics kernel walk a state pair's own frames instead of its layer's.
+__device__ __forceinline__ double wave_shr1d(double v, double fill) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1d(double v, double fill) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ xnum xn_wave_shr1(xnum v, xnum fill) {
+    return xnum{wave_shr1d(v.f, fill.f), __builtin_amdgcn_update_dpp(fill.e, v.e, 0x138, 0xF, 0xF, false)};
+}
+__device__ __forceinline__ xnum xn_wave_shl1(xnum v, xnum fill) {
+    return xnum{wave_shl1d(v.f, fill.f), __builtin_amdgcn_update_dpp(fill.e, v.e, 0x130, 0xF, 0xF, false)};
+}
+
+template <typename ET, int N, bool SKIP, bool OCC_LDS>
+__global__ __launch_bounds__(64) void fb_seq_cell_kernel(gh_fbseq_args a) {
+#ifndef GH_FBSEQ_CELL_PF
+#define GH_FBSEQ_CELL_PF 4
+#endif
+    constexpr int PF = GH_FBSEQ_CELL_PF;
+    extern __shared__ __attribute__((aligned(16))) double seq_lds[];   // OCC_LDS: [S] occupancies of a frame
+    __shared__ int lay_lo[GH_SEQ_MAXK], lay_hi[GH_SEQ_MAXK];
+    const int lane = threadIdx.x;
+    const int64_t slot = a.slot0 + blockIdx.x;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const gh_seqgraph* g = a.graphs + (a.utt_lat ? a.utt_lat[u] : 0);
+    const int K = g->K, C = K * N;
+    const int k = lane / N, s = lane - k * N;
+    const bool lact = lane < C;
+    const int64_t f0 = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - f0);
+    const double INF = INFINITY;
+    if (OCC_LDS) for (int i = lane; i < a.S; i += 64) seq_lds[i] = 0.0;
+    if (lane < GH_SEQ_MAXK) { lay_lo[lane] = 0x7fffffff; lay_hi[lane] = -1; }
+    __syncthreads();
+    const gh_seqword* wd = a.words + (lact ? g->word[k] : 0);
+    const xnum Z = xn_zero();
+    const xnum p0 = lact ? xn_exp_neg(wd->c0[s]) : Z;
+    const xnum p1 = (lact && s >= 1) ? xn_exp_neg(wd->c1[s]) : Z;
+    const xnum p2 = (SKIP && lact && s >= 2) ? xn_exp_neg(wd->c2[s]) : Z;
+    const xnum pin = (lact && s == 0) ? xn_exp_neg(wd->cin) : Z;          // hand-over INTO a layer: its first state
+    const xnum pout = (lact && s == N - 1) ? xn_exp_neg(wd->cout) : Z;    // ... OUT of a layer: its last state
+    const int st = lact ? wd->state[s] : 0;
+    const bool is_end = lact && a.end_slot[g->row_base + k * (N + 1) + 1 + s] >= 0;
+    const ET* nll = static_cast<const ET*>(a.nll) + f0 * a.S + st;
+    const int lane_c = lact ? lane : 0;                                     // (idle lanes read along with lane 0: no branch around a load)
+    double* alf = a.alpha_scratch + a.scratch_off[slot] + lane_c;           // [T, C]
+    int* ale = reinterpret_cast<int*>(a.alpha_scratch + a.scratch_off[slot] + (int64_t)T * C) + lane_c;
+    if (T <= 0) {
+        if (lane == 0 && a.logp) a.logp[u] = -INF;
+        if (a.seg_lo && lane < GH_SEQ_MAXK) { a.seg_lo[u * GH_SEQ_MAXK + lane] = 0x7fffffff; a.seg_hi[u * GH_SEQ_MAXK + lane] = -1; }
+        return;
+    }
+    // The read-ahead rings are filled by UNCONDITIONAL loads from clamped columns, and the columns behind the last one of a
+    // PF-group are computed and thrown away: a load inside a branch (or an exec-masked region) comes with an s_waitcnt
+    // vmcnt(0) where the paths join -- every column then waited a whole memory round trip, 2 500 cycles for ~100
+    // instructions of arithmetic, and no read-ahead depth changed that.
+    const int Tp = (T + PF - 1) / PF * PF;
+    // ---- forward ----
+    ET ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) ring[p] = nll[(int64_t)min(p, T - 1) * a.S];
+    xnum al = Z;
+    for (int t0 = 0; t0 < Tp; t0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int t = t0 + p;
+            const bool on = t < T;
+            const xnum b = xn_exp_neg_sc((double)ring[p]);
+            ring[p] = nll[(int64_t)min(t + PF, T - 1) * a.S];
+            const xnum pr1 = xn_wave_shr1(al, Z);
+            const xnum a0 = xn_mul(al, p0), a1 = xn_mul(pr1, p1);
+            const xnum x = SKIP ? xn_add3(a0, a1, xn_mul(xn_wave_shr1(pr1, Z), p2)) : xn_add(a0, a1);
+            const xnum y = xn_norm(xn_mul(x, b));                       // final for every state but a layer's first
+            const xnum nin = xn_wave_shr1(xn_mul(y, pout), (t == 0) ? xn_one() : Z);   // lane 0: the start row
+            const xnum z = xn_norm(xn_mul(xn_add(a0, xn_mul(nin, pin)), b));
+            const xnum an = (s == 0) ? z : y;
+            al.f = on ? an.f : al.f;
+            al.e = on ? an.e : al.e;
+            if (lact && on) { alf[(int64_t)t * C] = al.f; ale[(int64_t)t * C] = al.e; }
+        }
+    }
+    xnum P = is_end ? al : Z;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        xnum q;
+        q.f = __shfl_xor(P.f, o);
+        q.e = __shfl_xor(P.e, o);
+        P = xn_add(P, q);
+    }
+    P = xn_norm(P);
+    if (lane == 0 && a.logp) a.logp[u] = xn_log(P);
+    if (!a.occ && !a.self_xi_parts) return;
+    const bool reach = P.f > 0.0;                             // log P = -inf: every gamma is 0 (the generic kernel's NaN -> 0)
+    const double inv_pf = 1.0 / P.f;
+    // ---- backward (column t = T - 1 - i) ----
+    xnum be = Z, bn = xn_one();                               // beta and emission probability of column t + 1
+    double xi = 0.0;
+    int seg_first = 0x7fffffff, seg_last = -1;
+    ET ering[PF];
+    double arf[PF];
+    int are[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int t = max(T - 1 - p, 0);
+        ering[p] = nll[(int64_t)t * a.S];
+        arf[p] = alf[(int64_t)t * C];
+        are[p] = ale[(int64_t)t * C];
+    }
+    for (int i0 = 0; i0 < Tp; i0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int i = i0 + p;
+            const int t = T - 1 - i;
+            const bool on = t >= 0;
+            const xnum b = xn_exp_neg_sc((double)ering[p]);
+            const xnum av = xnum{arf[p], are[p]};
+            const xnum w = xn_mul(be, bn);                            // column t + 1 seen from column t, before the arc
+            const xnum ws = xn_mul(w, p0);                            // ... through the self arc
+            const xnum q1 = xn_wave_shl1(xn_mul(w, p1), Z);           // ... the cell above, through ITS arc from below (0 across words)
+            xnum sum = SKIP ? xn_add3(ws, q1, xn_wave_shl1(xn_wave_shl1(xn_mul(w, p2), Z), Z)) : xn_add(ws, q1);
+            // (the end rows add 1 in the LAST column only: a scalar branch, taken once, instead of two sums per column)
+            if (i == 0 && is_end) sum = xn_add(sum, xn_one());
+            const xnum nba = xn_norm(sum);                            // final for every state but a layer's last
+            // the non-emitting row in front of the NEXT layer (its only successor: that layer's first state, same column)
+            const xnum nesb = xn_wave_shl1(xn_mul(xn_mul(nba, pin), b), Z);
+            xnum sl = xn_add(ws, xn_mul(nesb, pout));
+            if (i == 0 && is_end) sl = xn_add(sl, xn_one());
+            const xnum nb = (s == N - 1) ? xn_norm(sl) : nba;
+            if (on) {                                                 // (uniform; nothing in here is loaded from HBM)
+                if (lact && reach) {
+                    if (a.self_xi_parts && i > 0) xi += xn_ratio(av, ws, inv_pf, P.e);
+                    if (a.occ) {
+                        const double gm = xn_ratio(av, nb, inv_pf, P.e);
+                        if (OCC_LDS) { if (gm != 0.0) atomicAdd(seq_lds + st, gm); }   // ds_add_f64 (a word may stand in several layers)
+                        else if (gm != 0.0) unsafeAtomicAdd(a.occ + (f0 + t) * a.S + st, gm);
+                        if (gm > a.occ_floor || gm != gm) { seg_first = t; seg_last = max(seg_last, t); }   // (t descends)
+                    }
+                }
+                if (OCC_LDS && a.occ) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    double* orow = a.occ + (f0 + t) * a.S;
+                    for (int j = lane; j < a.S; j += 64) { orow[j] = seq_lds[j]; seq_lds[j] = 0.0; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+            be = nb;                                                  // (columns behind the first: nothing reads them any more)
+            bn = b;
+            {   // column t - PF into the ring slot this column has just freed (issued any earlier, the old and the new value
+                // are both live and the loop's back edge copies registers -- behind an s_waitcnt vmcnt(0))
+                const int tn = max(t - PF, 0);
+                ering[p] = nll[(int64_t)tn * a.S];
+                arf[p] = alf[(int64_t)tn * C];
+                are[p] = ale[(int64_t)tn * C];
+            }
+        }
+    }
+    if (a.row_lo && lact) {
+        a.row_lo[(u * GH_SEQ_MAXK + k) * GH_LAYERS_MAXN + s] = seg_first;
+        a.row_hi[(u * GH_SEQ_MAXK + k) * GH_LAYERS_MAXN + s] = seg_last;
+    }
+    if (a.seg_lo) {
+        if (lact && seg_last >= seg_first) { atomicMin(&lay_lo[k], seg_first); atomicMax(&lay_hi[k], seg_last); }
+        __syncthreads();
+        if (lane < GH_SEQ_MAXK) {
+            a.seg_lo[u * GH_SEQ_MAXK + lane] = lane < K ? lay_lo[lane] : 0x7fffffff;
+            a.seg_hi[u * GH_SEQ_MAXK + lane] = lane < K ? lay_hi[lane] : -1;
+        }
+    }
+    if (a.self_xi_parts && lact && xi != 0.0)
+        unsafeAtomicAdd(a.self_xi_parts + (size_t)(blockIdx.x % GH_FBSEQ_XI_PARTS) * a.S + st, xi);
+}
+
 }  // namespace
 
 size_t gh_seq_bp_entries(int N, int skip, int64_t T) {
@@ -496,10 +688,43 @@ int gh_launch_seq_backtrace(gh_ctx* ctx, const gh_layers_args& a, int N, int ski
     return GH_OK;
 }
 
+// 1: the launch below takes the lane = cell kernel (one utterance per wave; every graph has <= 64 cells), which also
+// fills row_lo / row_hi; GMMHMM_FBSEQ=layer keeps the lane = layer kernel
+int gh_fb_seq_by_cell(const gh_fbseq_args& a, int N) {
+    const char* e = getenv("GMMHMM_FBSEQ");
+    return a.max_cells > 0 && a.max_cells <= 64 && N >= 2 && !(e && !strcmp(e, "layer"));
+}
+
 int gh_launch_fb_seq(gh_ctx* ctx, const gh_fbseq_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64) {
     if (n_utts <= 0) return GH_OK;
     gh_fbseq_args b = a;
     b.slot0 = u_begin;
+    if (gh_fb_seq_by_cell(a, N)) {
+        const dim3 grid((unsigned)n_utts), blk(64);
+        const bool occ_lds = a.occ && a.occ_in_lds;
+#define GH_FC(ET, NN, SK)                                                                                                    \
+    do {                                                                                                                     \
+        if (occ_lds) hipLaunchKernelGGL((fb_seq_cell_kernel<ET, NN, SK, true>), grid, blk, (size_t)a.S * 8, ctx->stream, b); \
+        else hipLaunchKernelGGL((fb_seq_cell_kernel<ET, NN, SK, false>), grid, blk, 0, ctx->stream, b);                      \
+    } while (0)
+#define GH_FC_N(ET)                                                                          \
+    switch (N) {                                                                             \
+        case 2: GH_FC(ET, 2, false); break;                                                  \
+        case 3: if (skip) GH_FC(ET, 3, true); else GH_FC(ET, 3, false); break;               \
+        case 4: if (skip) GH_FC(ET, 4, true); else GH_FC(ET, 4, false); break;               \
+        case 5: if (skip) GH_FC(ET, 5, true); else GH_FC(ET, 5, false); break;               \
+        case 6: if (skip) GH_FC(ET, 6, true); else GH_FC(ET, 6, false); break;               \
+        case 7: if (skip) GH_FC(ET, 7, true); else GH_FC(ET, 7, false); break;               \
+        case 8: if (skip) GH_FC(ET, 8, true); else GH_FC(ET, 8, false); break;               \
+        default: gh_set_error("gh_forward_backward: sequence form with %d states per word", N); return GH_ERR_UNSUPPORTED; \
+    }
+        if (f64) { GH_FC_N(double) } else { GH_FC_N(float) }
+#undef GH_FC_N
+#undef GH_FC
+        GH_HIP(hipGetLastError());
+        return GH_OK;
+    }
+    b.row_lo = b.row_hi = nullptr;
     const dim3 grid((unsigned)((n_utts + 3) / 4)), blk(64);
     const int64_t slot_end = u_begin + n_utts;
     const bool occ_lds = a.occ && a.occ_in_lds;

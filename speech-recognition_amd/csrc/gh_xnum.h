@@ -46,6 +46,41 @@ __device__ __forceinline__ xnum xn_exp_neg(double c) {
     return o;
 }
 
+// The same function with the polynomial written as v_fma_f64 with the coefficient in an SGPR pair: left to itself the
+// compiler turns every step into v_mov_b64 (coefficient -> accumulator) + v_fmac_f64 -- 12 extra issue slots per
+// exponential, a tenth of a lane-per-cell forward-backward column.  Same operations in the same order: same bits.
+__device__ __forceinline__ double xn_fma_sc(double p, double r, double c) {
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+    return o;
+}
+__device__ __forceinline__ xnum xn_exp_neg_sc(double c) {
+    const double x = -c;
+    const bool tiny = !(x >= -1.0e9);
+    const double xc = tiny ? 0.0 : fmin(x, 1.0e9);
+    const double n = rint(xc * 1.4426950408889634);
+    double r = fma(-n, 0x1.62e42fefa39efp-1, xc);
+    r = fma(-n, 0x1.abc9e3b39803fp-56, r);
+    double p = 1.0 / 6227020800.0;
+    p = xn_fma_sc(p, r, 1.0 / 479001600.0);
+    p = xn_fma_sc(p, r, 1.0 / 39916800.0);
+    p = xn_fma_sc(p, r, 1.0 / 3628800.0);
+    p = xn_fma_sc(p, r, 1.0 / 362880.0);
+    p = xn_fma_sc(p, r, 1.0 / 40320.0);
+    p = xn_fma_sc(p, r, 1.0 / 5040.0);
+    p = xn_fma_sc(p, r, 1.0 / 720.0);
+    p = xn_fma_sc(p, r, 1.0 / 120.0);
+    p = xn_fma_sc(p, r, 1.0 / 24.0);
+    p = xn_fma_sc(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    xnum o;
+    o.f = tiny ? ((x != x) ? x : 0.0) : p;
+    o.e = tiny ? XN_ZERO_E : (int)n;
+    return o;
+}
+
 __device__ __forceinline__ xnum xn_mul(xnum a, xnum b) { return xnum{a.f * b.f, a.e + b.e}; }
 
 // sums are left UNNORMALISED (f may be anything >= 0): normalise once per cell with xn_norm

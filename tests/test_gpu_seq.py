@@ -181,12 +181,15 @@ def test_sequence_kernel_long_utterances_many_graphs(hip, ctx):
     gmm.close()
 
 
-@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (4, 2, False, 16), (6, 3, True, 9), (3, 8, True, 5), (7, 6, False, 1)])
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (4, 2, False, 16), (6, 3, True, 9), (3, 8, True, 5), (7, 6, False, 1),
+                                           (3, 8, True, 12), (5, 4, True, 16)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, Kmax, dtype):
-    """log P, frame x state occupancies and expected self transitions of the lane-per-layer kernel against the generic
-    row-per-lane forward-backward (GMMHMM_FB=generic) -- reachable and unreachable utterances, repeated words in one
-    transcript (the occupancies of their layers add up), single-frame utterances."""
+    """log P, frame x state occupancies and expected self transitions of the sequence-form kernels -- lane = cell, one
+    utterance per wave (graphs of <= 64 cells) and lane = layer, four per wave (the last shape: up to 96 cells; and
+    GMMHMM_FBSEQ=layer) -- against the generic row-per-lane forward-backward (GMMHMM_FB=generic): reachable and
+    unreachable utterances, repeated words in one transcript (the occupancies of their layers add up), single-frame
+    utterances."""
     rng = np.random.default_rng(31 * W + 7 * n + Kmax)
     U = 70
     means, vars_, w, wt, xs, labels, graphs, utt_graph = make_task(rng, W, n, skip, Kmax, U)
@@ -214,6 +217,13 @@ def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, K
         assert (r > 1 - 1e-9).all() and (r < 2 + 1e-9).all()
     only = lat.forward_backward(b, utt_lattice=utt_graph)            # log P alone: no backward sweep
     np.testing.assert_array_equal(only["logp"], got["logp"])
+    # the two lane mappings do the same arithmetic per cell in the same order: same bits (occupancies of a repeated
+    # word's layers meet in one LDS cell in either order: last bits there)
+    with forced(GMMHMM_FBSEQ="layer"):
+        lay = lat.forward_backward(b, utt_lattice=utt_graph, want_occ=True, want_self_xi=True)
+    np.testing.assert_array_equal(lay["logp"], got["logp"])
+    np.testing.assert_allclose(lay["occ"], got["occ"], rtol=1e-14, atol=1e-300)
+    np.testing.assert_allclose(lay["self_xi"], got["self_xi"], rtol=1e-13)
     b.close()
     lat.close()
     gmm.close()
