@@ -64,20 +64,26 @@ struct UploadLayout {
         for (auto& it : items) *it.dst = static_cast<char*>(base) + it.off;
         // every maximal run of consecutive pieces WITH host data travels as one copy; a piece that is "left as it is"
         // (no source) between two runs is not touched (one copy over [first, last) would have zeroed it)
-        std::vector<char> stage(total, 0);
-        bool any = false;
-        size_t i = 0;
-        while (i < items.size()) {
+        // (the staging buffer holds the RUNS, not the region: a session arena is tens of MB to GBs of device-only
+        //  pieces behind a few KB of tables -- zero-filling a region-sized buffer cost 14 ms per gh_fit_create)
+        struct run { size_t first, last, lo, hi, at; };
+        std::vector<run> runs;
+        size_t need = 0;
+        for (size_t i = 0; i < items.size();) {
             if (!items[i].src_bytes) { ++i; continue; }
-            size_t j = i, lo = items[i].off, hi = lo;
-            while (j < items.size() && items[j].src_bytes) {
-                memcpy(stage.data() + items[j].off, items[j].src, items[j].src_bytes);
-                hi = items[j].off + items[j].src_bytes;
-                ++j;
-            }
-            GH_HIP(hipMemcpyAsync(static_cast<char*>(base) + lo, stage.data() + lo, hi - lo, hipMemcpyHostToDevice, st));
-            any = true;
+            size_t j = i, hi = items[i].off;
+            while (j < items.size() && items[j].src_bytes) { hi = items[j].off + items[j].src_bytes; ++j; }
+            runs.push_back({i, j, items[i].off, hi, need});
+            need += hi - items[i].off;
             i = j;
+        }
+        std::vector<char> stage(need, 0);
+        bool any = false;
+        for (const run& r : runs) {
+            for (size_t j = r.first; j < r.last; ++j)
+                memcpy(stage.data() + r.at + (items[j].off - r.lo), items[j].src, items[j].src_bytes);
+            GH_HIP(hipMemcpyAsync(static_cast<char*>(base) + r.lo, stage.data() + r.at, r.hi - r.lo, hipMemcpyHostToDevice, st));
+            any = true;
         }
         if (any || sync) GH_HIP(hipStreamSynchronize(st));    // (`stage` is pageable host memory of this call)
         return GH_OK;

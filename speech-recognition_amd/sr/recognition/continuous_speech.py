@@ -380,7 +380,8 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             cuts = np.concatenate([[0], np.cumsum(n_frames)])
             first = by_state[cuts[:-1]] if len(uniq) else np.zeros(0, dtype=np.int64)
             n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
-            rows_of = {int(sid): used[by_state[cuts[i]:cuts[i + 1]]] for i, sid in enumerate(uniq)}
+            ordered = used[by_state]          # ONE gather of the row indices; a state's rows are a slice of it
+            rows_of = {int(sid): ordered[cuts[i]:cuts[i + 1]] for i, sid in enumerate(uniq)}
             n_of = {int(sid): int(c) for sid, c in zip(uniq, n_frames)}
             print('Complete data rearrangement')
             print("=" * 25)
