@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void viterbi_seq_kernel(gh_layers_args a, int64
         sto[s] = (unsigned)(lact ? wd->state[s] : 0) * (unsigned)sizeof(ET);
     }
     const double cin = lact ? wd->cin : INF, cout = lact ? wd->cout : INF;
-    const char* nllb = static_cast<const char*>(a.nll) + f0 * a.S * (int64_t)sizeof(ET);
+    const char* nllb = static_cast<const char*>(a.nll) + (T > 0 ? f0 : 0) * a.S * (int64_t)sizeof(ET);   // (no frames: frame 0)
     const int64_t rowb = (int64_t)a.S * (int64_t)sizeof(ET);
     ET ring[PF][N];
 #pragma unroll
@@ -85,16 +85,10 @@ __global__ __launch_bounds__(64) void viterbi_seq_kernel(gh_layers_args a, int64
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int t = t0 + p;
-            if (t >= Tmax) break;
+            double e[N];
+#pragma unroll
+            for (int s = 0; s < N; ++s) e[s] = (double)ring[p][s];
             if (t < T) {
-                double e[N];
-#pragma unroll
-                for (int s = 0; s < N; ++s) e[s] = (double)ring[p][s];
-                if (t + PF < T) {
-                    const char* colp = nllb + (int64_t)(t + PF) * rowb;
-#pragma unroll
-                    for (int s = 0; s < N; ++s) ring[p][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
-                }
                 const double base0 = c0[0] + prev[0];
 #pragma unroll
                 for (int s = N - 1; s >= 1; --s) {
@@ -129,6 +123,15 @@ __global__ __launch_bounds__(64) void viterbi_seq_kernel(gh_layers_args a, int64
                         word = 0;
                     }
                 }
+            }
+            {   // the slot's refill: unconditional, from a clamped column, OUTSIDE the divergent region and behind the last
+                // use of the old value.  (A load under `if (t + PF < T)`, a `break` out of the unrolled group, or a refill
+                // issued while the old value is live each put an s_waitcnt vmcnt(0) into every column or group: the ring
+                // never ran ahead.)  Rows without frames read frame 0 (some row has frames, or this loop would not run).
+                const int tn = (t + PF < T) ? t + PF : (T > 0 ? T - 1 : 0);
+                const char* colp = nllb + (int64_t)tn * rowb;
+#pragma unroll
+                for (int s = 0; s < N; ++s) ring[p][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
             }
         }
     }

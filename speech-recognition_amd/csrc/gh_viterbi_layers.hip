@@ -124,67 +124,81 @@ __global__ __launch_bounds__(64) void viterbi_layers_kernel(gh_layers_args a) {
     uint32_t* bp = WANT_BP ? reinterpret_cast<uint32_t*>(a.bp + a.bp_off[slot]) + lane : nullptr;
     int cw = 0;                                               // columns already pushed into `word`
 
-    for (int t0 = 0; t0 < T; t0 += PF) {
+    // Read-ahead (round 4, found in the ISA): a load under `if (t + PF < T)`, a `break` out of the unrolled group, a
+    // per-column `if (t < T)` or a refill issued while the slot's old value is still live each put an s_waitcnt vmcnt(0)
+    // (behind register copies) into every column or every group -- the ring never ran ahead.  So: the main loop takes
+    // WHOLE groups of PF columns with no condition around a column, a slot is refilled, unconditionally and from a clamped
+    // column, at the END of the column that consumed it, and the last T mod PF columns run from the ring without refills.
+    // (the ring's first fill sits in branches: with it still in flight at the loop header the compiler can only count on
+    //  "no load issued behind it" and waits for vmcnt(0) at the top of EVERY group; drained here, the header's wait is
+    //  the back edge's -- the 15 loads of the three younger slots stay in flight)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto column = [&](int t, const ET (&ev)[N]) {
+        double e[N];
+#pragma unroll
+        for (int s = 0; s < N; ++s) e[s] = (double)ev[s];
+        double carry = (t == 0) ? 0.0 : INF;              // the start row: cost 0 in column 0 only (decode.py:99-101)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const double base0 = c0[0] + prev[h][0];      // state 0 from its own previous column
+            // states N-1 .. 1 from the previous column (in place, descending: the neighbours are still old)
+#pragma unroll
+            for (int s = N - 1; s >= 1; --s) {
+                const double v0 = c0[s] + prev[h][s];
+                const double v1 = c1[s] + prev[h][s - 1];
+                double best;
+                if (SKIP && s >= 2) {                     // ascending origin order: s-2, s-1, s; strict '<'
+                    const double v2 = c2[s] + prev[h][s - 2];
+                    const bool b_a = v1 < v2;
+                    const double m = vmin(v1, v2);
+                    const bool b_b = v0 < m;
+                    best = vmin(v0, m);
+                    if (WANT_BP) { push_bit(word, __ballot(b_a)); push_bit(word, __ballot(b_b)); }
+                } else {
+                    const bool b = v0 < v1;
+                    best = vmin(v0, v1);
+                    if (WANT_BP) push_bit(word, __ballot(b));
+                }
+                prev[h][s] = vmin(best + e[s], INF);      // min(inf, nan) keeps inf (decode.py:124)
+            }
+            // the non-emitting row behind this layer: minimum over the words' last states, same column
+            const double cand = prev[h][N - 1] + cout[h];
+            const double rm = row_min16(cand);
+            if (WANT_BP) push_bit(word, __ballot(cand == rm));
+            // ... handed to the next layer: rows 1-3 take the row above, row 0 the start row / layer 3
+            const double nin = dpp_f64<0x142, 0xE>(carry, rm);
+            carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rm), 63),
+                                     __builtin_amdgcn_readlane(__double2loint(rm), 63));
+            // state 0: the non-emitting row (lower row index: it wins ties) against the self arc
+            const double cn = nin + cin[h];
+            const bool b0 = base0 < cn;
+            if (WANT_BP) push_bit(word, __ballot(b0));
+            prev[h][0] = vmin(vmin(base0, cn) + e[0], INF);
+        }
+        if (WANT_BP) {
+            if (++cw == CPW || t == T - 1) {
+                if (CPW > 1 && cw < CPW) word <<= BITS * (CPW - cw);   // last, partly filled word: left aligned
+                bp[(int64_t)(t / CPW) * 64] = word;
+                word = 0;
+                cw = 0;
+            }
+        }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= T; t0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int t = t0 + k;
-            if (t >= T) break;
-            double e[N];
+            column(t, ring[k]);
+            const int tn = (t + PF < T) ? t + PF : T - 1;
+            const char* colp = nllb + (int64_t)tn * rowb;
 #pragma unroll
-            for (int s = 0; s < N; ++s) e[s] = (double)ring[k][s];
-            if (t + PF < T) {
-                const char* colp = nllb + (int64_t)(t + PF) * rowb;
-#pragma unroll
-                for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
-            }
-            double carry = (t == 0) ? 0.0 : INF;              // the start row: cost 0 in column 0 only (decode.py:99-101)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double base0 = c0[0] + prev[h][0];      // state 0 from its own previous column
-                // states N-1 .. 1 from the previous column (in place, descending: the neighbours are still old)
-#pragma unroll
-                for (int s = N - 1; s >= 1; --s) {
-                    const double v0 = c0[s] + prev[h][s];
-                    const double v1 = c1[s] + prev[h][s - 1];
-                    double best;
-                    if (SKIP && s >= 2) {                     // ascending origin order: s-2, s-1, s; strict '<'
-                        const double v2 = c2[s] + prev[h][s - 2];
-                        const bool b_a = v1 < v2;
-                        const double m = vmin(v1, v2);
-                        const bool b_b = v0 < m;
-                        best = vmin(v0, m);
-                        if (WANT_BP) { push_bit(word, __ballot(b_a)); push_bit(word, __ballot(b_b)); }
-                    } else {
-                        const bool b = v0 < v1;
-                        best = vmin(v0, v1);
-                        if (WANT_BP) push_bit(word, __ballot(b));
-                    }
-                    prev[h][s] = vmin(best + e[s], INF);      // min(inf, nan) keeps inf (decode.py:124)
-                }
-                // the non-emitting row behind this layer: minimum over the words' last states, same column
-                const double cand = prev[h][N - 1] + cout[h];
-                const double rm = row_min16(cand);
-                if (WANT_BP) push_bit(word, __ballot(cand == rm));
-                // ... handed to the next layer: rows 1-3 take the row above, row 0 the start row / layer 3
-                const double nin = dpp_f64<0x142, 0xE>(carry, rm);
-                carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rm), 63),
-                                         __builtin_amdgcn_readlane(__double2loint(rm), 63));
-                // state 0: the non-emitting row (lower row index: it wins ties) against the self arc
-                const double cn = nin + cin[h];
-                const bool b0 = base0 < cn;
-                if (WANT_BP) push_bit(word, __ballot(b0));
-                prev[h][0] = vmin(vmin(base0, cn) + e[0], INF);
-            }
-            if (WANT_BP) {
-                if (++cw == CPW || t == T - 1) {
-                    if (CPW > 1 && cw < CPW) word <<= BITS * (CPW - cw);   // last, partly filled word: left aligned
-                    bp[(int64_t)(t / CPW) * 64] = word;
-                    word = 0;
-                    cw = 0;
-                }
-            }
+            for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
         }
     }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t0 + k < T) column(t0 + k, ring[k]);
 
     // ---- end costs, end selection ('>=': the last of equal minima, decode.py:129-134) ----
     double best_v = INF;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int6
         sto[s] = (unsigned)lf->state[wc][s] * (unsigned)sizeof(ET);
     }
     const double cin = wact ? lf->cin[wc] : INF, cin0 = wact ? lf->cin0[wc] : INF, cout = wact ? lf->cout[wc] : INF;
-    const char* nllb = static_cast<const char*>(a.nll) + f0 * a.S * (int64_t)sizeof(ET);   // per row
+    const char* nllb = static_cast<const char*>(a.nll) + (T > 0 ? f0 : 0) * a.S * (int64_t)sizeof(ET);   // per row (no frames: frame 0)
     const int64_t rowb = (int64_t)a.S * (int64_t)sizeof(ET);
     ET ring[PF][N];
 #pragma unroll
@@ -270,20 +284,14 @@ __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int6
     uint32_t word = 0;
     uint32_t* bp = (WANT_BP && has_utt) ? reinterpret_cast<uint32_t*>(a.bp + a.bp_off[slot]) + w : nullptr;
 
-    for (int t0 = 0; t0 < Tmax; t0 += PF) {
+    for (int t0 = 0; t0 < Tmax; t0 += PF) {                    // (the columns behind Tmax in the last group: no row is in them)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int t = t0 + k;
-            if (t >= Tmax) break;
+            double e[N];
+#pragma unroll
+            for (int s = 0; s < N; ++s) e[s] = (double)ring[k][s];
             if (t < T) {                                       // row-uniform: the rows of finished utterances sit out
-                double e[N];
-#pragma unroll
-                for (int s = 0; s < N; ++s) e[s] = (double)ring[k][s];
-                if (t + PF < T) {
-                    const char* colp = nllb + (int64_t)(t + PF) * rowb;
-#pragma unroll
-                    for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
-                }
                 const double base0 = c0[0] + prev[0];
 #pragma unroll
                 for (int s = N - 1; s >= 1; --s) {
@@ -324,6 +332,14 @@ __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int6
                         word = 0;
                     }
                 }
+            }
+            {   // the slot's refill: unconditional, from a clamped column, OUTSIDE the divergent region and behind the last
+                // use of the old value (see viterbi_layers_kernel); rows without frames read frame 0 of the matrix (some
+                // row has frames, or this loop would not run)
+                const int tn = (t + PF < T) ? t + PF : (T > 0 ? T - 1 : 0);
+                const char* colp = nllb + (int64_t)tn * rowb;
+#pragma unroll
+                for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
             }
         }
     }
