@@ -856,7 +856,9 @@ def _training_config(ctx, U, K=7):
     continuous_speech.py:56-179): (a) the alignment + regrouping step of continuous_train -- own-state likelihoods,
     forced-alignment Viterbi through one graph per distinct transcript, frames regrouped per state
     (gh_lattices_create_transcripts + gh_loglik_sets + gh_align_segments); (b) one soft-EM iteration on the same
-    transcripts (forward-backward in sequence form + statistics + host M-step, graphs rebuilt from the new costs)."""
+    transcripts: the device-resident session over word strings (gh_em_create_transcripts -- likelihoods of the
+    transcripts' words, sequence-form forward-backward with lane = cell, statistics, M-step and re-pack on one stream;
+    round 3 ran it call by call with a host M-step and graphs rebuilt from the new costs: 5.6 ms)."""
     from sr.recognition import _hip
     from sr.recognition.train import BaumWelchTrainer
     wl = synth_workload(1003, U * K)
@@ -885,12 +887,25 @@ def _training_config(ctx, U, K=7):
     tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device)
     hist = [tr.iteration()]
     t_em, _ = _timeit(lambda: hist.append(tr.iteration()), reps=3)
+    resident = tr.session is not None and getattr(tr.session, "word_strings", False)
+    phases = None
+    if resident:      # HIP events between the phases of an iteration, on the stream its kernels run on (gh_em_profile)
+        tr.session.profile(True)
+        ph = []
+        for _ in range(3):
+            hist.append(tr.iteration())
+            ph.append(tr.session.phase_ms())
+        tr.session.profile(False)
+        ph = np.median(np.array(ph), axis=0)
+        phases = {"loglik_states_of_the_transcripts_words_ms": float(ph[0]), "fb_seq_cell_plus_ranges_ms": float(ph[1]),
+                  "bw_fused_statistics_ms": float(ph[2]), "tail_allreduce_mstep_repack_ms": float(ph[3])}
     tr.close()
     N = int(off[-1])
     return {"workload": "configs[2] model, %d utterances of %d words (%d frames, %d distinct transcripts)" % (U, K, N, len(keys)),
             "align_and_regroup": {"ms_per_call": t_align * 1e3, "utterances_per_s": U / t_align, "frames_per_s": N / t_align,
                                   "frames_assigned_to_a_state": float(np.mean(fs >= 0))},
-            "soft_em_iteration": {"ms_per_iteration": t_em * 1e3, "utterances_per_s": U / t_em,
+            "soft_em_iteration": {"ms_per_iteration": t_em * 1e3, "utterances_per_s": U / t_em, "frames_per_s": N / t_em,
+                                  "device_resident_iteration": bool(resident), "phases": phases,
                                   "loglik_monotone": bool(all(y >= x - 1e-7 * abs(x) for x, y in zip(hist, hist[1:])))}}
 
 

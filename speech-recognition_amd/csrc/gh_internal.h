@@ -84,6 +84,7 @@ struct gh_gmm {
     // GMM.evaluate then needs the per-component test of gh_loglik_underflow_fix (written by gh_gmm_create and by
     // every device-side re-pack)
     int* dAnyPos = nullptr;
+    int any_pos_host = -1;   // what the host knows of *dAnyPos: 0 / 1 after gh_gmm_create, -1 after a re-pack on the device
     // MFMA operand packing (gh_loglik_mfma.hip): mixtures padded to M_pad components,
     // Gaussians to n_tiles*16 rows; Apk[tile][kstep][lane] fragments, Cpk[tile*16 + j]
     int M_pad, n_tiles;

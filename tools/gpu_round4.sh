@@ -19,12 +19,13 @@ python3 tools/time_fused.py 100000 13 > $O/fused_plain.log 2>&1; echo "fused pla
 python3 tools/time_fused.py 20000 39 > $O/fused_d39.log 2>&1; echo "fused d39 exit $?"
 python3 tools/time_lse.py > $O/lse_f32exp.json 2> $O/lse_f32exp.err; echo "lse exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_em -o em -- python3 tools/time_em.py 12500 > $O/em.log 2>&1; echo "em prof exit $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_emstr -o es -- python3 tools/time_em_strings.py > $O/em_strings.log 2>&1; echo "em strings prof exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ctrain -o ct -- python3 tools/time_ctrain.py 2000 7 6 > $O/ctrain_prof.log 2>&1; echo "ctrain prof exit $?"
 CTRAIN_PROFILE=0 python3 tools/time_ctrain.py 2000 7 8 > $O/ctrain.log 2>&1; echo "ctrain exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o c5 -- python3 tools/time_c5.py 125000 > $O/c5.json 2> $O/c5.err; echo "c5 prof exit $?"
 python3 bench.py --gpus 2 --same-gpu --steps 20 --warmup 5 --no-cpu-baseline --c5-utts 20000 --c4-utts 2000 > $O/bench_2ranks_same_gpu.json 2> $O/bench_2ranks_same_gpu.err; echo "2-rank bench exit $?"
 # fold: kernel stats csv files next to the logs, raw profiler directories removed
-for d in headline fused em ctrain c5; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
+for d in headline fused em emstr ctrain c5; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 for d in fetch write fused_fetch fused_write fused_sq; do f=$(find $O/pmc_$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/pmc_${d}.csv; done
 python3 tools/pmc_traffic.py $O/pmc_fetch.csv $O/pmc_write.csv $O/pmc_traffic_f64.json 999364 f64 > /dev/null 2>&1
 python3 tools/pmc_kernel.py $O/pmc_fused_sq.csv viterbi_fused > $O/pmc_fused_sq.txt 2>&1
