@@ -127,6 +127,10 @@ int gh_batch_wrap(gh_ctx* ctx, gh_dtype dtype, int D, int64_t N, int64_t U,
  * segments) without a trip through the host. */
 int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* idx /*[n]*/, int64_t n, int64_t U,
                     const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
+/* Runs of consecutive rows instead of single rows: rows [start[r], start[r] + len[r]) of `src` become rows
+ * [dest[r], ...) of the result (n rows in all; the runs must tile it exactly). */
+int gh_batch_gather_runs(gh_ctx* ctx, const gh_batch* src, int64_t n_runs, const int64_t* start, const int64_t* len,
+                         const int64_t* dest, int64_t n, int64_t U, const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
 /* `reps` copies of a resident batch back to back as a new resident batch of reps * U utterances (device-to-device
  * copies; measurement plumbing: a large batch from a small upload; no reference counterpart) */
 int gh_batch_tile(gh_ctx* ctx, const gh_batch* src, int reps, gh_batch** out);
@@ -307,6 +311,13 @@ int gh_viterbi_labels(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
 int gh_align_segments(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b,
                       const int32_t* utt_lattice /*[U] or NULL*/,
                       double* out_end_cost, int32_t* out_best_end, int32_t* out_frame_state /*[N]*/);
+/* The same alignment with the runs themselves as the result (round 4): out_runs [U, run_cap, 3] = (state, first frame
+ * inside the utterance, frames) of every run of an utterance in time order, out_run_cnt [U] their number (above run_cap:
+ * the table was too small; run_cap = the most rows a graph has is always enough).  ~N / 20 runs instead of N labels, and
+ * a run's frames are contiguous in the batch -- gh_batch_gather_runs regroups them (continuous_speech.py:90-113). */
+int gh_align_runs(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice /*[U] or NULL*/,
+                  double* out_end_cost, int32_t* out_best_end, int run_cap, int32_t* out_runs /*[U,run_cap,3]*/,
+                  int32_t* out_run_cnt /*[U]*/);
 
 /* The same with a PACKED result: every utterance may produce up to `max_labels` labels (device-side slots), but only
  * the labels that exist come back: out_labels holds utterance 0's labels, then utterance 1's, ... (utterance u at

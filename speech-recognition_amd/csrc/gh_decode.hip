@@ -54,24 +54,31 @@ __global__ __launch_bounds__(64) void path_labels_kernel(const int32_t* __restri
 __global__ void cut_segments_kernel(const int32_t* __restrict__ path, const int64_t* __restrict__ path_off,
                                     const int32_t* __restrict__ path_len, const int32_t* __restrict__ utt_lat,
                                     const gh_lattices::desc* __restrict__ descs, const int32_t* __restrict__ row_state,
-                                    const int64_t* __restrict__ utt_off, int64_t U, int32_t* __restrict__ frame_state) {
+                                    const int64_t* __restrict__ utt_off, int64_t U, int32_t* __restrict__ frame_state,
+                                    int32_t* __restrict__ run_buf, int32_t* __restrict__ run_cnt, int run_cap) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
     const int2* p = reinterpret_cast<const int2*>(path) + path_off[u];
     const int32_t* rs = row_state + descs[utt_lat ? utt_lat[u] : 0].row_base;
-    int32_t* out = frame_state + utt_off[u];
-    int open_row = -1, open_at = -1;
+    int32_t* out = frame_state ? frame_state + utt_off[u] : nullptr;
+    int32_t* rb = run_buf ? run_buf + u * (int64_t)run_cap * 3 : nullptr;     // (state, first frame in the utterance, frames), in time order
+    int open_row = -1, open_at = -1, nr = 0;
     for (int i = path_len[u] - 1; i >= 0; --i) {
         const int2 cell = p[i];
         if (open_at < 0 && rs[cell.x] >= 0) { open_row = cell.x; open_at = cell.y; }
         if (cell.x != open_row && open_at >= 0 && open_at < cell.y) {
             const int sid = rs[open_row];
-            out[open_at] = sid | GH_SEGMENT_START;
-            for (int f = open_at + 1; f < cell.y; ++f) out[f] = sid;
+            if (out) {
+                out[open_at] = sid | GH_SEGMENT_START;
+                for (int f = open_at + 1; f < cell.y; ++f) out[f] = sid;
+            }
+            if (rb && nr < run_cap) { rb[3 * nr] = sid; rb[3 * nr + 1] = open_at; rb[3 * nr + 2] = cell.y - open_at; }
+            ++nr;
             open_row = -1;
             open_at = -1;
         }
     }
+    if (run_cnt) run_cnt[u] = nr;
 }
 
 // label mode, packed result: utterance u's labels move from its slot (label_off[u], capacity) to packed[pack_off[u] ...]
@@ -102,7 +109,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
                         const int64_t* path_off, int32_t* out_path_len, double* out_costs,
                         const int64_t* costs_off, const int32_t* row_label, int32_t* out_labels,
                         const int64_t* label_off, int32_t* out_n_labels, int64_t packed_cap = -1,
-                        int32_t* out_frame_state = nullptr, const gh_gmm* fused = nullptr, int fused_log_domain = 0) {
+                        int32_t* out_frame_state = nullptr, const gh_gmm* fused = nullptr, int fused_log_domain = 0,
+                        int run_cap = 0, int32_t* out_runs = nullptr, int32_t* out_run_cnt = nullptr) {
     GH_REQUIRE(ctx && lat && b, "gh_viterbi: NULL argument");
     GH_REQUIRE(fused || b->nll || b->N == 0, "gh_viterbi: gh_loglik has not been run on this batch");
     GH_REQUIRE(!out_path || (path_off && out_path_len), "gh_viterbi: out_path needs path_off and out_path_len");
@@ -136,7 +144,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         }
     }
     const bool want_labels = out_labels != nullptr;
-    const bool want_segments = out_frame_state != nullptr;
+    const bool want_runs = out_runs != nullptr && out_run_cnt != nullptr && run_cap > 0;
+    const bool want_segments = out_frame_state != nullptr || want_runs;
     const bool uniform = utt_lattice == nullptr;
     // chain kernel: one left-to-right graph for the whole batch, no single-frame utterance (T == 1 has
     // the reference's wrap-around semantics, which only the lean / generic kernels implement)
@@ -247,7 +256,7 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
     uint16_t* d_bp = nullptr;
     int* d_flag2;  // [flag | best_end | end_cost] are carved back to back: ONE D2H copy into pinned memory
     size_t small_bytes = 0;
-    int32_t* d_framestate = nullptr;
+    int32_t *d_framestate = nullptr, *d_runs = nullptr, *d_runcnt = nullptr;
     double* d_fpar = nullptr;
     const int fused_rp = (lat->max_R + 63) & ~63;
     int32_t *d_rowlabel = nullptr, *d_labels = nullptr, *d_nlabels = nullptr;
@@ -268,7 +277,8 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         if (want_path && !labels_direct) { cv.add(&d_pathoff, U + 1); cv.add(&d_path, 2 * n_path); cv.add(&d_pathlen, U); }
         if (want_bp) cv.add(&d_bp, bp_max);
         if (out_costs) { cv.add(&d_costsoff, U + 1); cv.add(&d_costs, n_costs); }
-        if (want_segments) cv.add(&d_framestate, b->N);
+        if (out_frame_state) cv.add(&d_framestate, b->N);
+        if (want_runs) { cv.add(&d_runs, (size_t)U * run_cap * 3); cv.add(&d_runcnt, U); }
         if (want_labels) {
             cv.add(&d_rowlabel, n_rows_total); cv.add(&d_labeloff, U + 1);
             cv.add(&d_nlabels, U); cv.add(&d_labels, label_off[U]);   // [n_labels | labels] back to back: one copy
@@ -467,11 +477,17 @@ static int viterbi_impl(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, 
         } else if (label_off[U] > 0) GH_HIP(hipMemcpyAsync(out_labels, d_labels, label_off[U] * 4, hipMemcpyDeviceToHost, st));
     }
     if (want_segments && b->N > 0) {
-        GH_HIP(hipMemsetAsync(d_framestate, 0xFF, (size_t)b->N * 4, st));
+        if (d_framestate) GH_HIP(hipMemsetAsync(d_framestate, 0xFF, (size_t)b->N * 4, st));
         hipLaunchKernelGGL(cut_segments_kernel, dim3((unsigned)((U + 63) / 64)), dim3(64), 0, st, d_path, d_pathoff, d_pathlen, d_uttlat,
-                           lat->d_desc, lat->d_row_state, b->d_offsets, U, d_framestate);
+                           lat->d_desc, lat->d_row_state, b->d_offsets, U, d_framestate, d_runs, d_runcnt, run_cap);
         GH_HIP(hipGetLastError());
-        GH_HIP(hipMemcpyAsync(out_frame_state, d_framestate, (size_t)b->N * 4, hipMemcpyDeviceToHost, st));
+        if (out_frame_state) GH_HIP(hipMemcpyAsync(out_frame_state, d_framestate, (size_t)b->N * 4, hipMemcpyDeviceToHost, st));
+        if (want_runs) {
+            GH_HIP(hipMemcpyAsync(out_runs, d_runs, (size_t)U * run_cap * 3 * 4, hipMemcpyDeviceToHost, st));
+            GH_HIP(hipMemcpyAsync(out_run_cnt, d_runcnt, (size_t)U * 4, hipMemcpyDeviceToHost, st));
+        }
+    } else if (want_runs) {
+        memset(out_run_cnt, 0, (size_t)U * 4);
     }
     trace.mark("labels");
     GH_HIP(hipMemcpyAsync(pin, d_flag2, small_bytes, hipMemcpyDeviceToHost, st));
@@ -887,6 +903,19 @@ extern "C" int gh_align_segments(gh_ctx* ctx, const gh_lattices* lat, const gh_b
     GH_REQUIRE(ctx && lat && b && out_frame_state, "gh_align_segments: NULL argument");
     return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, nullptr, nullptr, nullptr, nullptr, nullptr,
                         nullptr, nullptr, nullptr, nullptr, -1, out_frame_state);
+}
+
+// The alignment of gh_align_segments with the result as RUNS instead of one label per frame: out_runs [U, run_cap, 3] =
+// (state, first frame inside the utterance, frames) of every run of an utterance's best path in time order, out_run_cnt [U]
+// their number (a count above run_cap: the table was too small -- run_cap = the most emitting rows a graph has is
+// always enough).  ~N / 20 runs instead of N labels: what continuous_train's regrouping (continuous_speech.py:90-113)
+// needs, at 1 MB instead of 5.6 MB per 1.4 M frames, and the frames of a run are contiguous in the batch
+// (gh_batch_gather_runs).
+extern "C" int gh_align_runs(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,
+                             double* out_end_cost, int32_t* out_best_end, int run_cap, int32_t* out_runs, int32_t* out_run_cnt) {
+    GH_REQUIRE(ctx && lat && b && out_runs && out_run_cnt && run_cap > 0, "gh_align_runs: NULL argument / run_cap=%d", run_cap);
+    return viterbi_impl(ctx, lat, b, utt_lattice, out_end_cost, out_best_end, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, -1, nullptr, nullptr, 0, run_cap, out_runs, out_run_cnt);
 }
 
 extern "C" int gh_viterbi_labels_packed(gh_ctx* ctx, const gh_lattices* lat, const gh_batch* b, const int32_t* utt_lattice,

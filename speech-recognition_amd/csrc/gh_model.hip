@@ -467,6 +467,60 @@ extern "C" int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* 
     return GH_OK;
 }
 
+// Runs of consecutive rows of a resident batch as a new resident batch: run r = rows [start[r], start[r] + len[r]) of
+// `src`, copied to rows [dest[r], ...) of the result (n = the result's rows; the runs must tile it).  What gh_batch_gather
+// does row by row from 8 bytes of index per row, from 24 bytes per run -- the regrouped frames of continuous_train are
+// ~20-frame runs (gh_align_runs).  One workgroup per run: a contiguous copy.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_runs_kernel(const T* __restrict__ src, const int64_t* __restrict__ runs /*[R,3]*/, int D,
+                                                          T* __restrict__ dst) {
+    const int64_t* r = runs + (int64_t)blockIdx.x * 3;
+    const T* s = src + r[0] * D;
+    T* d = dst + r[2] * D;
+    const int64_t total = r[1] * D;
+    for (int64_t i = threadIdx.x; i < total; i += 256) d[i] = s[i];
+}
+
+extern "C" int gh_batch_gather_runs(gh_ctx* ctx, const gh_batch* src, int64_t n_runs, const int64_t* start, const int64_t* len,
+                                    const int64_t* dest, int64_t n, int64_t U, const int64_t* off, gh_batch** out) {
+    GH_REQUIRE(ctx && src && out && ((start && len && dest) || n_runs == 0) && n_runs >= 0 && n >= 0, "gh_batch_gather_runs: NULL argument");
+    int64_t covered = 0;
+    for (int64_t r = 0; r < n_runs; ++r) {
+        GH_REQUIRE(len[r] >= 0 && start[r] >= 0 && start[r] + len[r] <= src->N && dest[r] >= 0 && dest[r] + len[r] <= n,
+                   "gh_batch_gather_runs: run %lld out of range", (long long)r);
+        covered += len[r];
+    }
+    GH_REQUIRE(covered == n, "gh_batch_gather_runs: the runs hold %lld rows, the result %lld", (long long)covered, (long long)n);
+    int rc = batch_common(ctx, src->dtype, src->D, n, U, off, out);
+    if (rc) return rc;
+    gh_batch* b = *out;
+    const size_t es = src->dtype == GH_F64 ? 8 : 4;
+    b->owns_feats = true;
+    if (n > 0) {
+        std::vector<int64_t> tab((size_t)n_runs * 3);
+        for (int64_t r = 0; r < n_runs; ++r) { tab[3 * r] = start[r]; tab[3 * r + 1] = len[r]; tab[3 * r + 2] = dest[r]; }
+        int64_t* d_tab = nullptr;
+        hipError_t e = hipMalloc(&b->feats, (size_t)n * src->D * es);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_tab, tab.size() * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const dim3 grid((unsigned)n_runs), blk(256);
+            if (src->dtype == GH_F64) hipLaunchKernelGGL(gather_runs_kernel<double>, grid, blk, 0, ctx->stream, (const double*)src->feats, d_tab, src->D, (double*)b->feats);
+            else hipLaunchKernelGGL(gather_runs_kernel<float>, grid, blk, 0, ctx->stream, (const float*)src->feats, d_tab, src->D, (float*)b->feats);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (d_tab) hipFree(d_tab);
+        if (e != hipSuccess) {
+            gh_set_error("gh_batch_gather_runs: %s", hipGetErrorString(e));
+            gh_batch_destroy(b);
+            *out = nullptr;
+            return e == hipErrorOutOfMemory ? GH_ERR_NOMEM : GH_ERR_HIP;
+        }
+    }
+    return GH_OK;
+}
+
 // `reps` copies of a resident batch back to back (device-to-device): a large batch from a small upload
 extern "C" int gh_batch_tile(gh_ctx* ctx, const gh_batch* src, int reps, gh_batch** out) {
     GH_REQUIRE(ctx && src && out && reps >= 1, "gh_batch_tile: NULL argument / reps=%d", reps);

@@ -47,6 +47,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_void_p)]),
     "gh_host_unpin": (C.c_int, [C.c_void_p]),
     "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
+    "gh_batch_gather_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _c_i64p, _c_i64p, _c_i64p, C.c_int64, C.c_int64, _c_i64p,
+                                       C.POINTER(C.c_void_p)]),
     "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gh_device_sync": (C.c_int, [C.c_void_p]),
     "gh_ctx_last_chunks": (C.c_int, [C.c_void_p]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "gh_viterbi_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, _c_f64p, _c_i32p, _c_i32p,
                                     _c_i64p, _c_i32p]),
     "gh_align_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, _c_i32p]),
+    "gh_align_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_f64p, _c_i32p, C.c_int, _c_i32p, _c_i32p]),
     "gh_viterbi_labels_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_i32p, _c_i32p, C.c_int, _c_f64p, _c_i32p,
                                            _c_i32p, C.c_int64, _c_i32p]),
     "gh_dtw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f64p,
@@ -825,6 +828,22 @@ class Batch:
         new.h = h
         return new
 
+    def gather_runs(self, start, length, dest, n, offsets=None):
+        """Runs of consecutive rows -- rows [start[r], start[r] + length[r]) of this batch become rows [dest[r], ...) of a new
+        resident batch of n rows (gh_batch_gather_runs: one contiguous copy per run, 24 bytes of table per run instead of 8
+        bytes of index per row)."""
+        start, length, dest = (np.ascontiguousarray(a, dtype=np.int64) for a in (start, length, dest))
+        off = np.ascontiguousarray([0, int(n)] if offsets is None else offsets, dtype=np.int64)
+        new = Batch.__new__(Batch)
+        new.ctx, new.np_dtype = self.ctx, self.np_dtype
+        new.offsets, new.N, new.D, new.U, new.S = off, int(n), self.D, len(off) - 1, None
+        h = C.c_void_p()
+        _check(self.ctx.lib, self.ctx.lib.gh_batch_gather_runs(self.ctx.h, self.h, len(start), _ptr(start, _c_i64p),
+                                                               _ptr(length, _c_i64p), _ptr(dest, _c_i64p), int(n), new.U,
+                                                               _ptr(off, _c_i64p), C.byref(h)))
+        new.h = h
+        return new
+
     def tile(self, reps):
         """`reps` copies of this batch back to back as a new resident batch (gh_batch_tile: device-to-device)."""
         new = Batch.__new__(Batch)
@@ -1125,6 +1144,28 @@ class Lattices:
         start = (fs >= 0) & ((fs & self.SEGMENT_START) != 0)
         fs[start] &= ~self.SEGMENT_START
         return dict(frame_state=fs, segment_start=start, end_cost_flat=end_cost, best_end=best_end)
+
+    def align_runs(self, batch, utt_lattice=None):
+        """The alignment of `align_segments` with the RUNS as the result (gh_align_runs): dict(state int32 [R], start int64
+        [R] (row of the batch), length int64 [R]) in utterance / time order -- ~N / 20 runs instead of N labels; end_cost,
+        best_end as there."""
+        lib, U = self.ctx.lib, batch.U
+        lat = None if utt_lattice is None else np.ascontiguousarray(utt_lattice, dtype=np.int32)
+        lidx = np.zeros(U, dtype=np.int64) if lat is None else lat.astype(np.int64)
+        n_end = np.asarray(self.n_end, dtype=np.int64)[lidx]
+        end_cost = np.empty(int(n_end.sum()))
+        best_end = np.empty(U, dtype=np.int32)
+        cap = int(np.max(self.R)) if len(np.atleast_1d(self.R)) else 1
+        runs = np.empty((U, cap, 3), dtype=np.int32)
+        cnt = np.empty(U, dtype=np.int32)
+        _check(lib, lib.gh_align_runs(self.ctx.h, self.h, batch.h, _ptr(lat, _c_i32p), _ptr(end_cost, _c_f64p),
+                                      _ptr(best_end, _c_i32p), cap, _ptr(runs, _c_i32p), _ptr(cnt, _c_i32p)))
+        assert U == 0 or int(cnt.max()) <= cap, "align_runs: run table too small"
+        keep = np.arange(cap)[None, :] < cnt[:, None]                     # [U, cap]: utterance / time order when flattened
+        flat = runs[keep]
+        start = flat[:, 1].astype(np.int64) + np.repeat(np.asarray(batch.offsets[:-1], dtype=np.int64), cnt)
+        return dict(state=np.ascontiguousarray(flat[:, 0]), start=start, length=flat[:, 2].astype(np.int64),
+                    end_cost_flat=end_cost, best_end=best_end)
 
     def forward_backward(self, batch, utt_lattice=None, want_matrices=False, want_occ=False, fetch_occ=True, want_self_xi=False):
         """A13: log P per utterance [+ log alpha / log beta / gamma matrices [R,T]] [+ occ [N,S]].

@@ -282,6 +282,18 @@ def aligned_frame_states(frames, models, label_seqs, plan=None):
     return res["frame_state"], res["segment_start"]
 
 
+def aligned_runs(frames, models, label_seqs, plan=None):
+    """The same alignment with the RUNS as the result (`Lattices.align_runs`, gh_align_runs): dict(state [R], start [R] (row
+    of `frames`), length [R]) in utterance / time order, or None when the binding has no such call (the test double)."""
+    lat, _, utt_graph = _alignment_lattices(frames, models, label_seqs, plan)
+    try:
+        if not hasattr(lat, "align_runs"):
+            return None
+        return lat.align_runs(frames, utt_lattice=utt_graph)
+    finally:
+        lat.close()
+
+
 def cut_segments(path, row_state):
     """Frame ranges per visited state from one alignment (continuous_speech.py:90-106).
 
@@ -355,6 +367,7 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     if not on_device:
         all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
     plan = AlignmentPlan(label_seqs, n, n_models)
+    use_runs = os.environ.get("GMMHMM_CTRAIN_RUNS", "1") != "0"      # (0: one label per frame comes back, regrouped with numpy)
     try:
         for it in range(max_iteration):
             print('=' * 25)
@@ -363,26 +376,48 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             print('Rearranging data, this may take a while...')
             # alignment + regrouping on the device; per state, its frames in utterance / time order -- what the
             # reference's vstack of the segments holds (:90-113) -- and the states in first-visit order
-            if len(data):
-                frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs, plan)
-            else:       # nothing to align on this rank: it only contributes zeros to the collectives below
-                frame_state, seg_start = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)
-            used = np.flatnonzero(frame_state >= 0)
-            sid_of = frame_state[used]
-            # stable grouping by state: 16-bit keys take numpy's radix sort (a comparison sort of 1.4 M int32 keys plus
-            # np.unique's second sort were 30 ms of every outer iteration); the first occurrence of a state is the first
-            # entry of its group because the sort is stable
-            key = sid_of.astype(np.uint16) if n_models * n < 65536 else sid_of
-            by_state = np.argsort(key, kind="stable")
-            per_state = np.bincount(sid_of, minlength=n_models * n)
-            uniq = np.flatnonzero(per_state)
-            n_frames = per_state[uniq]
-            cuts = np.concatenate([[0], np.cumsum(n_frames)])
-            first = by_state[cuts[:-1]] if len(uniq) else np.zeros(0, dtype=np.int64)
-            n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
-            ordered = used[by_state]          # ONE gather of the row indices; a state's rows are a slice of it
-            rows_of = {int(sid): ordered[cuts[i]:cuts[i + 1]] for i, sid in enumerate(uniq)}
-            n_of = {int(sid): int(c) for sid, c in zip(uniq, n_frames)}
+            runs = aligned_runs(frames, new_models, label_seqs, plan) if (on_device and len(data) and use_runs) else None
+            if runs is None:
+                use_runs = False
+            run_source = None
+            if runs is not None:
+                # The alignment came back as ~N / 20 runs (state, first row, rows) in utterance / time order instead of one
+                # label per frame: the regrouping below is the same arithmetic on the runs -- a stable sort of 70 000 run
+                # states instead of 1.4 M frame labels -- and the frames of a run are gathered as one contiguous copy.
+                n_states = n_models * n
+                rs, rstart, rlen = runs["state"].astype(np.int64), runs["start"], runs["length"]
+                per_state = np.bincount(rs, weights=rlen, minlength=n_states).astype(np.int64)
+                n_runs = np.bincount(rs, minlength=n_states)
+                uniq = np.flatnonzero(per_state)
+                order = np.argsort(rs.astype(np.uint16) if n_states < 65536 else rs, kind="stable")   # by state, time order kept
+                cuts_r = np.concatenate([[0], np.cumsum(n_runs[uniq])])
+                first = rstart[order[cuts_r[:-1]]] if len(uniq) else np.zeros(0, dtype=np.int64)
+                runs_of = {int(sid): order[cuts_r[i]:cuts_r[i + 1]] for i, sid in enumerate(uniq)}
+                n_of = {int(sid): int(per_state[sid]) for sid in uniq}
+                rows_of = {}
+                frame_state = seg_start = None
+            else:
+                if len(data):
+                    frame_state, seg_start = aligned_frame_states(frames, new_models, label_seqs, plan)
+                else:       # nothing to align on this rank: it only contributes zeros to the collectives below
+                    frame_state, seg_start = np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)
+            used = np.flatnonzero(frame_state >= 0) if runs is None else None
+            if runs is None:
+                sid_of = frame_state[used]
+                # stable grouping by state: 16-bit keys take numpy's radix sort (a comparison sort of 1.4 M int32 keys plus
+                # np.unique's second sort were 30 ms of every outer iteration); the first occurrence of a state is the first
+                # entry of its group because the sort is stable
+                key = sid_of.astype(np.uint16) if n_models * n < 65536 else sid_of
+                by_state = np.argsort(key, kind="stable")
+                per_state = np.bincount(sid_of, minlength=n_models * n)
+                uniq = np.flatnonzero(per_state)
+                n_frames = per_state[uniq]
+                cuts = np.concatenate([[0], np.cumsum(n_frames)])
+                first = by_state[cuts[:-1]] if len(uniq) else np.zeros(0, dtype=np.int64)
+                n_runs = np.bincount(frame_state[seg_start], minlength=n_models * n)
+                ordered = used[by_state]          # ONE gather of the row indices; a state's rows are a slice of it
+                rows_of = {int(sid): ordered[cuts[i]:cuts[i + 1]] for i, sid in enumerate(uniq)}
+                n_of = {int(sid): int(c) for sid, c in zip(uniq, n_frames)}
             print('Complete data rearrangement')
             print("=" * 25)
 
@@ -399,8 +434,15 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                 glob = reducer(loc)
                 keys = [sid for sid in range(n_models * n) if glob[sid, 0] > 0]
                 seg_counts = {sid: (glob[sid, 1], glob[sid, 0]) for sid in keys}
-            rows = np.concatenate([rows_of.get(sid, np.zeros(0, dtype=np.int64)) for sid in keys]) if keys else np.zeros(0, np.int64)
             lengths = [n_of.get(sid, 0) for sid in keys]
+            if runs is not None:
+                ridx = (np.concatenate([runs_of.get(sid, np.zeros(0, dtype=np.int64)) for sid in keys]) if keys
+                        else np.zeros(0, np.int64))
+                rl = rlen[ridx]
+                rows = ("runs", rstart[ridx], rl, np.cumsum(rl) - rl, int(rl.sum()))
+            else:
+                rows = (np.concatenate([rows_of.get(sid, np.zeros(0, dtype=np.int64)) for sid in keys]) if keys
+                        else np.zeros(0, np.int64))
             segs = None if on_device else [all_frames[rows_of[sid]] if sid in rows_of else np.zeros((0, dim)) for sid in keys]
             fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None, source=(frames, rows),
                                     lengths=lengths, dim=dim, kmax=kmax, compat_cov=compat_cov)

@@ -63,8 +63,13 @@ class LockstepFitter:
         self.reducer = reducer
         self.sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
         if self.S and source is not None and hasattr(source[0], "gather") and source[0].np_dtype == np.float64:
-            assert len(source[1]) == int(self.seg_off[-1])
-            self.batch = source[0].gather(source[1])
+            if isinstance(source[1], tuple) and source[1][0] == "runs":     # (start, length, dest, rows): contiguous runs of rows
+                _, r_start, r_len, r_dest, r_n = source[1]
+                assert r_n == int(self.seg_off[-1])
+                self.batch = source[0].gather_runs(r_start, r_len, r_dest, r_n)
+            else:
+                assert len(source[1]) == int(self.seg_off[-1])
+                self.batch = source[0].gather(source[1])
         else:
             assert self.segs is not None, "LockstepFitter: frames neither on the host nor in a resident fp64 batch"
             self.batch = _hip.Batch(self.ctx, feats=np.concatenate(self.segs) if self.S else np.zeros((0, 1)),

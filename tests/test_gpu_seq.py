@@ -259,6 +259,29 @@ def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, K
     np.testing.assert_array_equal(got["frame_state"], want)
     np.testing.assert_array_equal(got["segment_start"], want_start)
     assert (want >= 0).mean() > 0.5 and want_start.sum() >= U
+    # the same alignment as RUNS (gh_align_runs): expanded, they are the frame labels; gathered run by run, the same rows
+    runs = lat.align_runs(b, utt_lattice=utt_graph)
+    np.testing.assert_array_equal(runs["end_cost_flat"], got["end_cost_flat"])
+    exp = np.full(b.N, -1, dtype=np.int32)
+    exp_start = np.zeros(b.N, dtype=bool)
+    for sid, lo, ln in zip(runs["state"], runs["start"], runs["length"]):
+        assert ln > 0 and (exp[lo:lo + ln] == -1).all()
+        exp[lo:lo + ln] = sid
+        exp_start[lo] = True
+    np.testing.assert_array_equal(exp, want)
+    np.testing.assert_array_equal(exp_start, want_start)
+    assert (np.diff(runs["start"]) > 0).all()                                  # utterance / time order
+    order = np.argsort(runs["state"], kind="stable")
+    rl = runs["length"][order]
+    g_runs = b.gather_runs(runs["start"][order], rl, np.cumsum(rl) - rl, int(rl.sum()))
+    rows = np.concatenate([np.arange(lo, lo + ln) for lo, ln in zip(runs["start"][order], rl)])
+    g_rows = b.gather(rows)
+    Xall = np.concatenate(xs)
+    gm = hip.PackedGMM(ctx, np.zeros((1, 1, Xall.shape[1])), np.ones((1, 1, Xall.shape[1])), np.ones((1, 1)))
+    np.testing.assert_array_equal(g_runs.loglik(gm), g_rows.loglik(gm))        # (the same rows in the same order)
+    np.testing.assert_allclose(g_runs.loglik(gm)[:, 0],
+                               0.5 * (Xall[rows] ** 2).sum(axis=1) + 0.5 * Xall.shape[1] * np.log(2 * np.pi), rtol=1e-12)
+    gm.close(); g_runs.close(); g_rows.close()
     # the same through the layer-form and the lean kernels (one graph for the whole batch)
     one = hip.Lattices(ctx, [graphs[utt_graph[0]]])
     p1 = one.viterbi(b, want_path=True)
