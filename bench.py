@@ -855,7 +855,7 @@ def _training_config(ctx, U, K=7):
     """configs[2]'s model on K-word transcripts (the reference's own training data are digit strings,
     continuous_speech.py:56-179): (a) the alignment + regrouping step of continuous_train -- own-state likelihoods,
     forced-alignment Viterbi through one graph per distinct transcript, frames regrouped per state
-    (gh_lattices_create_transcripts + gh_loglik_sets + gh_align_segments); (b) one soft-EM iteration on the same
+    (gh_lattices_create_transcripts + gh_loglik_sets + gh_align_runs); (b) one soft-EM iteration on the same
     transcripts: the device-resident session over word strings (gh_em_create_transcripts -- likelihoods of the
     transcripts' words, sequence-form forward-backward with lane = cell, statistics, M-step and re-pack on one stream;
     round 3 ran it call by call with a host M-step and graphs rebuilt from the new costs: 5.6 ms)."""
@@ -878,11 +878,11 @@ def _training_config(ctx, U, K=7):
     def align():
         lat = _hip.Lattices.from_transcripts(ctx, [wl["trans"]] * W, n, list(keys))
         b.loglik(gmm, fetch=False, state_sets=sets)
-        r = lat.align_segments(b, utt_lattice=utt_graph)
+        r = lat.align_runs(b, utt_lattice=utt_graph)       # the runs of every best path (state, first row, rows): ~N / 20 of them
         lat.close()
         return r
     t_align, r = _timeit(align)
-    fs = r["frame_state"]
+    assigned = float(r["length"].sum()) / float(b.N)
     b.close(); gmm.close()
     tr = BaumWelchTrainer(means0, wl["vars"], wl["w"], [wl["trans"]] * W, data, labels, device=ctx.device)
     hist = [tr.iteration()]
@@ -903,7 +903,7 @@ def _training_config(ctx, U, K=7):
     N = int(off[-1])
     return {"workload": "configs[2] model, %d utterances of %d words (%d frames, %d distinct transcripts)" % (U, K, N, len(keys)),
             "align_and_regroup": {"ms_per_call": t_align * 1e3, "utterances_per_s": U / t_align, "frames_per_s": N / t_align,
-                                  "frames_assigned_to_a_state": float(np.mean(fs >= 0))},
+                                  "frames_assigned_to_a_state": assigned, "runs": int(len(r["state"]))},
             "soft_em_iteration": {"ms_per_iteration": t_em * 1e3, "utterances_per_s": U / t_em, "frames_per_s": N / t_em,
                                   "device_resident_iteration": bool(resident), "phases": phases,
                                   "loglik_monotone": bool(all(y >= x - 1e-7 * abs(x) for x, y in zip(hist, hist[1:])))}}

@@ -38,6 +38,40 @@ def _variance_rows(x):
     return np.cov(x.T).diagonal()
 
 
+def _fast_partition_ok():
+    """np.random.randint(0, k, n) for a power of two k draws one 32-bit number per value and masks it (numpy's legacy
+    RandomState, `_rand_int64` with rng < 2^32 and mask == rng: no rejection) -- the SAME draws as a full-range uint32
+    randint.  Checked once against the installed numpy (state restored); False keeps the plain call."""
+    st = np.random.get_state()
+    try:
+        np.random.seed(12345)
+        a = [np.random.randint(0, k, 257) for k in (2, 4, 8, 16, 32)]
+        tail_a = np.random.randint(0, 1 << 30, 4)
+        np.random.seed(12345)
+        b = [np.random.randint(0, 1 << 32, 257, dtype=np.uint32) & np.uint32(k - 1) for k in (2, 4, 8, 16, 32)]
+        tail_b = np.random.randint(0, 1 << 30, 4)
+        return all(np.array_equal(x, y) for x, y in zip(a, b)) and np.array_equal(tail_a, tail_b)
+    except Exception:
+        return False
+    finally:
+        np.random.set_state(st)
+
+
+_FAST_PARTITION = None
+
+
+def random_partition(k, n):
+    """The random partition of kmeans.py:171 -- np.random.randint(0, k, n), the same values from the same draws of numpy's
+    global generator -- as uint8 from 32-bit draws when k is a power of two (half the time of the int64 path: 31 -> 14 ms
+    per outer iteration of continuous_train on 1.3 M frames x three binary splits)."""
+    global _FAST_PARTITION
+    if _FAST_PARTITION is None:
+        _FAST_PARTITION = _fast_partition_ok()
+    if _FAST_PARTITION and 2 <= k <= 256 and (k & (k - 1)) == 0:
+        return (np.random.randint(0, 1 << 32, int(n), dtype=np.uint32) & np.uint32(k - 1)).astype(np.uint8)
+    return np.random.randint(0, k, int(n))
+
+
 class LockstepFitter:
     """segments: list of [N_s, D] arrays, one per state, in the order the reference would train them.
     source: (resident batch, row indices) -- the rows of an fp64 batch that, in this order, ARE the concatenated
@@ -130,7 +164,7 @@ class LockstepFitter:
         if self.fit is not None:
             lens = np.diff(off)
             if partitions is None:
-                partitions = [np.random.randint(0, k, int(n)) for n in lens]
+                partitions = [random_partition(k, n) for n in lens]
             part = np.concatenate([np.asarray(p, dtype=np.uint8) for p in partitions]) if S else np.zeros(0, np.uint8)
             cen, cov, cnt, its = self.fit.kmeans(k, centroids, part, max_iteration=max_iteration, comm=self.comm)
             if self.comm is not None:
@@ -143,7 +177,7 @@ class LockstepFitter:
         cov = np.empty((S, k, D))
         part_stats = np.zeros((S, 2 * D + 1))
         for s, x in enumerate(self.segs):
-            part = np.random.randint(0, k, x.shape[0]) if partitions is None else partitions[s]
+            part = random_partition(k, x.shape[0]) if partitions is None else partitions[s]
             if self.sharded:      # variance of cluster 0 from sums over all ranks (ddof = 1), the only row that is used
                 x0 = x[part == 0]
                 part_stats[s, 0] = len(x0)
@@ -262,7 +296,7 @@ class LockstepFitter:
         # numpy's global generator is consumed the way the sequential algorithm consumes it: state after state, and
         # inside a state split after split (one draw of N_s cluster ids per kmeans call, kmeans.py:171; nothing else
         # in the refit draws) -- the draws only depend on the frame counts, so they can all be made up front
-        parts = [[np.random.randint(0, 2 ** (i + 1), int(n_s)) for i in range(n_splits)] for n_s in np.diff(self.seg_off)]
+        parts = [[random_partition(2 ** (i + 1), n_s) for i in range(n_splits)] for n_s in np.diff(self.seg_off)]
         for i in range(n_splits):
             k = 2 ** (i + 1)
             centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=1)

@@ -50,7 +50,7 @@ which = os.environ.get("LEVEL", "outer")
 tab = ((_hip.Batch, ["loglik"]), (_hip.Lattices, ["align_segments"]), (_hip.PackedGMM, ["update"]),
        (lockstep.LockstepFitter, ["split_and_fit", "segment_means", "__init__"]))
 if which == "inner":      # the calls inside the fitter instead of the fitter's own methods
-    tab = ((_hip.Batch, ["loglik", "gather", "close"]), (_hip.Lattices, ["align_segments", "from_transcripts", "close"]),
+    tab = ((_hip.Batch, ["loglik", "gather", "gather_runs", "close"]), (_hip.Lattices, ["align_segments", "align_runs", "from_transcripts", "close"]),
            (_hip.FitSession, ["__init__", "kmeans", "em", "segment_means", "close", "clusters", "group_stats"]))
 for cls, names in tab:
     for nm in names:
