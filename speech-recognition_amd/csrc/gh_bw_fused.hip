@@ -129,23 +129,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int m_j = WIDE ? (p - row_a * chunks) * 16 + j : (j & 7);
     const bool valid = s_j >= 0 && m_j < M;
     const int64_t g_j = valid ? (int64_t)s_j * M + m_j : 0;
+    // (round 4: the set-up used to be ~30 dependent memory round trips per wave -- every operand under `if (valid && d < D)`
+    //  was followed by s_waitcnt vmcnt(0), and sum mu^2 / var walked its D dimensions one load pair at a time.  Now: this
+    //  lane's KS / 2 dimensions d = 4 ks + q of mean and 1 / var in ONE batch of unconditional loads from clamped indices;
+    //  they are both operands AND this lane's share of sum mu^2 / var, which two shuffles add up over the four lane groups.)
     double P[KS];
+    double mu_r[KS / 2], iv_r[KS / 2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k = 4 * ks + q;
-        const int d = (k < KP) ? k : k - KP;
-        double v = 0.0;
-        if (valid && d < D) {
-            const double iv = ivar[g_j * D + d];
-            v = (k < KP) ? -0.5 * iv : mean[g_j * D + d] * iv;
-        }
-        P[ks] = v * GH_LSE_SCALE64;
+    for (int ks = 0; ks < KS / 2; ++ks) {
+        const int d = 4 * ks + q;
+        const int64_t at = g_j * D + (d < D ? d : 0);
+        mu_r[ks] = mean[at];
+        iv_r[ks] = ivar[at];
     }
+    const double lc = logc[g_j];
+    double sm2 = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS / 2; ++ks) {
+        const bool in = valid && 4 * ks + q < D;
+        const double iv = in ? iv_r[ks] : 0.0, mu = in ? mu_r[ks] : 0.0;
+        P[ks] = -0.5 * iv * GH_LSE_SCALE64;                    // k = 4 ks + q < KP: the x^2 half
+        P[KS / 2 + ks] = mu * iv * GH_LSE_SCALE64;            // k - KP: the x half, same dimension
+        sm2 = fma(mu * iv, mu, sm2);
+    }
+    sm2 += __shfl_xor(sm2, 16);
+    sm2 += __shfl_xor(sm2, 32);
     double Cj = GH_LSE_OFF64;
     if (valid) {
-        double sm2 = 0;
-        for (int d = 0; d < D; ++d) { const double mu = mean[g_j * D + d]; sm2 = fma(mu * ivar[g_j * D + d], mu, sm2); }
-        const double c = logc[g_j] - 0.5 * sm2;
+        const double c = lc - 0.5 * sm2;
         Cj = (c == -INFINITY) ? GH_LSE_OFF64 : bwf_vmax(c * GH_LSE_SCALE64, GH_LSE_OFF64);
     }
     // accumulation operand A = Z^T: this lane feeds column 16 t + j of the linear tiles (x[d] - c[d]; d = D: the ones
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int t = 0; t < LT; ++t) {
         const int d = t * 16 + j;
         dd[t] = (d <= D && d < DP) ? d : D;                     // columns behind the ones column read the zero padding too
-        cs[t] = (d < D) ? mean[(int64_t)sa * M * D + d] : (d == D ? -1.0 : 0.0);
+        const double cm = mean[(int64_t)sa * M * D + (d < D ? d : 0)];   // (unconditional: see above)
+        cs[t] = (d < D) ? cm : (d == D ? -1.0 : 0.0);
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = (v4d){0, 0, 0, 0};
