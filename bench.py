@@ -733,6 +733,14 @@ def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D
     off_b = np.concatenate([[0], np.cumsum(T)]).astype(np.int64)
     base = _hip.Batch(ctx, feats=np.ascontiguousarray(X, dtype=npdt), offsets=off_b, dtype=npdt)
     b = base.tile(reps)
+    # every copy becomes an utterance of its own: independent noise of a quarter of a standard deviation per feature,
+    # generated on the device (gh_batch_jitter) -- synthesising 39 M distinct frames on the host costs ~12 GB and ~1 min
+    # per rank; copy 0 stays what the host made, so the distinct-utterance checks below still see `base`
+    jitter = 0.25
+    if reps > 1 and hasattr(b, "jitter"):
+        b.jitter(seed=1005 + 7919 * group.rank, scale=jitter)
+    else:
+        jitter = 0.0
     N = b.N
     gmm = _hip.PackedGMM(ctx, means.reshape(S, M, D), vars_.reshape(S, M, D), wl["w"].reshape(S, M))
     group.barrier()
@@ -769,8 +777,10 @@ def _continuous_config(ctx, group, U_total, U_base, npdt, K=7, W=10, n=5, M=8, D
         tm = group.maxv([t_ll, t_dec])
         tot = group.sum([float(U), float(N), acc, path_mis, lab_mis])
         g_ll, g_dec = float(tm[0]), float(tm[1])
-        out[key] = {"workload": "configs[4] per-GPU share: %d utterances (%d distinct, tiled x%d on the device), K=%d words, "
-                                "%d lattice rows" % (U, U_base, reps, K, R),
+        out[key] = {"workload": "configs[4] per-GPU share: %d utterances (%d synthesised on the host, tiled x%d on the device%s), "
+                                "K=%d words, %d lattice rows"
+                                % (U, U_base, reps, ", every copy with its own N(0, %.2f^2) noise per feature" % jitter if jitter else "", K, R),
+                    "distinct_utterances": int(U if jitter else U_base),
                     "n_gpus": group.world, "utterances": int(tot[0]), "frames": int(tot[1]), "lattice_rows": R,
                     "ms": (g_ll + g_dec) * 1e3, "loglik_ms": g_ll * 1e3, "viterbi_labels_ms": g_dec * 1e3,
                     "value": tot[0] / (g_ll + g_dec), "unit": "utterances/s", "dp_cells_per_s": tot[1] * R / g_dec,

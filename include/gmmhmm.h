@@ -131,6 +131,10 @@ int gh_batch_gather(gh_ctx* ctx, const gh_batch* src, const int64_t* idx /*[n]*/
  * [dest[r], ...) of the result (n rows in all; the runs must tile it exactly). */
 int gh_batch_gather_runs(gh_ctx* ctx, const gh_batch* src, int64_t n_runs, const int64_t* start, const int64_t* len,
                          const int64_t* dest, int64_t n, int64_t U, const int64_t* utt_offsets /*[U+1]*/, gh_batch** out);
+/* feats += scale * z, z ~ N(0, 1) independent per feature from a counter-based generator keyed on (seed, element): the
+ * copies of a tiled batch (gh_batch_tile) become utterances of their own on the device.  Not in the reference (its data
+ * come from files); for synthetic workloads at sizes whose host synthesis would cost more than the run. */
+int gh_batch_jitter(gh_ctx* ctx, gh_batch* b, uint64_t seed, double scale);
 /* `reps` copies of a resident batch back to back as a new resident batch of reps * U utterances (device-to-device
  * copies; measurement plumbing: a large batch from a small upload; no reference counterpart) */
 int gh_batch_tile(gh_ctx* ctx, const gh_batch* src, int reps, gh_batch** out);

@@ -47,6 +47,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_void_p)]),
     "gh_host_unpin": (C.c_int, [C.c_void_p]),
     "gh_batch_gather": (C.c_int, [C.c_void_p, C.c_void_p, _c_i64p, C.c_int64, C.c_int64, _c_i64p, C.POINTER(C.c_void_p)]),
+    "gh_batch_jitter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double]),
     "gh_batch_gather_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _c_i64p, _c_i64p, _c_i64p, C.c_int64, C.c_int64, _c_i64p,
                                        C.POINTER(C.c_void_p)]),
     "gh_batch_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -843,6 +844,12 @@ class Batch:
                                                                _ptr(off, _c_i64p), C.byref(h)))
         new.h = h
         return new
+
+    def jitter(self, seed, scale):
+        """feats += scale * N(0, 1), independent per feature, generated on the device (gh_batch_jitter): the copies of a
+        tiled batch become utterances of their own."""
+        _check(self.ctx.lib, self.ctx.lib.gh_batch_jitter(self.ctx.h, self.h, int(seed) & (2 ** 64 - 1), float(scale)))
+        return self
 
     def tile(self, reps):
         """`reps` copies of this batch back to back as a new resident batch (gh_batch_tile: device-to-device)."""

@@ -1067,3 +1067,36 @@ def test_chain_forward_backward_with_16_lanes_equals_generic(hip, ctx, n, dtype,
     np.testing.assert_allclose(got["self_xi"], ref["self_xi"], rtol=1e-8, atol=1e-10)
     for h in (b, lat, gmm):
         h.close()
+
+
+def test_batch_jitter_makes_the_copies_of_a_tiled_batch_distinct():
+    """gh_batch_jitter: independent N(0, scale^2) noise per feature from a counter-based generator -- deterministic for a
+    seed, different for another, mean / variance as asked, fp32 and fp64; the likelihoods of the jittered batch are those
+    of its own (changed) frames."""
+    from sr.recognition import _hip
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(4)
+    D, T = 7, 500
+    X = rng.normal(size=(T, D))
+    gm = _hip.PackedGMM(ctx, np.zeros((1, 1, D)), np.ones((1, 1, D)), np.ones((1, 1)))
+
+    def frames_of(b):        # recover sum x^2 per frame from the unit Gaussian's cost
+        return 2.0 * (b.loglik(gm)[:, 0].astype(np.float64) - 0.5 * D * np.log(2 * np.pi))
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        base = _hip.Batch(ctx, feats=X.astype(dt), offsets=[0, T], dtype=dt)
+        a = base.tile(40).jitter(seed=11, scale=0.5)
+        b = base.tile(40).jitter(seed=11, scale=0.5)
+        c = base.tile(40).jitter(seed=12, scale=0.5)
+        qa, qb, qc, q0 = frames_of(a), frames_of(b), frames_of(c), frames_of(base)
+        np.testing.assert_array_equal(qa, qb)
+        assert np.mean(qa != qc) > 0.999
+        # E[sum (x + e)^2 - sum x^2] = D scale^2; copies differ from each other
+        d = qa.reshape(40, T) - q0[None, :]
+        np.testing.assert_allclose(d.mean(), D * 0.25, rtol=0.05)
+        assert np.mean(qa.reshape(40, T)[0] != qa.reshape(40, T)[1]) > 0.999
+        # scale 0 changes nothing
+        z = base.tile(3).jitter(seed=5, scale=0.0)
+        np.testing.assert_allclose(frames_of(z).reshape(3, T), np.tile(q0, (3, 1)), rtol=tol, atol=tol)
+        for h in (a, b, c, z, base):
+            h.close()
+    gm.close()
