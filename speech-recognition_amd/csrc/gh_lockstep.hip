@@ -21,20 +21,43 @@ constexpr int LS_MAXD = 64;   // feature dimensions a lane keeps in registers
 
 struct ls_tile { int64_t first; int32_t state, count; };
 
-// stage a tile of <= 64 frames: coalesced global -> LDS [64][D + 1], then lane = frame -> registers
+// stage a tile of <= 64 frames: coalesced global -> LDS [64][D | 1], then lane = frame -> registers.
+// Row stride TS = D | 1: odd, so the lane = frame reads below touch 32 banks (stride D + 1 = 40 doubles for D = 39 put them
+// on 4: an 8-way conflict per read); for odd D the tile is simply the frames as they lie in memory, element i at slot i.
+__device__ __forceinline__ int tile_stride(int D) { return D | 1; }
 template <int DR>
 __device__ __forceinline__ void stage_tile(const double* __restrict__ X, int64_t first, int count, int D, double* tile,
                                            double (&x)[DR]) {
     const int lane = threadIdx.x;
     const double* src = X + first * D;
-    const int nelem = count * D;
-    for (int i = lane; i < nelem; i += 64) {
-        const int f = i / D, d = i - f * D;
-        tile[f * (D + 1) + d] = src[i];
+    const int nelem = count * D;                 // 1 .. 64 D <= 64 DR
+    const int TS = tile_stride(D);
+    // ALL the tile's loads in flight before the first LDS write (round 4: the loop `tile[..] = src[i]` was one HBM round
+    // trip per 64 elements -- 39 in a row for a 64 x 39 tile -- and an integer division per element); unconditional, from
+    // a clamped index
+    double r[DR];
+#pragma unroll
+    for (int it = 0; it < DR; ++it) {
+        const int i = lane + 64 * it;
+        r[it] = src[i < nelem ? i : nelem - 1];
+    }
+    if (D & 1) {
+#pragma unroll
+        for (int it = 0; it < DR; ++it) if (lane + 64 * it < nelem) tile[lane + 64 * it] = r[it];
+    } else {                                     // one pad slot per frame: element i of frame f at slot i + f
+        int f = lane / D, d = lane - f * D;
+        const int q64 = 64 / D, r64 = 64 - q64 * D;
+#pragma unroll
+        for (int it = 0; it < DR; ++it) {
+            if (lane + 64 * it < nelem) tile[lane + 64 * it + f] = r[it];
+            d += r64;
+            f += q64;
+            if (d >= D) { d -= D; ++f; }
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < DR; ++d) x[d] = (d < D && lane < count) ? tile[lane * (D + 1) + d] : 0.0;
+    for (int d = 0; d < DR; ++d) x[d] = (d < D && lane < count) ? tile[lane * TS + d] : 0.0;
     __syncthreads();
 }
 
@@ -204,6 +227,7 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
     if (active && !active[tl.state]) return;
     const int lane = threadIdx.x;
     const double* c0 = cent + (int64_t)tl.state * k * D;
+#pragma unroll 8
     for (int i = lane; i < k * D; i += 64) sc[i] = c0[i];
     if (var) for (int i = lane; i < D; i += 64) {     // (vstride: [S,k,D] variances, cluster 0's row)
         const double v = var[(int64_t)tl.state * (vstride ? vstride : D) + i];
@@ -214,13 +238,16 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
     double best = 0;
     int bi = 0;
     const double ld = var ? logdet[tl.state] : 0.0;
+    double svr[DR];                                               // the state's (inverse) variances: read from LDS once, not once per cluster
+#pragma unroll
+    for (int d = 0; d < DR; ++d) svr[d] = (var && d < D) ? sv[d] : 1.0;
     for (int c = 0; c < k; ++c) {
         double q = 0, dist;
         if (var) {
 #pragma unroll
             for (int d = 0; d < DR; ++d) if (d < D) {
                 const double t = sc[c * D + d] - x[d];
-                if (RECIP) q += t * sv[d] * t; else q += t / sv[d] * t;
+                if (RECIP) q += t * svr[d] * t; else q += t / svr[d] * t;
             }
             dist = ld + 0.5 * q;                                   // mahalanobis(centroid, x, cov[0]), kmeans.py:183
         } else {
@@ -292,6 +319,7 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
     if (active && !active[tl.state]) return;
     const int lane = threadIdx.x;
     const int64_t pbase = (int64_t)tl.state * k;
+#pragma unroll 8
     for (int i = lane; i < k * D; i += 64) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
     for (int i = lane; i < k; i += 64) pc[i] = logc[pbase + i];
     double x[DR];
@@ -324,6 +352,7 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
     }
     __syncthreads();
     const int Wd = 1 + 2 * D;
+    const int TS = tile_stride(D);
     double* out = partial + (int64_t)blockIdx.x * (k * Wd + 1);
     for (int p = lane; p < k * (D + 1); p += 64) {      // lane = (component, dimension) pair; dimension D = the occupancy
         const int c = p / (D + 1), d = p - c * (D + 1);
@@ -335,7 +364,7 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
         } else {
             const double m = pm[c * D + d];
             for (int f = 0; f < tl.count; ++f) {
-                const double xv = tile[f * (D + 1) + d] - m;    // centred on the current mean
+                const double xv = tile[f * TS + d] - m;         // centred on the current mean
                 const double rx = r[f] * xv;
                 a1 += rx;
                 a2 = fma(rx, xv, a2);
