@@ -39,7 +39,11 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ X, int64_t
 #pragma unroll
     for (int it = 0; it < DR; ++it) {
         const int i = lane + 64 * it;
+#ifdef EMV_NOSTAGE
+        r[it] = 0.001 * (double)(i & 255);
+#else
         r[it] = src[i < nelem ? i : nelem - 1];
+#endif
     }
     if (D & 1) {
 #pragma unroll
@@ -332,7 +336,11 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
         for (int c = 0; c < k; ++c) {
             double q = 0;
 #pragma unroll
+#ifdef EMV_NOPHASE1   // diagnostic builds (tools/emv_variants.sh): timing only, results wrong
+            for (int d = 0; d < 1; ++d) q = x[c % DR];
+#else
             for (int d = 0; d < DR; ++d) if (d < D) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
+#endif
             double l = pc[c] - 0.5 * q;
             bad |= (l != l);
             if (-0.5 * q < LS_LN_UNDERFLOW || l < LS_LN_UNDERFLOW) l = -INFINITY;   // the reference's linear-domain product is 0
@@ -341,7 +349,11 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
         }
         double sum = 0;
         for (int c = 0; c < k; ++c) {
+#ifdef EMV_NOEXP
+            const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
+#else
             const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
+#endif
             rt[c * 64 + lane] = e;
             sum += e;
         }
@@ -354,7 +366,12 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
     const int Wd = 1 + 2 * D;
     const int TS = tile_stride(D);
     double* out = partial + (int64_t)blockIdx.x * (k * Wd + 1);
+#ifdef EMV_NOPHASE2
+    if (lane < k) out[lane * Wd] = rt[lane * 64];
+    for (int p = lane + 1000000; p < k * (D + 1); p += 64) {
+#else
     for (int p = lane; p < k * (D + 1); p += 64) {      // lane = (component, dimension) pair; dimension D = the occupancy
+#endif
         const int c = p / (D + 1), d = p - c * (D + 1);
         const double* r = rt + c * 64;
         double a1 = 0, a2 = 0;
