@@ -68,7 +68,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
             h.mu, h.sigma, h.transitions, h.segments = _km.skmeans(ys, n_segments, return_segmented_data=True)
         else:
             h.mu, h.sigma, h.transitions, starts = fitted[w]
-            h.segments = _km.segment_data(ys, len(ys), n_segments, starts)
+            h.segments = _km.segment_data_fast(ys, n_segments, starts)
     if not use_gmm:
         return models
     for h in models:
@@ -100,12 +100,16 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
         frames.close()
         lat.close()
     off = np.concatenate([[0], np.cumsum([len(ts) for ts in templates_by_word])])
+    # get_segments_from_path for all templates at once: visits of every chain row on the path, cumulated (kmeans.py:98-108)
+    paths = res["paths"]
+    plen = np.array([len(p) for p in paths], dtype=np.int64)
+    rows = (np.concatenate([np.asarray(p)[:, 0] for p in paths]) if len(paths) and plen.sum() else np.zeros(0, dtype=np.int64)).astype(np.int64)
+    tid = np.repeat(np.arange(len(paths)), plen)
+    counts = np.bincount(tid * n + rows, minlength=len(paths) * n).reshape(len(paths), n)   # (rows: chain rows 0 .. n-1 of the word's own graph)
+    starts_all = np.zeros((len(paths), n), dtype=np.int64)
+    np.cumsum(counts[:, :-1], axis=1, out=starts_all[:, 1:])
     for w, h in enumerate(models):
-        ys = templates_by_word[w]
-        starts = np.zeros((len(ys), n), dtype=np.int64)
-        for r in range(len(ys)):
-            starts[r, 1:] = _km.get_segments_from_path(res["paths"][off[w] + r], n)
-        h.segments = _km.segment_data(ys, len(ys), n, starts)
+        h.segments = _km.segment_data_fast(templates_by_word[w], n, starts_all[off[w]:off[w + 1]])
     return models
 
 
