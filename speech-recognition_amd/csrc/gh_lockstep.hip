@@ -214,38 +214,72 @@ __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restr
 // the refit (437 us per sweep of 1.4 M frames).  The two forms differ in the last bit of a term; an assignment changes
 // only where two centroids tie to ~1e-16 relative.  The device-resident refit takes RECIP (goldens G8 / G10 / G11 / G17:
 // identical cluster ids); GMMHMM_KMEANS_EXACT=1 and the call-by-call gh_kmeans_assign_multi keep the division.
+// TWO waves per tile, like em_multi_kernel below: the waves share the tile (here only a transposition buffer) and the
+// centroids; each takes half of the clusters, and wave 0 joins the two candidates with the rule of the one-wave loop
+// (np.argmin: the first minimum, a NaN before everything) -- the same assignment, the chains of 39 dependent terms per
+// cluster running two abreast on twice the waves per CU.
 template <int DR, bool RECIP = false>
-__global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
-                                                          const double* __restrict__ cent /*[S,k,D]*/,
-                                                          const double* __restrict__ var /*[S,D] or null*/,
-                                                          const double* __restrict__ logdet /*[S]*/,
-                                                          int32_t* __restrict__ clusters /*[N] in/out*/,
-                                                          int32_t* __restrict__ changed /*[S] or null*/,
-                                                          int32_t* __restrict__ counts /*[tiles][k] or null*/,
-                                                          const uint8_t* __restrict__ active = nullptr, int vstride = 0) {
+__global__ __launch_bounds__(128) void kmeans_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
+                                                           const double* __restrict__ cent /*[S,k,D]*/,
+                                                           const double* __restrict__ var /*[S,D] or null*/,
+                                                           const double* __restrict__ logdet /*[S]*/,
+                                                           int32_t* __restrict__ clusters /*[N] in/out*/,
+                                                           int32_t* __restrict__ changed /*[S] or null*/,
+                                                           int32_t* __restrict__ counts /*[tiles][k] or null*/,
+                                                           const uint8_t* __restrict__ active = nullptr, int vstride = 0) {
+    static_assert(DR % 2 == 0, "the tile is staged by 128 threads");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* sc = sm;                  // [k][D]
     double* sv = sc + k * D;          // [D]
-    double* tile = sv + D;            // [64][D+1]
+    double* tile = sv + D;            // [64][D | 1]; afterwards: wave 1's candidates
     const ls_tile tl = tiles[blockIdx.x];
     if (active && !active[tl.state]) return;
-    const int lane = threadIdx.x;
-    const double* c0 = cent + (int64_t)tl.state * k * D;
-#pragma unroll 8
-    for (int i = lane; i < k * D; i += 64) sc[i] = c0[i];
-    if (var) for (int i = lane; i < D; i += 64) {     // (vstride: [S,k,D] variances, cluster 0's row)
-        const double v = var[(int64_t)tl.state * (vstride ? vstride : D) + i];
-        sv[i] = RECIP ? 1.0 / v : v;
-    }
-    double x[DR];
-    stage_tile<DR>(X, tl.first, tl.count, D, tile, x);
-    double best = 0;
-    int bi = 0;
-    const double ld = var ? logdet[tl.state] : 0.0;
-    double svr[DR];                                               // the state's (inverse) variances: read from LDS once, not once per cluster
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int TS = tile_stride(D);
+    {
+        const double* src = X + tl.first * D;
+        const int nelem = tl.count * D;
+        double r[DR / 2];
 #pragma unroll
-    for (int d = 0; d < DR; ++d) svr[d] = (var && d < D) ? sv[d] : 1.0;
-    for (int c = 0; c < k; ++c) {
+        for (int it = 0; it < DR / 2; ++it) {
+            const int i = tid + 128 * it;
+            r[it] = src[i < nelem ? i : nelem - 1];
+        }
+        const double* c0 = cent + (int64_t)tl.state * k * D;
+#pragma unroll 4
+        for (int i = tid; i < k * D; i += 128) sc[i] = c0[i];
+        if (var && tid < D) {                         // (vstride: [S,k,D] variances, cluster 0's row; D <= 64)
+            const double v = var[(int64_t)tl.state * (vstride ? vstride : D) + tid];
+            sv[tid] = RECIP ? 1.0 / v : v;
+        }
+        if (D & 1) {
+#pragma unroll
+            for (int it = 0; it < DR / 2; ++it) if (tid + 128 * it < nelem) tile[tid + 128 * it] = r[it];
+        } else {
+            int f = tid / D, d = tid - f * D;
+            const int q128 = 128 / D, r128 = 128 - q128 * D;
+#pragma unroll
+            for (int it = 0; it < DR / 2; ++it) {
+                if (tid + 128 * it < nelem) tile[tid + 128 * it + f] = r[it];
+                d += r128;
+                f += q128;
+                if (d >= D) { d -= D; ++f; }
+            }
+        }
+    }
+    __syncthreads();
+    double x[DR], svr[DR];
+#pragma unroll
+    for (int d = 0; d < DR; ++d) {
+        x[d] = (d < D && lane < tl.count) ? tile[lane * TS + d] : 0.0;
+        svr[d] = (var && d < D) ? sv[d] : 1.0;        // the state's (inverse) variances: out of LDS once, not once per cluster
+    }
+    __syncthreads();                                  // (the tile has been read: it becomes the exchange buffer)
+    const double ld = var ? logdet[tl.state] : 0.0;
+    const int kh = (k + 1) >> 1, c_lo = wv * kh, c_hi = (c_lo + kh < k) ? c_lo + kh : k;
+    double best = 0;
+    int bi = -1;                                      // (-1: this wave has no cluster, k = 1)
+    for (int c = c_lo; c < c_hi; ++c) {
         double q = 0, dist;
         if (var) {
 #pragma unroll
@@ -259,7 +293,17 @@ __global__ __launch_bounds__(64) void kmeans_multi_kernel(const double* __restri
             for (int d = 0; d < DR; ++d) if (d < D) { const double t = sc[c * D + d] - x[d]; q = fma(t, t, q); }
             dist = sqrt(q);
         }
-        if (c == 0 || dist < best || (dist != dist && best == best)) { best = dist; bi = c; }   // np.argmin
+        if (c == c_lo || dist < best || (dist != dist && best == best)) { best = dist; bi = c; }   // np.argmin
+    }
+    double* xb = tile;                                             // [64] wave 1's best distance
+    int* xi = reinterpret_cast<int*>(tile + 64);                   // [64] ... and its cluster
+    if (wv == 1) { xb[lane] = best; xi[lane] = bi; }
+    __syncthreads();
+    if (wv == 1) return;
+    {
+        const double d1 = xb[lane];
+        const int b1 = xi[lane];
+        if (b1 >= 0 && (d1 < best || (d1 != d1 && best == best))) { best = d1; bi = b1; }
     }
     const bool act = lane < tl.count;
     if (act) {
@@ -306,71 +350,116 @@ __global__ __launch_bounds__(256) void tiles_reduce_kernel(const double* __restr
 // ------------------------------------------------------------------------------------------------ EM E-step
 constexpr double LS_LN_UNDERFLOW = -745.1332191019412;   // exp(x) rounds to +0 in fp64 below this (see gh_train.hip)
 
+// TWO waves per tile (round 4, after tools/emv_variants.sh: the kernel is arithmetic on dependent chains -- 39 fma per
+// density, 64 adds per sum -- at 1.25 waves per SIMD, held there by its 30 KB of LDS): the waves share the tile and the
+// parameters in LDS; each takes half of the components in phase 1 and half of the (component, dimension) sums in phase 2,
+// so every chain is as long as before but twice as many run side by side, on twice the waves per CU.  Every number is
+// computed by the same operations in the same order as with one wave: the results are bitwise those of the one-wave kernel.
 template <int DR>
-__global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
-                                                      const double* __restrict__ mean /*[S,k,D]*/,
-                                                      const double* __restrict__ ivar /*[S,k,D]*/,
-                                                      const double* __restrict__ logc /*[S,k]*/,
-                                                      double* __restrict__ partial /*[tiles][k*(1+2D) + 1]*/,
-                                                      const uint8_t* __restrict__ active = nullptr) {
+__global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
+                                                       const double* __restrict__ mean /*[S,k,D]*/,
+                                                       const double* __restrict__ ivar /*[S,k,D]*/,
+                                                       const double* __restrict__ logc /*[S,k]*/,
+                                                       double* __restrict__ partial /*[tiles][k*(1+2D) + 1]*/,
+                                                       const uint8_t* __restrict__ active = nullptr) {
+    static_assert(DR % 2 == 0, "the tile is staged by 128 threads");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* pm = sm;                  // [k][D]
     double* pv = pm + k * D;          // [k][D]
     double* pc = pv + k * D;          // [k]
-    double* rt = pc + k;              // [k][64] responsibilities
-    double* tile = rt + k * 64;       // [64][D+1]
+    double* rt = pc + k;              // [k][64] log-densities, then responsibilities
+    double* tile = rt + k * 64;       // [64][D | 1]
     const ls_tile tl = tiles[blockIdx.x];
     if (active && !active[tl.state]) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int TS = tile_stride(D);
     const int64_t pbase = (int64_t)tl.state * k;
-#pragma unroll 8
-    for (int i = lane; i < k * D; i += 64) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
-    for (int i = lane; i < k; i += 64) pc[i] = logc[pbase + i];
-    double x[DR];
-    stage_tile<DR>(X, tl.first, tl.count, D, tile, x);
-    double ll = 0;   // (the frames stay in LDS: the centred sums below read them again)
+    // ---- the tile's frames (all loads in flight first, see stage_tile) and the state's parameters ----
     {
-        double mx = -INFINITY;
-        bool bad = false;
-#pragma unroll 1
-        for (int c = 0; c < k; ++c) {
-            double q = 0;
+        const double* src = X + tl.first * D;
+        const int nelem = tl.count * D;
+        double r[DR / 2];
 #pragma unroll
-#ifdef EMV_NOPHASE1   // diagnostic builds (tools/emv_variants.sh): timing only, results wrong
-            for (int d = 0; d < 1; ++d) q = x[c % DR];
+        for (int it = 0; it < DR / 2; ++it) {
+            const int i = tid + 128 * it;
+#ifdef EMV_NOSTAGE   // diagnostic builds (tools/emv_variants.sh): timing only, results wrong
+            r[it] = 0.001 * (double)(i & 255);
 #else
-            for (int d = 0; d < DR; ++d) if (d < D) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
+            r[it] = src[i < nelem ? i : nelem - 1];
 #endif
-            double l = pc[c] - 0.5 * q;
-            bad |= (l != l);
-            if (-0.5 * q < LS_LN_UNDERFLOW || l < LS_LN_UNDERFLOW) l = -INFINITY;   // the reference's linear-domain product is 0
-            rt[c * 64 + lane] = l;
-            mx = fmax(mx, l);
         }
-        double sum = 0;
-        for (int c = 0; c < k; ++c) {
-#ifdef EMV_NOEXP
-            const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
-#else
-            const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
-#endif
-            rt[c * 64 + lane] = e;
-            sum += e;
+#pragma unroll 4
+        for (int i = tid; i < k * D; i += 128) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
+        if (tid < k) pc[tid] = logc[pbase + tid];
+        if (D & 1) {
+#pragma unroll
+            for (int it = 0; it < DR / 2; ++it) if (tid + 128 * it < nelem) tile[tid + 128 * it] = r[it];
+        } else {                                 // one pad slot per frame: element i of frame f at slot i + f
+            int f = tid / D, d = tid - f * D;
+            const int q128 = 128 / D, r128 = 128 - q128 * D;
+#pragma unroll
+            for (int it = 0; it < DR / 2; ++it) {
+                if (tid + 128 * it < nelem) tile[tid + 128 * it + f] = r[it];
+                d += r128;
+                f += q128;
+                if (d >= D) { d -= D; ++f; }
+            }
         }
-        const double inv = bad ? NAN : (sum > 0 ? 1.0 / sum : 0.0);
-        const bool act = lane < tl.count;
-        for (int c = 0; c < k; ++c) rt[c * 64 + lane] = act ? (bad ? NAN : rt[c * 64 + lane] * inv) : 0.0;
-        if (act) ll = bad ? NAN : (sum > 0 ? mx + log(sum) : 0.0);
     }
     __syncthreads();
+    double x[DR];
+#pragma unroll
+    for (int d = 0; d < DR; ++d) x[d] = (d < D && lane < tl.count) ? tile[lane * TS + d] : 0.0;
+    // ---- phase 1: log-densities of this wave's half of the components, frame = lane ----
+    const int kh = (k + 1) >> 1, c_lo = wv * kh, c_hi = (c_lo + kh < k) ? c_lo + kh : k;
+#pragma unroll 1
+    for (int c = c_lo; c < c_hi; ++c) {
+        double q = 0;
+#pragma unroll
+#ifdef EMV_NOPHASE1
+        for (int d = 0; d < 1; ++d) q = x[c % DR];
+#else
+        for (int d = 0; d < DR; ++d) if (d < D) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
+#endif
+        double l = pc[c] - 0.5 * q;
+        const bool nan_l = l != l;
+        if (-0.5 * q < LS_LN_UNDERFLOW || l < LS_LN_UNDERFLOW) l = -INFINITY;   // the reference's linear-domain product is 0
+        rt[c * 64 + lane] = nan_l ? NAN : l;     // (a NaN stays visible to both waves: everything of the frame is NaN then)
+    }
+    __syncthreads();
+    // ---- both waves: maximum and sum over ALL components, in component order (the one-wave kernel's order) ----
+    double mx = -INFINITY, sum = 0, ll = 0;
+    bool bad = false;
+    for (int c = 0; c < k; ++c) { const double l = rt[c * 64 + lane]; bad |= (l != l); mx = fmax(mx, l); }
+    for (int c = 0; c < k; ++c) {
+#ifdef EMV_NOEXP
+        const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
+#else
+        const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
+#endif
+        sum += e;
+    }
+    const double inv = bad ? NAN : (sum > 0 ? 1.0 / sum : 0.0);
+    const bool act = lane < tl.count;
+    if (act && wv == 0) ll = bad ? NAN : (sum > 0 ? mx + log(sum) : 0.0);
+    __syncthreads();                              // (every log-density has been read: the responsibilities may replace them)
+    for (int c = c_lo; c < c_hi; ++c) {
+#ifdef EMV_NOEXP
+        const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
+#else
+        const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
+#endif
+        rt[c * 64 + lane] = act ? (bad ? NAN : e * inv) : 0.0;
+    }
+    __syncthreads();
+    // ---- phase 2: thread = (component, dimension) pair; dimension D = the occupancy; the sums run over the frames in order ----
     const int Wd = 1 + 2 * D;
-    const int TS = tile_stride(D);
     double* out = partial + (int64_t)blockIdx.x * (k * Wd + 1);
 #ifdef EMV_NOPHASE2
-    if (lane < k) out[lane * Wd] = rt[lane * 64];
-    for (int p = lane + 1000000; p < k * (D + 1); p += 64) {
+    if (tid < k) out[tid * Wd] = rt[tid * 64];
+    for (int p = tid + 1000000; p < k * (D + 1); p += 128) {
 #else
-    for (int p = lane; p < k * (D + 1); p += 64) {      // lane = (component, dimension) pair; dimension D = the occupancy
+    for (int p = tid; p < k * (D + 1); p += 128) {
 #endif
         const int c = p / (D + 1), d = p - c * (D + 1);
         const double* r = rt + c * 64;
@@ -390,10 +479,12 @@ __global__ __launch_bounds__(64) void em_multi_kernel(const double* __restrict__
             out[c * Wd + 1 + D + d] = a2;
         }
     }
-    // log-likelihood of the tile
+    // log-likelihood of the tile (wave 0 holds it)
+    if (wv == 0) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ll += __shfl_xor(ll, o);
-    if (lane == 0) out[k * Wd] = ll;
+        for (int o = 32; o >= 1; o >>= 1) ll += __shfl_xor(ll, o);
+        if (lane == 0) out[k * Wd] = ll;
+    }
 }
 
 int build_tiles(int S, const int64_t* seg_off, const uint8_t* active, std::vector<ls_tile>& tiles, std::vector<int32_t>& tile_ptr) {
@@ -496,7 +587,7 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     if (var) GH_HIP(hipMemcpyAsync(d_var, var, (size_t)S * D * 8, hipMemcpyHostToDevice, st));
     const size_t lds = ((size_t)k * D + D + 64 * (size_t)(D + 1)) * 8 + 64 * 4 + 16;
     GH_REQUIRE(lds <= 150 * 1024, "gh_kmeans_assign_multi: k=%d x D=%d does not fit LDS", k, D);
-    const dim3 grid((unsigned)tiles.size()), blk(64);
+    const dim3 grid((unsigned)tiles.size()), blk(128);
 #define GH_KM(DR) hipLaunchKernelGGL((kmeans_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_cent, \
                                      d_var, d_ld, d_cl, out_changed ? d_changed : nullptr, d_tilecnt, nullptr)
     if (D <= 16) GH_KM(16); else if (D <= 40) GH_KM(40); else GH_KM(64);
@@ -508,7 +599,7 @@ extern "C" int gh_kmeans_assign_multi(gh_ctx* ctx, const gh_batch* b, int S, con
         GH_HIP(hipMemsetAsync(d_sums, 0, (size_t)S * plen * 8, st));
         GH_HIP(hipMemcpyAsync(d_tptr, tile_ptr.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(kmeans_scan_kernel, dim3((unsigned)S), dim3(256), 0, st, d_tptr, k, d_tilecnt, d_counts, d_cbase, nullptr);
-        hipLaunchKernelGGL(kmeans_scatter_kernel, grid, blk, 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists, nullptr);
+        hipLaunchKernelGGL(kmeans_scatter_kernel, grid, dim3(64), 0, st, d_tiles, k, d_cl, d_segoff, d_tilecnt, d_cbase, d_lists, nullptr);   // (one wave per tile)
         hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, dim3((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64)), dim3(64), 0, st,
                            (const double*)b->feats, D, k, d_segoff, d_active, d_lists, d_counts, d_cbase, d_sums, plen, nullptr, 0);
         GH_HIP(hipGetLastError());
@@ -566,7 +657,7 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     const size_t lds = ((size_t)2 * k * D + k + (size_t)k * 64 + 64 * (size_t)(D + 1)) * 8 + 16;
     GH_REQUIRE(lds <= 150 * 1024, "gh_em_accumulate_multi: k=%d x D=%d does not fit LDS", k, D);
     if (!tiles.empty()) {
-        const dim3 grid((unsigned)tiles.size()), blk(64);
+        const dim3 grid((unsigned)tiles.size()), blk(128);
 #define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_mean, d_ivar, \
                                      d_logc, d_part, nullptr)
         if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
@@ -1047,7 +1138,7 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         const int blkn = std::min(check_every, n_it - it);
         for (int j = 0; j < blkn; ++j) {
             if (f->n_tiles > 0) {
-                const dim3 grid((unsigned)f->n_tiles), blk(64);
+                const dim3 grid((unsigned)f->n_tiles), blk(128);
 #define GH_KM(DR, RC) hipLaunchKernelGGL((kmeans_multi_kernel<DR, RC>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_cent, \
                                      (const double*)f->d_cov, (const double*)f->d_logdet, f->d_ids, f->d_changed, f->d_tilecnt, (const uint8_t*)f->d_active, k * D)
                 if (exact_div) { if (D <= 16) GH_KM(16, false); else if (D <= 40) GH_KM(40, false); else GH_KM(64, false); }
@@ -1149,7 +1240,7 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
             hipLaunchKernelGGL(fit_em_prepare_kernel, dim3((unsigned)((S * k + 63) / 64)), dim3(64), 0, st, S, k, D, (const double*)f->d_var,
                                (const double*)f->d_weight, (const uint8_t*)f->d_active, f->d_ivar, f->d_logc, f->d_counter);
             if (f->n_tiles > 0) {
-                const dim3 grid((unsigned)f->n_tiles), blk(64);
+                const dim3 grid((unsigned)f->n_tiles), blk(128);
 #define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_mean, \
                                      (const double*)f->d_ivar, (const double*)f->d_logc, f->d_part, (const uint8_t*)f->d_active)
                 if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
