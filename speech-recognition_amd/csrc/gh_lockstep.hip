@@ -355,14 +355,18 @@ constexpr double LS_LN_UNDERFLOW = -745.1332191019412;   // exp(x) rounds to +0 
 // parameters in LDS; each takes half of the components in phase 1 and half of the (component, dimension) sums in phase 2,
 // so every chain is as long as before but twice as many run side by side, on twice the waves per CU.  Every number is
 // computed by the same operations in the same order as with one wave: the results are bitwise those of the one-wave kernel.
+#ifndef GH_EM_WAVES
+#define GH_EM_WAVES 2                 // waves per tile (1, 2 or 4; 4: 434 -> 413 us per full pass, nothing at the application)
+#endif
 template <int DR>
-__global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
+__global__ __launch_bounds__(64 * GH_EM_WAVES) void em_multi_kernel(const double* __restrict__ X, int D, int k, const ls_tile* __restrict__ tiles,
                                                        const double* __restrict__ mean /*[S,k,D]*/,
                                                        const double* __restrict__ ivar /*[S,k,D]*/,
                                                        const double* __restrict__ logc /*[S,k]*/,
                                                        double* __restrict__ partial /*[tiles][k*(1+2D) + 1]*/,
                                                        const uint8_t* __restrict__ active = nullptr) {
-    static_assert(DR % 2 == 0, "the tile is staged by 128 threads");
+    constexpr int NW = GH_EM_WAVES, NT = 64 * NW;
+    static_assert(DR % NW == 0, "the tile is staged by all the block's threads");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* pm = sm;                  // [k][D]
     double* pv = pm + k * D;          // [k][D]
@@ -378,10 +382,10 @@ __global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict_
     {
         const double* src = X + tl.first * D;
         const int nelem = tl.count * D;
-        double r[DR / 2];
+        double r[DR / NW];
 #pragma unroll
-        for (int it = 0; it < DR / 2; ++it) {
-            const int i = tid + 128 * it;
+        for (int it = 0; it < DR / NW; ++it) {
+            const int i = tid + NT * it;
 #ifdef EMV_NOSTAGE   // diagnostic builds (tools/emv_variants.sh): timing only, results wrong
             r[it] = 0.001 * (double)(i & 255);
 #else
@@ -389,19 +393,19 @@ __global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict_
 #endif
         }
 #pragma unroll 4
-        for (int i = tid; i < k * D; i += 128) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
+        for (int i = tid; i < k * D; i += NT) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
         if (tid < k) pc[tid] = logc[pbase + tid];
         if (D & 1) {
 #pragma unroll
-            for (int it = 0; it < DR / 2; ++it) if (tid + 128 * it < nelem) tile[tid + 128 * it] = r[it];
+            for (int it = 0; it < DR / NW; ++it) if (tid + NT * it < nelem) tile[tid + NT * it] = r[it];
         } else {                                 // one pad slot per frame: element i of frame f at slot i + f
             int f = tid / D, d = tid - f * D;
-            const int q128 = 128 / D, r128 = 128 - q128 * D;
+            const int qn = NT / D, rn = NT - qn * D;
 #pragma unroll
-            for (int it = 0; it < DR / 2; ++it) {
-                if (tid + 128 * it < nelem) tile[tid + 128 * it + f] = r[it];
-                d += r128;
-                f += q128;
+            for (int it = 0; it < DR / NW; ++it) {
+                if (tid + NT * it < nelem) tile[tid + NT * it + f] = r[it];
+                d += rn;
+                f += qn;
                 if (d >= D) { d -= D; ++f; }
             }
         }
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict_
 #pragma unroll
     for (int d = 0; d < DR; ++d) x[d] = (d < D && lane < tl.count) ? tile[lane * TS + d] : 0.0;
     // ---- phase 1: log-densities of this wave's half of the components, frame = lane ----
-    const int kh = (k + 1) >> 1, c_lo = wv * kh, c_hi = (c_lo + kh < k) ? c_lo + kh : k;
+    const int kh = (k + NW - 1) / NW, c_lo = (wv * kh < k) ? wv * kh : k, c_hi = (c_lo + kh < k) ? c_lo + kh : k;
 #pragma unroll 1
     for (int c = c_lo; c < c_hi; ++c) {
         double q = 0;
@@ -457,9 +461,9 @@ __global__ __launch_bounds__(128) void em_multi_kernel(const double* __restrict_
     double* out = partial + (int64_t)blockIdx.x * (k * Wd + 1);
 #ifdef EMV_NOPHASE2
     if (tid < k) out[tid * Wd] = rt[tid * 64];
-    for (int p = tid + 1000000; p < k * (D + 1); p += 128) {
+    for (int p = tid + 1000000; p < k * (D + 1); p += NT) {
 #else
-    for (int p = tid; p < k * (D + 1); p += 128) {
+    for (int p = tid; p < k * (D + 1); p += NT) {
 #endif
         const int c = p / (D + 1), d = p - c * (D + 1);
         const double* r = rt + c * 64;
@@ -657,7 +661,7 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
     const size_t lds = ((size_t)2 * k * D + k + (size_t)k * 64 + 64 * (size_t)(D + 1)) * 8 + 16;
     GH_REQUIRE(lds <= 150 * 1024, "gh_em_accumulate_multi: k=%d x D=%d does not fit LDS", k, D);
     if (!tiles.empty()) {
-        const dim3 grid((unsigned)tiles.size()), blk(128);
+        const dim3 grid((unsigned)tiles.size()), blk(64 * GH_EM_WAVES);
 #define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, (const double*)b->feats, D, k, d_tiles, d_mean, d_ivar, \
                                      d_logc, d_part, nullptr)
         if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
@@ -1240,7 +1244,7 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
             hipLaunchKernelGGL(fit_em_prepare_kernel, dim3((unsigned)((S * k + 63) / 64)), dim3(64), 0, st, S, k, D, (const double*)f->d_var,
                                (const double*)f->d_weight, (const uint8_t*)f->d_active, f->d_ivar, f->d_logc, f->d_counter);
             if (f->n_tiles > 0) {
-                const dim3 grid((unsigned)f->n_tiles), blk(128);
+                const dim3 grid((unsigned)f->n_tiles), blk(64 * GH_EM_WAVES);
 #define GH_EM(DR) hipLaunchKernelGGL((em_multi_kernel<DR>), grid, blk, lds, st, X, D, k, f->d_tiles, (const double*)f->d_mean, \
                                      (const double*)f->d_ivar, (const double*)f->d_logc, f->d_part, (const uint8_t*)f->d_active)
                 if (D <= 16) GH_EM(16); else if (D <= 40) GH_EM(40); else GH_EM(64);
