@@ -88,6 +88,44 @@ def test_em_accumulate_multi_equals_single_state_calls():
     b.close()
 
 
+@pytest.mark.parametrize("k,D", [(1, 5), (2, 6), (3, 13), (5, 39), (8, 40), (7, 2)])
+def test_tile_kernels_for_every_split_of_the_components_over_their_two_waves(k, D):
+    """The two tile kernels run two waves per tile, each with half of the clusters / components (k = 1: the second wave has
+    none; odd k: uneven halves; D even: padded tile rows): assignments == the one-state kernel's, statistics == the
+    one-state kernel's (another kernel: 1e-11) and numpy's responsibilities."""
+    from sr.recognition import _hip
+    ctx = _hip.default_context()
+    rng, segs = _problem(seed=100 + k, S=5, D=D, k=max(k, 2))
+    S = len(segs)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in segs])]).astype(np.int64)
+    b = _hip.Batch(ctx, feats=np.concatenate(segs), offsets=[0, int(off[-1])])
+    cent = rng.normal(size=(S, k, D)) * 2
+    var1 = rng.uniform(0.5, 2.0, size=(S, D))
+    for v in (var1, None):
+        clusters, changed, sums = b.kmeans_assign_multi(off, cent, var=v, want_sums=True)
+        for s in range(S):
+            ref = b.kmeans_assign(cent[s], var=None if v is None else v[s], first=int(off[s]), count=len(segs[s]))
+            np.testing.assert_array_equal(clusters[off[s]:off[s + 1]], ref)
+            x = segs[s]
+            d2 = ((x[:, None, :] - cent[s][None]) ** 2 / (1.0 if v is None else v[s][None, None, :])).sum(axis=2)
+            assert np.mean(np.argmin(d2, axis=1) == ref) > 0.999            # (numpy's own summation order: ties aside)
+            for c in range(k):
+                assert sums[s, c, D] == np.sum(ref == c)
+    mean = rng.normal(size=(S, k, D)) * 2
+    var = rng.uniform(0.5, 2.0, size=(S, k, D))
+    w = rng.dirichlet(np.ones(k), size=S)
+    stats, ll = b.em_accumulate_multi(off, mean, var, w)
+    for s in range(S):
+        ref, rl = b.em_accumulate(mean[s], var[s], w[s], first=int(off[s]), count=len(segs[s]))
+        np.testing.assert_allclose(stats[s], ref, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(ll[s], rl, rtol=1e-12)
+        p = np.array([O.gmm_evaluate(x, mean[s], var[s], w[s], neg_log=False) for x in segs[s]])
+        rs = p.sum(axis=1, keepdims=True)
+        r = np.where(rs == 0, 0.0, p / np.where(rs == 0, 1.0, rs))
+        np.testing.assert_allclose(stats[s][:, 0], r.sum(axis=0), rtol=1e-9, atol=1e-12)
+    b.close()
+
+
 def test_lockstep_fitter_equals_state_after_state():
     """LockstepFitter.split_and_fit on 6 states == the sequential loop of the reference (kmeans + GMM.em per state, in
     order) under the same seed: parameters 1e-9, the same number of EM iterations per state."""
