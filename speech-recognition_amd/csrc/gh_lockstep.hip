@@ -14,6 +14,7 @@
 // broadcast.  Per-tile partial results are summed per state in tile order by a second kernel (deterministic).
 #include "gh_internal.h"
 #include "gh_host.h"
+#include "gh_refit.h"
 
 namespace {
 
@@ -718,7 +719,13 @@ struct gh_fit {
     int nch;             // pieces of FIT_CHUNK list entries the longest state's lists are cut into (d_psum [S][kmax][nch][D+1])
     int* d_counter;      // [0] states still active after the last iteration, [1] error bits (16: zero variance)
     double *d_mean, *d_var, *d_weight, *d_ivar, *d_logc, *d_old_mu, *d_old_sigma, *d_old_w, *d_nframes, *d_part, *d_stats;
-    int* h_pin;          // pinned [4]
+    int* h_pin;          // pinned [16]
+    // streaming matrix-core form of the two per-iteration kernels (gh_refit_mfma.hip): items, packed operands, slabs
+    bool mfma;           // k <= 8 and not switched off (GMMHMM_REFIT=tiles)
+    int n_items, kcap;   // kcap: the component count the buffers below are sized for (min(kmax, 8))
+    rf_item* d_items;
+    int32_t *d_iptr, *d_done;
+    double *d_P, *d_shift, *d_kscale, *d_rpart;
 };
 
 namespace {
@@ -1023,6 +1030,36 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
     lay.add((void**)&f->d_nframes, (size_t)S * 8, nullptr);
     lay.add((void**)&f->d_part, nt * plen * 8, nullptr);
     lay.add((void**)&f->d_stats, (size_t)S * plen * 8, nullptr);
+    // items of the streaming kernels: a state's frames cut into pieces of item_frames (a state without frames: one empty
+    // item, whose tail still runs the state's update)
+    std::vector<rf_item> items;
+    std::vector<int32_t> iptr(S + 1, 0);
+    {
+        const char* e = getenv("GMMHMM_REFIT");
+        f->mfma = !(e && !strcmp(e, "tiles"));
+        int item_frames = 512;
+        if (const char* ei = getenv("GMMHMM_REFIT_ITEM")) item_frames = std::max(64, atoi(ei) & ~15);
+        f->kcap = std::min(kmax, 8);
+        for (int s = 0; s < S; ++s) {
+            iptr[s] = (int32_t)items.size();
+            const int64_t n = seg_off[s + 1] - seg_off[s];
+            if (n == 0) items.push_back(rf_item{seg_off[s], s, 0});
+            for (int64_t o = 0; o < n; o += item_frames)
+                items.push_back(rf_item{seg_off[s] + o, s, (int32_t)std::min<int64_t>(item_frames, n - o)});
+        }
+        iptr[S] = (int32_t)items.size();
+        f->n_items = (int)items.size();
+        if (f->mfma) {
+            const size_t pst = std::max(rf_em_pstride(f->kcap, D), rf_km_pstride(f->kcap, D));
+            lay.add((void**)&f->d_items, items.size() * sizeof(rf_item), items.data(), items.size() * sizeof(rf_item));
+            lay.add((void**)&f->d_iptr, (size_t)(S + 1) * 4, iptr.data(), (size_t)(S + 1) * 4);
+            lay.add((void**)&f->d_done, (size_t)S * 4, nullptr);
+            lay.add((void**)&f->d_P, (size_t)S * pst * 8, nullptr);
+            lay.add((void**)&f->d_shift, (size_t)S * D * 8, nullptr);
+            lay.add((void**)&f->d_kscale, (size_t)S * 8, nullptr);
+            lay.add((void**)&f->d_rpart, items.size() * ((size_t)f->kcap * Wd + 1) * 8, nullptr);
+        }
+    }
     hipError_t he = hipMalloc(&f->d_arena, lay.total);
     if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_pin, 64, hipHostMallocDefault);
     if (he != hipSuccess) {
@@ -1033,6 +1070,7 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
     rc = lay.commit(f->d_arena, ctx->stream, true);
     if (!rc && hipMemsetAsync(f->d_counter, 0, 64, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
     if (!rc && hipMemsetAsync(f->d_changed, 0, (size_t)S * 4, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
+    if (!rc && f->mfma && hipMemsetAsync(f->d_done, 0, (size_t)S * 4, ctx->stream) != hipSuccess) rc = GH_ERR_HIP;
     if (rc) { gh_fit_destroy(f); return rc; }
     *out = f;
     return GH_OK;
@@ -1062,14 +1100,32 @@ static int fit_build_lists(gh_fit* f, int k, bool from_assign_counts, const uint
     return GH_OK;
 }
 
-static int fit_poll(gh_fit* f, gh_comm* comm, int* n_active, int* flags) {
+// slot: where the last iteration left the number of states still active (0: the tile kernels' counter; 2 + (it & 7):
+// the streaming kernels', which count per iteration so that nothing has to be cleared between launches)
+static int fit_poll(gh_fit* f, gh_comm* comm, int* n_active, int* flags, int slot = 0) {
     hipStream_t st = f->ctx->stream;
-    GH_HIP(hipMemcpyAsync(f->h_pin, f->d_counter, 8, hipMemcpyDeviceToHost, st));
+    GH_HIP(hipMemcpyAsync(f->h_pin, f->d_counter, 64, hipMemcpyDeviceToHost, st));
     const int rc_ = gh_stream_wait(f->ctx, comm, "gh_fit");
     if (rc_) return rc_;
-    *n_active = f->h_pin[0];
+    *n_active = f->h_pin[slot];
     *flags = f->h_pin[1];
     return GH_OK;
+}
+
+// the point a state's frames and parameters are taken relative to by the streaming kernels: the average of the state's
+// (finite) component means -- any point near the data serves; it only has to be the same on every rank
+static void fit_shift_points(int S, int k, int D, const double* mean, std::vector<double>& shift) {
+    shift.assign((size_t)S * D, 0.0);
+    for (int s = 0; s < S; ++s)
+        for (int d = 0; d < D; ++d) {
+            double acc = 0;
+            int n = 0;
+            for (int c = 0; c < k; ++c) {
+                const double v = mean[((size_t)s * k + c) * D + d];
+                if (v - v == 0.0) { acc += v; ++n; }
+            }
+            shift[(size_t)s * D + d] = n ? acc / n : 0.0;
+        }
 }
 
 extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const double* centroids_in, const uint8_t* part,
@@ -1138,6 +1194,50 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     const size_t lds = ((size_t)k * D + D + 64 * (size_t)(D + 1)) * 8 + 64 * 4 + 16;
     const int n_it = std::max(max_iteration, 1);
     check_every = std::max(1, check_every);
+    // Streaming matrix-core form (gh_refit_mfma.hip): assignment, cluster sums, centroid update, stop rule and the next
+    // iteration's operands in ONE launch per iteration (sums, collective, update with a communicator).  The assignments are
+    // the reference's: near-ties are re-tested with its own division (so GMMHMM_KMEANS_EXACT only adds the frame-order
+    // sums in every iteration, which the tile kernels below still provide).
+    const bool streaming = f->mfma && !exact_env && k <= f->kcap && rf_supported(k, D);
+    if (streaming) {
+        std::vector<double> shift;
+        fit_shift_points(S, k, D, centroids_in, shift);
+        GH_HIP(hipMemcpyAsync(f->d_shift, shift.data(), shift.size() * 8, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemsetAsync(f->d_counter, 0, 64, st));
+        GH_HIP(hipMemsetAsync(f->d_done, 0, (size_t)S * 4, st));
+        rf_km_args a;
+        memset(&a, 0, sizeof a);
+        a.c.X = X; a.c.D = D; a.c.k = k; a.c.S = S; a.c.items = f->d_items; a.c.item_ptr = f->d_iptr; a.c.shift = f->d_shift;
+        a.c.active = f->d_active; a.c.done = f->d_done; a.c.partial = f->d_rpart; a.c.counter = f->d_counter; a.c.fused = comm ? 0 : 1;
+        a.P = f->d_P; a.kscale = f->d_kscale; a.cent = f->d_cent; a.var = f->d_cov; a.logdet = f->d_logdet; a.ids = f->d_ids;
+        a.sums = f->d_sums; a.iters = f->d_iters;
+        rc = rf_launch_km_update(ctx, a, 1);
+        if (rc) return rc;
+        for (int it = 0; it < n_it;) {
+            const int blkn = std::min(check_every, n_it - it);
+            for (int j = 0; j < blkn; ++j) {
+                a.c.it = it + j;
+                rc = rf_launch_km(ctx, a, f->n_items);
+                if (rc) return rc;
+                if (comm) {
+                    hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((sstride + 127) / 128), (unsigned)S), dim3(128), 0, st, S, sstride,
+                                       (const uint8_t*)f->d_active, f->d_sums);
+                    rc = gh_comm_allreduce_enqueue(comm, f->d_sums, (int64_t)S * sstride);
+                    if (!rc) rc = rf_launch_km_update(ctx, a, 0);
+                    if (rc) return rc;
+                }
+            }
+            it += blkn;
+            int n_active = 0, flags = 0;
+            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7));
+            if (rc) return rc;
+            if (n_active == 0) break;
+        }
+        GH_HIP(hipMemsetAsync(f->d_counts, 0, (size_t)S * k * 4, st));
+        GH_HIP(hipMemsetAsync(f->d_cbase, 0, (size_t)S * k * 4, st));
+        rc = fit_build_lists(f, k, false, nullptr);       // the final assignment's cluster lists and sizes
+        if (rc) return rc;
+    } else
     for (int it = 0; it < n_it;) {
         const int blkn = std::min(check_every, n_it - it);
         for (int j = 0; j < blkn; ++j) {
@@ -1238,6 +1338,47 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
     const size_t lds = ((size_t)2 * k * D + k + (size_t)k * 64 + 64 * (size_t)(D + 1)) * 8 + 16;
     check_every = std::max(1, check_every);
     int rc;
+    // Streaming matrix-core form (gh_refit_mfma.hip): E-step sums, their reduction, GMM.em_update and the next iteration's
+    // operands in ONE launch per iteration (sums, collective, update with a communicator)
+    if (f->mfma && k <= f->kcap && rf_supported(k, D)) {
+        std::vector<double> shift;
+        fit_shift_points(S, k, D, mean_io, shift);
+        GH_HIP(hipMemcpyAsync(f->d_shift, shift.data(), shift.size() * 8, hipMemcpyHostToDevice, st));
+        GH_HIP(hipMemsetAsync(f->d_counter, 0, 64, st));
+        GH_HIP(hipMemsetAsync(f->d_done, 0, (size_t)S * 4, st));
+        rf_em_args a;
+        memset(&a, 0, sizeof a);
+        a.c.X = X; a.c.D = D; a.c.k = k; a.c.S = S; a.c.items = f->d_items; a.c.item_ptr = f->d_iptr; a.c.shift = f->d_shift;
+        a.c.active = f->d_active; a.c.done = f->d_done; a.c.partial = f->d_rpart; a.c.counter = f->d_counter; a.c.fused = comm ? 0 : 1;
+        a.P = f->d_P; a.exp_tab = ctx->d_fp64_tables; a.stats = f->d_stats; a.nframes = f->d_nframes; a.mean = f->d_mean; a.var = f->d_var;
+        a.weight = f->d_weight; a.old_mu = f->d_old_mu; a.old_sigma = f->d_old_sigma; a.old_w = f->d_old_w; a.conv_at = f->d_iters;
+        rc = rf_launch_em_update(ctx, a, 1);
+        if (rc) return rc;
+        for (int it = 0; it < max_iteration;) {
+            const int blkn = std::min(check_every, max_iteration - it);
+            for (int j = 0; j < blkn; ++j) {
+                a.c.it = it + j;
+                rc = rf_launch_em(ctx, a, f->n_items);
+                if (rc) return rc;
+                if (comm) {
+                    hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, S, plen,
+                                       (const uint8_t*)f->d_active, f->d_stats);
+                    rc = gh_comm_allreduce_enqueue(comm, f->d_stats, (int64_t)S * plen);
+                    if (!rc) rc = rf_launch_em_update(ctx, a, 0);
+                    if (rc) return rc;
+                }
+            }
+            it += blkn;
+            int n_active = 0, flags = 0;
+            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7));
+            if (rc) return rc;
+            if (flags & 16) {
+                gh_set_error("gh_fit_em: a variance is 0 (singular covariance)");
+                return GH_ERR_INVALID;
+            }
+            if (n_active == 0) break;
+        }
+    } else
     for (int it = 0; it < max_iteration;) {
         const int blkn = std::min(check_every, max_iteration - it);
         for (int j = 0; j < blkn; ++j) {
