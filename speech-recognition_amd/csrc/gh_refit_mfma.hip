@@ -299,12 +299,13 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     int sl = wv;
     rf_stage<KSM> stg;
     if (sl < nsl) stg.load(lane, a.c.X + (item.first + (int64_t)sl * 16) * D, min(16, item.count - sl * 16) * D);
-    if (!a.c.active[s]) return;
+    const uint8_t live = a.c.active[s];           // (tested below: the operands' loads share its round trip)
     for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
     if (tid < 128) sT[tid] = a.exp_tab[tid];
     double* tb = sBuf + wv * bufsz;
     rf_init_pads(tb, lane, D, TS);
     stg.init(lane, D, TS, a.c.shift + (int64_t)s * D);
+    if (!live) return;
     __syncthreads();
     // lane roles: operands (k, b, i) = (lane >> 4, (lane >> 2) & 3, lane & 3); results: (i, b, j) in the same places
     const int kk = lane >> 4, bq = (lane >> 2) & 3, lo = lane & 3;
@@ -522,12 +523,13 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     int sl = wv;
     rf_stage<KSM> stg;
     if (sl < nsl) stg.load(lane, a.c.X + (item.first + (int64_t)sl * 16) * D, min(16, item.count - sl * 16) * D);
-    if (!a.c.active[s]) return;
+    const uint8_t live = a.c.active[s];
     for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
     double* tb = sBuf + wv * bufsz;
     rf_init_pads(tb, lane, D, TS);
     stg.init(lane, D, TS, a.c.shift + (int64_t)s * D);
     if (tid < 4) sFlag[4 + tid] = 0;
+    if (!live) return;
     __syncthreads();
     const int kk = lane >> 4, bq = (lane >> 2) & 3, lo = lane & 3;
     const int a1 = rf_frame(bq, lo) * TS + kk;

@@ -12,6 +12,7 @@ uses the HIP k-means / EM kernels through `kmeans` and `GMM.em`.
 import copy
 import os
 import pickle
+import threading
 import warnings
 from typing import List, AnyStr
 
@@ -22,7 +23,7 @@ from . import _pack
 from .kmeans import kmeans
 from .hmm_state import GMM, NES, mahalanobis
 from .hmm import HMM
-from .lockstep import LockstepFitter
+from .lockstep import LockstepFitter, PartitionStream, fast_partition_ok
 
 __all__ = ["build_state_sequences", "build_loop_grammar", "continuous_train", "forced_alignments", "aligned_frame_states",
            "cut_segments"]
@@ -313,6 +314,89 @@ def cut_segments(path, row_state):
             open_row, open_at = None, None
 
 
+def _clone_models(models):
+    """copy.deepcopy(models) for lists of GMM word models, without the generic walk: new HMM / GMM / MultivariateNormal
+    objects with their own parameter arrays, state ids kept (a copy hashes like its original, as with deepcopy).  The
+    D x D `inv_cov` matrices are SHARED with the originals: nothing writes into one (assigning `cov` installs a new
+    matrix), and copying 400 of them was most of the 3.7 ms a deep copy of ten 5-state 8-mixture words took.
+    Anything that is not such a model goes through copy.deepcopy."""
+    if not all(type(m) is HMM and m.use_gmm and m.gmm_states is not None and all(type(g) is GMM for g in m.gmm_states)
+               for m in models):
+        return copy.deepcopy(models)
+    memo = {}
+    out = []
+    for m in models:
+        nm = HMM.__new__(HMM)
+        memo[id(m)] = nm
+        for key, v in m.__dict__.items():
+            if key != "gmm_states":
+                nm.__dict__[key] = v.copy() if type(v) is np.ndarray and v.dtype != object else copy.deepcopy(v, memo)
+        states = []
+        for g in m.gmm_states:
+            ng = GMM.__new__(GMM)
+            memo[id(g)] = ng
+            for key, v in g.__dict__.items():
+                if key == "dists":
+                    continue
+                if key == "parent":
+                    ng.__dict__[key] = memo.get(id(v)) if v is not None and id(v) in memo else copy.deepcopy(v, memo)
+                else:
+                    ng.__dict__[key] = v.copy() if type(v) is np.ndarray and v.dtype != object else copy.deepcopy(v, memo)
+            dists = []
+            for d in g.dists:
+                nd = d.__class__.__new__(d.__class__)
+                dd = nd.__dict__
+                for key, v in d.__dict__.items():
+                    if key == "inv_cov":
+                        dd[key] = v
+                    else:
+                        dd[key] = v.copy() if type(v) is np.ndarray and v.dtype != object else copy.deepcopy(v, memo)
+                dists.append(nd)
+            ng.__dict__["dists"] = dists
+            states.append(ng)
+        nm.__dict__["gmm_states"] = states
+        out.append(nm)
+    return out
+
+
+class _PickleWriter:
+    """The per-iteration pickles of continuous_train (continuous_speech.py:167-170) written on a worker thread while
+    the next iteration's alignment runs on the device: the models handed over are not touched again (the next
+    iteration trains a copy).  `wait()` before the next hand-over and before returning: every iteration's files exist
+    when the next one's are written, errors surface there."""
+
+    def __init__(self):
+        self.thread = None
+        self.error = None
+
+    def write(self, models, output_path):
+        self.wait()
+
+        def run():
+            try:
+                for i, m in enumerate(models):
+                    # (written under a private name and renamed: the ranks of a sharded run may share `output_path`, and
+                    #  they all hold the same models)
+                    final = os.path.join(output_path, str(i) + '.pkl')
+                    tmp = final + '.%d.tmp' % os.getpid()
+                    with open(tmp, 'wb') as f:
+                        pickle.dump(m, f)
+                    os.replace(tmp, final)
+            except BaseException as e:
+                self.error = e
+
+        self.thread = threading.Thread(target=run, name="gmmhmm-pickles", daemon=True)
+        self.thread.start()
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+
 def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List[List[int]], output_path: AnyStr,
                      n_gaussians: int = 4,
                      n_segments: int = 5,
@@ -340,7 +424,7 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
     identical on every golden); it brings the frames and the refit loop back to the host (round 2's path)."""
     sharded = bool(reducer is not None and getattr(reducer, "enabled", False) and reducer.world_size > 1)
     old_models = models
-    new_models = copy.deepcopy(models)
+    new_models = _clone_models(models)
     n_models = len(new_models)
     # The reference keeps the state objects of this first copy in a dict for the whole run
     # (:64-71).  Later iterations train fresh deep copies with the same uuid hash, so its
@@ -368,12 +452,18 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
         all_frames = np.concatenate([np.asarray(x, dtype=np.float64) for x in data]) if len(data) else np.zeros((0, dim))
     plan = AlignmentPlan(label_seqs, n, n_models)
     use_runs = os.environ.get("GMMHMM_CTRAIN_RUNS", "1") != "0"      # (0: one label per frame comes back, regrouped with numpy)
+    writer = _PickleWriter()
+    n_splits = int(np.log(n_gaussians))
+    ahead = on_device and n_splits > 0 and os.environ.get("GMMHMM_CTRAIN_AHEAD", "1") != "0" and fast_partition_ok()
+    stream = None
     try:
         for it in range(max_iteration):
             print('=' * 25)
             print('Continuous training iteration:', it)
             print('Building state sequences')
             print('Rearranging data, this may take a while...')
+            # the refit's random partitions are drawn on a worker thread while the device aligns (lockstep.PartitionStream)
+            stream = PartitionStream(int(frames.N) * n_splits) if ahead and frames.N else None
             # alignment + regrouping on the device; per state, its frames in utterance / time order -- what the
             # reference's vstack of the segments holds (:90-113) -- and the states in first-visit order
             runs = aligned_runs(frames, new_models, label_seqs, plan) if (on_device and len(data) and use_runs) else None
@@ -446,6 +536,9 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
             segs = None if on_device else [all_frames[rows_of[sid]] if sid in rows_of else np.zeros((0, dim)) for sid in keys]
             fitter = LockstepFitter(segs, ctx=frames.ctx, reducer=reducer if sharded else None, source=(frames, rows),
                                     lengths=lengths, dim=dim, kmax=kmax, compat_cov=compat_cov)
+            parts = None
+            if stream is not None:
+                parts, stream = stream.take(lengths, n_splits), None
             try:
                 # start centroids: the mean of every state's frames (:116), over all ranks when sharded
                 if sharded and keys:
@@ -460,7 +553,7 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                 fitter.split_and_fit([new_models[sid // n].gmm_states[sid % n] for sid in keys],
                                      start_centroids=starts,
                                      weight_divisor=[n_segments] * len(keys),          # (:127, :135-137)
-                                     n_gaussians=n_gaussians, use_em=True)
+                                     n_gaussians=n_gaussians, use_em=True, parts=parts)
             finally:
                 fitter.close()
 
@@ -479,19 +572,18 @@ def continuous_train(data: List[np.ndarray], models: List[HMM], label_seqs: List
                         new_models[mi].transitions[si + 1, si] = -np.log(p_jump)
                     new_models[mi].transitions[si, si] = -np.log(1 - p_jump)
 
-            for i, m in enumerate(new_models):
-                # (written under a private name and renamed: the ranks of a sharded run may share `output_path`, and
-                #  they all hold the same models)
-                final = os.path.join(output_path, str(i) + '.pkl')
-                tmp = final + '.%d.tmp' % os.getpid()
-                with open(tmp, 'wb') as f:
-                    pickle.dump(m, f)
-                os.replace(tmp, final)
+            # (:167-170) this iteration's pickles: on the worker, while the comparison below and the next alignment run
+            writer.write(new_models, output_path)
             if all(new_m == old_m for new_m, old_m in zip(new_models, old_models)):
                 print('Continuous training converged')
                 break
             old_models = new_models
-            new_models = copy.deepcopy(old_models)
+            new_models = _clone_models(old_models)
     finally:
-        plan.close()
-        frames.close()
+        if stream is not None:
+            stream.cancel()
+        try:
+            writer.wait()
+        finally:
+            plan.close()
+            frames.close()

@@ -25,12 +25,14 @@ part of each state's frames; cluster sums / counts and the EM statistics are all
 lock-step iteration.  Summation order then differs from the single-process run, and the random
 partitions are per rank: parity is statistical there, as the survey says.
 """
+import threading
+
 import numpy as np
 
 from . import _hip
 from .hmm_state import GMM
 
-__all__ = ["LockstepFitter"]
+__all__ = ["LockstepFitter", "PartitionStream"]
 
 
 def _variance_rows(x):
@@ -70,6 +72,83 @@ def random_partition(k, n):
     if _FAST_PARTITION and 2 <= k <= 256 and (k & (k - 1)) == 0:
         return (np.random.randint(0, 1 << 32, int(n), dtype=np.uint32) & np.uint32(k - 1)).astype(np.uint8)
     return np.random.randint(0, k, int(n))
+
+
+def fast_partition_ok():
+    global _FAST_PARTITION
+    if _FAST_PARTITION is None:
+        _FAST_PARTITION = _fast_partition_ok()
+    return _FAST_PARTITION
+
+
+class PartitionStream:
+    """The random partitions of a whole refit (kmeans.py:171, one np.random.randint(0, k, n_s) per state and split) drawn
+    AHEAD on a worker thread -- while the device aligns the utterances -- instead of between alignment and refit
+    (4.5 ms of every continuous_train outer iteration on 1.4 M frames x two splits).
+
+    For a power of two k every value is ONE 32-bit output of numpy's global MT19937, masked (`fast_partition_ok`
+    checks that against the installed numpy), and the sequential algorithm consumes them state after state, split after
+    split.  How many it consumes is only known after the alignment (frames on state entries are dropped), so the worker
+    draws `n_max` outputs from a COPY of the global generator's state in chunks, remembering the state in front of
+    every chunk; `take(lengths, n_splits)` cuts the words the refit really uses and leaves the global generator exactly
+    where those draws leave it (the snapshot in front of the last chunk + the remainder drawn again).  Nothing else may
+    draw from np.random between construction and take()."""
+
+    CHUNK = 1 << 16
+
+    def __init__(self, n_max):
+        self.n_max = int(n_max)
+        self.state0 = np.random.get_state()
+        self.buf = np.empty(self.n_max, dtype=np.uint32)
+        self.snaps = []
+        self.error = None
+        self.thread = threading.Thread(target=self._run, name="gmmhmm-partitions", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            rs = np.random.RandomState()
+            rs.set_state(self.state0)
+            for a in range(0, self.n_max, self.CHUNK):
+                self.snaps.append(rs.get_state())
+                b = min(self.n_max, a + self.CHUNK)
+                self.buf[a:b] = rs.randint(0, 1 << 32, b - a, dtype=np.uint32)
+        except BaseException as e:        # (re-raised by take)
+            self.error = e
+
+    def take(self, lengths, n_splits):
+        """-> parts[s][i]: uint8 partition of state s's n_s frames for split i (k = 2^(i+1))."""
+        self.thread.join()
+        if self.error is not None:
+            np.random.set_state(self.state0)
+            raise self.error
+        lengths = [int(n) for n in lengths]
+        used = n_splits * sum(lengths)
+        assert used <= self.n_max, "PartitionStream: the refit draws more values than were made"
+        rs = np.random.RandomState()
+        j = used // self.CHUNK
+        if j < len(self.snaps):
+            rs.set_state(self.snaps[j])
+            rem = used - j * self.CHUNK
+        else:                              # (exactly n_max, a whole number of chunks)
+            rs.set_state(self.snaps[-1] if self.snaps else self.state0)
+            rem = used - (len(self.snaps) - 1) * self.CHUNK if self.snaps else 0
+        if rem:
+            rs.randint(0, 1 << 32, rem, dtype=np.uint32)
+        np.random.set_state(rs.get_state())
+        parts, at = [], 0
+        for n in lengths:
+            row = []
+            for i in range(n_splits):
+                row.append((self.buf[at:at + n] & np.uint32(2 ** (i + 1) - 1)).astype(np.uint8))
+                at += n
+            parts.append(row)
+        return parts
+
+    def cancel(self):
+        """Nothing was used: the global generator stays where it was."""
+        self.thread.join()
+        np.random.set_state(self.state0)
 
 
 class LockstepFitter:
@@ -279,7 +358,7 @@ class LockstepFitter:
                 break
 
     # ------------------------------------------------------------------ the whole refit of hmm.py:97-124
-    def split_and_fit(self, states, start_centroids, n_gaussians, weight_divisor, use_em=True):
+    def split_and_fit(self, states, start_centroids, n_gaussians, weight_divisor, use_em=True, parts=None):
         """Binary-split k-means + EM of every state: for i in range(int(ln n_gaussians)): centroids x 0.9 / x 1.1,
         k-means under the mahalanobis distance, weights = cluster counts / weight_divisor[s] (looked up by cluster id,
         hmm.py:116-118), update_models, EM on the first 2^(i+1) components.
@@ -296,11 +375,43 @@ class LockstepFitter:
         # numpy's global generator is consumed the way the sequential algorithm consumes it: state after state, and
         # inside a state split after split (one draw of N_s cluster ids per kmeans call, kmeans.py:171; nothing else
         # in the refit draws) -- the draws only depend on the frame counts, so they can all be made up front
-        parts = [[random_partition(2 ** (i + 1), n_s) for i in range(n_splits)] for n_s in np.diff(self.seg_off)]
+        # (`parts`: the same draws made ahead by a PartitionStream)
+        if parts is None:
+            parts = [[random_partition(2 ** (i + 1), n_s) for i in range(n_splits)] for n_s in np.diff(self.seg_off)]
         for i in range(n_splits):
             k = 2 ** (i + 1)
             centroids = np.concatenate([centroids * 0.9, centroids * 1.1], axis=1)
             clusters, centroids, cov = self.kmeans(k, centroids, partitions=[p[i] for p in parts], want_clusters=False)
+            if self.fit is not None:
+                # device-resident session: the mixtures travel as arrays; the state objects are written ONCE, after the last
+                # split (every split overwrites the first 2^(i+1) components the previous one wrote, nothing reads them in
+                # between -- 400 MultivariateNormal updates per outer iteration of continuous_train were 3.6 ms of host time)
+                counts = self.last_counts                      # cluster sizes (over all ranks when sharded), from the device
+                for s in range(S):
+                    ids = np.nonzero(counts[s])[0]             # np.unique(clusters): the ids that occur, ascending ...
+                    cnt = counts[s] if self.sharded else counts[s][ids]     # ... and their sizes
+                    for c in ids:
+                        # looked up by cluster ID (hmm.py:116-118) -- the reference's indexing; an IndexError there too
+                        weights[s, c] = cnt[c] / div[s]
+                if np.any(cov == 0):
+                    raise np.linalg.LinAlgError("Singular matrix")   # MultivariateNormal.cov's np.linalg.inv (hmm_state.py:30)
+                mean_a, var_a, w_a = np.ascontiguousarray(centroids), np.ascontiguousarray(cov), np.ascontiguousarray(weights[:, :k])
+                if use_em:
+                    mean_a, var_a, w_a = mean_a.copy(), var_a.copy(), w_a.copy()
+                    mu_old = np.ascontiguousarray(np.array([g.mu_old[:k, :] for g in states], dtype=np.float64))
+                    sg_old = np.ascontiguousarray(np.array([g.sigma_old[:k, :] for g in states], dtype=np.float64))
+                    w_old = np.ascontiguousarray(np.array([g.w_old[:k] for g in states], dtype=np.float64))
+                    conv = self.fit.em(k, mean_a, var_a, w_a, mu_old, sg_old, w_old, self.n_global, max_iteration=10000, comm=self.comm)
+                    if self.comm is not None:
+                        self.collectives += int(np.where(conv >= 0, conv + 1, 10000).max(initial=0))
+                    for s, g in enumerate(states):
+                        g.mu_old[:k, :], g.sigma_old[:k, :], g.w_old[:k] = mu_old[s], sg_old[s], w_old[s]
+                        if conv[s] >= 0:
+                            print("EM converged at iteration:", int(conv[s]))
+                if i == n_splits - 1 or not use_em:
+                    for s, g in enumerate(states):
+                        g.update_models(mean_a[s], var_a[s], w_a[s])
+                continue
             if self.fit is not None:
                 counts = self.last_counts                      # cluster sizes (over all ranks when sharded), from the device
             elif self.sharded:

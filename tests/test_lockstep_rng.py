@@ -18,3 +18,30 @@ def test_random_partition_is_np_random_randint_draw_for_draw():
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(after_want, after_got)
         assert got[2].dtype == (np.uint8 if k & (k - 1) == 0 else want[2].dtype)
+
+
+def test_partition_stream_draws_ahead_what_the_sequential_refit_draws():
+    """PartitionStream: the partitions of a whole refit drawn ahead on a worker thread from a copy of the global
+    generator -- the values np.random.randint(0, 2^(i+1), n_s) gives state after state, split after split, and the global
+    generator left exactly where those draws leave it (whatever upper bound the worker was given)."""
+    from sr.recognition import lockstep
+    for lengths, n_splits, slack in (([5, 0, 70000, 131072 - 70005, 3], 2, 12345), ([1000, 2000], 3, 0), ([], 2, 777),
+                                      ([65536], 1, 0), ([65536, 65536], 2, 65536)):
+        np.random.seed(11)
+        want = [[np.random.randint(0, 2 ** (i + 1), n) for i in range(n_splits)] for n in lengths]
+        after_want = np.random.random(3)
+        np.random.seed(11)
+        st = lockstep.PartitionStream(n_splits * sum(lengths) + slack)
+        got = st.take(lengths, n_splits)
+        after_got = np.random.random(3)
+        assert len(got) == len(want)
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+                assert y.dtype == np.uint8
+        np.testing.assert_array_equal(after_want, after_got)
+    np.random.seed(5)
+    want = np.random.random(2)
+    np.random.seed(5)
+    lockstep.PartitionStream(1000).cancel()
+    np.testing.assert_array_equal(np.random.random(2), want)
