@@ -1,0 +1,218 @@
+# -*- coding: utf-8 -*-
+"""The streaming matrix-core kernels of the device-resident refit (csrc/gh_refit_mfma.hip: refit_km_kernel / refit_em_kernel
+behind gh_fit_kmeans / gh_fit_em): against the oracle's kmeans / gmm_em state by state (reference kmeans.py:167-193,
+hmm_state.py:122-159), against the tile kernels they replace (GMMHMM_REFIT=tiles) over shapes that exercise every
+instantiation and edge (D = 2 .. 64, k = 1 .. 8, empty / one-frame / slab-sized states), and on the cases the fast path
+hands to the reference's own arithmetic: exact ties, NaN centroids, densities that underflow."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _session(segs, kmax, tiles=False):
+    from sr.recognition import _hip
+    ctx = _hip.default_context()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in segs])]).astype(np.int64)
+    b = _hip.Batch(ctx, feats=np.concatenate(segs), offsets=[0, int(off[-1])])
+    old = os.environ.pop("GMMHMM_REFIT", None)
+    try:
+        if tiles:
+            os.environ["GMMHMM_REFIT"] = "tiles"
+        fit = _hip.FitSession(ctx, b, off, kmax)
+    finally:
+        os.environ.pop("GMMHMM_REFIT", None)
+        if old is not None:
+            os.environ["GMMHMM_REFIT"] = old
+    return b, fit, off
+
+
+def _mixture_data(rng, lens, D, k, spread=3.0):
+    segs = []
+    for n in lens:
+        c = rng.normal(size=(max(k, 1), D)) * spread + rng.normal(size=D) * 4
+        segs.append(c[rng.integers(0, max(k, 1), n)] + rng.normal(size=(n, D)) * rng.uniform(0.5, 1.5, size=D))
+    return segs
+
+
+@pytest.mark.parametrize("D,k,lens", [(2, 2, (40, 90, 33)), (13, 4, (150, 64, 257, 16)), (13, 8, (300, 500)), (39, 4, (700, 333)),
+                                      (39, 2, (90, 1000))])
+def test_streaming_refit_equals_the_oracle_state_by_state(D, k, lens):
+    rng = np.random.default_rng(100 * D + k)
+    segs = _mixture_data(rng, lens, D, k)
+    S = len(segs)
+    c0 = np.stack([np.stack([x.mean(axis=0) * f for f in np.linspace(0.85, 1.15, k)]) for x in segs])
+    # the oracle, state after state, drawing its partitions from the global generator; the same draws for the session
+    np.random.seed(4)
+    parts = [np.random.randint(0, k, len(x)) for x in segs]
+    np.random.seed(4)
+    want = []
+    with np.errstate(all="ignore"):
+        for s in range(S):
+            want.append(O.kmeans(segs[s], k, c0[s].copy(), dist="mahalanobis", max_iteration=300))
+    b, fit, off = _session(segs, k)
+    cen, cov, cnt, its = fit.kmeans(k, c0, np.concatenate(parts).astype(np.uint8), max_iteration=300)
+    ids = fit.clusters()
+    for s in range(S):
+        cl, ce, cv = want[s]
+        np.testing.assert_array_equal(ids[off[s]:off[s + 1]], cl)
+        np.testing.assert_array_equal(cen[s], ce)                        # sums in frame order: numpy's means, bit for bit
+        np.testing.assert_allclose(cov[s], cv, rtol=1e-11)
+        np.testing.assert_array_equal(cnt[s], np.bincount(cl, minlength=k))
+    # EM from there (the first k components of a fresh state, hmm_state.py:104-112)
+    w0 = cnt / np.diff(off)[:, None]
+    mean, var, w = cen.copy(), cov.copy(), w0.copy()
+    mu_old = np.array([np.tile(x.mean(axis=0), (k, 1)) for x in segs])
+    sg_old = np.array([np.tile(x.var(axis=0), (k, 1)) for x in segs])
+    w_old = np.full((S, k), 1.0 / k)
+    want_it = []
+    ref = []
+    for s in range(S):
+        m, v, ww = cen[s].copy(), cov[s].copy(), w0[s].copy()
+        old = (mu_old[s].copy(), sg_old[s].copy(), w_old[s].copy())
+        want_it.append(O.gmm_em(segs[s], m, v, ww, k, max_iteration=40, old=old))
+        ref.append((m, v, ww, old))
+    conv = fit.em(k, mean, var, w, mu_old, sg_old, w_old, np.diff(off).astype(np.float64), max_iteration=40)
+    for s in range(S):
+        m, v, ww, old = ref[s]
+        assert (conv[s] + 1 if conv[s] >= 0 else 40) == want_it[s]
+        np.testing.assert_allclose(mean[s], m, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(var[s], v, rtol=1e-8)
+        np.testing.assert_allclose(w[s], ww, rtol=1e-9)
+        np.testing.assert_allclose(mu_old[s], old[0], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(sg_old[s], old[1], rtol=1e-8)
+    fit.close()
+    b.close()
+
+
+def _both(segs, k, c0, part, kmax=None, em_iters=25, km_iters=60):
+    out = []
+    for tiles in (False, True):
+        b, fit, off = _session(segs, kmax or max(k, 2), tiles=tiles)
+        cen, cov, cnt, its = fit.kmeans(k, c0, part, max_iteration=km_iters)
+        ids = fit.clusters()
+        n = np.diff(off).astype(np.float64)
+        with np.errstate(all="ignore"):
+            mean, var, w = cen.copy(), cov.copy(), cnt / np.maximum(n, 1.0)[:, None]
+        ok = np.isfinite(var).all() and (var != 0).all() and np.isfinite(mean).all()
+        res = dict(cen=cen, cov=cov, cnt=cnt, its=its, ids=ids)
+        if ok:
+            mu_old, sg_old, w_old = np.zeros_like(mean), np.ones_like(mean), np.zeros_like(w)
+            conv = fit.em(k, mean, var, w, mu_old, sg_old, w_old, n, max_iteration=em_iters)
+            res.update(mean=mean, var=var, w=w, conv=conv, mu_old=mu_old)
+        out.append(res)
+        fit.close()
+        b.close()
+    return out
+
+
+@pytest.mark.parametrize("D", [2, 3, 12, 13, 15, 16, 17, 38, 39, 40, 47, 64])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8])
+def test_streaming_kernels_equal_the_tile_kernels(D, k):
+    """Every instantiation (one or two component groups; 4, 10 or 17 accumulator columns, exact or not) and every edge of the
+    slab walk: states with 0, 1, 15, 16, 17 frames, one exactly an item long, one a little longer."""
+    rng = np.random.default_rng(7 * D + k)
+    lens = (0, 1, 15, 16, 17, 512, 530, 200)
+    segs = _mixture_data(rng, lens, D, k)
+    N = sum(lens)
+    part = rng.integers(0, k, size=N).astype(np.uint8)
+    c0 = np.stack([np.stack([(x.mean(axis=0) if len(x) else np.zeros(D)) * f + 0.01 * j for j, f in enumerate(np.linspace(0.8, 1.2, k))])
+                   for x in segs])
+    new, old = _both(segs, k, c0, part)
+    np.testing.assert_array_equal(new["ids"], old["ids"])
+    np.testing.assert_array_equal(new["its"], old["its"])
+    np.testing.assert_array_equal(new["cnt"], old["cnt"])
+    np.testing.assert_array_equal(new["cen"], old["cen"])
+    np.testing.assert_array_equal(new["cov"], old["cov"])
+    assert ("mean" in new) == ("mean" in old)
+    if "mean" in new:
+        np.testing.assert_array_equal(new["conv"], old["conv"])
+        for name in ("mean", "var", "w", "mu_old"):
+            np.testing.assert_allclose(new[name], old[name], rtol=1e-9, atol=1e-11, equal_nan=True)
+
+
+def test_ties_nan_centroids_and_far_frames_take_the_reference_arithmetic():
+    """Two identical centroids (every frame ties exactly: np.argmin's first index), a NaN centroid (its distance is NaN for
+    every frame: np.argmin returns it), data far from zero and from each other (the expanded form's terms cancel at
+    1e8 and must not decide anything), an infinite feature value."""
+    rng = np.random.default_rng(5)
+    D, k = 13, 4
+    segs = _mixture_data(rng, (300, 300, 400, 120), D, k)
+    segs[2] = segs[2] + 1e4                                    # far from the origin, tight clusters
+    segs[3][7, 3] = np.inf
+    N = sum(len(x) for x in segs)
+    part = rng.integers(0, k, size=N).astype(np.uint8)
+    c0 = np.stack([np.stack([x[np.isfinite(x).all(axis=1)].mean(axis=0) * f for f in (0.9, 0.9, 1.1, 1.2)]) for x in segs])
+    c0[1, 2] = np.nan
+    with np.errstate(all="ignore"):
+        new, old = _both(segs, k, c0, part, km_iters=3)
+    np.testing.assert_array_equal(new["ids"], old["ids"])
+    np.testing.assert_array_equal(new["cnt"], old["cnt"])
+    np.testing.assert_array_equal(new["cen"], old["cen"])
+    # and against numpy directly for the first sweep of state 0: duplicates go to the lower index
+    b, fit, off = _session(segs, k)
+    fit.kmeans(k, c0, part, max_iteration=1)
+    ids = fit.clusters()
+    x = segs[0]
+    cl = part[:len(x)]
+    var0 = np.cov(x[cl == 0].T).diagonal()
+    d = np.array([[O.mahalanobis(c0[0, c], x[i], var0) for c in range(k)] for i in range(len(x))])
+    np.testing.assert_array_equal(ids[:len(x)], np.argmin(d, axis=1))
+    assert not np.any(ids[:len(x)] == 1)                       # (centroid 1 duplicates centroid 0)
+    np.testing.assert_array_equal(ids[off[1]:off[2]], 2)       # the NaN centroid takes every frame of its state
+    fit.close()
+    b.close()
+
+
+def test_em_densities_that_underflow_weigh_nothing():
+    """A frame whose every component density underflows in the linear domain (hmm_state.py:114-120 multiplies
+    exp(-q/2) by the normaliser) has no responsibilities at all; one whose exponent alone underflows drops that
+    component.  Against the oracle's gmm_em (one iteration at a time) and the tile kernels."""
+    rng = np.random.default_rng(9)
+    D, k = 13, 4
+    segs = _mixture_data(rng, (600, 500), D, k, spread=1.0)
+    far = [np.arange(0, 600, 50), np.arange(0, 500, 70)]
+    segs[0][far[0]] += 300.0                                   # ~300 standard deviations out in every dimension: q ~ 1e6
+    segs[1][far[1]] -= 250.0
+    S = len(segs)
+    n = np.array([len(x) for x in segs], dtype=np.float64)
+    mean0 = np.stack([np.stack([np.delete(x, f, axis=0).mean(axis=0) + 0.3 * j for j in range(k)]) for x, f in zip(segs, far)])
+    var0 = np.stack([np.tile(np.delete(x, f, axis=0).var(axis=0), (k, 1)) for x, f in zip(segs, far)])
+    w0 = np.full((S, k), 0.25)
+    res = []
+    for tiles in (False, True):
+        b, fit, off = _session(segs, k, tiles=tiles)
+        mean, var, w = mean0.copy(), var0.copy(), w0.copy()
+        mu_old, sg_old, w_old = np.zeros_like(mean), np.ones_like(mean), np.zeros_like(w)
+        conv = fit.em(k, mean, var, w, mu_old, sg_old, w_old, n, max_iteration=3)
+        res.append((mean, var, w, conv))
+        fit.close()
+        b.close()
+    for s in range(S):
+        m, v, ww = mean0[s].copy(), var0[s].copy(), w0[s].copy()
+        O.gmm_em(segs[s], m, v, ww, k, max_iteration=3, old=(np.zeros((k, D)), np.ones((k, D)), np.zeros(k)))
+        for mean, var, w, conv in res:
+            np.testing.assert_allclose(mean[s], m, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(var[s], v, rtol=1e-8)
+            np.testing.assert_allclose(w[s], ww, rtol=1e-9)
+        # the far frames weigh nothing: the weights add up to the share of the others
+        np.testing.assert_allclose(res[0][2][s].sum(), 1.0 - len(far[s]) / n[s], rtol=1e-12)
+
+
+def test_more_than_eight_components_keep_the_tile_kernels():
+    rng = np.random.default_rng(2)
+    D, k = 13, 16
+    segs = _mixture_data(rng, (900, 700), D, k)
+    N = sum(len(x) for x in segs)
+    part = rng.integers(0, k, size=N).astype(np.uint8)
+    c0 = np.stack([np.stack([x.mean(axis=0) * f for f in np.linspace(0.7, 1.3, k)]) for x in segs])
+    new, old = _both(segs, k, c0, part, kmax=16, em_iters=5, km_iters=10)
+    np.testing.assert_array_equal(new["ids"], old["ids"])
+    np.testing.assert_array_equal(new["cen"], old["cen"])
+    assert ("mean" in new) == ("mean" in old)
+    if "mean" in new:
+        np.testing.assert_array_equal(new["mean"], old["mean"])       # (the same kernels ran: the same bits)
