@@ -60,15 +60,81 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
         h.use_gmm, h.use_em = use_gmm, use_em
     if use_gmm:
         print('Doing segmental k-means')
-    fitted = _km.skmeans_multi(templates_by_word, n_segments) if _km._device_skmeans_possible(templates_by_word[0]) and 2 <= n_segments <= 32 \
-        else None
+    n = n_segments
+    kmax = 2 ** max(1, int(np.log(n_gaussians)))
+    on_device = bool(W) and all(len(ts) for ts in templates_by_word) and _km._device_skmeans_possible(templates_by_word[0]) and 2 <= n <= 32
+    if not on_device:
+        return _train_words_by_segments(templates_by_word, models, n, n_gaussians, use_gmm, use_em)
+    # ONE resident batch of all templates for the three stages (round 4 uploaded the frames three times and regrouped them
+    # on the host twice: 28 of the 50 ms of ten words x 200 templates)
+    ctx = _hip.default_context()
+    n_temps = np.array([len(ts) for ts in templates_by_word], dtype=np.int64)
+    lengths = np.array([len(t) for ts in templates_by_word for t in ts], dtype=np.int64)
+    D = np.asarray(templates_by_word[0][0]).shape[1]
+    X = np.concatenate([np.asarray(t, dtype=np.float64).reshape(-1, D) for ts in templates_by_word for t in ts])
+    off_t = np.concatenate([[0], np.cumsum(lengths)])
+    frames = _hip.Batch(ctx, feats=X, offsets=off_t)
+    try:
+        fitted = _km.skmeans_multi(templates_by_word, n, frames=frames)
+        tpl_off = np.concatenate([[0], np.cumsum(n_temps)])
+        for w, h in enumerate(models):
+            h.mu, h.sigma, h.transitions, _ = fitted[w]
+        starts = np.concatenate([f[3] for f in fitted])
+        order, counts = _km.segment_order(lengths, n_temps, starts, n)
+        if not use_gmm:
+            for h, segs in zip(models, _km.split_segments(_km.gather_rows(X, order), counts)):
+                h.segments = segs
+            return models
+        for h in models:
+            h.gmm_states = [GMM(m, s, n_gaussians) for m, s in zip(h.mu, h.sigma)]
+        # the mixtures of all W x n states: their frames gathered on the device from the resident batch
+        fitter = LockstepFitter(None, ctx=ctx, source=(frames, order), lengths=[int(c) for c in counts.reshape(-1)], dim=D, kmax=kmax)
+        try:
+            fitter.split_and_fit([g for h in models for g in h.gmm_states],
+                                 start_centroids=np.concatenate([h.mu for h in models]),
+                                 weight_divisor=[int(c) for c in counts.reshape(-1)],     # hmm.py:108,118: len(segment)
+                                 n_gaussians=n_gaussians, use_em=use_em)
+        finally:
+            fitter.close()
+        # re-alignment of every template against its word's mixtures (hmm.py:95), all words in one launch
+        utt_word = np.repeat(np.arange(W), n_temps).astype(np.int32)
+        gmm = _pack.device_gmm(ctx, [g for h in models for g in h.gmm_states])
+        lat = _hip.Lattices(ctx, [_pack.graph_from_dense(np.arange(n) + w * n, h.transitions, [0], [n - 1]) for w, h in enumerate(models)])
+        try:
+            frames.loglik(gmm, fetch=False, state_ranges=(utt_word * n, utt_word * n + n))
+            res = lat.viterbi(frames, utt_lattice=utt_word, want_path=True)
+        finally:
+            lat.close()
+    finally:
+        frames.close()
+    starts_all = _starts_from_paths(res["paths"], n)
+    order, counts = _km.segment_order(lengths, n_temps, starts_all, n)
+    for h, segs in zip(models, _km.split_segments(_km.gather_rows(X, order), counts)):
+        h.segments = segs
+    return models
+
+
+def _starts_from_paths(paths, n):
+    """get_segments_from_path for all templates at once: visits of every chain row on the path, cumulated (kmeans.py:98-108)."""
+    plen = np.array([len(p) for p in paths], dtype=np.int64)
+    rows = (np.concatenate([np.asarray(p)[:, 0] for p in paths]) if len(paths) and plen.sum() else np.zeros(0, dtype=np.int64)).astype(np.int64)
+    tid = np.repeat(np.arange(len(paths)), plen)
+    counts = np.bincount(tid * n + rows, minlength=len(paths) * n).reshape(len(paths), n)   # (rows: chain rows 0 .. n-1 of the word's own graph)
+    starts_all = np.zeros((len(paths), n), dtype=np.int64)
+    np.cumsum(counts[:, :-1], axis=1, out=starts_all[:, 1:])
+    return starts_all
+
+
+def _train_words_by_segments(templates_by_word, models, n_segments, n_gaussians, use_gmm, use_em):
+    """train_words with the frames regrouped on the host (one feature dimension, word lists with an empty entry, the test
+    double of the binding): the stages of `HMM.fit`, the refit and the re-alignment still one launch sequence for all words."""
+    import importlib
+    _km = importlib.import_module(__package__ + ".kmeans")
+    from .hmm_state import GMM
+    from .lockstep import LockstepFitter
+    W = len(templates_by_word)
     for w, h in enumerate(models):
-        ys = templates_by_word[w]
-        if fitted is None:
-            h.mu, h.sigma, h.transitions, h.segments = _km.skmeans(ys, n_segments, return_segmented_data=True)
-        else:
-            h.mu, h.sigma, h.transitions, starts = fitted[w]
-            h.segments = _km.segment_data_fast(ys, n_segments, starts)
+        h.mu, h.sigma, h.transitions, h.segments = _km.skmeans(templates_by_word[w], n_segments, return_segmented_data=True)
     if not use_gmm:
         return models
     for h in models:
@@ -81,17 +147,12 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
                              n_gaussians=n_gaussians, use_em=use_em)
     finally:
         fitter.close()
-    # re-alignment of every template against its word's mixtures (hmm.py:95), all words in one launch
     ctx = _hip.default_context()
     flat = [np.asarray(t, dtype=np.float64) for ts in templates_by_word for t in ts]
     utt_word = np.repeat(np.arange(W), [len(ts) for ts in templates_by_word]).astype(np.int32)
     n = n_segments
     gmm = _pack.device_gmm(ctx, [g for h in models for g in h.gmm_states])
-    graphs = []
-    for w, h in enumerate(models):
-        g = _pack.graph_from_dense(np.arange(n) + w * n, h.transitions, [0], [n - 1])
-        graphs.append(g)
-    lat = _hip.Lattices(ctx, graphs)
+    lat = _hip.Lattices(ctx, [_pack.graph_from_dense(np.arange(n) + w * n, h.transitions, [0], [n - 1]) for w, h in enumerate(models)])
     frames = _hip.Batch(ctx, flat)
     try:
         frames.loglik(gmm, fetch=False, state_ranges=(utt_word * n, utt_word * n + n))
@@ -100,14 +161,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
         frames.close()
         lat.close()
     off = np.concatenate([[0], np.cumsum([len(ts) for ts in templates_by_word])])
-    # get_segments_from_path for all templates at once: visits of every chain row on the path, cumulated (kmeans.py:98-108)
-    paths = res["paths"]
-    plen = np.array([len(p) for p in paths], dtype=np.int64)
-    rows = (np.concatenate([np.asarray(p)[:, 0] for p in paths]) if len(paths) and plen.sum() else np.zeros(0, dtype=np.int64)).astype(np.int64)
-    tid = np.repeat(np.arange(len(paths)), plen)
-    counts = np.bincount(tid * n + rows, minlength=len(paths) * n).reshape(len(paths), n)   # (rows: chain rows 0 .. n-1 of the word's own graph)
-    starts_all = np.zeros((len(paths), n), dtype=np.int64)
-    np.cumsum(counts[:, :-1], axis=1, out=starts_all[:, 1:])
+    starts_all = _starts_from_paths(res["paths"], n)
     for w, h in enumerate(models):
         h.segments = _km.segment_data_fast(templates_by_word[w], n, starts_all[off[w]:off[w + 1]])
     return models

@@ -150,24 +150,72 @@ def _starts_from_ids(ids, lengths, n_segments):
     return starts
 
 
-def skmeans_multi(templates_by_word, n_segments, max_iteration=1000):
+def segment_order(lengths, n_temps, seg_starts, n_segments):
+    """The frames of MANY words' templates (back to back, word after word, template after template) regrouped the way
+    `segment_data` regroups them (kmeans.py:33-50): -> (order [N]: frame numbers grouped by (word, segment), inside a group
+    template after template in time order; counts [W, n]: frames per group).  seg_starts [R, n] as `skmeans` holds them
+    (cumulative visit counts: monotone), the last segment runs to the end of its template."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    R, N = len(lengths), int(np.sum(lengths))
+    W = len(n_temps)
+    t_in = (np.arange(N) - np.repeat(np.cumsum(lengths) - lengths, lengths)).astype(np.int32)
+    starts = np.asarray(seg_starts, dtype=np.int32)
+    small = W * n_segments < 65536
+    key = np.repeat((np.repeat(np.arange(W), n_temps) * n_segments).astype(np.uint16 if small else np.int64), lengths)
+    for s in range(1, n_segments):                                  # (block copies of a column instead of a gather per frame)
+        key += t_in >= np.repeat(starts[:, s], lengths)
+    order = np.argsort(key, kind="stable")                          # (16-bit keys: numpy's radix sort)
+    counts = np.bincount(key, minlength=W * n_segments).reshape(W, n_segments)
+    return order, counts
+
+
+def gather_rows(X, order):
+    """X[order] for a big row-major matrix, the copy spread over a few threads (np.take releases the GIL): the 62 MB of
+    the segments of ten words x 200 templates take 2-3 ms instead of 8."""
+    import threading
+    N = len(order)
+    out = np.empty((N,) + X.shape[1:], dtype=X.dtype)
+    n_thr = 4 if N * X.shape[1] >= (1 << 20) else 1
+    if n_thr == 1:
+        np.take(X, order, axis=0, out=out)
+        return out
+    cuts = np.linspace(0, N, n_thr + 1).astype(np.int64)
+    thr = [threading.Thread(target=np.take, args=(X, order[cuts[i]:cuts[i + 1]]), kwargs=dict(axis=0, out=out[cuts[i]:cuts[i + 1]]))
+           for i in range(n_thr)]
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    return out
+
+
+def split_segments(Xo, counts):
+    """The regrouped frames as `segment_data` returns them: per word a list of n arrays (np.array([]) for an empty one)."""
+    W, n = counts.shape
+    cuts = np.concatenate([[0], np.cumsum(counts.reshape(-1))])
+    return [[Xo[cuts[w * n + s]:cuts[w * n + s + 1]] if counts[w, s] else np.array([]) for s in range(n)] for w in range(W)]
+
+
+def skmeans_multi(templates_by_word, n_segments, max_iteration=1000, frames=None):
     """Segmental k-means (kmeans.py:111-155, Euclidean frame distance) of every word model at once.
 
     templates_by_word: list over words of lists of [T_r, D] arrays.  Returns a list over words of
     (means [n,D], variances [n,D], transition costs [n,n], seg_starts [n_temps, n]) -- per word exactly what `skmeans`
     computes for it alone: the words only share the launches.  As in the reference the transition costs are those of
     the initial uniform segmentation for the whole loop (`seg_lens` is never refreshed, :139), the variances are the
-    last ones computed, and on convergence the means of the PREVIOUS iteration are returned (:146-148)."""
+    last ones computed, and on convergence the means of the PREVIOUS iteration are returned (:146-148).
+    frames: the templates as a resident fp64 batch (word after word, template after template), when the caller holds one."""
     assert max_iteration > 0
     W = len(templates_by_word)
-    flat = [np.asarray(t, dtype=np.float64) for ts in templates_by_word for t in ts]
     n_temps = np.array([len(ts) for ts in templates_by_word], dtype=np.int64)
-    lengths = np.array([len(t) for t in flat], dtype=np.int64)
+    lengths = np.array([len(t) for ts in templates_by_word for t in ts], dtype=np.int64)
     if np.any(lengths < 5):
         raise NameError('template is too small, cannot do dtw on it')
     utt_word = np.repeat(np.arange(W), n_temps).astype(np.int32)
     ctx = _ctx()
-    frames = _hip.Batch(ctx, flat)
+    own = frames is None
+    if own:
+        frames = _hip.Batch(ctx, [np.asarray(t, dtype=np.float64) for ts in templates_by_word for t in ts])
     tpl_off = np.concatenate([[0], np.cumsum(n_temps)])
     word_off = frames.offsets[tpl_off]                      # a word's templates sit back to back in the batch
     ids, seg_lens = _uniform_segments(lengths, n_segments)
@@ -191,7 +239,8 @@ def skmeans_multi(templates_by_word, n_segments, max_iteration=1000):
         ids = fit.clusters()
     finally:
         fit.close()
-        frames.close()
+        if own:
+            frames.close()
     starts = _starts_from_ids(ids, lengths, n_segments)
     return [(res[w], vars_[w], trans[w], starts[tpl_off[w]:tpl_off[w + 1]]) for w in range(W)]
 

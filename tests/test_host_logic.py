@@ -303,3 +303,31 @@ def test_deepcopy_of_models_equals_the_generic_deepcopy():
     mc = copy.deepcopy(m)
     np.testing.assert_array_equal(mc.inv_cov, m.inv_cov)
     assert mc.inv_cov is not m.inv_cov
+
+
+def test_segment_order_regroups_like_segment_data():
+    """kmeans.segment_order / gather_rows / split_segments (train_words: the frames of all words regrouped by (word, segment)
+    with one sort and one gather) against segment_data, the reference's slices (kmeans.py:33-50), word by word -- including
+    empty segments, which stay `np.array([])`."""
+    import importlib
+    km = importlib.import_module("sr.recognition.kmeans")
+    rng = np.random.default_rng(0)
+    W, n = 3, 5
+    tw = [[rng.normal(size=(int(rng.integers(5, 30)), 4)) for _ in range(int(rng.integers(1, 6)))] for _ in range(W)]
+    n_temps = np.array([len(t) for t in tw])
+    lengths = np.array([len(t) for ts in tw for t in ts])
+    starts = np.array([np.sort(np.concatenate([[0], rng.integers(0, L, n - 1)])) for L in lengths])
+    starts[0, 2] = starts[0, 1]                                   # an empty segment
+    X = np.concatenate([t for ts in tw for t in ts])
+    order, counts = km.segment_order(lengths, n_temps, starts, n)
+    segs = km.split_segments(km.gather_rows(X, order), counts)
+    off = np.concatenate([[0], np.cumsum(n_temps)])
+    for w in range(W):
+        ref = km.segment_data(tw[w], len(tw[w]), n, starts[off[w]:off[w + 1]])
+        assert len(ref) == len(segs[w]) == n
+        for a, b in zip(ref, segs[w]):
+            assert a.shape == b.shape
+            np.testing.assert_array_equal(a, b)
+    big = rng.normal(size=(40000, 39))
+    idx = rng.permutation(40000)
+    np.testing.assert_array_equal(km.gather_rows(big, idx), big[idx])      # (the threaded copy)
