@@ -310,13 +310,14 @@ from sr.recognition.train import BaumWelchTrainer
 from test_gpu_configs import c3_problem
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 fail_at = int(os.environ["FAIL_AT"])
+fail_rank = int(os.environ.get("FAIL_RANK", "1"))
 ctx = _hip.default_context(int(os.environ["GMMHMM_DEVICE"]))
 red = NativeReducer(ctx, timeout=120)
 state = {}
 
 def work():
-    if fail_at == 0 and rank == 1:
-        raise RuntimeError("rank 1 fails before its first collective")
+    if fail_at == 0 and rank == fail_rank:
+        raise RuntimeError("rank %d fails before its first collective" % rank)
     if fail_at == 0:
         t0 = time.perf_counter()
         try:
@@ -332,8 +333,8 @@ def work():
         assert tr.session is not None
         tr.iteration()
         tr.iteration()
-        if rank == 1:
-            raise RuntimeError("rank 1 fails between two EM iterations")
+        if rank == fail_rank:
+            raise RuntimeError("rank %d fails between two EM iterations" % rank)
         t0 = time.perf_counter()
         try:
             if fail_at == 3:            # iterations ENQUEUED without a read-back: the wait is in the history read
@@ -395,6 +396,47 @@ def test_two_native_rccl_ranks_equal_one_rank(tmp_path):
     fin = np.isfinite(np.array(tr.transitions))
     _close(r0["trans"][fin], np.array(tr.transitions)[fin], 1e-8, 1e-10)
     tr.close()
+
+
+def test_five_native_rccl_ranks_equal_one_rank(tmp_path):
+    """The communicator beyond two ranks: the id hand-over serves four peers, ncclCommInitRank builds a five-rank ring
+    (all ranks on GPU 0 of a one-GPU box: socket transport), every EM iteration's statistics cross it on the stream --
+    and the five ranks end with the one-rank model.  (Five, not eight: a GPU box admits six processes on its card, and
+    this test process holds the card too; bench.py --gpus 6 --same-gpu is rehearsed in profiles/.)"""
+    from sr.recognition.train import BaumWelchTrainer
+    world = 5
+    _spawn_ranks(tmp_path, world)
+    means, vars_, w, trans, data, labels = c3_problem(1200)
+    tr = BaumWelchTrainer(means, vars_, w, trans, data, labels)
+    hist = tr.fit(3)
+    rs = [np.load(tmp_path / ("native%d.npz" % r)) for r in range(world)]
+    assert all(int(r["count"]) == world for r in rs)                       # ncclCommCount
+    assert sum(int(r["frames"]) for r in rs) == tr.batch.N and all(int(r["frames"]) > 0 for r in rs)
+    for r in rs[1:]:
+        for k in ("means", "vars", "w", "hist", "trans"):
+            np.testing.assert_array_equal(rs[0][k], r[k])                 # every rank ends with the same bits
+    _close(rs[0]["hist"], hist, 1e-10)
+    _close(rs[0]["means"], tr.means, 1e-8, 1e-10)
+    _close(rs[0]["vars"], tr.vars, 1e-7)
+    _close(rs[0]["w"], tr.weights, 1e-8, 1e-12)
+    tr.close()
+
+
+def test_one_of_five_ranks_failing_is_an_error_on_the_other_four(tmp_path):
+    """Rank 3 of 5 dies between two EM iterations: each of the other four comes back from its next collective with
+    CommError within the deadline, and every later call on the communicator fails at once."""
+    import time
+    t0 = time.perf_counter()
+    outs = _spawn_ranks(tmp_path, 5, {"FAIL_AT": "2", "FAIL_RANK": "3", "GMMHMM_COMM_TIMEOUT": "20"}, script_text=_FAIL_SCRIPT,
+                        expect_status=[0, 0, 0, 1, 0])
+    assert time.perf_counter() - t0 < 300
+    assert "rank 3 fails" in outs[3]
+    for r in (0, 1, 2, 4):
+        res = np.load(tmp_path / ("fail%d.npz" % r))
+        assert str(res["outcome"]) == "CommError", (r, str(res["outcome"]), outs[r][-2000:])
+        assert float(res["seconds"]) < 40.0
+        assert str(res["after"]) == "CommError" and float(res["after_seconds"]) < 1.0 and int(res["count"]) == 0
+    assert not os.path.exists(tmp_path / "fail3.npz")
 
 
 def test_a_rank_without_utterances_still_joins_every_collective(tmp_path):

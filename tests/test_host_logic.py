@@ -331,3 +331,66 @@ def test_segment_order_regroups_like_segment_data():
     big = rng.normal(size=(40000, 39))
     idx = rng.permutation(40000)
     np.testing.assert_array_equal(km.gather_rows(big, idx), big[idx])      # (the threaded copy)
+
+
+def test_id_hand_over_serves_eight_ranks_and_ignores_strangers():
+    """parallel.exchange_from_rank0 at the world size the scaling run uses (8): rank 0 hands its 128-byte payload to seven
+    peers that arrive in any order, a connection that does not open with the magic word / world size / token is not
+    counted, and a peer that arrives before rank 0 listens keeps retrying."""
+    import socket
+    import threading
+    import time
+    from sr.recognition.parallel import exchange_from_rank0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, payload, got, errs = 8, bytes(range(128)), {}, []
+
+    def run(rank, delay):
+        try:
+            time.sleep(delay)
+            got[rank] = exchange_from_rank0(rank, world, lambda: payload, addr="127.0.0.1", ports=[port], timeout=60.0, token=b"run-42")
+        except Exception as e:            # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    def stranger():
+        time.sleep(0.4)
+        for _ in range(3):
+            try:
+                with socket.create_connection(("127.0.0.1", port), timeout=2.0) as c:
+                    c.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"x" * 64)
+                    time.sleep(0.05)
+            except OSError:
+                pass
+
+    thr = [threading.Thread(target=run, args=(r, 0.3 if r == 0 else 0.05 * (r % 3))) for r in range(world)]
+    thr.append(threading.Thread(target=stranger))
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join(90)
+    assert not errs, errs
+    assert sorted(got) == list(range(world)) and all(v == payload for v in got.values())
+    # another run's token is not served: the peer gives up at its deadline, rank 0 at its own
+    got.clear()
+
+    def wrong():
+        try:
+            exchange_from_rank0(1, 2, lambda: b"", addr="127.0.0.1", ports=[port], timeout=3.0, token=b"other-run")
+            errs.append("a foreign token was served")
+        except RuntimeError:
+            pass
+
+    def right0():
+        try:
+            exchange_from_rank0(0, 2, lambda: payload, addr="127.0.0.1", ports=[port], timeout=4.0, token=b"run-42")
+            errs.append("rank 0 counted a foreign peer")
+        except RuntimeError:
+            pass
+    ts = [threading.Thread(target=right0), threading.Thread(target=wrong)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert not errs, errs
