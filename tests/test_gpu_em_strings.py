@@ -201,3 +201,100 @@ def test_a_rank_of_one_word_transcripts_shares_the_collective_with_a_rank_of_wor
     _close(r0["means"], tr.means, 1e-8, 1e-10)
     _close(r0["vars"], tr.vars, 1e-7)
     tr.close()
+
+
+@pytest.mark.parametrize("K", [2, 4, 7])
+def test_word_string_iteration_against_the_oracle_directly(K):
+    """ONE iteration of the word-string session (likelihoods of the transcript's words -> fb_seq kernels -> occupancy ranges
+    merged per word -> matrix-core statistics -> M-step) against the CPU oracle with nothing of this repo's GPU code in
+    between (parity softness 1): the oracle's likelihoods (`gmm_neg_loglik_batch`) on the transcript's expanded
+    lattice (continuous_speech.py:13-53 as `packed_lattice` lays it out, one word per layer), its forward-backward
+    (`O.forward_backward`: the brute-force-pinned sum-product twin of decode.py:80-146), numpy for the statistics of
+    hmm_state.py:134-148 and the M-step.  Strings with a word repeated (adjacent layers and distant ones)."""
+    import bench
+    from oracle import ref_numpy as O
+    from sr.recognition.continuous_speech import packed_lattice
+    from sr.recognition.train import BaumWelchTrainer
+    W, n, M, D, U = 4, 5, 4, 13, 18
+    wl = bench.synth_workload(777 + K, U * K, W=W, n=n, M=M, D=D, tmin=8, tmax=20)
+    words = wl["words"].reshape(U, K)
+    off = wl["off"][::K]
+    data = [wl["X"][off[u]:off[u + 1]] for u in range(U)]
+    labels = [[int(w) for w in words[u]] for u in range(U)]
+    for u in range(0, U, 2):                      # a word twice in a row, and once more at the end
+        labels[u][1] = labels[u][0]
+        labels[u][-1] = labels[u][0]
+    S = W * n
+    means0 = (wl["means"] + 0.3 * np.random.default_rng(5).normal(size=wl["means"].shape)).reshape(S, M, D)
+    vars0, w0, trans = wl["vars"].reshape(S, M, D), wl["w"].reshape(S, M), wl["trans"]
+    tr = BaumWelchTrainer(means0.reshape(W, n, M, D), wl["vars"], wl["w"], [trans] * W, data, labels, occ_floor=0.0)
+    assert tr.session is not None and tr.session.word_strings
+    ll = tr.iteration()
+    packed = tr.session.packed()
+    n_stats = S * M * (1 + 2 * D)
+    # ---- the oracle's E-step on every utterance's own lattice ----
+    stats = np.zeros((S, M, 1 + 2 * D))
+    xi = np.zeros(S)
+    logp_total = 0.0
+    logc = np.log(w0) - 0.5 * (D * np.log(2 * np.pi) + np.log(vars0).sum(axis=2))
+    nll_all = O.gmm_neg_loglik_batch(np.concatenate(data), means0, vars0, w0)           # [N, S]
+    at = 0
+    for x, lab in zip(data, labels):
+        T = len(x)
+        nll = nll_all[at:at + T]
+        at += T
+        g = packed_lattice([trans] * W, n, [[l] for l in lab])[0]
+        R = len(g["row_state"])
+        dense = np.full((R, R), np.inf)
+        dense[g["arc_to"], g["arc_from"]] = g["arc_cost"]
+        is_nes = g["row_state"] < 0
+        E = np.zeros((R, T))
+        E[~is_nes] = nll[:, g["row_state"][~is_nes]].T
+        la, lb, gamma, logp = O.forward_backward(E, is_nes, dense, g["end_rows"])
+        logp_total += logp
+        occ = np.zeros((S, T))                     # a state's occupancy: its rows in every layer of the word
+        for r in np.flatnonzero(~is_nes):
+            s = int(g["row_state"][r])
+            occ[s] += gamma[r]
+            with np.errstate(over="ignore", invalid="ignore"):
+                xi[s] += np.exp(la[r, :-1] - dense[r, r] - nll[1:, s] + lb[r, 1:] - logp).sum()
+        for s in np.flatnonzero(occ.sum(axis=1) > 0):
+            ll_c = logc[s][None, :] - 0.5 * (((x[:, None, :] - means0[s][None]) ** 2) / vars0[s][None]).sum(axis=2)
+            r_ = np.exp(ll_c - ll_c.max(axis=1, keepdims=True))
+            r_ = occ[s][:, None] * r_ / r_.sum(axis=1, keepdims=True)
+            for m in range(M):
+                d = x - means0[s, m]
+                stats[s, m, 0] += r_[:, m].sum()
+                stats[s, m, 1:1 + D] += (r_[:, [m]] * d).sum(axis=0)
+                stats[s, m, 1 + D:] += (r_[:, [m]] * d * d).sum(axis=0)
+    _close(packed[:n_stats].reshape(S, M, 1 + 2 * D), stats, 1e-8, 1e-10)
+    _close(packed[n_stats:n_stats + S], xi, 1e-8, 1e-10)
+    _close(packed[n_stats + S], logp_total, 1e-10)
+    _close(ll, logp_total, 1e-10)
+    assert packed[-1] == U
+    # every frame is occupied once, the frame on a word boundary twice (the non-emitting row hands over in the same column)
+    _close(stats[:, :, 0].sum(), sum(len(x) for x in data) + U * (K - 1), 1e-9)
+    # ---- the M-step (hmm_state.py:134-148 with soft counts; the trainer's variance floor) and the transition costs ----
+    s0 = stats[:, :, 0]
+    seen = s0.sum(axis=1) > 0
+    with np.errstate(all="ignore"):
+        mu = means0 + stats[:, :, 1:1 + D] / s0[:, :, None]
+        delta = mu - means0
+        sigma = np.maximum((stats[:, :, 1 + D:] - delta * (2.0 * stats[:, :, 1:1 + D] - delta * s0[:, :, None])) / s0[:, :, None],
+                           tr.var_floor)
+        wgt = s0 / s0.sum(axis=1, keepdims=True)
+    _close(tr.means[seen], mu[seen], 1e-8, 1e-10)
+    _close(tr.vars[seen], sigma[seen], 1e-7, 1e-10)
+    _close(tr.weights[seen], wgt[seen], 1e-8, 1e-12)
+    counts = s0.sum(axis=1)
+    for wi in range(W):
+        t = tr.transitions[wi]
+        for si in range(n):
+            s = wi * n + si
+            if counts[s] > 0:
+                p_stay = min(max(xi[s] / counts[s], 0.0), 1.0)
+                with np.errstate(divide="ignore"):
+                    _close(t[si, si], -np.log(p_stay), 1e-8, 1e-10)
+                    if si < n - 1:
+                        _close(t[si + 1, si], -np.log(1.0 - p_stay), 1e-8, 1e-10)
+    tr.close()
