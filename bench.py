@@ -124,6 +124,24 @@ def profiled_traffic(dtype, n_frames):
     return None
 
 
+def profiled_fused_traffic(n_frames, D, esz):
+    """HBM bytes per launch of the fused single-Gaussian sweep from the committed PMC passes (the newest
+    profiles/*_pmc_fused_traffic.json: FETCH_SIZE calibrated on tools/hbm_stream.hip in the kernel's own access width
+    -- 8 B per lane reads are tallied at half their bytes, like the 16 B ones -- plus WRITE_SIZE; tools/pmc_calibrated.py);
+    None when no profile matches this workload (compulsory reads = n_frames x D x esz)."""
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fused_traffic.json")))):
+        try:
+            ks = json.load(open(path))["kernels"]
+            for k in ks.values():
+                want = float(n_frames) * D * esz
+                if abs(k["compulsory_read_bytes"] - want) <= 0.02 * want and k.get("corrected_read_bytes"):
+                    return k["corrected_read_bytes"] + k.get("write_bytes", 0.0)
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(wl, n_utts=20):
     """The numpy oracle run the way the reference runs (per-frame GMM.evaluate through dense
     inverse covariances, per-cell Python DP), one core, on the first `n_utts` utterances."""
@@ -581,6 +599,7 @@ def _isolated_config(ctx, group, name, seed, U, W, n, M, D, npdt, peak_flops, mi
                                "unit": "TFLOP/s", "frac": flops_f / t_f / peak_flops,
                                "hbm_achieved": bytes_f / t_f / 1e9, "hbm_frac": bytes_f / t_f / PEAK_HBM,
                                "bytes_per_frame": esz * D + 4, "flop_per_frame": 4 * D * S,
+                               "traffic": profiled_fused_traffic(N, D, esz),
                                "note": "the sweep is bound by the vector pipe (2 D fma + 7 recurrence instructions per cell "
                                        "column, 50 of 64 lanes), not by HBM; wall time of the synchronous call"}})
     lat.close(); b.close(); gmm.close()

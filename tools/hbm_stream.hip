@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 typedef double v2d __attribute__((ext_vector_type(2)));
 __global__ void k_read(const v2d* __restrict__ in, size_t n, double* sink) {
     v2d acc = {0, 0};
@@ -22,6 +23,21 @@ __global__ void k_mix(const v2d* __restrict__ in, v2d* __restrict__ out, size_t 
         for (int k = 0; k < 4; ++k) out[k * n_in + i] = v * (double)(k + 1);   // four coalesced output streams
     }
 }
+// calibration kernels for the PMC byte counters (FETCH_SIZE is only documented for 16 B per lane): the access shapes of the
+// kernels whose traffic is quoted -- 8 B per lane, contiguous (the fused sweep's and the refit's slab loads), one pass
+__global__ void k_read8(const double* __restrict__ in, size_t n, double* sink) {
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += in[i];
+    if (acc == 12345.678) sink[0] = acc;
+}
+// one wave reads one contiguous piece of `len` doubles with 64 x 8 B loads (a tile of frames), pieces back to back
+__global__ void k_read8_tiles(const double* __restrict__ in, size_t n_tiles, int len, double* sink) {
+    double acc = 0;
+    const int lane = threadIdx.x & 63;
+    for (size_t t = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < n_tiles; t += (size_t)gridDim.x * (blockDim.x >> 6))
+        for (int e = lane; e < len; e += 64) acc += in[t * len + e];
+    if (acc == 12345.678) sink[0] = acc;
+}
 template <typename F> double timeit(F launch, int reps = 20) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
@@ -35,7 +51,24 @@ template <typename F> double timeit(F launch, int reps = 20) {
     hipEventElapsedTime(&ms, a, b);
     return ms / reps * 1e-3;
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "calib")) {
+        // ONE launch of every calibration kernel over 2 GiB (beyond the 256 MiB Infinity Cache), for rocprofv3 --pmc:
+        //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -o c -- tools/bin/hbm_stream calib
+        const size_t bytes = (size_t)2 << 30;
+        double *a, *sink;
+        hipMalloc(&a, bytes); hipMalloc(&sink, 8);
+        hipMemset(a, 0, bytes);
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(k_read, dim3(8192), dim3(256), 0, 0, (const v2d*)a, bytes / 16, sink);
+        hipLaunchKernelGGL(k_read8, dim3(8192), dim3(256), 0, 0, (const double*)a, bytes / 8, sink);
+        hipLaunchKernelGGL(k_read8_tiles, dim3(8192), dim3(256), 0, 0, (const double*)a, bytes / 8 / 416, 416, sink);   // 32 frames x 13
+        hipLaunchKernelGGL(k_read8_tiles, dim3(8192), dim3(256), 0, 0, (const double*)a, bytes / 8 / 624, 624, sink);   // 16 frames x 39
+        hipDeviceSynchronize();
+        printf("calib: k_read (16 B per lane) %zu bytes, k_read8 (8 B per lane) %zu bytes, k_read8_tiles len 416: %zu bytes, len 624: %zu bytes\n",
+               bytes, bytes, bytes / 8 / 416 * 416 * 8, bytes / 8 / 624 * 624 * 8);
+        return 0;
+    }
     const size_t GB = (size_t)1 << 30, bytes = 4 * GB, n = bytes / 16;
     v2d *a, *b;
     double* sink;
