@@ -261,7 +261,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             // and the start row must not be fed
             for (int k = 0; ok && k < A; ++k) if (arc_to[a0 + k] == start_row && start_row != em[0]) ok = false;
             ok = ok && !std::isinf(fc.c0);
-            for (int j = 0; j < fc.n; ++j) if (!std::isinf(fc.skip_c[j])) fc.pad = 1;   // pad = "has skip arcs"
+            for (int j = 0; ok && j < fc.n; ++j) if (!std::isinf(fc.skip_c[j])) fc.pad = 1;   // pad = "has skip arcs" (ok: fc.n <= GH_FBCHAIN_MAX -- found by ASan: a graph with more emitting rows read past the arrays)
             if (ok) lt->h_fbchain.push_back(fc); else { lt->fbchain_ok = false; lt->h_fbchain.clear(); }
         }
 #undef GH_LFAIL
