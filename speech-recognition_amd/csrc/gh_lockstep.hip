@@ -26,46 +26,6 @@ struct ls_tile { int64_t first; int32_t state, count; };
 // Row stride TS = D | 1: odd, so the lane = frame reads below touch 32 banks (stride D + 1 = 40 doubles for D = 39 put them
 // on 4: an 8-way conflict per read); for odd D the tile is simply the frames as they lie in memory, element i at slot i.
 __device__ __forceinline__ int tile_stride(int D) { return D | 1; }
-template <int DR>
-__device__ __forceinline__ void stage_tile(const double* __restrict__ X, int64_t first, int count, int D, double* tile,
-                                           double (&x)[DR]) {
-    const int lane = threadIdx.x;
-    const double* src = X + first * D;
-    const int nelem = count * D;                 // 1 .. 64 D <= 64 DR
-    const int TS = tile_stride(D);
-    // ALL the tile's loads in flight before the first LDS write (round 4: the loop `tile[..] = src[i]` was one HBM round
-    // trip per 64 elements -- 39 in a row for a 64 x 39 tile -- and an integer division per element); unconditional, from
-    // a clamped index
-    double r[DR];
-#pragma unroll
-    for (int it = 0; it < DR; ++it) {
-        const int i = lane + 64 * it;
-#ifdef EMV_NOSTAGE
-        r[it] = 0.001 * (double)(i & 255);
-#else
-        r[it] = src[i < nelem ? i : nelem - 1];
-#endif
-    }
-    if (D & 1) {
-#pragma unroll
-        for (int it = 0; it < DR; ++it) if (lane + 64 * it < nelem) tile[lane + 64 * it] = r[it];
-    } else {                                     // one pad slot per frame: element i of frame f at slot i + f
-        int f = lane / D, d = lane - f * D;
-        const int q64 = 64 / D, r64 = 64 - q64 * D;
-#pragma unroll
-        for (int it = 0; it < DR; ++it) {
-            if (lane + 64 * it < nelem) tile[lane + 64 * it + f] = r[it];
-            d += r64;
-            f += q64;
-            if (d >= D) { d -= D; ++f; }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < DR; ++d) x[d] = (d < D && lane < count) ? tile[lane * TS + d] : 0.0;
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------ k-means
 // Cluster sums in FRAME ORDER: numpy reduces a C-contiguous [n, D] array over axis 0 row after row (pairwise summation
 // only applies along the contiguous axis), so cluster_centroids' np.mean(data[clusters == c], axis=0)
@@ -213,8 +173,9 @@ __global__ __launch_bounds__(64) void kmeans_rowsum_kernel(const double* __restr
 // RECIP: (t * (1/var)) * t instead of the reference's t / var * t (mahalanobis, hmm_state.py:58: `m / variance * m`).  The
 // division is ~25 fp64 instructions per (cluster, dimension) -- 8 x 39 of them per frame made this kernel the longest of
 // the refit (437 us per sweep of 1.4 M frames).  The two forms differ in the last bit of a term; an assignment changes
-// only where two centroids tie to ~1e-16 relative.  The device-resident refit takes RECIP (goldens G8 / G10 / G11 / G17:
-// identical cluster ids); GMMHMM_KMEANS_EXACT=1 and the call-by-call gh_kmeans_assign_multi keep the division.
+// only where two centroids tie to ~1e-16 relative.  Opt-in (GMMHMM_KMEANS_RECIP=1) since round 5: the device-resident refit
+// now runs the streaming kernel of gh_refit_mfma.hip (k <= 8), which re-tests near-ties with the division, and what is left
+// to this kernel (k > 8, GMMHMM_REFIT=tiles, the call-by-call gh_kmeans_assign_multi) keeps the reference's operations.
 // TWO waves per tile, like em_multi_kernel below: the waves share the tile (here only a transposition buffer) and the
 // centroids; each takes half of the clusters, and wave 0 joins the two candidates with the rule of the one-wave loop
 // (np.argmin: the first minimum, a NaN before everything) -- the same assignment, the chains of 39 dependent terms per
@@ -387,11 +348,7 @@ __global__ __launch_bounds__(64 * GH_EM_WAVES) void em_multi_kernel(const double
 #pragma unroll
         for (int it = 0; it < DR / NW; ++it) {
             const int i = tid + NT * it;
-#ifdef EMV_NOSTAGE   // diagnostic builds (tools/emv_variants.sh): timing only, results wrong
-            r[it] = 0.001 * (double)(i & 255);
-#else
             r[it] = src[i < nelem ? i : nelem - 1];
-#endif
         }
 #pragma unroll 4
         for (int i = tid; i < k * D; i += NT) { pm[i] = mean[pbase * D + i]; pv[i] = ivar[pbase * D + i]; }
@@ -421,11 +378,7 @@ __global__ __launch_bounds__(64 * GH_EM_WAVES) void em_multi_kernel(const double
     for (int c = c_lo; c < c_hi; ++c) {
         double q = 0;
 #pragma unroll
-#ifdef EMV_NOPHASE1
-        for (int d = 0; d < 1; ++d) q = x[c % DR];
-#else
         for (int d = 0; d < DR; ++d) if (d < D) { const double t = x[d] - pm[c * D + d]; q = fma(t * pv[c * D + d], t, q); }
-#endif
         double l = pc[c] - 0.5 * q;
         const bool nan_l = l != l;
         if (-0.5 * q < LS_LN_UNDERFLOW || l < LS_LN_UNDERFLOW) l = -INFINITY;   // the reference's linear-domain product is 0
@@ -437,11 +390,7 @@ __global__ __launch_bounds__(64 * GH_EM_WAVES) void em_multi_kernel(const double
     bool bad = false;
     for (int c = 0; c < k; ++c) { const double l = rt[c * 64 + lane]; bad |= (l != l); mx = fmax(mx, l); }
     for (int c = 0; c < k; ++c) {
-#ifdef EMV_NOEXP
-        const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
-#else
         const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
-#endif
         sum += e;
     }
     const double inv = bad ? NAN : (sum > 0 ? 1.0 / sum : 0.0);
@@ -449,23 +398,14 @@ __global__ __launch_bounds__(64 * GH_EM_WAVES) void em_multi_kernel(const double
     if (act && wv == 0) ll = bad ? NAN : (sum > 0 ? mx + log(sum) : 0.0);
     __syncthreads();                              // (every log-density has been read: the responsibilities may replace them)
     for (int c = c_lo; c < c_hi; ++c) {
-#ifdef EMV_NOEXP
-        const double e = (mx == -INFINITY) ? 0.0 : 1.0 + (rt[c * 64 + lane] - mx);
-#else
         const double e = (mx == -INFINITY) ? 0.0 : exp(rt[c * 64 + lane] - mx);
-#endif
         rt[c * 64 + lane] = act ? (bad ? NAN : e * inv) : 0.0;
     }
     __syncthreads();
     // ---- phase 2: thread = (component, dimension) pair; dimension D = the occupancy; the sums run over the frames in order ----
     const int Wd = 1 + 2 * D;
     double* out = partial + (int64_t)blockIdx.x * (k * Wd + 1);
-#ifdef EMV_NOPHASE2
-    if (tid < k) out[tid * Wd] = rt[tid * 64];
-    for (int p = tid + 1000000; p < k * (D + 1); p += NT) {
-#else
     for (int p = tid; p < k * (D + 1); p += NT) {
-#endif
         const int c = p / (D + 1), d = p - c * (D + 1);
         const double* r = rt + c * 64;
         double a1 = 0, a2 = 0;
@@ -1185,7 +1125,9 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     // iteration.  GMMHMM_KMEANS_EXACT=1 keeps the frame-order sums and the np.array_equal rule in every iteration.
     const bool exact_env = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }();
     const bool exact_order = exact_env && !comm;
-    const bool exact_div = exact_env;          // the reference's division in the distance (see kmeans_multi_kernel)
+    // the tile kernels (k > 8, GMMHMM_REFIT=tiles) take the reference's division in the distance; its reciprocal form
+    // (25 fewer instructions per term, assignments that can differ on ties at the last bit) is opt-in: GMMHMM_KMEANS_RECIP=1
+    const bool exact_div = exact_env || ![] { const char* e = getenv("GMMHMM_KMEANS_RECIP"); return e && *e && *e != '0'; }();
     GH_HIP(hipMemcpyAsync(f->d_cent, centroids_in, (size_t)S * k * D * 8, hipMemcpyHostToDevice, st));
     GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
     GH_HIP(hipMemsetAsync(f->d_iters, 0, (size_t)S * 4, st));

@@ -601,7 +601,7 @@ extern "C" void gh_batch_destroy(gh_batch* b) {
 // normaliser -- or once the product is.  The likelihood kernels test the largest total logarithm a = log(w norm) - q/2
 // against ln 2^-1075, which is the whole rule while every log(w norm) <= 0 (ordinary variances).  With a component whose
 // w * norm > 1 (variances below ~1/2pi on average) a frame can have a > ln 2^-1075 and -q/2 below it: this pass finds the
-// entries in that band (cost within max(log(w norm), 0) of the threshold: next to none) and re-tests them per component.
+// entries in that band (cost within max(log(w norm), 0) + log M of the threshold: next to none) and re-tests them per component.
 template <typename T>
 __global__ void loglik_underflow_fix_kernel(const T* __restrict__ X, int64_t N, int S, int M, int D, const double* __restrict__ mean,
                                             const double* __restrict__ ivar, const double* __restrict__ logc,
@@ -616,7 +616,9 @@ __global__ void loglik_underflow_fix_kernel(const T* __restrict__ X, int64_t N, 
         for (int m = 0; m < M; ++m) P = fmax(P, logc[s * M + m]);     // (-inf for a switched-off component)
         if (!(P > 0.0)) continue;
         const double v = (double)nll[idx];
-        if (!(v > thr - P) || v == INFINITY) continue;
+        // a term whose exponent underflows has a = log(w norm) - q/2 < P - thr; with all M terms like that the cost
+        // -logsumexp(a) can still be as low as thr - P - log M (the band used to stop at thr - P)
+        if (!(v > thr - P - log((double)M)) || v == INFINITY) continue;
         bool survives = false;
         for (int m = 0; m < M && !survives; ++m) {
             const double lc = logc[s * M + m];

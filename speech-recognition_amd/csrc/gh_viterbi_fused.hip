@@ -100,9 +100,16 @@ __global__ __launch_bounds__(64) void viterbi_fused_kernel(gh_fused_args fa) {
     int cur_g = -1, rr = 0, es = -1;
 
     const int64_t G = gridDim.x;
+    // several row groups per utterance (items = utterance x group) and a grid that is a multiple of the group count: the
+    // serpentine runs over the utterances of ONE group, so a wave keeps its group -- and the 2 D + 2 constants it loaded --
+    // in odd rounds too (G - 1 - blockIdx.x has another residue than blockIdx.x)
+    const int ng = a.n_groups;
+    const bool own_group = ng > 1 && G % ng == 0;
+    const int64_t Gq = own_group ? G / ng : G, q = own_group ? blockIdx.x / ng : blockIdx.x, gl = own_group ? blockIdx.x % ng : 0;
     for (int64_t round = 0;; ++round) {
         // serpentine over the longest-first launch order: the waves' frame totals stay within one utterance of each other
-        const int64_t item = round * G + ((round & 1) ? G - 1 - blockIdx.x : blockIdx.x);
+        const int64_t sq = round * Gq + ((round & 1) ? Gq - 1 - q : q);
+        const int64_t item = own_group ? sq * ng + gl : sq;
         if (round * G >= fa.n_items) break;
         if (item >= fa.n_items) continue;
         const int64_t slot = a.slot0 + item / a.n_groups;
