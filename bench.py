@@ -1353,6 +1353,11 @@ def main():
                 "hbm_achieved_GBps": bytes_per_frame * N_frames / ll_avg_s / 1e9,
                 "hbm_frac": bytes_per_frame * N_frames / ll_avg_s / PEAK_HBM,
                 "note": "algorithmic flops = 2*(2D)*S*M per frame; peak = dense %s rate" % args.dtype,
+                # which log-sum-exp epilogue `value` and `frac` were measured with: "fp64" is what a caller gets by default
+                # (likelihoods to 1e-10 of the oracle); "f32exp" (GMMHMM_LSE=f32exp / gh_ctx_set_compat bit 1: the
+                # exponentials in fp32, |delta nll| <= 2.6e-7 = 3e-9 relative, no decode changes) is the opt-in fast mode,
+                # whose fraction is copied into `frac_f32exp` from the C2_lse_f32exp leg below when that leg runs
+                "lse": ("f32exp" if os.environ.get("GMMHMM_LSE") == "f32exp" else "fp64") if args.dtype == "f64" else "f32",
             },
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a rank-0, single-GPU-run measurement
@@ -1377,6 +1382,10 @@ def main():
             out["em"] = em
         if configs is not None:
             out["configs"] = configs
+            fe = configs.get("C2_lse_f32exp")
+            if isinstance(fe, dict) and "frac_f32exp" in fe:
+                out["roofline"]["frac_f32exp"] = fe["frac_f32exp"]          # (kernel alone, HIP events; the default mode's
+                out["roofline"]["frac_fp64_alone"] = fe["frac_fp64_epilogue"]   #  fraction measured the same way beside it)
         if world == 1 and not args.no_extra_configs:
             try:
                 out["pcie_inclusive"] = pcie_inclusive(dev, wl, npdt)

@@ -1081,6 +1081,9 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     const double* X = (const double*)f->b->feats;
     const dim3 skz((unsigned)S, (unsigned)k, (unsigned)((D + 63) / 64));
     int rc;
+    const bool exact_env = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }();
+    // Streaming matrix-core form (gh_refit_mfma.hip): see the loop below
+    const bool streaming = f->mfma && !exact_env && k <= f->kcap && rf_supported(k, D);
     // ---- the random partition and its variances (kmeans.py:171-177) ----
     {
         void* stage;
@@ -1090,6 +1093,26 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
             GH_HIP(hipMemcpyAsync(stage, part, (size_t)f->N, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(fit_u8_to_i32_kernel, dim3((unsigned)((f->N + 255) / 256)), dim3(256), 0, st, (const uint8_t*)stage, f->N, f->d_ids);
         }
+        if (streaming) {
+            // ONE streaming pass: count | sum (x - shift) | sum (x - shift)^2 of every (state, group) on the matrix cores, the
+            // variances from those (the shift sits inside the data, so the one-pass form loses nothing; round 3-4: cluster
+            // lists + two frame-order passes, 0.6 ms per call on 1.4 M frames).  Sharded: cluster 0's sums over all ranks.
+            std::vector<double> shift;
+            fit_shift_points(S, k, D, centroids_in, shift);
+            GH_HIP(hipMemcpyAsync(f->d_shift, shift.data(), shift.size() * 8, hipMemcpyHostToDevice, st));
+            GH_HIP(hipMemsetAsync(f->d_active, 1, (size_t)S, st));
+            GH_HIP(hipMemsetAsync(f->d_counter, 0, 64, st));
+            GH_HIP(hipMemsetAsync(f->d_done, 0, (size_t)S * 4, st));
+            rf_em_args h;
+            memset(&h, 0, sizeof h);
+            h.c.X = X; h.c.D = D; h.c.k = k; h.c.S = S; h.c.items = f->d_items; h.c.item_ptr = f->d_iptr; h.c.shift = f->d_shift;
+            h.c.active = f->d_active; h.c.done = f->d_done; h.c.partial = f->d_rpart; h.c.counter = f->d_counter;
+            h.stats = f->d_stats; h.hard_ids = f->d_ids;
+            rc = rf_launch_partition_sums(ctx, h, f->n_items);
+            if (!rc && comm) rc = gh_comm_allreduce_enqueue(comm, f->d_stats, (int64_t)S * (k * (1 + 2 * D) + 1));
+            if (!rc) rc = rf_launch_partvar(ctx, S, k, D, f->d_stats, comm ? 1 : 0, f->d_cov);
+            if (rc) return rc;
+        } else {
         GH_HIP(hipMemsetAsync(f->d_counts, 0, (size_t)S * k * 4, st));
         GH_HIP(hipMemsetAsync(f->d_cbase, 0, (size_t)S * k * 4, st));
         rc = fit_build_lists(f, k, false, nullptr);
@@ -1111,6 +1134,7 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         GH_HIP(hipGetLastError());
         hipLaunchKernelGGL(fit_partvar_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
                            (const double*)f->d_sums, (const double*)f->d_sq, comm ? 1 : 0, f->d_cov);
+        }
         hipLaunchKernelGGL(fit_logdet_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, S, k, D, (const double*)f->d_cov, f->d_logdet);
         GH_HIP(hipGetLastError());
     }
@@ -1123,7 +1147,6 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     // frame-order pass over the final assignment produces the centroids, which are then numpy's bit for bit.  What can
     // differ: a frame whose two nearest centroids tie to within an ulp might be assigned differently in an intermediate
     // iteration.  GMMHMM_KMEANS_EXACT=1 keeps the frame-order sums and the np.array_equal rule in every iteration.
-    const bool exact_env = [] { const char* e = getenv("GMMHMM_KMEANS_EXACT"); return e && *e && *e != '0'; }();
     const bool exact_order = exact_env && !comm;
     // the tile kernels (k > 8, GMMHMM_REFIT=tiles) take the reference's division in the distance; its reciprocal form
     // (25 fewer instructions per term, assignments that can differ on ties at the last bit) is opt-in: GMMHMM_KMEANS_RECIP=1
@@ -1140,11 +1163,8 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     // iteration's operands in ONE launch per iteration (sums, collective, update with a communicator).  The assignments are
     // the reference's: near-ties are re-tested with its own division (so GMMHMM_KMEANS_EXACT only adds the frame-order
     // sums in every iteration, which the tile kernels below still provide).
-    const bool streaming = f->mfma && !exact_env && k <= f->kcap && rf_supported(k, D);
     if (streaming) {
-        std::vector<double> shift;
-        fit_shift_points(S, k, D, centroids_in, shift);
-        GH_HIP(hipMemcpyAsync(f->d_shift, shift.data(), shift.size() * 8, hipMemcpyHostToDevice, st));
+        // (the shift points are already in place: the partition pass above uses the same ones)
         GH_HIP(hipMemsetAsync(f->d_counter, 0, 64, st));
         GH_HIP(hipMemsetAsync(f->d_done, 0, (size_t)S * 4, st));
         rf_km_args a;

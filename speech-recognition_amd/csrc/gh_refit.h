@@ -43,6 +43,7 @@ struct rf_em_args {
     const double* nframes;
     double *mean, *var, *weight, *old_mu, *old_sigma, *old_w;
     int32_t* conv_at;
+    const int32_t* hard_ids;    // HARD pass only: the group of every frame (the random partition)
 };
 
 struct rf_km_args {
@@ -60,6 +61,8 @@ struct rf_km_args {
 
 int rf_launch_em(gh_ctx* ctx, const rf_em_args& a, int n_items);
 int rf_launch_em_update(gh_ctx* ctx, const rf_em_args& a, int pack_only);      // one block per state: (update +) pack
+int rf_launch_partition_sums(gh_ctx* ctx, const rf_em_args& a, int n_items);   // count | sum x' | sum x'^2 of given groups -> a.stats
+int rf_launch_partvar(gh_ctx* ctx, int S, int k, int D, const double* stats, int first_only, double* cov);
 int rf_launch_km(gh_ctx* ctx, const rf_km_args& a, int n_items);
 int rf_launch_km_update(gh_ctx* ctx, const rf_km_args& a, int pack_only);
 bool rf_supported(int k, int D);

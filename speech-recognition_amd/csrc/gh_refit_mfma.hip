@@ -281,7 +281,10 @@ __device__ bool em_update_state(const rf_em_args& a, int s, const double* __rest
 
 // KSM: accumulator columns (steps of 4 features) the instantiation holds; EXACT: the state has exactly KSM steps, every
 // loop over them is straight-line code (the shapes that matter: D = 12..15 and 36..39); otherwise KS <= KSM at run time
-template <int CG, int KSM, bool EXACT>
+// HARD: the responsibilities are GIVEN -- 1 for the component a.hard_ids names for the frame, 0 for the others -- and the pass
+// only sums: count | sum (x - shift) | sum (x - shift)^2 per (state, group), the one-pass variances of kmeans.py:171-177's
+// random partitions (no operands, no densities, no update in the tail).
+template <int CG, int KSM, bool EXACT, bool HARD = false>
 __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(CG == 1 && KSM <= 10 ? 3 : (CG == 2 && KSM > 10 ? 1 : 2), 8))) void refit_em_kernel(const rf_em_args a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.c.D, k = a.c.k, KS = EXACT ? KSM : rf_steps(D), TS = 4 * KS + 2;
@@ -300,8 +303,10 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     rf_stage<KSM> stg;
     if (sl < nsl) stg.load(lane, a.c.X + (item.first + (int64_t)sl * 16) * D, min(16, item.count - sl * 16) * D);
     const uint8_t live = a.c.active[s];           // (tested below: the operands' loads share its round trip)
-    for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
-    if (tid < 128) sT[tid] = a.exp_tab[tid];
+    if (!HARD) {
+        for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
+        if (tid < 128) sT[tid] = a.exp_tab[tid];
+    }
     double* tb = sBuf + wv * bufsz;
     rf_init_pads(tb, lane, D, TS);
     stg.init(lane, D, TS, a.c.shift + (int64_t)s * D);
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     const double thr = RF_LN_UNDERFLOW * GH_LSE_SCALE64;
     double cst[CG];                                                // the constant of component 4 cg + j (exponent-only test)
 #pragma unroll
-    for (int cg = 0; cg < CG; ++cg) cst[cg] = sP[((cg * 2 + 1) * KS + (D >> 2)) * 16 + 4 * lo + (D & 3)];
+    for (int cg = 0; cg < CG; ++cg) cst[cg] = HARD ? 0.0 : sP[((cg * 2 + 1) * KS + (D >> 2)) * 16 + 4 * lo + (D & 3)];
     double Sx[CG][KSM], Sq[CG][KSM];
 #pragma unroll
     for (int cg = 0; cg < CG; ++cg)
@@ -328,6 +333,13 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
         stg.store(tb);
         if (sl + RF_WAVES < nsl)
             stg.load(lane, a.c.X + (item.first + (int64_t)(sl + RF_WAVES) * 16) * D, min(16, item.count - (sl + RF_WAVES) * 16) * D);
+        double l[CG];
+        const bool act = my_frame < cnt;
+        if (HARD) {
+            const int id = act ? a.hard_ids[item.first + (int64_t)sl * 16 + my_frame] : -1;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) l[cg] = (id == 4 * cg + lo) ? 1.0 : 0.0;
+        } else {
         // ---- phase 1: scaled log-densities ----
         double aq[CG], al[CG];
 #pragma unroll
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
             }
         }
         // ---- responsibilities: the components of a frame sit in the CG registers of a quad of lanes ----
-        double l[CG], mx = -INFINITY;
+        double mx = -INFINITY;
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) { l[cg] = aq[cg] + al[cg]; mx = rf_vmax(mx, l[cg]); }
         mx = rf_vmax(mx, rf_dpp<0xB1>(mx));
@@ -361,9 +373,9 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
         sum += rf_dpp<0xB1>(sum);
         sum += rf_dpp<0x4E>(sum);
         const double inv = (sum == 0.0) ? 0.0 : rf_rcp(sum);          // (a NaN stays a NaN)
-        const bool act = my_frame < cnt;
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) l[cg] = act ? l[cg] * inv : 0.0;
+        }
         // ---- phase 2: S[col][comp] += sum over the block's four frames of x r, x^2 r (col D: the occupancy) ----
 #pragma unroll
         for (int g = 0; g < KSM; ++g)
@@ -411,12 +423,24 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     double* st = a.stats + (int64_t)s * plen;
     rf_reduce_slabs(a.c.partial, plen, i0, i1, k * Wd, st, sBuf);
     if (tid == 0) st[k * Wd] = 0.0;       // (log-likelihood column of the call-by-call layout: not computed here)
-    if (!a.c.fused) return;
+    if (HARD || !a.c.fused) return;
     __syncthreads();
     if (em_update_state(a, s, st, sFlag)) {
         __syncthreads();
         em_pack_state(a, s, sBuf);
     }
+}
+
+// variances of the random partitions (kmeans.py:171-177: np.cov(...).diagonal(), ddof 1) from the HARD pass's sums:
+// (sum x'^2 - (sum x')^2 / n) / (n - 1), x' = x - shift (the shift sits inside the data: nothing cancels); n <= 1 -> NaN
+// like numpy's 0 * (1 / 0).  first_only: cluster 0's variance for every cluster (the sharded rule, sums over all ranks).
+__global__ void refit_partvar_kernel(int S, int k, int D, const double* __restrict__ stats, int first_only, double* __restrict__ cov) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * k * D) return;
+    const int s = i / (k * D), c = first_only ? 0 : (i / D) % k, d = i % D, Wd = 1 + 2 * D;
+    const double* st = stats + (int64_t)s * (k * Wd + 1) + (int64_t)c * Wd;
+    const double n = st[0], s1 = st[1 + d], s2 = st[1 + D + d];
+    cov[i] = n > 1.0 ? (s2 - s1 * s1 / n) / (n - 1.0) : NAN;
 }
 
 // one block per state: (update +) pack; the first pack of a session, and the update behind a collective
@@ -685,6 +709,13 @@ size_t rf_km_lds(int k, int D) {
             launched = true;                                                                                    \
         }                                                                                                       \
     } while (0)
+#define RF_DISPATCH_HARD(CGV, KSV, EX, LDS)                                                                     \
+    do {                                                                                                        \
+        if (!launched && (CGV) == c_g && (KSV) == ksm && (!(EX) || rf_steps(a.c.D) == (KSV))) {                 \
+            hipLaunchKernelGGL((refit_em_kernel<CGV, KSV, EX, true>), dim3((unsigned)n_items), dim3(64 * RF_WAVES), LDS, ctx->stream, a); \
+            launched = true;                                                                                    \
+        }                                                                                                       \
+    } while (0)
 #define RF_ALL(KERNEL, LDS)                                                                  \
     RF_DISPATCH(KERNEL, 1, 4, true, LDS); RF_DISPATCH(KERNEL, 2, 4, true, LDS);              \
     RF_DISPATCH(KERNEL, 1, 10, true, LDS); RF_DISPATCH(KERNEL, 2, 10, true, LDS);            \
@@ -699,6 +730,25 @@ int rf_launch_em(gh_ctx* ctx, const rf_em_args& a, int n_items) {
     bool launched = false;
     RF_ALL(refit_em_kernel, lds);
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
+
+int rf_launch_partition_sums(gh_ctx* ctx, const rf_em_args& a, int n_items) {
+    if (n_items <= 0) return GH_OK;
+    const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
+    const size_t lds = rf_em_lds(a.c.k, a.c.D);
+    bool launched = false;
+    RF_DISPATCH_HARD(1, 4, true, lds); RF_DISPATCH_HARD(2, 4, true, lds); RF_DISPATCH_HARD(1, 10, true, lds); RF_DISPATCH_HARD(2, 10, true, lds);
+    RF_DISPATCH_HARD(1, 4, false, lds); RF_DISPATCH_HARD(2, 4, false, lds); RF_DISPATCH_HARD(1, 10, false, lds); RF_DISPATCH_HARD(2, 10, false, lds);
+    RF_DISPATCH_HARD(1, 17, false, lds); RF_DISPATCH_HARD(2, 17, false, lds);
+    GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
+    GH_HIP(hipGetLastError());
+    return GH_OK;
+}
+
+int rf_launch_partvar(gh_ctx* ctx, int S, int k, int D, const double* stats, int first_only, double* cov) {
+    hipLaunchKernelGGL(refit_partvar_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, ctx->stream, S, k, D, stats, first_only, cov);
     GH_HIP(hipGetLastError());
     return GH_OK;
 }

@@ -2,7 +2,7 @@
 """TEST-ONLY build: the HOST halves of speech-recognition_amd/csrc/*.hip under AddressSanitizer + UndefinedBehaviorSanitizer,
 linked against tests/hipstub/hipstub.cpp instead of the HIP runtime -> libgmmhmm_san.so (no GPU, no device code).
 
-    python tests/hipstub/build_sanitized.py [out_dir]      (default: speech-recognition_amd/build/san, git- and gpurun-ignored)
+    python tests/hipstub/build_sanitized.py [out_dir]      (default: <tmp>/gmmhmm_san_build: nothing of it belongs in the tree)
 
 hipcc --cuda-host-only compiles the product sources as they are (kernels become launch stubs); every translation unit
 refers to its device image as an external `__hip_fatbin_<hash>`, which a generated C file defines as a few zero bytes."""
@@ -31,7 +31,8 @@ def asan_runtime():
 
 
 def build(out_dir=None, verbose=False):
-    out_dir = out_dir or os.path.join(ROOT, "speech-recognition_amd", "build", "san")
+    import tempfile
+    out_dir = out_dir or os.environ.get("GMMHMM_SAN_DIR") or os.path.join(tempfile.gettempdir(), "gmmhmm_san_build_%d" % os.getuid())
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libgmmhmm_san.so")
     headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "gmmhmm.h")]

@@ -389,7 +389,7 @@ def test_device_session_equals_the_host_loop():
     for a, b in zip(cl_e, cl_h):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ce_e, ce_h)
-    np.testing.assert_array_equal(cov_e, cov_d)
+    np.testing.assert_allclose(cov_e, cov_d, rtol=1e-12)      # (two frame-order passes against one streaming pass around the shift point)
     # EM from the k-means result, "old" parameters as a fresh GMM holds them
     def states():
         out = []

@@ -127,7 +127,10 @@ def test_streaming_kernels_equal_the_tile_kernels(D, k):
     np.testing.assert_array_equal(new["its"], old["its"])
     np.testing.assert_array_equal(new["cnt"], old["cnt"])
     np.testing.assert_array_equal(new["cen"], old["cen"])
-    np.testing.assert_array_equal(new["cov"], old["cov"])
+    # the partition variances: ONE streaming pass around the state's shift point against two frame-order passes; the one-pass
+    # form loses ~ (distance of the group from the shift point / its own spread)^2 ulps -- nothing for groups of real size
+    # (test_device_session_equals_the_host_loop holds them to 1e-12 of np.cov), a few digits for the 2-5 frame groups here
+    np.testing.assert_allclose(new["cov"], old["cov"], rtol=1e-9, equal_nan=True)
     assert ("mean" in new) == ("mean" in old)
     if "mean" in new:
         np.testing.assert_array_equal(new["conv"], old["conv"])
