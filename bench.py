@@ -179,6 +179,56 @@ def cpu_baseline(wl, n_utts=20):
     return out
 
 
+_CPU_WL = None
+
+
+def _cpu_all_cores_worker(rng_):
+    """utterances [lo, hi) of the forked parent's workload on the vectorised oracle path: (frames, correct)"""
+    from oracle import ref_numpy as O
+    wl = _CPU_WL
+    W, n = wl["W"], wl["n"]
+    S = W * n
+    nes = np.zeros(n, dtype=bool)
+    means, vars_, w = (wl["means"].reshape(S, *wl["means"].shape[2:]), wl["vars"].reshape(S, *wl["vars"].shape[2:]),
+                       wl["w"].reshape(S, -1))
+    frames = correct = 0
+    for u in range(*rng_):
+        x = wl["X"][wl["off"][u]:wl["off"][u + 1]]
+        nll = O.gmm_neg_loglik_batch(x, means, vars_, w)                     # [T, S], log domain, numpy-vectorised
+        ev = [O.decode_states(nll[:, i * n:(i + 1) * n].T, nes, wl["trans"])[0][-1, -1] for i in range(W)]
+        correct += int(np.argmin(ev) == wl["words"][u])
+        frames += len(x)
+    return frames, correct
+
+
+def cpu_all_cores(wl, seconds=8.0):
+    """SURVEY.md 8(d)'s all-cores CPU leg: the same workload on EVERY host core of the box -- multiprocessing over
+    utterances, each worker the oracle's vectorised path (batch log-likelihoods in numpy, the DP per cell) -- on a sample
+    sized for about `seconds`.  Runs BEFORE anything touches the GPU (forked workers, no exec) and before the rank pins
+    itself to its cores.  A reported baseline, not a target."""
+    import multiprocessing as mp
+    global _CPU_WL
+    _CPU_WL = wl
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    t0 = time.perf_counter()
+    _cpu_all_cores_worker((0, 4))                                         # one core's rate, to size the sample
+    per_utt = (time.perf_counter() - t0) / 4
+    n_utts = int(max(cores * 4, min(len(wl["words"]), seconds * cores / max(per_utt, 1e-4))))
+    chunks = [(i, min(n_utts, i + 8)) for i in range(0, n_utts, 8)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_all_cores_worker, chunks)
+    dt = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    S = wl["W"] * wl["n"]
+    return dict(value=frames * S / dt, unit="frame-state loglik/s", cores=cores, kind="port",
+                sample="first %d utterances (%d frames), oracle/ref_numpy.py vectorised likelihoods + per-cell DP, "
+                       "multiprocessing over utterances, %.1f s" % (n_utts, frames, dt),
+                utterances_per_s=n_utts / dt, accuracy=sum(r[1] for r in res) / n_utts)
+
+
 class native_stdout_to_stderr:
     """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; the contract of this
     script is ONE JSON line on stdout, so native writes to fd 1 are sent to stderr while a process group starts."""
@@ -1176,6 +1226,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-cores", action="store_true", help="skip the all-cores CPU leg (multiprocessing over utterances, ~10 s)")
     ap.add_argument("--cpu-utts", type=int, default=80)
     # rehearsal of the N > 1 path on a box with fewer GPUs: --backend gloo --device 0 lets every rank share GPU 0
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -1217,6 +1268,12 @@ def main():
         # (also under a launcher: RCCL reads these when the communicator comes up, not when the process starts)
         os.environ.update(NCCL_HOSTID="gmmhmm-bench-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
                           NCCL_SHM_DISABLE="1")
+    all_cores = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_all_cores:
+        try:      # (before the GPU is touched and before this process pins itself: see cpu_all_cores)
+            all_cores = cpu_all_cores(synth_workload(1002, args.utts))
+        except Exception as e:
+            all_cores = {"error": repr(e)[:200]}
     # host cores: before anything touches the GPU (and before numpy / the ranks' host threads start working)
     pinned = None if args.no_pin else pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), dev)
     from sr.recognition import _hip
@@ -1362,6 +1419,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is a rank-0, single-GPU-run measurement
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_utts)
+            if all_cores is not None:
+                out["cpu_baseline"]["all_cores"] = all_cores
     # ---- everything below runs after (and outside) the timed region; it never changes value / ms_per_step
     for l in lanes:
         l.lat.close(); l.batch.close(); l.gmm.close(); l.ctx.close()

@@ -692,6 +692,7 @@ int launch_mfma_t(gh_ctx* ctx, const gh_gmm* g, gh_batch* b, const T* Apk, const
     const int64_t n_blocks = subset ? n_blk : (N + 31) / 32;
     const int per_block = std::max(1, max_tiles * KS * 2);
     int bpw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (512 + per_block - 1) / per_block));
+    if (const char* e = getenv("GMMHMM_LOGLIK_BPW")) bpw = std::max(1, std::min(16, atoi(e)));   // tuning knob (blocks of 32 frames per wave)
     if (subset) bpw = std::max(bpw, 2);   // the block table lives in the multi-block instantiation
     const unsigned grid = (unsigned)((n_blocks + bpw - 1) / bpw);
     const T* X = static_cast<const T*>(b->feats);
