@@ -651,7 +651,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     if (want_occ) b->seq_seg_valid = false;
     if (lat->deferred_src) {   // a transcripts handle: everything but the sequence-form kernel runs on its expanded twin
         const char* e = getenv("GMMHMM_FB");
-        if (out_alpha || out_beta || out_gamma || (e && !strcmp(e, "generic"))) {
+        if (out_alpha || out_beta || out_gamma || (e && !strcmp(e, "generic")) || lat->seq_N > GH_LAYERFORM_MAXN) {   // (12 / 16 states per word: Viterbi only)
             const int rc0 = gh_lattices_full(lat, &lat);
             if (rc0) return rc0;
         }
@@ -691,7 +691,7 @@ extern "C" int gh_forward_backward(gh_ctx* ctx, const gh_lattices* lat, gh_batch
     }
     // alpha scratch, chunked (<= gh_scratch_budget() bytes per launch), launch order = longest first
     const size_t BUDGET = gh_scratch_budget(ctx);
-    const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
+    const bool use_fbseq = [&] { const char* e = getenv("GMMHMM_FB"); return lat->seq_ok && lat->seq_N <= GH_LAYERFORM_MAXN && !(out_alpha || out_beta || out_gamma) && !(e && !strcmp(e, "generic")); }();
     GH_REQUIRE(!lat->deferred_src || use_fbseq, "gh_forward_backward: internal: a transcripts handle left the sequence-form path unexpanded");
     std::vector<int64_t> soff(U, 0), chunk_begin{0};
     size_t acc = 0, smax = 0;

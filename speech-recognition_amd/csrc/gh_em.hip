@@ -436,9 +436,9 @@ extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, 
     *out = nullptr;
     const int D = b->D, S = W * n;
     const int64_t U = b->U;
-    if (b->dtype != GH_F64 || n < 2 || n > GH_LAYERS_MAXN || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
+    if (b->dtype != GH_F64 || n < 2 || n > GH_LAYERFORM_MAXN || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
         gh_set_error("gh_em_create_transcripts: shape outside the device-resident path (fp64 batch, 2 <= n <= %d, M <= 64, D <= 47)",
-                     GH_LAYERS_MAXN);
+                     GH_LAYERFORM_MAXN);
         return GH_ERR_UNSUPPORTED;
     }
     for (int64_t u = 0; u < U; ++u)

@@ -171,8 +171,12 @@ struct gh_lattice_host {
 // and states in every layer.  gh_viterbi runs such graphs with one WAVE per utterance: lane = (layer mod 4, word),
 // the N states of a word in registers (gh_viterbi_layers.hip).
 #define GH_LAYERS_MAXW 16
-#define GH_LAYERS_MAXN 8
+#define GH_LAYERS_MAXN 16          // states per word the word templates hold (sequence form: 2..8, 12, 16: gh_seq_n_ok)
+#define GH_LAYERFORM_MAXN 8        // ... that the layer / loop form kernels and the sequence-form forward-backward are built for
 #define GH_LAYERS_MAXK 8
+// states per word the sequence-form Viterbi kernels are instantiated for (gh_seq.hip): every count up to 8, and the 12 and 16
+// of wide word models (BASELINE configs[3]: 16 states per word), whose N costs still live in one lane's registers
+static inline bool gh_seq_n_ok(int N) { return (N >= 2 && N <= 8) || N == 12 || N == 16; }
 // LOOP form (K = 1, loop = 1): the word-loop grammar of continuous_speech.build_loop_grammar -- row 0 = non-emitting
 // start; rows 1 .. W*(N-1) = states 1..N-1 of every word; row loop_row = 1 + W*(N-1) = the non-emitting loop row;
 // rows loop_row+1+w = state 0 of word w.  Last states feed the loop row, the start row (cost cin0) and the loop row

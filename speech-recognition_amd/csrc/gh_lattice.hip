@@ -156,7 +156,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
                 int r = 1;
                 while (r < R && h_state[r0 + r] >= 0) ++r;
                 N = r - 1;
-                ok = N >= 2 && N <= GH_LAYERS_MAXN && r < R && (R - 1) % (N + 1) == 0 && (lt->seq_N == 0 || lt->seq_N == N);
+                ok = gh_seq_n_ok(N) && r < R && (R - 1) % (N + 1) == 0 && (lt->seq_N == 0 || lt->seq_N == N);
             }
             const int K = ok ? (R - 1) / (N + 1) : 0;
             ok = ok && K >= 1 && K <= GH_SEQ_MAXK;
@@ -376,7 +376,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
                 if (W == 0) { ok = false; break; }
             }
             if (ok && W == 1) N = P;
-            ok = ok && N >= 2 && N <= GH_LAYERS_MAXN && W <= GH_LAYERS_MAXW && W * N == P;
+            ok = ok && N >= 2 && N <= GH_LAYERFORM_MAXN && W <= GH_LAYERS_MAXW && W * N == P;
         }
         bool skip = false;
         for (int pos = 0; ok && pos < P; ++pos) {
@@ -423,7 +423,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         const int W = ok ? R - 1 - Lr : 0;
         ok = ok && W >= 1 && W <= GH_LAYERS_MAXW && (Lr - 1) % W == 0;
         const int N = ok ? (Lr - 1) / W + 1 : 0;
-        ok = ok && N >= 2 && N <= GH_LAYERS_MAXN;
+        ok = ok && N >= 2 && N <= GH_LAYERFORM_MAXN;
         ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);
         auto row_of = [&](int w, int sx) { return sx == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (sx - 1); };
         std::vector<int> wof(R, -1), sof(R, -1);

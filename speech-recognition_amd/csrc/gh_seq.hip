@@ -42,9 +42,10 @@ __device__ __forceinline__ void sq_push_bit(uint32_t& word, unsigned long long m
 
 template <typename ET, int N, bool SKIP, bool WANT_BP>
 __global__ __launch_bounds__(64) void viterbi_seq_kernel(gh_layers_args a, int64_t slot_end) {
-    constexpr int HB = N + (SKIP ? N - 2 : 0);                // decision bits per column and lane
+    constexpr int HB = N + (SKIP ? N - 2 : 0);                // decision bits per column and lane (<= 30: N = 16 with skips)
     constexpr int CPW = 32 / HB;
-    constexpr int PF = 4;
+    constexpr int PF = N > 8 ? 2 : 4;                          // columns of emissions in flight (12 / 16 states: the ring is registers)
+    static_assert(HB < 32, "the decision bits of a column and lane live in one word");
     const int lane = threadIdx.x, kk = lane >> 4, k = lane & 15;
     const int64_t slot = a.slot0 + (int64_t)blockIdx.x * 4 + kk;
     const bool has_utt = slot < slot_end;
@@ -660,6 +661,8 @@ int gh_launch_viterbi_seq(gh_ctx* ctx, const gh_layers_args& a, int N, int skip,
         case 6: if (skip) GH_SQ(ET, 6, true); else GH_SQ(ET, 6, false); break;               \
         case 7: if (skip) GH_SQ(ET, 7, true); else GH_SQ(ET, 7, false); break;               \
         case 8: if (skip) GH_SQ(ET, 8, true); else GH_SQ(ET, 8, false); break;               \
+        case 12: if (skip) GH_SQ(ET, 12, true); else GH_SQ(ET, 12, false); break;            \
+        case 16: if (skip) GH_SQ(ET, 16, true); else GH_SQ(ET, 16, false); break;            \
         default: gh_set_error("gh_viterbi: sequence form with %d states per word", N); return GH_ERR_UNSUPPORTED; \
     }
     if (f64) { GH_SQ_N(double) } else { GH_SQ_N(float) }
@@ -684,6 +687,8 @@ int gh_launch_seq_backtrace(gh_ctx* ctx, const gh_layers_args& a, int N, int ski
         case 6: if (skip) GH_SB(6, true); else GH_SB(6, false); break;
         case 7: if (skip) GH_SB(7, true); else GH_SB(7, false); break;
         case 8: if (skip) GH_SB(8, true); else GH_SB(8, false); break;
+        case 12: if (skip) GH_SB(12, true); else GH_SB(12, false); break;
+        case 16: if (skip) GH_SB(16, true); else GH_SB(16, false); break;
         default: gh_set_error("gh_viterbi: sequence form with %d states per word", N); return GH_ERR_UNSUPPORTED;
     }
 #undef GH_SB

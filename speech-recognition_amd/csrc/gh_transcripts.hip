@@ -83,7 +83,7 @@ extern "C" int gh_lattices_create_transcripts(gh_ctx* ctx, int W, int n, const d
     for (int w = 0; w < W; ++w) src->base[w] = state_base ? state_base[w] : w * n;
     src->label_off.assign(label_off, label_off + L + 1);
     src->labels.assign(labels, labels + label_off[L]);
-    bool direct = n >= 2 && n <= GH_LAYERS_MAXN && L <= 0x7fffffff;
+    bool direct = gh_seq_n_ok(n) && L <= 0x7fffffff;
     bool all_single = true;
     for (int64_t l = 0; l < L; ++l) {
         const int64_t K = label_off[l + 1] - label_off[l];

@@ -75,7 +75,9 @@ def make_task(rng, W, n, skip, Kmax, U, M=2, D=6, short=8):
 
 
 @pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (4, 2, False, 16), (6, 3, True, 9), (3, 8, True, 5),
-                                           (5, 4, False, 12), (2, 7, True, 3), (7, 6, False, 1)])
+                                           (5, 4, False, 12), (2, 7, True, 3), (7, 6, False, 1),
+                                           # 12 and 16 states per word (BASELINE configs[3]'s word models): round 5
+                                           (3, 12, False, 5), (2, 12, True, 4), (3, 16, False, 4), (2, 16, True, 6)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sequence_kernel_equals_lean_kernel(hip, ctx, W, n, skip, Kmax, dtype):
     """end costs BITWISE, chosen end and paths equal -- reachable and unreachable utterances, transcripts of 1..Kmax
@@ -229,7 +231,7 @@ def test_sequence_forward_backward_equals_generic_kernel(hip, ctx, W, n, skip, K
     gmm.close()
 
 
-@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (4, 2, False, 16)])
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (4, 2, False, 16), (3, 16, True, 4), (2, 12, False, 5)])
 def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, Kmax):
     """gh_align_segments (alignment + the regrouping loop of continuous_speech.py:90-106 on the device, one int per
     frame back) against the ORACLE's restatement of that loop (O.cut_segments) over the paths of gh_viterbi -- per
@@ -297,7 +299,7 @@ def test_align_segments_equals_cut_segments_of_the_paths(hip, ctx, W, n, skip, K
     gmm.close()
 
 
-@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (3, 8, True, 5)])
+@pytest.mark.parametrize("W,n,skip,Kmax", [(10, 5, False, 7), (6, 3, True, 9), (3, 8, True, 5), (3, 16, True, 4), (4, 12, False, 3)])
 def test_transcripts_handle_equals_arc_list_handle(hip, ctx, W, n, skip, Kmax):
     """gh_lattices_create_transcripts (graphs from W word models + label strings, sequence form written directly, the
     row-per-lane arrays expanded lazily) against gh_lattices_create on the arc lists of `packed_lattice`: Viterbi
