@@ -643,6 +643,7 @@ extern "C" int gh_em_accumulate_multi(gh_ctx* ctx, const gh_batch* b, int S, con
 //   * sharded (comm != NULL): cluster sums + changed counts, cluster counts, partition sums and EM statistics are summed
 //     over the ranks with gh_comm's all-reduce ON THE DEVICE BUFFERS, between the kernels that produce and consume them.
 constexpr int FIT_CHUNK = 512;   // list entries per wave of the chunked cluster sums (see gh_fit_kmeans)
+constexpr int FIT_TAIL_ITERS = 64;   // iterations a TAIL launch may run (its workgroups leave when their state stops)
 
 struct gh_fit {
     gh_ctx* ctx;
@@ -662,10 +663,17 @@ struct gh_fit {
     int* h_pin;          // pinned [16]
     // streaming matrix-core form of the two per-iteration kernels (gh_refit_mfma.hip): items, packed operands, slabs
     bool mfma;           // k <= 8 and not switched off (GMMHMM_REFIT=tiles)
+    bool tail;           // TAIL launches allowed (GMMHMM_REFIT_TAIL=0 switches them off)
     int n_items, kcap;   // kcap: the component count the buffers below are sized for (min(kmax, 8))
     rf_item* d_items;
-    int32_t *d_iptr, *d_done;
+    int32_t *d_iptr, *d_done, *d_tail_ids, *d_gen;
     double *d_P, *d_shift, *d_kscale, *d_rpart;
+    std::vector<int32_t>* h_iptr;     // host copy of the item table's per-state ranges
+    std::vector<int32_t>* h_tail_ids; // the items of the last tail launch (what d_tail_ids holds) ...
+    std::vector<uint8_t>* h_tail_mask;   // ... and the active mask they were made from
+    int tail_n;
+    long n_tail_launches, n_tail_iters, n_plain_launches, n_tail_refused;   // (GMMHMM_REFIT_DEBUG=1 prints them when the session ends)
+    uint8_t* h_act;      // pinned [S]: the active mask as of the last poll
 };
 
 namespace {
@@ -898,7 +906,14 @@ extern "C" void gh_fit_destroy(gh_fit* f) {
     hipSetDevice(f->ctx->device);
     hipStreamSynchronize(f->ctx->stream);
     if (f->d_arena) hipFree(f->d_arena);
+    if (getenv("GMMHMM_REFIT_DEBUG"))
+        fprintf(stderr, "[gh_fit] %d states, %d items: %ld tail launches (%ld iterations), %ld refused, %ld ordinary launches\n", f->S, f->n_items,
+                f->n_tail_launches, f->n_tail_iters, f->n_tail_refused, f->n_plain_launches);
     if (f->h_pin) hipHostFree(f->h_pin);
+    if (f->h_act) hipHostFree(f->h_act);
+    delete f->h_iptr;
+    delete f->h_tail_ids;
+    delete f->h_tail_mask;
     delete f;
 }
 
@@ -989,11 +1004,21 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
         }
         iptr[S] = (int32_t)items.size();
         f->n_items = (int)items.size();
+        f->h_iptr = new std::vector<int32_t>(iptr);
+        f->h_tail_ids = new std::vector<int32_t>();
+        f->h_tail_mask = new std::vector<uint8_t>();
+        f->tail_n = 0;
+        {
+            const char* et = getenv("GMMHMM_REFIT_TAIL");
+            f->tail = !(et && *et == '0');
+        }
         if (f->mfma) {
             const size_t pst = std::max(rf_em_pstride(f->kcap, D), rf_km_pstride(f->kcap, D));
             lay.add((void**)&f->d_items, items.size() * sizeof(rf_item), items.data(), items.size() * sizeof(rf_item));
             lay.add((void**)&f->d_iptr, (size_t)(S + 1) * 4, iptr.data(), (size_t)(S + 1) * 4);
             lay.add((void**)&f->d_done, (size_t)S * 4, nullptr);
+            lay.add((void**)&f->d_gen, (size_t)S * 4, nullptr);
+            lay.add((void**)&f->d_tail_ids, items.size() * 4, nullptr);
             lay.add((void**)&f->d_P, (size_t)S * pst * 8, nullptr);
             lay.add((void**)&f->d_shift, (size_t)S * D * 8, nullptr);
             lay.add((void**)&f->d_kscale, (size_t)S * 8, nullptr);
@@ -1002,6 +1027,7 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
     }
     hipError_t he = hipMalloc(&f->d_arena, lay.total);
     if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_pin, 64, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_act, (size_t)std::max(S, 1), hipHostMallocDefault);
     if (he != hipSuccess) {
         gh_set_error("gh_fit_create: %s", hipGetErrorString(he));
         gh_fit_destroy(f);
@@ -1042,14 +1068,47 @@ static int fit_build_lists(gh_fit* f, int k, bool from_assign_counts, const uint
 
 // slot: where the last iteration left the number of states still active (0: the tile kernels' counter; 2 + (it & 7):
 // the streaming kernels', which count per iteration so that nothing has to be cleared between launches)
-static int fit_poll(gh_fit* f, gh_comm* comm, int* n_active, int* flags, int slot = 0) {
+static int fit_poll(gh_fit* f, gh_comm* comm, int* n_active, int* flags, int slot = 0, bool want_mask = false) {
     hipStream_t st = f->ctx->stream;
     GH_HIP(hipMemcpyAsync(f->h_pin, f->d_counter, 64, hipMemcpyDeviceToHost, st));
+    if (want_mask) GH_HIP(hipMemcpyAsync(f->h_act, f->d_active, (size_t)f->S, hipMemcpyDeviceToHost, st));
     const int rc_ = gh_stream_wait(f->ctx, comm, "gh_fit");
     if (rc_) return rc_;
     *n_active = f->h_pin[slot];
+    if (want_mask) {                   // (a tail launch runs more iterations than there are slots: count the mask itself)
+        int n = 0;
+        for (int s = 0; s < f->S; ++s) n += f->h_act[s] != 0;
+        *n_active = n;
+    }
     *flags = f->h_pin[1];
     return GH_OK;
+}
+
+// TAIL launches: the items of the states that are still active (as of the last poll), when they are few enough for all of
+// their workgroups to be resident at once -- the workgroups then run the next iterations inside ONE launch, handing over
+// through the state's generation word (gh_refit_mfma.hip).  Returns the number of items written to d_tail_ids (0: none).
+static int fit_tail_items(gh_fit* f, int limit) {
+    const std::vector<int32_t>& ip = *f->h_iptr;
+    std::vector<uint8_t>& had = *f->h_tail_mask;
+    bool same = f->tail_n > 0 && (int)had.size() == f->S;
+    for (int s = 0; same && s < f->S; ++s) same = (had[s] != 0) == (f->h_act[s] != 0);
+    if (!same) {                       // (the same states as for the last tail launch: the list on the device still holds)
+        std::vector<int32_t>& ids = *f->h_tail_ids;
+        ids.clear();
+        for (int s = 0; s < f->S; ++s)
+            if (f->h_act[s]) {
+                if ((int)ids.size() + (ip[s + 1] - ip[s]) > limit) { f->tail_n = 0; return 0; }
+                for (int t = ip[s]; t < ip[s + 1]; ++t) ids.push_back(t);
+            }
+        f->tail_n = 0;
+        if (ids.empty()) return 0;
+        // (`ids` lives in the session: the copy needs no wait; a later rebuild only happens behind a poll's synchronisation)
+        if (hipMemcpyAsync(f->d_tail_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, f->ctx->stream) != hipSuccess) return 0;
+        had.assign(f->h_act, f->h_act + f->S);
+        f->tail_n = (int)ids.size();
+    }
+    if (hipMemsetAsync(f->d_gen, 0, (size_t)f->S * 4, f->ctx->stream) != hipSuccess) return 0;
+    return f->tail_n;
 }
 
 // the point a state's frames and parameters are taken relative to by the streaming kernels: the average of the state's
@@ -1175,12 +1234,28 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
         a.sums = f->d_sums; a.iters = f->d_iters;
         rc = rf_launch_km_update(ctx, a, 1);
         if (rc) return rc;
+        const bool tail_ok = f->tail && !comm;
+        int tail_n = 0;                     // > 0: the next block of iterations is ONE launch over these items
+        f->tail_n = 0;
         for (int it = 0; it < n_it;) {
-            const int blkn = std::min(check_every, n_it - it);
-            for (int j = 0; j < blkn; ++j) {
+            int blkn = std::min(check_every, n_it - it);
+            GH_HIP(hipMemsetAsync(f->d_counter + 2, 0, 32, st));      // the per-iteration slots of this block
+            bool tailed = false;
+            if (tail_n > 0) {
+                const int blk_tail = std::min(FIT_TAIL_ITERS, n_it - it);
+                blkn = blk_tail;
+                a.c.it = it; a.c.item_ids = f->d_tail_ids; a.c.gen = f->d_gen; a.c.n_iter = blkn;
+                rc = rf_launch_km(ctx, a, tail_n);
+                if (rc < 0) return rc;
+                tailed = rc == 0;
+                if (tailed) { ++f->n_tail_launches; f->n_tail_iters += blkn; } else { ++f->n_tail_refused; blkn = std::min(check_every, n_it - it); }
+                a.c.item_ids = nullptr; a.c.gen = nullptr; a.c.n_iter = 1;
+            }
+            for (int j = 0; !tailed && j < blkn; ++j) {
                 a.c.it = it + j;
                 rc = rf_launch_km(ctx, a, f->n_items);
                 if (rc) return rc;
+                ++f->n_plain_launches;
                 if (comm) {
                     hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((sstride + 127) / 128), (unsigned)S), dim3(128), 0, st, S, sstride,
                                        (const uint8_t*)f->d_active, f->d_sums);
@@ -1191,9 +1266,11 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
             }
             it += blkn;
             int n_active = 0, flags = 0;
-            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7));
+            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7), tail_ok);
             if (rc) return rc;
+            if (flags & 32) { gh_set_error("gh_fit_kmeans: a workgroup of a tail launch waited for its state in vain"); return GH_ERR_HIP; }
             if (n_active == 0) break;
+            tail_n = tail_ok ? fit_tail_items(f, 4096) : 0;
         }
         GH_HIP(hipMemsetAsync(f->d_counts, 0, (size_t)S * k * 4, st));
         GH_HIP(hipMemsetAsync(f->d_cbase, 0, (size_t)S * k * 4, st));
@@ -1316,12 +1393,28 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
         a.weight = f->d_weight; a.old_mu = f->d_old_mu; a.old_sigma = f->d_old_sigma; a.old_w = f->d_old_w; a.conv_at = f->d_iters;
         rc = rf_launch_em_update(ctx, a, 1);
         if (rc) return rc;
+        const bool tail_ok = f->tail && !comm;
+        int tail_n = 0;                     // > 0: the next block of iterations is ONE launch over these items
+        f->tail_n = 0;
         for (int it = 0; it < max_iteration;) {
-            const int blkn = std::min(check_every, max_iteration - it);
-            for (int j = 0; j < blkn; ++j) {
+            int blkn = std::min(check_every, max_iteration - it);
+            GH_HIP(hipMemsetAsync(f->d_counter + 2, 0, 32, st));      // the per-iteration slots of this block
+            bool tailed = false;
+            if (tail_n > 0) {
+                const int blk_tail = std::min(FIT_TAIL_ITERS, max_iteration - it);
+                blkn = blk_tail;
+                a.c.it = it; a.c.item_ids = f->d_tail_ids; a.c.gen = f->d_gen; a.c.n_iter = blkn;
+                rc = rf_launch_em(ctx, a, tail_n);
+                if (rc < 0) return rc;
+                tailed = rc == 0;
+                if (tailed) { ++f->n_tail_launches; f->n_tail_iters += blkn; } else { ++f->n_tail_refused; blkn = std::min(check_every, max_iteration - it); }
+                a.c.item_ids = nullptr; a.c.gen = nullptr; a.c.n_iter = 1;
+            }
+            for (int j = 0; !tailed && j < blkn; ++j) {
                 a.c.it = it + j;
                 rc = rf_launch_em(ctx, a, f->n_items);
                 if (rc) return rc;
+                ++f->n_plain_launches;
                 if (comm) {
                     hipLaunchKernelGGL(fit_zero_inactive_kernel, dim3((unsigned)((plen + 127) / 128), (unsigned)S), dim3(128), 0, st, S, plen,
                                        (const uint8_t*)f->d_active, f->d_stats);
@@ -1332,13 +1425,15 @@ extern "C" int gh_fit_em(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, double* m
             }
             it += blkn;
             int n_active = 0, flags = 0;
-            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7));
+            rc = fit_poll(f, comm, &n_active, &flags, 2 + ((it - 1) & 7), tail_ok);
             if (rc) return rc;
             if (flags & 16) {
                 gh_set_error("gh_fit_em: a variance is 0 (singular covariance)");
                 return GH_ERR_INVALID;
             }
+            if (flags & 32) { gh_set_error("gh_fit_em: a workgroup of a tail launch waited for its state in vain"); return GH_ERR_HIP; }
             if (n_active == 0) break;
+            tail_n = tail_ok ? fit_tail_items(f, 4096) : 0;
         }
     } else
     for (int it = 0; it < max_iteration;) {

@@ -30,8 +30,13 @@ struct rf_common {
     int32_t* done;              // [S] arrival counters (zero between launches)
     double* partial;            // [n_items][plen]
     int* counter;               // [0] unused, [1] error bits, [2 + (it & 7)] states still active after iteration it
-    int it;                     // iteration number of this launch
+    int it;                     // iteration number of this launch (its first one, with n_iter > 1)
     int fused;                  // 1: the last arriver also runs the update + packs the next operands (no collective in between)
+    // TAIL launches (few states left, every one of their workgroups resident at once): the grid is the items item_ids[0 ..]
+    // and a workgroup stays for up to n_iter iterations, waiting on its state's generation word between them
+    const int32_t* item_ids;    // null: the grid is all items
+    int32_t* gen;               // [S] zero at launch; j + 1 when iteration j of the launch is done for the state, -1 when it stopped
+    int n_iter;                 // iterations this launch runs (1: the ordinary launch)
 };
 
 struct rf_em_args {

@@ -35,6 +35,7 @@
 
 namespace {
 
+constexpr int RF_TAIL_POLLS = 1 << 22;                    // several seconds of waiting for a state's generation word, then an error bit
 constexpr double RF_LN_UNDERFLOW = -745.1332191019412;   // exp(x) rounds to +0 below this (hmm_state.py's linear domain)
 
 __device__ __forceinline__ double rf_mfma(double a, double b, double c) {
@@ -125,6 +126,10 @@ __device__ __forceinline__ void rf_init_pads(double* __restrict__ tb, int lane, 
 __device__ __forceinline__ void rf_publish(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void rf_publish(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rf_publish(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Everything a state's LAST workgroup writes (statistics, parameters, stop flags, the next operands) is stored write-through
+// as well: in a TAIL launch the next iteration's workgroups -- on other CUs, other XCDs -- read it after one acquire.
 __device__ __forceinline__ bool rf_arrive(int32_t* done, int s, int n_items, int* lds_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -172,7 +177,7 @@ __device__ void rf_reduce_slabs(const double* __restrict__ partial, int plen, in
         }
         lds[wv * 64 + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         __syncthreads();
-        if (wv == 0 && i < n) out[i] = (lds[lane] + lds[64 + lane]) + (lds[128 + lane] + lds[192 + lane]);
+        if (wv == 0 && i < n) rf_publish(out + i, (lds[lane] + lds[64 + lane]) + (lds[128 + lane] + lds[192 + lane]));
         __syncthreads();
     }
 }
@@ -220,19 +225,21 @@ __device__ void em_pack_state(const rf_em_args& a, int s, double* __restrict__ l
                 v = h == 0 ? -0.5 * iv * GH_LSE_SCALE64 : iv * (mean[c * D + d] - sh[d]) * GH_LSE_SCALE64;
             } else if (d == D && h == 1) v = cst[c];
         } else if (d == D && h == 1) v = GH_LSE_OFF64;              // padding component: never weighs anything
-        P[i] = v;
+        rf_publish(P + i, v);
     }
 }
 
 // GMM.em_update (hmm_state.py:134-159) of one state by the whole block, from sums centred on `shift`
 // (st: occupancy | sum r (x - shift) | sum r (x - shift)^2 per component).  Returns (block-uniform) whether the state goes on.
-__device__ bool em_update_state(const rf_em_args& a, int s, const double* __restrict__ st, int* __restrict__ lds_i /*[2]*/) {
+__device__ bool em_update_state(const rf_em_args& a, int s, int it, const double* __restrict__ st, int* __restrict__ lds_i /*[2]*/) {
     const int D = a.c.D, k = a.c.k, Wd = 1 + 2 * D, tid = threadIdx.x;
     if (tid == 0) { lds_i[0] = 0; lds_i[1] = 0; }
     __syncthreads();
     const double* sh = a.c.shift + (int64_t)s * D;
     int mine = 0, diff = 0;
     auto same = [](double x, double y) { return x == y || (x != x && y != y); };
+    double mu_l[2], sg_l[2], w_l = 0.0;            // this thread's entries (k D <= 512 = 2 per thread of a 256-thread block)
+    int n_l = 0;
     for (int i = tid; i < k * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
         const int64_t at = ((int64_t)s * k + c) * D + d;
@@ -245,14 +252,17 @@ __device__ bool em_update_state(const rf_em_args& a, int s, const double* __rest
         const double dl = mu - m0;
         const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
         diff += !same(mu, m0) + !same(sg, a.var[at]);
-        a.mean[at] = mu;
-        a.var[at] = sg;
+        rf_publish(a.mean + at, mu);
+        rf_publish(a.var + at, sg);
+        if (n_l < 2) { mu_l[n_l] = mu; sg_l[n_l] = sg; }
+        ++n_l;
         mine += !rf_close(mu, a.old_mu[at]) + !rf_close(sg, a.old_sigma[at]);
     }
     if (tid < k) {
         const double w = st[tid * Wd] / a.nframes[s];
         diff += !same(w, a.weight[(int64_t)s * k + tid]);
-        a.weight[(int64_t)s * k + tid] = w;
+        rf_publish(a.weight + (int64_t)s * k + tid, w);
+        w_l = w;
         mine += !rf_close(w, a.old_w[(int64_t)s * k + tid]);
     }
     if (mine) atomicAdd(&lds_i[0], mine);
@@ -260,22 +270,23 @@ __device__ bool em_update_state(const rf_em_args& a, int s, const double* __rest
     __syncthreads();
     const int bad = lds_i[0], moved = lds_i[1];
     if (bad == 0) {                                  // np.allclose on all three: converged, the old values stay
-        if (tid == 0) { a.c.active[s] = 0; a.conv_at[s] = a.c.it; }
+        if (tid == 0) { rf_publish(a.c.active + s, (uint8_t)0); rf_publish(a.conv_at + s, (int32_t)it); }
         return false;
     }
-    for (int i = tid; i < k * D; i += blockDim.x) {
+    n_l = 0;
+    for (int i = tid; i < k * D; i += blockDim.x, ++n_l) {
         const int64_t at = (int64_t)s * k * D + i;
-        a.old_mu[at] = a.mean[at];
-        a.old_sigma[at] = a.var[at];
+        rf_publish(a.old_mu + at, n_l < 2 ? mu_l[n_l] : a.mean[at]);
+        rf_publish(a.old_sigma + at, n_l < 2 ? sg_l[n_l] : a.var[at]);
     }
-    if (tid < k) a.old_w[(int64_t)s * k + tid] = a.weight[(int64_t)s * k + tid];
+    if (tid < k) rf_publish(a.old_w + (int64_t)s * k + tid, w_l);
     // bit for bit the parameters that went in (NaN = NaN): a fixed point the allclose test cannot see (see
     // fit_em_update_kernel in gh_lockstep.hip) -- the state stops with the values the full loop would end with
     if (moved == 0) {
-        if (tid == 0) a.c.active[s] = 0;
+        if (tid == 0) rf_publish(a.c.active + s, (uint8_t)0);
         return false;
     }
-    if (tid == 0) atomicAdd(a.c.counter + 2 + (a.c.it & 7), 1);
+    if (tid == 0) atomicAdd(a.c.counter + 2 + (it & 7), 1);
     return true;
 }
 
@@ -294,8 +305,10 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     double* sBuf = sT + 128;                      // [RF_WAVES][bufsz]; afterwards the cross-wave sums
     int* sFlag = reinterpret_cast<int*>(sBuf + RF_WAVES * bufsz + 64);   // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar slab addresses)
-    if (blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;   // the next iteration's slot
-    const rf_item item = a.c.items[blockIdx.x];
+    const bool tail = !HARD && a.c.n_iter > 1;      // a TAIL launch: this workgroup stays for several iterations (see the loop's end)
+    if (!tail && blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;   // the next iteration's slot
+    const int bid = a.c.item_ids ? a.c.item_ids[blockIdx.x] : (int)blockIdx.x;
+    const rf_item item = a.c.items[bid];
     const int s = item.state;
     // the first slab's loads go out before anything else of the prologue (they need nothing but the item)
     const int nsl = (item.count + 15) >> 4;
@@ -319,6 +332,11 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     const int a2 = rf_frame(bq, kk) * TS + lo;                     // phase 2, A: x[F(b, k)][4 g + i]
     const int my_frame = rf_frame(bq, kk);                         // phase 1 result / phase 2 B: frame F(b, i), comp 4 cg + j
     const double thr = RF_LN_UNDERFLOW * GH_LSE_SCALE64;
+    const int Wd = 1 + 2 * D, plen = k * Wd + 1;
+    double* out = a.c.partial + (int64_t)bid * plen;
+    const int i0 = a.c.item_ptr[s], i1 = a.c.item_ptr[s + 1];
+    for (int j = 0;; ++j) {
+    const int it = a.c.it + j;
     double cst[CG];                                                // the constant of component 4 cg + j (exponent-only test)
 #pragma unroll
     for (int cg = 0; cg < CG; ++cg) cst[cg] = HARD ? 0.0 : sP[((cg * 2 + 1) * KS + (D >> 2)) * 16 + 4 * lo + (D & 3)];
@@ -405,8 +423,6 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
         }
         __syncthreads();
     }
-    const int Wd = 1 + 2 * D, plen = k * Wd + 1;
-    double* out = a.c.partial + (int64_t)blockIdx.x * plen;
     for (int e = tid; e < CG * 2 * KS * 16; e += 64 * RF_WAVES) {      // entry (cg, h, g, i, j): lanes 16 i + 4 b + j, b = 0..3
         const int j = e & 3, i = (e >> 2) & 3, g = (e >> 4) % KS, h = ((e >> 4) / KS) & 1, cg = (e >> 4) / (2 * KS);
         const int c = 4 * cg + j, col = 4 * g + i;
@@ -417,17 +433,50 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
             else if (col == D && h == 0) rf_publish(out + c * Wd, v);
         }
     }
-    const int i0 = a.c.item_ptr[s], i1 = a.c.item_ptr[s + 1];
-    if (!rf_arrive(a.c.done, s, i1 - i0, sFlag)) return;
-    // ---- last workgroup of the state: slabs in item order -> statistics -> update -> next operands ----
-    double* st = a.stats + (int64_t)s * plen;
-    rf_reduce_slabs(a.c.partial, plen, i0, i1, k * Wd, st, sBuf);
-    if (tid == 0) st[k * Wd] = 0.0;       // (log-likelihood column of the call-by-call layout: not computed here)
-    if (HARD || !a.c.fused) return;
-    __syncthreads();
-    if (em_update_state(a, s, st, sFlag)) {
+    const bool last = rf_arrive(a.c.done, s, i1 - i0, sFlag);
+    bool alive = false;
+    if (last) {
+        // ---- last workgroup of the state: slabs in a fixed order -> statistics -> update -> next operands ----
+        double* st = a.stats + (int64_t)s * plen;
+        rf_reduce_slabs(a.c.partial, plen, i0, i1, k * Wd, st, sBuf);
+        if (tid == 0) rf_publish(st + k * Wd, 0.0);       // (log-likelihood column of the call-by-call layout: not computed here)
+        if (!HARD && a.c.fused) {
+            __syncthreads();
+            alive = em_update_state(a, s, it, st, sFlag);
+            if (alive) {
+                __syncthreads();
+                em_pack_state(a, s, sBuf);
+            }
+        }
+    }
+    if (!tail || j + 1 >= a.c.n_iter) return;
+    // ---- TAIL launch: every workgroup of the state waits for its last one to finish the iteration (the state's generation
+    //      word: j + 1 = go on, -1 = the state has stopped), then takes the new operands; polls are bounded ----
+    if (last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        em_pack_state(a, s, sBuf);
+        if (tid == 0) {
+            rf_publish(a.c.gen + s, alive ? j + 1 : -1);
+            sFlag[2] = alive ? j + 1 : -1;
+        }
+    } else if (tid == 0) {
+        int g = j, polls = 0;
+        while ((g = __hip_atomic_load(a.c.gen + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == j && ++polls < RF_TAIL_POLLS)
+            __builtin_amdgcn_s_sleep(8);
+        if (g == j) { atomicOr(a.c.counter + 1, 32); g = -1; }     // (never seen: some workgroup of the grid was not resident)
+        sFlag[2] = g;
+    }
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (sFlag[2] < 0) return;
+    sl = wv;
+    if (sl < nsl) stg.load(lane, a.c.X + (item.first + (int64_t)sl * 16) * D, min(16, item.count - sl * 16) * D);
+    for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
+    rf_init_pads(tb, lane, D, TS);                 // (the slab buffers served as scratch for the sums since)
+    __syncthreads();
     }
 }
 
@@ -452,7 +501,7 @@ __global__ __launch_bounds__(256) void refit_em_update_kernel(const rf_em_args a
     if (!a.c.active[s]) return;
     if (!pack_only) {
         const int plen = a.c.k * (1 + 2 * a.c.D) + 1;
-        if (!em_update_state(a, s, a.stats + (int64_t)s * plen, lds_i)) return;
+        if (!em_update_state(a, s, a.c.it, a.stats + (int64_t)s * plen, lds_i)) return;
         __syncthreads();
     }
     em_pack_state(a, s, lds);
@@ -483,7 +532,7 @@ __device__ void km_pack_state(const rf_km_args& a, int s, double* __restrict__ l
     if (tid == 0) {
         double m = 0;
         for (int c = 0; c < k; ++c) { const double v = fabs(cc[c]); if (v == v && v > m && v < INFINITY) m = v; }
-        a.kscale[s] = 2.0 * m + 2.0 * fabs(a.logdet[s]);
+        rf_publish(a.kscale + s, 2.0 * m + 2.0 * fabs(a.logdet[s]));
     }
     double* P = a.P + (int64_t)s * ((CG + 1) * KS * 16);
     for (int i = tid; i < (CG + 1) * KS * 16; i += blockDim.x) {
@@ -495,24 +544,24 @@ __device__ void km_pack_state(const rf_km_args& a, int s, double* __restrict__ l
             if (d < D) v = -2.0 * (1.0 / var[d]) * (cen[c * D + d] - sh[d]);
             else if (d == D) v = cc[c];
         } else if (d == D) v = 1e300;                               // padding centroid: never the nearest
-        P[i] = v;
+        rf_publish(P + i, v);
     }
 }
 
 // centroid update + stop rule of one state by the whole block (kmeans.py:187-192 with lockstep's rule "no assignment
 // changed"): su = sum (x - shift) | count per cluster, then the number of assignments that changed
-__device__ bool km_update_state(const rf_km_args& a, int s, const double* __restrict__ su) {
+__device__ bool km_update_state(const rf_km_args& a, int s, int it, const double* __restrict__ su) {
     const int D = a.c.D, k = a.c.k, tid = threadIdx.x;
     const double* sh = a.c.shift + (int64_t)s * D;
     double* ce = a.cent + (int64_t)s * k * D;
     for (int i = tid; i < k * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
-        ce[i] = sh[d] + su[c * (D + 1) + d] / su[c * (D + 1) + D];   // an empty cluster: 0 / 0 = NaN, like np.mean of nothing
+        rf_publish(ce + i, sh[d] + su[c * (D + 1) + d] / su[c * (D + 1) + D]);   // an empty cluster: 0 / 0 = NaN, like np.mean of nothing
     }
     const bool stop = su[k * (D + 1)] == 0.0;
     if (tid == 0) {
-        a.iters[s] += 1;
-        if (stop) a.c.active[s] = 0; else atomicAdd(a.c.counter + 2 + (a.c.it & 7), 1);
+        rf_publish(a.iters + s, a.iters[s] + 1);
+        if (stop) rf_publish(a.c.active + s, (uint8_t)0); else atomicAdd(a.c.counter + 2 + (it & 7), 1);
     }
     return !stop;
 }
@@ -540,8 +589,10 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     double* sBuf = sP + pstride;                  // [RF_WAVES][bufsz]; afterwards the cross-wave sums
     int* sFlag = reinterpret_cast<int*>(sBuf + RF_WAVES * bufsz + 64);   // [8]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar slab addresses)
-    if (blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;
-    const rf_item item = a.c.items[blockIdx.x];
+    const bool tail = a.c.n_iter > 1;               // a TAIL launch: see refit_em_kernel
+    if (!tail && blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;
+    const int bid = a.c.item_ids ? a.c.item_ids[blockIdx.x] : (int)blockIdx.x;
+    const rf_item item = a.c.items[bid];
     const int s = item.state;
     const int nsl = (item.count + 15) >> 4;
     int sl = wv;
@@ -560,10 +611,15 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     const int pb = 4 * lo + kk;
     const int a2 = rf_frame(bq, kk) * TS + lo;
     const int my_frame = rf_frame(bq, kk);
-    const double kscale = a.kscale[s];
     const double* cen = a.cent + (int64_t)s * k * D;
     const double* var = a.var + (int64_t)s * k * D;
     const double ld = a.logdet[s];
+    const int plen = k * (D + 1) + 1;
+    double* out = a.c.partial + (int64_t)bid * plen;
+    const int i0 = a.c.item_ptr[s], i1 = a.c.item_ptr[s + 1];
+    for (int j = 0;; ++j) {
+    const int it = a.c.it + j;
+    const double kscale = a.kscale[s];
     double Sx[CG][KSM];
 #pragma unroll
     for (int cg = 0; cg < CG; ++cg)
@@ -654,8 +710,6 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
         }
         __syncthreads();
     }
-    const int plen = k * (D + 1) + 1;
-    double* out = a.c.partial + (int64_t)blockIdx.x * plen;
     for (int e = tid; e < CG * KS * 16; e += 64 * RF_WAVES) {
         const int j = e & 3, i = (e >> 2) & 3, g = (e >> 4) % KS, cg = (e >> 4) / KS;
         const int c = 4 * cg + j, col = 4 * g + i;
@@ -663,15 +717,48 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
         if (c < k && col <= D) rf_publish(out + c * (D + 1) + col, (p[0] + p[4]) + (p[8] + p[12]));
     }
     if (tid == 0) rf_publish(out + k * (D + 1), (double)(sFlag[4] + sFlag[5] + sFlag[6] + sFlag[7]));
-    const int i0 = a.c.item_ptr[s], i1 = a.c.item_ptr[s + 1];
-    if (!rf_arrive(a.c.done, s, i1 - i0, sFlag)) return;
-    double* su = a.sums + (int64_t)s * plen;
-    rf_reduce_slabs(a.c.partial, plen, i0, i1, plen, su, sBuf);
-    if (!a.c.fused) return;
-    __syncthreads();
-    if (km_update_state(a, s, su)) {
+    const bool last = rf_arrive(a.c.done, s, i1 - i0, sFlag);
+    bool alive = false;
+    if (last) {
+        double* su = a.sums + (int64_t)s * plen;
+        rf_reduce_slabs(a.c.partial, plen, i0, i1, plen, su, sBuf);
+        if (a.c.fused) {
+            __syncthreads();
+            alive = km_update_state(a, s, it, su);
+            if (alive) {
+                __syncthreads();
+                km_pack_state(a, s, sBuf);
+            }
+        }
+    }
+    if (!tail || j + 1 >= a.c.n_iter) return;
+    // ---- TAIL launch: on to the state's next iteration, or out (see refit_em_kernel) ----
+    if (last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        km_pack_state(a, s, sBuf);
+        if (tid == 0) {
+            rf_publish(a.c.gen + s, alive ? j + 1 : -1);
+            sFlag[2] = alive ? j + 1 : -1;
+        }
+    } else if (tid == 0) {
+        int g = j, polls = 0;
+        while ((g = __hip_atomic_load(a.c.gen + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == j && ++polls < RF_TAIL_POLLS)
+            __builtin_amdgcn_s_sleep(8);
+        if (g == j) { atomicOr(a.c.counter + 1, 32); g = -1; }
+        sFlag[2] = g;
+    }
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (sFlag[2] < 0) return;
+    sl = wv;
+    if (sl < nsl) stg.load(lane, a.c.X + (item.first + (int64_t)sl * 16) * D, min(16, item.count - sl * 16) * D);
+    for (int i = tid; i < pstride; i += 64 * RF_WAVES) sP[i] = a.P[(int64_t)s * pstride + i];
+    rf_init_pads(tb, lane, D, TS);
+    n_changed = 0;
+    __syncthreads();
     }
 }
 
@@ -682,7 +769,7 @@ __global__ __launch_bounds__(256) void refit_km_update_kernel(const rf_km_args a
     if (!a.c.active[s]) return;
     if (!pack_only) {
         const int plen = a.c.k * (a.c.D + 1) + 1;
-        if (!km_update_state(a, s, a.sums + (int64_t)s * plen)) return;
+        if (!km_update_state(a, s, a.c.it, a.sums + (int64_t)s * plen)) return;
         __syncthreads();
     }
     km_pack_state(a, s, lds);
@@ -702,9 +789,17 @@ size_t rf_km_lds(int k, int D) {
     return ((size_t)rf_km_pstride(k, D) + (size_t)RF_WAVES * (16 * rf_row_stride(D) + 8) + 64) * 8 + 64;
 }
 
+// A TAIL launch (a.c.n_iter > 1) is only made when every workgroup of the grid is resident at once -- its workgroups wait
+// for each other between iterations: the instantiation's own occupancy times the CUs, with a quarter held back; otherwise
+// `refused` and the caller keeps the ordinary launches.
 #define RF_DISPATCH(KERNEL, CGV, KSV, EX, LDS)                                                                  \
     do {                                                                                                        \
-        if (!launched && (CGV) == c_g && (KSV) == ksm && (!(EX) || rf_steps(a.c.D) == (KSV))) {                 \
+        if (!launched && !refused && (CGV) == c_g && (KSV) == ksm && (!(EX) || rf_steps(a.c.D) == (KSV))) {     \
+            if (a.c.n_iter > 1) {                                                                               \
+                int occ = 0;                                                                                    \
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)KERNEL<CGV, KSV, EX>, 64 * RF_WAVES, LDS) != hipSuccess) occ = 0; \
+                if ((int64_t)n_items * 4 > (int64_t)occ * ctx->n_cu * 3) { refused = true; break; }             \
+            }                                                                                                   \
             hipLaunchKernelGGL((KERNEL<CGV, KSV, EX>), dim3((unsigned)n_items), dim3(64 * RF_WAVES), LDS, ctx->stream, a); \
             launched = true;                                                                                    \
         }                                                                                                       \
@@ -723,12 +818,14 @@ size_t rf_km_lds(int k, int D) {
     RF_DISPATCH(KERNEL, 1, 10, false, LDS); RF_DISPATCH(KERNEL, 2, 10, false, LDS);          \
     RF_DISPATCH(KERNEL, 1, 17, false, LDS); RF_DISPATCH(KERNEL, 2, 17, false, LDS)
 
+// returns 1 when a TAIL launch was refused (not every workgroup would be resident): nothing was launched
 int rf_launch_em(gh_ctx* ctx, const rf_em_args& a, int n_items) {
     if (n_items <= 0) return GH_OK;
     const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
     const size_t lds = rf_em_lds(a.c.k, a.c.D);
-    bool launched = false;
+    bool launched = false, refused = false;
     RF_ALL(refit_em_kernel, lds);
+    if (refused) return 1;
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
     GH_HIP(hipGetLastError());
     return GH_OK;
@@ -757,8 +854,9 @@ int rf_launch_km(gh_ctx* ctx, const rf_km_args& a, int n_items) {
     if (n_items <= 0) return GH_OK;
     const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
     const size_t lds = rf_km_lds(a.c.k, a.c.D);
-    bool launched = false;
+    bool launched = false, refused = false;
     RF_ALL(refit_km_kernel, lds);
+    if (refused) return 1;
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
     GH_HIP(hipGetLastError());
     return GH_OK;

@@ -371,22 +371,29 @@ class _PickleWriter:
 
     def write(self, models, output_path):
         self.wait()
+        if os.environ.get("GMMHMM_CTRAIN_PICKLE_THREAD", "1") == "0":      # (A/B switch: write them here and now)
+            self._dump(models, output_path)
+            return
 
         def run():
             try:
-                for i, m in enumerate(models):
-                    # (written under a private name and renamed: the ranks of a sharded run may share `output_path`, and
-                    #  they all hold the same models)
-                    final = os.path.join(output_path, str(i) + '.pkl')
-                    tmp = final + '.%d.tmp' % os.getpid()
-                    with open(tmp, 'wb') as f:
-                        pickle.dump(m, f)
-                    os.replace(tmp, final)
+                self._dump(models, output_path)
             except BaseException as e:
                 self.error = e
 
         self.thread = threading.Thread(target=run, name="gmmhmm-pickles", daemon=True)
         self.thread.start()
+
+    @staticmethod
+    def _dump(models, output_path):
+        for i, m in enumerate(models):
+            # (written under a private name and renamed: the ranks of a sharded run may share `output_path`, and
+            #  they all hold the same models)
+            final = os.path.join(output_path, str(i) + '.pkl')
+            tmp = final + '.%d.tmp' % os.getpid()
+            with open(tmp, 'wb') as f:
+                pickle.dump(m, f)
+            os.replace(tmp, final)
 
     def wait(self):
         if self.thread is not None:

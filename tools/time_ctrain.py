@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "speech-recognition_amd")):
     sys.path.insert(0, p)
 import numpy as np
+if os.environ.get('PYSWITCH'):
+    sys.setswitchinterval(float(os.environ['PYSWITCH']))
 import bench
 from sr.recognition import continuous_speech as cs
 from sr.recognition.model_io import models_from_arrays
