@@ -295,8 +295,10 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
 // HARD: the responsibilities are GIVEN -- 1 for the component a.hard_ids names for the frame, 0 for the others -- and the pass
 // only sums: count | sum (x - shift) | sum (x - shift)^2 per (state, group), the one-pass variances of kmeans.py:171-177's
 // random partitions (no operands, no densities, no update in the tail).
-template <int CG, int KSM, bool EXACT, bool HARD = false>
-__global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(CG == 1 && KSM <= 10 ? 3 : (CG == 2 && KSM > 10 ? 1 : 2), 8))) void refit_em_kernel(const rf_em_args a) {
+// TAIL: the multi-iteration form (its own instantiation: the loop around the kernel body and the values it keeps alive cost the
+// ordinary launch 10-40 % when both forms shared one -- 121 -> 178 us for a full pass at k = 4)
+template <int CG, int KSM, bool EXACT, bool HARD = false, bool TAIL = false>
+__global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu((CG == 1 || TAIL) && KSM <= 10 ? 3 : (CG == 2 && KSM > 10 ? 1 : 2), 8))) void refit_em_kernel(const rf_em_args a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.c.D, k = a.c.k, KS = EXACT ? KSM : rf_steps(D), TS = 4 * KS + 2;
     const int pstride = CG * 2 * KS * 16, bufsz = 16 * TS + 8;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(C
     double* sBuf = sT + 128;                      // [RF_WAVES][bufsz]; afterwards the cross-wave sums
     int* sFlag = reinterpret_cast<int*>(sBuf + RF_WAVES * bufsz + 64);   // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar slab addresses)
-    const bool tail = !HARD && a.c.n_iter > 1;      // a TAIL launch: this workgroup stays for several iterations (see the loop's end)
+    constexpr bool tail = TAIL && !HARD;           // a TAIL launch: this workgroup stays for several iterations (see the loop's end)
     if (!tail && blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;   // the next iteration's slot
     const int bid = a.c.item_ids ? a.c.item_ids[blockIdx.x] : (int)blockIdx.x;
     const rf_item item = a.c.items[bid];
@@ -580,7 +582,7 @@ __device__ int km_exact(const double* __restrict__ x, const double* __restrict__
     return bi;
 }
 
-template <int CG, int KSM, bool EXACT>
+template <int CG, int KSM, bool EXACT, bool TAIL = false>
 __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(KSM <= 10 ? 3 : 2, 8))) void refit_km_kernel(const rf_km_args a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.c.D, k = a.c.k, KS = EXACT ? KSM : rf_steps(D), TS = 4 * KS + 2;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     double* sBuf = sP + pstride;                  // [RF_WAVES][bufsz]; afterwards the cross-wave sums
     int* sFlag = reinterpret_cast<int*>(sBuf + RF_WAVES * bufsz + 64);   // [8]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar slab addresses)
-    const bool tail = a.c.n_iter > 1;               // a TAIL launch: see refit_em_kernel
+    constexpr bool tail = TAIL;                    // a TAIL launch: see refit_em_kernel
     if (!tail && blockIdx.x == 0 && tid == 0) a.c.counter[2 + ((a.c.it + 1) & 7)] = 0;
     const int bid = a.c.item_ids ? a.c.item_ids[blockIdx.x] : (int)blockIdx.x;
     const rf_item item = a.c.items[bid];
@@ -792,16 +794,28 @@ size_t rf_km_lds(int k, int D) {
 // A TAIL launch (a.c.n_iter > 1) is only made when every workgroup of the grid is resident at once -- its workgroups wait
 // for each other between iterations: the instantiation's own occupancy times the CUs, with a quarter held back; otherwise
 // `refused` and the caller keeps the ordinary launches.
-#define RF_DISPATCH(KERNEL, CGV, KSV, EX, LDS)                                                                  \
+#define RF_GO(KFN, LDS)                                                                                         \
+    do {                                                                                                        \
+        if (a.c.n_iter > 1) {                                                                                   \
+            int occ = 0;                                                                                        \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)KFN, 64 * RF_WAVES, LDS) != hipSuccess) occ = 0; \
+            if ((int64_t)n_items * 4 > (int64_t)occ * ctx->n_cu * 3) { refused = true; break; }                 \
+        }                                                                                                       \
+        hipLaunchKernelGGL(KFN, dim3((unsigned)n_items), dim3(64 * RF_WAVES), LDS, ctx->stream, a);             \
+        launched = true;                                                                                        \
+    } while (0)
+#define RF_DISPATCH_EM(CGV, KSV, EX, LDS)                                                                       \
     do {                                                                                                        \
         if (!launched && !refused && (CGV) == c_g && (KSV) == ksm && (!(EX) || rf_steps(a.c.D) == (KSV))) {     \
-            if (a.c.n_iter > 1) {                                                                               \
-                int occ = 0;                                                                                    \
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)KERNEL<CGV, KSV, EX>, 64 * RF_WAVES, LDS) != hipSuccess) occ = 0; \
-                if ((int64_t)n_items * 4 > (int64_t)occ * ctx->n_cu * 3) { refused = true; break; }             \
-            }                                                                                                   \
-            hipLaunchKernelGGL((KERNEL<CGV, KSV, EX>), dim3((unsigned)n_items), dim3(64 * RF_WAVES), LDS, ctx->stream, a); \
-            launched = true;                                                                                    \
+            if (a.c.n_iter > 1) RF_GO((refit_em_kernel<CGV, KSV, EX, false, true>), LDS);                       \
+            else RF_GO((refit_em_kernel<CGV, KSV, EX, false, false>), LDS);                                     \
+        }                                                                                                       \
+    } while (0)
+#define RF_DISPATCH_KM(CGV, KSV, EX, LDS)                                                                       \
+    do {                                                                                                        \
+        if (!launched && !refused && (CGV) == c_g && (KSV) == ksm && (!(EX) || rf_steps(a.c.D) == (KSV))) {     \
+            if (a.c.n_iter > 1) RF_GO((refit_km_kernel<CGV, KSV, EX, true>), LDS);                              \
+            else RF_GO((refit_km_kernel<CGV, KSV, EX, false>), LDS);                                            \
         }                                                                                                       \
     } while (0)
 #define RF_DISPATCH_HARD(CGV, KSV, EX, LDS)                                                                     \
@@ -811,12 +825,12 @@ size_t rf_km_lds(int k, int D) {
             launched = true;                                                                                    \
         }                                                                                                       \
     } while (0)
-#define RF_ALL(KERNEL, LDS)                                                                  \
-    RF_DISPATCH(KERNEL, 1, 4, true, LDS); RF_DISPATCH(KERNEL, 2, 4, true, LDS);              \
-    RF_DISPATCH(KERNEL, 1, 10, true, LDS); RF_DISPATCH(KERNEL, 2, 10, true, LDS);            \
-    RF_DISPATCH(KERNEL, 1, 4, false, LDS); RF_DISPATCH(KERNEL, 2, 4, false, LDS);            \
-    RF_DISPATCH(KERNEL, 1, 10, false, LDS); RF_DISPATCH(KERNEL, 2, 10, false, LDS);          \
-    RF_DISPATCH(KERNEL, 1, 17, false, LDS); RF_DISPATCH(KERNEL, 2, 17, false, LDS)
+#define RF_ALL(DISPATCH, LDS)                                                                \
+    DISPATCH(1, 4, true, LDS); DISPATCH(2, 4, true, LDS);                                    \
+    DISPATCH(1, 10, true, LDS); DISPATCH(2, 10, true, LDS);                                  \
+    DISPATCH(1, 4, false, LDS); DISPATCH(2, 4, false, LDS);                                  \
+    DISPATCH(1, 10, false, LDS); DISPATCH(2, 10, false, LDS);                                \
+    DISPATCH(1, 17, false, LDS); DISPATCH(2, 17, false, LDS)
 
 // returns 1 when a TAIL launch was refused (not every workgroup would be resident): nothing was launched
 int rf_launch_em(gh_ctx* ctx, const rf_em_args& a, int n_items) {
@@ -824,7 +838,7 @@ int rf_launch_em(gh_ctx* ctx, const rf_em_args& a, int n_items) {
     const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
     const size_t lds = rf_em_lds(a.c.k, a.c.D);
     bool launched = false, refused = false;
-    RF_ALL(refit_em_kernel, lds);
+    RF_ALL(RF_DISPATCH_EM, lds);
     if (refused) return 1;
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
     GH_HIP(hipGetLastError());
@@ -836,9 +850,7 @@ int rf_launch_partition_sums(gh_ctx* ctx, const rf_em_args& a, int n_items) {
     const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
     const size_t lds = rf_em_lds(a.c.k, a.c.D);
     bool launched = false;
-    RF_DISPATCH_HARD(1, 4, true, lds); RF_DISPATCH_HARD(2, 4, true, lds); RF_DISPATCH_HARD(1, 10, true, lds); RF_DISPATCH_HARD(2, 10, true, lds);
-    RF_DISPATCH_HARD(1, 4, false, lds); RF_DISPATCH_HARD(2, 4, false, lds); RF_DISPATCH_HARD(1, 10, false, lds); RF_DISPATCH_HARD(2, 10, false, lds);
-    RF_DISPATCH_HARD(1, 17, false, lds); RF_DISPATCH_HARD(2, 17, false, lds);
+    RF_ALL(RF_DISPATCH_HARD, lds);
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
     GH_HIP(hipGetLastError());
     return GH_OK;
@@ -855,7 +867,7 @@ int rf_launch_km(gh_ctx* ctx, const rf_km_args& a, int n_items) {
     const int c_g = rf_comp_groups(a.c.k), ksm = rf_ksm(a.c.D);
     const size_t lds = rf_km_lds(a.c.k, a.c.D);
     bool launched = false, refused = false;
-    RF_ALL(refit_km_kernel, lds);
+    RF_ALL(RF_DISPATCH_KM, lds);
     if (refused) return 1;
     GH_REQUIRE(launched, "refit: k=%d, D=%d has no kernel", a.c.k, a.c.D);
     GH_HIP(hipGetLastError());
