@@ -102,12 +102,16 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
         lat = _hip.Lattices(ctx, [_pack.graph_from_dense(np.arange(n) + w * n, h.transitions, [0], [n - 1]) for w, h in enumerate(models)])
         try:
             frames.loglik(gmm, fetch=False, state_ranges=(utt_word * n, utt_word * n + n))
-            res = lat.viterbi(frames, utt_lattice=utt_word, want_path=True)
+            res = lat.viterbi(frames, utt_lattice=utt_word, want_path=True, flat_paths=True)
         finally:
             lat.close()
     finally:
         frames.close()
-    starts_all = _starts_from_paths(res["paths"], n)
+    # get_segments_from_path for all templates at once: visits of every chain row on the path, cumulated (kmeans.py:98-108)
+    tid = np.repeat(np.arange(len(lengths)), res["path_len"])
+    visits = np.bincount(tid * n + res["path_flat"][:, 0], minlength=len(lengths) * n).reshape(len(lengths), n)
+    starts_all = np.zeros((len(lengths), n), dtype=np.int64)
+    np.cumsum(visits[:, :-1], axis=1, out=starts_all[:, 1:])
     order, counts = _km.segment_order(lengths, n_temps, starts_all, n)
     for h, segs in zip(models, _km.split_segments(_km.gather_rows(X, order), counts)):
         h.segments = segs

@@ -156,7 +156,14 @@ class GMM(HMMState):
         super().__init__()
         self.n_gaussians = n_gaussians
         self.w = np.full(n_gaussians, 1 / n_gaussians)
-        self.dists = [MultivariateNormal(mean=mu, cov=sigma) for _ in range(n_gaussians)]
+        # n_gaussians copies of N(mu, diag(sigma)) (hmm_state.py:108): the singular-covariance check and the inverse are
+        # worked out once, every copy gets an inverse of its own (400 np.diag calls for ten 5-state 8-mixture words were 2 ms)
+        first = MultivariateNormal(mean=mu, cov=sigma)
+        self.dists = [first]
+        for _ in range(n_gaussians - 1):
+            d = MultivariateNormal.__new__(MultivariateNormal)
+            d.__dict__.update(mean=mu, _cov=sigma, inv_cov=first.inv_cov.copy())
+            self.dists.append(d)
         self.mu_old = np.tile(mu, (n_gaussians, 1))
         self.sigma_old = np.tile(sigma, (n_gaussians, 1))
         self.w_old = np.full(n_gaussians, 1 / n_gaussians)
