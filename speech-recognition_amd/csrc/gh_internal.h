@@ -171,10 +171,10 @@ struct gh_lattice_host {
 // and states in every layer.  gh_viterbi runs such graphs with one WAVE per utterance: lane = (layer mod 4, word),
 // the N states of a word in registers (gh_viterbi_layers.hip).
 #define GH_LAYERS_MAXW 16
-#define GH_LAYERS_MAXN 16          // states per word the word templates hold (sequence form: 2..8, 12, 16: gh_seq_n_ok)
-#define GH_LAYERFORM_MAXN 8        // ... that the layer / loop form kernels and the sequence-form forward-backward are built for
+#define GH_LAYERS_MAXN 16          // states per word the word templates hold (Viterbi, all three forms: 2..8, 12, 16: gh_seq_n_ok)
+#define GH_LAYERFORM_MAXN 8        // ... that the sequence-form forward-backward (and the EM session on it) is built for
 #define GH_LAYERS_MAXK 8
-// states per word the sequence-form Viterbi kernels are instantiated for (gh_seq.hip): every count up to 8, and the 12 and 16
+// states per word the word-template Viterbi kernels are instantiated for (gh_seq.hip, gh_viterbi_layers.hip): every count up to 8, and the 12 and 16
 // of wide word models (BASELINE configs[3]: 16 states per word), whose N costs still live in one lane's registers
 static inline bool gh_seq_n_ok(int N) { return (N >= 2 && N <= 8) || N == 12 || N == 16; }
 // LOOP form (K = 1, loop = 1): the word-loop grammar of continuous_speech.build_loop_grammar -- row 0 = non-emitting

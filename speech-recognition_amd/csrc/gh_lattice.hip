@@ -376,7 +376,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
                 if (W == 0) { ok = false; break; }
             }
             if (ok && W == 1) N = P;
-            ok = ok && N >= 2 && N <= GH_LAYERFORM_MAXN && W <= GH_LAYERS_MAXW && W * N == P;
+            ok = ok && gh_seq_n_ok(N) && W <= GH_LAYERS_MAXW && W * N == P;
         }
         bool skip = false;
         for (int pos = 0; ok && pos < P; ++pos) {
@@ -423,7 +423,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         const int W = ok ? R - 1 - Lr : 0;
         ok = ok && W >= 1 && W <= GH_LAYERS_MAXW && (Lr - 1) % W == 0;
         const int N = ok ? (Lr - 1) / W + 1 : 0;
-        ok = ok && N >= 2 && N <= GH_LAYERFORM_MAXN;
+        ok = ok && gh_seq_n_ok(N);
         ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);
         auto row_of = [&](int w, int sx) { return sx == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (sx - 1); };
         std::vector<int> wof(R, -1), sof(R, -1);

@@ -66,14 +66,35 @@ __device__ __forceinline__ void push_bit(uint32_t& word, unsigned long long mask
     asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(word), "=s"(carry_out) : "v"(word), "s"(mask));
 }
 
+// ... and for the 64-bit decision words of the wide word models (12 / 16 states): the carry of the low half goes on
+__device__ __forceinline__ void push_bit(uint64_t& word, unsigned long long mask) {
+    uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+    unsigned long long c1, c2;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(lo), "=s"(c1) : "v"(lo), "s"(mask));
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(hi), "=s"(c2) : "v"(hi), "s"(c1));
+    word = ((uint64_t)hi << 32) | lo;
+}
+
+// decision bits of one column and lane in the layer form: two register sets of N + 1 (+ N - 2 with skip arcs); they
+// fit a 32-bit word up to 8 states per word (and 12 without skip arcs), a 64-bit word up to 16
+template <int N, bool SKIP> struct LayerBits {
+    static constexpr int HB = N + 1 + (SKIP ? N - 2 : 0);
+    static constexpr int BITS = 2 * HB;
+    static constexpr bool WIDE = BITS > 32;
+    static constexpr int CPW = (WIDE ? 64 : 32) / BITS;
+};
+template <bool WIDE> struct DecisionWord { using type = uint32_t; };
+template <> struct DecisionWord<true> { using type = uint64_t; };
+
 template <typename ET, int N, bool SKIP, bool WANT_BP>
 __global__ __launch_bounds__(64) void viterbi_layers_kernel(gh_layers_args a) {
     constexpr int H = 2;                                      // register sets: layers 0-3 and 4-7
-    constexpr int HB = N + 1 + (SKIP ? N - 2 : 0);            // decision bits per column and register set
-    constexpr int BITS = H * HB;
-    constexpr int CPW = 32 / BITS;                            // columns per 32-bit decision word
-    constexpr int PF = 4;                                     // columns of emissions in flight
-    static_assert(BITS <= 32 && CPW >= 1, "decision bits of a column must fit one word");
+    constexpr int HB = LayerBits<N, SKIP>::HB;                // decision bits per column and register set
+    constexpr int BITS = LayerBits<N, SKIP>::BITS;
+    constexpr int CPW = LayerBits<N, SKIP>::CPW;              // columns per decision word
+    constexpr int PF = N > 8 ? 2 : 4;                         // columns of emissions in flight
+    using WT = typename DecisionWord<LayerBits<N, SKIP>::WIDE>::type;
+    static_assert(CPW >= 1, "decision bits of a column must fit one word");
     const int lane = threadIdx.x, kk = lane >> 4, w = lane & 15;
     const gh_layerform* __restrict__ lf = a.lf;
     const int K = lf->K, W = lf->W, P = lf->P;
@@ -120,8 +141,8 @@ __global__ __launch_bounds__(64) void viterbi_layers_kernel(gh_layers_args a) {
     for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int s = 0; s < N; ++s) prev[h][s] = INF;
-    uint32_t word = 0;
-    uint32_t* bp = WANT_BP ? reinterpret_cast<uint32_t*>(a.bp + a.bp_off[slot]) + lane : nullptr;
+    WT word = 0;
+    WT* bp = WANT_BP ? reinterpret_cast<WT*>(a.bp + a.bp_off[slot]) + lane : nullptr;
     int cw = 0;                                               // columns already pushed into `word`
 
     // Read-ahead (round 4, found in the ISA): a load under `if (t + PF < T)`, a `break` out of the unrolled group, a
@@ -244,7 +265,7 @@ template <int N, bool SKIP> struct LoopBits {
 template <typename ET, int N, bool SKIP, bool WANT_BP>
 __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int64_t slot_end) {
     constexpr int HB = LoopBits<N, SKIP>::HB, CPW = LoopBits<N, SKIP>::CPW;
-    constexpr int PF = 4;
+    constexpr int PF = N > 8 ? 2 : 4;
     static_assert(CPW >= 1, "decision bits of a column must fit one word");
     const int lane = threadIdx.x, kk = lane >> 4, w = lane & 15;
     const gh_layerform* __restrict__ lf = a.lf;
@@ -381,10 +402,12 @@ __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int6
 // the utterance's slot and moved to its front at the end.
 template <int N, bool SKIP, bool LOOP, int MODE>
 __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a, int64_t slot_end) {
-    constexpr int HB = LOOP ? LoopBits<N, SKIP>::HB : N + 1 + (SKIP ? N - 2 : 0);
+    constexpr int HB = LOOP ? LoopBits<N, SKIP>::HB : LayerBits<N, SKIP>::HB;
     constexpr int BITS = LOOP ? HB : 2 * HB;
-    constexpr int CPW = 32 / BITS;
-    constexpr int LPW = LOOP ? 16 : 64;                       // dwords per word index
+    constexpr bool WIDE = !LOOP && LayerBits<N, SKIP>::WIDE;  // 64-bit decision words (viterbi_layers_kernel)
+    using WT = typename DecisionWord<WIDE>::type;
+    constexpr int CPW = (WIDE ? 64 : 32) / BITS;
+    constexpr int LPW = LOOP ? 16 : 64;                       // decision words per word index
     __shared__ uint8_t s_arcs[GH_LAYERS_MAXW * GH_LAYERS_MAXN];
     const gh_layerform* __restrict__ lf = a.lf;
     for (int i = threadIdx.x; i < GH_LAYERS_MAXW * GH_LAYERS_MAXN; i += 64) s_arcs[i] = (&lf->arcs[0][0])[i];
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
             bs = pos % N;
         }
     }
-    const uint32_t* bpu = reinterpret_cast<const uint32_t*>(a.bp + a.bp_off[slot]);
+    const WT* bpu = reinterpret_cast<const WT*>(a.bp + a.bp_off[slot]);
     int32_t* path = MODE == 0 ? a.path + 2 * a.path_off[u] : nullptr;
     int32_t* labs = MODE == 1 ? a.labels + a.label_off[u] : nullptr;
     const int64_t cap = MODE == 0 ? a.path_off[u + 1] - a.path_off[u] : a.label_off[u + 1] - a.label_off[u];
@@ -420,8 +443,8 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
     int prev_label = -1;                                      // MODE 1: label of the cell visited last
     int j = T - 1, kind = 0, kn = 0;                          // kind 0 emitting (bk, bw, bs); 1 non-emitting row kn; 2 start row
     int flag = 0;
-    int64_t key = -1;                                         // dword index of the decision word held in `cw`
-    uint32_t cw = 0, pw = 0;                                  // current word, and the one LPW dwords below it
+    int64_t key = -1;                                         // index of the decision word held in `cw`
+    WT cw = 0, pw = 0;                                        // current word, and the one LPW words below it
     auto visit = [&](int row, int col) {
         if (MODE == 0) {
             if (len >= cap) { flag |= 4; return; }
@@ -445,9 +468,9 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
             if (want != key) {
                 if (want == key - LPW) cw = pw; else cw = bpu[want];
                 key = want;
-                pw = (wi > 0) ? bpu[want - LPW] : 0u;
+                pw = (wi > 0) ? bpu[want - LPW] : WT(0);
             }
-            const uint32_t hb = (cw >> (shift + (LOOP ? 0 : (1 - (bk >> 2)) * HB))) & ((1u << HB) - 1u);
+            const uint32_t hb = (uint32_t)((cw >> (shift + (LOOP ? 0 : (1 - (bk >> 2)) * HB))) & (WT)((1ull << HB) - 1ull));
             const int arcs = s_arcs[bw * GH_LAYERS_MAXN + bs];
             if (bs >= 1) {
                 int before = 0;
@@ -485,15 +508,25 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
             if (!LOOP && kn == 0) { flag |= 2; break; }                       // the start row has no origin
             const int kp = LOOP ? 0 : kn - 1;
             const int eq_shift = shift + (LOOP ? 2 : (1 - (kp >> 2)) * HB + 1);
-            const uint4* rowp = reinterpret_cast<const uint4*>(bpu + (int64_t)wi * LPW + (LOOP ? 0 : (kp & 3) * 16));
             int found = -1;
+            if constexpr (WIDE) {
+                const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(bpu + (int64_t)wi * LPW + (kp & 3) * 16);
 #pragma unroll
-            for (int q4 = 3; q4 >= 0; --q4) {                                   // 16 word lanes = 64 contiguous bytes
-                const uint4 v = rowp[q4];
-                if ((v.w >> eq_shift) & 1u) found = 4 * q4 + 3;
-                if ((v.z >> eq_shift) & 1u) found = 4 * q4 + 2;
-                if ((v.y >> eq_shift) & 1u) found = 4 * q4 + 1;
-                if ((v.x >> eq_shift) & 1u) found = 4 * q4;
+                for (int q2 = 7; q2 >= 0; --q2) {                               // 16 word lanes = 128 contiguous bytes
+                    const ulonglong2 v = rowp[q2];
+                    if ((v.y >> eq_shift) & 1ull) found = 2 * q2 + 1;
+                    if ((v.x >> eq_shift) & 1ull) found = 2 * q2;
+                }
+            } else {
+                const uint4* rowp = reinterpret_cast<const uint4*>(bpu + (int64_t)wi * LPW + (LOOP ? 0 : (kp & 3) * 16));
+#pragma unroll
+                for (int q4 = 3; q4 >= 0; --q4) {                               // 16 word lanes = 64 contiguous bytes
+                    const uint4 v = rowp[q4];
+                    if ((v.w >> eq_shift) & 1u) found = 4 * q4 + 3;
+                    if ((v.z >> eq_shift) & 1u) found = 4 * q4 + 2;
+                    if ((v.y >> eq_shift) & 1u) found = 4 * q4 + 1;
+                    if ((v.x >> eq_shift) & 1u) found = 4 * q4;
+                }
             }
             if (found < 0 || found >= W) { flag |= 2; break; }                 // lowest word = lowest origin row (np.argmin)
             bw = found;
@@ -527,8 +560,9 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
         return (size_t)((T + cpw - 1) / cpw) * 16 * 2;
     }
     const int hb = f.N + 1 + (f.skip ? f.N - 2 : 0);
-    const int cpw = 32 / (2 * hb);
-    return (size_t)((T + cpw - 1) / cpw) * 64 * 2;
+    const int wbits = 2 * hb > 32 ? 64 : 32;                  // (LayerBits)
+    const int cpw = wbits / (2 * hb);
+    return (size_t)((T + cpw - 1) / cpw) * 64 * (wbits / 16);
 }
 
 #define GH_LY_CASES(ET, MACRO)                   \
@@ -540,6 +574,8 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
         case 6: if (f.skip) MACRO(ET, 6, true); else MACRO(ET, 6, false); break; \
         case 7: if (f.skip) MACRO(ET, 7, true); else MACRO(ET, 7, false); break; \
         case 8: if (f.skip) MACRO(ET, 8, true); else MACRO(ET, 8, false); break; \
+        case 12: if (f.skip) MACRO(ET, 12, true); else MACRO(ET, 12, false); break; \
+        case 16: if (f.skip) MACRO(ET, 16, true); else MACRO(ET, 16, false); break; \
         default: gh_set_error("gh_viterbi: layer form with %d states per word", f.N); return GH_ERR_UNSUPPORTED; \
     }
 
