@@ -67,7 +67,11 @@ def test_layers_kernel_reference_goldens(hip, ctx, dtype):
 
 @pytest.mark.parametrize("W,n,K,skip", [(10, 5, 7, False), (11, 5, 7, False), (1, 2, 1, False), (3, 2, 8, False),
                                         (16, 3, 4, True), (5, 8, 5, True), (7, 4, 3, False), (10, 5, 2, True),
-                                        (4, 6, 6, False), (2, 7, 8, True)])
+                                        (4, 6, 6, False), (2, 7, 8, True),
+                                        # wide word models: 12 states without skip arcs still pack two register sets into
+                                        # a 32-bit decision word; the others take 64-bit words
+                                        (4, 12, 3, False), (3, 12, 8, True), (5, 16, 2, False), (2, 16, 8, True),
+                                        (6, 16, 5, False)])
 def test_layers_kernel_equals_lean_kernel(hip, ctx, W, n, K, skip):
     """Random word models (per-word transition costs, optional skip arcs), utterances from far too short to long:
     end costs BITWISE equal, same chosen end, same paths -- including the unreachable cases, where every candidate is
@@ -96,6 +100,7 @@ def test_layers_kernel_equals_lean_kernel(hip, ctx, W, n, K, skip):
     gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
     graph = packed_lattice(wt, n, [list(range(W))] * K)[0]
     lat = hip.Lattices(ctx, [graph])
+    assert "layers" in lat.forms()
     b = hip.Batch(ctx, xs)
     b.loglik(gmm, fetch=False)
     U = b.U
@@ -211,7 +216,8 @@ def test_loop_kernel_reference_goldens(hip, ctx, dtype):
 
 
 @pytest.mark.parametrize("W,n,skip,penalty", [(10, 5, False, 0.0), (11, 5, False, 2.5), (1, 2, False, 0.0), (16, 3, True, 1.0),
-                                              (5, 8, True, 0.0), (7, 4, False, 0.7), (3, 6, True, 3.0), (2, 7, False, 0.0)])
+                                              (5, 8, True, 0.0), (7, 4, False, 0.7), (3, 6, True, 3.0), (2, 7, False, 0.0),
+                                              (4, 12, False, 0.5), (3, 12, True, 1.0), (5, 16, False, 0.0), (2, 16, True, 2.0)])
 def test_loop_kernel_equals_lean_kernel(hip, ctx, W, n, skip, penalty):
     """Random word models through the loop grammar: ragged utterances (1 .. 6 words, a few too short for even one
     word, counts that are not a multiple of the four utterances a wave holds): end costs BITWISE, chosen ends, paths
@@ -238,6 +244,7 @@ def test_loop_kernel_equals_lean_kernel(hip, ctx, W, n, skip, penalty):
     gmm = hip.PackedGMM(ctx, means.reshape(W * n, M, D), vars_.reshape(W * n, M, D), w.reshape(W * n, M))
     graph = packed_loop_lattice(wt, n, penalty)[0]
     lat = hip.Lattices(ctx, [graph])
+    assert "loop" in lat.forms()
     for dtype in (np.float64, np.float32):
         b = hip.Batch(ctx, xs, dtype=dtype)
         b.loglik(gmm, fetch=False)
