@@ -54,6 +54,14 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
     from .hmm import HMM
     from .hmm_state import GMM
     from .lockstep import LockstepFitter
+    import os
+    import sys
+    import time
+    marks = [("start", time.perf_counter())] if os.environ.get("GMMHMM_TRAIN_WORDS_TIMES") else None
+
+    def mark(name):
+        if marks is not None:
+            marks.append((name, time.perf_counter()))
     W = len(templates_by_word)
     models = [HMM(n_segments) for _ in range(W)]
     for h in models:
@@ -71,11 +79,36 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
     n_temps = np.array([len(ts) for ts in templates_by_word], dtype=np.int64)
     lengths = np.array([len(t) for ts in templates_by_word for t in ts], dtype=np.int64)
     D = np.asarray(templates_by_word[0][0]).shape[1]
-    X = np.concatenate([np.asarray(t, dtype=np.float64).reshape(-1, D) for ts in templates_by_word for t in ts])
+    X, release = _km.host_workspace((int(lengths.sum()), D))
+    try:
+        try:
+            np.concatenate([t for ts in templates_by_word for t in ts], out=X)      # [T, D] arrays: no per-template call
+        except (ValueError, TypeError):
+            np.concatenate([np.asarray(t).reshape(-1, D) for ts in templates_by_word for t in ts], out=X)
+    except BaseException:
+        release()
+        raise
     off_t = np.concatenate([[0], np.cumsum(lengths)])
+    mark("concatenate")
+    try:
+        return _train_words_resident(ctx, X, off_t, templates_by_word, models, n, n_gaussians, use_gmm, use_em, kmax, lengths, n_temps, mark, marks)
+    finally:
+        release()
+
+
+def _train_words_resident(ctx, X, off_t, templates_by_word, models, n, n_gaussians, use_gmm, use_em, kmax, lengths, n_temps, mark, marks):
+    """The three stages of `train_words` on ONE resident batch of all templates (X: the caller's frames back to back)."""
+    import importlib
+    import sys
+    _km = importlib.import_module(__package__ + ".kmeans")
+    from .hmm_state import GMM
+    from .lockstep import LockstepFitter
+    W, D = len(templates_by_word), X.shape[1]
     frames = _hip.Batch(ctx, feats=X, offsets=off_t)
+    mark("upload")
     try:
         fitted = _km.skmeans_multi(templates_by_word, n, frames=frames)
+        mark("segmental k-means")
         tpl_off = np.concatenate([[0], np.cumsum(n_temps)])
         for w, h in enumerate(models):
             h.mu, h.sigma, h.transitions, _ = fitted[w]
@@ -87,6 +120,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
             return models
         for h in models:
             h.gmm_states = [GMM(m, s, n_gaussians) for m, s in zip(h.mu, h.sigma)]
+        mark("segment order, GMM objects")
         # the mixtures of all W x n states: their frames gathered on the device from the resident batch
         fitter = LockstepFitter(None, ctx=ctx, source=(frames, order), lengths=[int(c) for c in counts.reshape(-1)], dim=D, kmax=kmax)
         try:
@@ -96,6 +130,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
                                  n_gaussians=n_gaussians, use_em=use_em)
         finally:
             fitter.close()
+        mark("refit")
         # re-alignment of every template against its word's mixtures (hmm.py:95), all words in one launch
         utt_word = np.repeat(np.arange(W), n_temps).astype(np.int32)
         gmm = _pack.device_gmm(ctx, [g for h in models for g in h.gmm_states])
@@ -105,6 +140,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
             res = lat.viterbi(frames, utt_lattice=utt_word, want_path=True, flat_paths=True)
         finally:
             lat.close()
+        mark("re-alignment")
     finally:
         frames.close()
     # get_segments_from_path for all templates at once: visits of every chain row on the path, cumulated (kmeans.py:98-108)
@@ -113,8 +149,12 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
     starts_all = np.zeros((len(lengths), n), dtype=np.int64)
     np.cumsum(visits[:, :-1], axis=1, out=starts_all[:, 1:])
     order, counts = _km.segment_order(lengths, n_temps, starts_all, n)
+    mark("segment order")
     for h, segs in zip(models, _km.split_segments(_km.gather_rows(X, order), counts)):
         h.segments = segs
+    mark("segments")
+    if marks is not None:
+        sys.stderr.write("train_words [ms]: " + ", ".join("%s %.2f" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:])) + "\n")
     return models
 
 

@@ -131,10 +131,11 @@ def _uniform_segments(lengths, n_segments):
     Returns (segment of every frame [sum T], seg_lens [n_temps, n] as the reference holds them: T // n each)."""
     lengths = np.asarray(lengths, dtype=np.int64)
     q = lengths // n_segments
-    within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
-    qq = np.repeat(q, lengths)
-    ids = np.where(qq > 0, np.minimum(within // np.maximum(qq, 1), n_segments - 1), n_segments - 1)
-    return ids.astype(np.int32), np.repeat(q[:, None], n_segments, axis=1)
+    # runs of q frames for the segments 0 .. n-2, the rest of the template for the last one (a template shorter than n: all last)
+    run_len = np.repeat(q[:, None], n_segments, axis=1)
+    run_len[:, -1] = lengths - q * (n_segments - 1)
+    ids = np.repeat(np.tile(np.arange(n_segments, dtype=np.int32), len(lengths)), run_len.reshape(-1))
+    return ids, np.repeat(q[:, None], n_segments, axis=1)
 
 
 def _starts_from_ids(ids, lengths, n_segments):
@@ -156,27 +157,59 @@ def segment_order(lengths, n_temps, seg_starts, n_segments):
     template after template in time order; counts [W, n]: frames per group).  seg_starts [R, n] as `skmeans` holds them
     (cumulative visit counts: monotone), the last segment runs to the end of its template."""
     lengths = np.asarray(lengths, dtype=np.int64)
-    R, N = len(lengths), int(np.sum(lengths))
-    W = len(n_temps)
-    t_in = (np.arange(N) - np.repeat(np.cumsum(lengths) - lengths, lengths)).astype(np.int32)
-    starts = np.asarray(seg_starts, dtype=np.int32)
-    small = W * n_segments < 65536
-    key = np.repeat((np.repeat(np.arange(W), n_temps) * n_segments).astype(np.uint16 if small else np.int64), lengths)
-    for s in range(1, n_segments):                                  # (block copies of a column instead of a gather per frame)
-        key += t_in >= np.repeat(starts[:, s], lengths)
-    order = np.argsort(key, kind="stable")                          # (16-bit keys: numpy's radix sort)
-    counts = np.bincount(key, minlength=W * n_segments).reshape(W, n_segments)
+    n_temps = np.asarray(n_temps, dtype=np.int64)
+    R, N, W, n = len(lengths), int(np.sum(lengths)), len(n_temps), n_segments
+    starts = np.asarray(seg_starts, dtype=np.int64).reshape(R, n)
+    # a template's frames of one segment are ONE run [start of the segment, start of the next one): R x n runs, put in
+    # (word, segment, template) order and expanded -- no per-frame key, no sort over the frames
+    begin = np.minimum(starts, lengths[:, None])
+    run_len = np.empty((R, n), dtype=np.int64)
+    run_len[:, :-1] = begin[:, 1:] - begin[:, :-1]
+    run_len[:, -1] = lengths - begin[:, -1]
+    group = np.repeat(np.arange(W), n_temps)[:, None] * n + np.arange(n)[None, :]       # [R, n]: (word, segment) of a run
+    perm = np.argsort(group.reshape(-1), kind="stable")                                  # templates stay in order inside a group
+    rl = run_len.reshape(-1)[perm]
+    rb = ((np.cumsum(lengths) - lengths)[:, None] + begin).reshape(-1)[perm]
+    order = np.repeat(rb - (np.cumsum(rl) - rl), rl) + np.arange(N)
+    counts = np.bincount(group.reshape(-1), weights=run_len.reshape(-1), minlength=W * n).astype(np.int64).reshape(W, n)
     return order, counts
 
 
+_host_ws = {"buf": None, "busy": False}
+
+
+def host_workspace(shape, dtype=np.float64):
+    """-> (array of `shape`, release()): scratch for a call's own copy of the caller's frames.  The buffer is kept between
+    calls (a fresh 62 MB array costs 5 ms of page faults when it is filled and 3 ms when it is freed -- a quarter of
+    `train_words` on ten words x 200 templates); it grows to the largest request up to GMMHMM_HOST_WORKSPACE_MB
+    (default 1024; 0: never kept).  A request while another call holds it, or beyond the cap, gets an ordinary array."""
+    import os
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    cap = int(os.environ.get("GMMHMM_HOST_WORKSPACE_MB", "1024")) << 20
+    if _host_ws["busy"] or nbytes > cap or nbytes == 0:
+        return np.empty(shape, dtype=dtype), lambda: None
+    _host_ws["busy"] = True                                         # (set under the GIL: no other thread sees it free)
+    buf = _host_ws["buf"]
+    if buf is None or buf.nbytes < nbytes:
+        _host_ws["buf"] = buf = None                                # (the old one goes before the new one comes)
+        _host_ws["buf"] = buf = np.empty(nbytes, dtype=np.uint8)
+
+    def release():
+        _host_ws["busy"] = False
+    return buf[:nbytes].view(dtype).reshape(shape), release
+
+
 def gather_rows(X, order):
-    """X[order] for a big row-major matrix, the copy spread over a few threads (np.take releases the GIL): the 62 MB of
-    the segments of ten words x 200 templates take 2-3 ms instead of 8."""
+    """X[order] for a big row-major matrix, the copy spread over a few threads (np.take releases the GIL;
+    GMMHMM_HOST_THREADS, default 8): the 62 MB of the segments of ten words x 200 templates take 4 ms instead of 20 -- 2 ms
+    of copying and 2-3.5 ms for the kernel to hand out 62 MB of zeroed pages, which threads do not speed up
+    (`tools/host_copy_probe.py`)."""
+    import os
     import threading
     N = len(order)
     out = np.empty((N,) + X.shape[1:], dtype=X.dtype)
-    n_thr = 4 if N * X.shape[1] >= (1 << 20) else 1
-    if n_thr == 1:
+    n_thr = min(int(os.environ.get("GMMHMM_HOST_THREADS", "8")), os.cpu_count() or 1) if N * X.shape[1] >= (1 << 20) else 1
+    if n_thr <= 1:
         np.take(X, order, axis=0, out=out)
         return out
     cuts = np.linspace(0, N, n_thr + 1).astype(np.int64)
