@@ -66,6 +66,9 @@ extern "C" void gh_ctx_destroy(gh_ctx* c) {
     hipStreamSynchronize(c->stream);
     if (c->scratch) hipFree(c->scratch);
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->fit_arena) hipFree(c->fit_arena);
+    if (c->fit_pin) hipHostFree(c->fit_pin);
+    if (c->fit_act) hipHostFree(c->fit_act);
     hipFree(c->d_flag);
     hipFree(c->d_fp64_tables);
     hipStreamDestroy(c->stream);

@@ -55,6 +55,14 @@ struct gh_ctx {
     int last_chunks;        // launches the last gh_viterbi* / gh_forward_backward call on this context was cut into (scratch budget)
     size_t budget_cache = 0;     // gh_scratch_budget's last answer (hipMemGetInfo is ~0.2 ms: asked again only when the arena
     int budget_age = 0;          //   changes size, an allocation fails, or after 64 calls)
+    // the device arena and the two page-locked blocks of the refit session closed last, for the next gh_fit_create on this
+    // context (continuous_train opens one session per outer iteration: hipMalloc + 2 hipHostMalloc + their frees were
+    // ~1.5 ms of each); an arena above GMMHMM_FIT_KEEP_MB (default 4096) is not kept
+    void* fit_arena = nullptr;
+    size_t fit_arena_bytes = 0;
+    void* fit_pin = nullptr;
+    void* fit_act = nullptr;
+    size_t fit_act_bytes = 0;
 };
 
 int gh_scratch(gh_ctx* ctx, size_t bytes, void** out);

@@ -651,6 +651,7 @@ struct gh_fit {
     int S, D, kmax, n_tiles;
     int64_t N;
     void* d_arena;
+    size_t arena_bytes, act_bytes;      // sizes of d_arena / h_act (both go back to the context when the session closes)
     ls_tile* d_tiles;
     int32_t* d_tptr;
     int64_t* d_segoff;
@@ -905,12 +906,32 @@ extern "C" void gh_fit_destroy(gh_fit* f) {
     if (!f) return;
     hipSetDevice(f->ctx->device);
     hipStreamSynchronize(f->ctx->stream);
-    if (f->d_arena) hipFree(f->d_arena);
+    // arena and page-locked blocks: kept in the context for the next session (the larger of the two arenas survives)
+    gh_ctx* c = f->ctx;
+    if (f->d_arena) {
+        static const size_t keep = [] { const char* e = getenv("GMMHMM_FIT_KEEP_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }();
+        if (f->arena_bytes <= keep && f->arena_bytes > c->fit_arena_bytes) {
+            if (c->fit_arena) hipFree(c->fit_arena);
+            c->fit_arena = f->d_arena;
+            c->fit_arena_bytes = f->arena_bytes;
+        } else {
+            hipFree(f->d_arena);
+        }
+    }
+    if (f->h_pin) { if (!c->fit_pin) c->fit_pin = f->h_pin; else hipHostFree(f->h_pin); }
+    if (f->h_act) {
+        if (f->act_bytes > c->fit_act_bytes) {
+            if (c->fit_act) hipHostFree(c->fit_act);
+            c->fit_act = f->h_act;
+            c->fit_act_bytes = f->act_bytes;
+        } else {
+            hipHostFree(f->h_act);
+        }
+    }
+    f->h_pin = nullptr; f->h_act = nullptr;
     if (getenv("GMMHMM_REFIT_DEBUG"))
         fprintf(stderr, "[gh_fit] %d states, %d items: %ld tail launches (%ld iterations), %ld refused, %ld ordinary launches\n", f->S, f->n_items,
                 f->n_tail_launches, f->n_tail_iters, f->n_tail_refused, f->n_plain_launches);
-    if (f->h_pin) hipHostFree(f->h_pin);
-    if (f->h_act) hipHostFree(f->h_act);
     delete f->h_iptr;
     delete f->h_tail_ids;
     delete f->h_tail_mask;
@@ -1025,9 +1046,34 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
             lay.add((void**)&f->d_rpart, items.size() * ((size_t)f->kcap * Wd + 1) * 8, nullptr);
         }
     }
-    hipError_t he = hipMalloc(&f->d_arena, lay.total);
-    if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_pin, 64, hipHostMallocDefault);
-    if (he == hipSuccess) he = hipHostMalloc((void**)&f->h_act, (size_t)std::max(S, 1), hipHostMallocDefault);
+    // the arena and the page-locked blocks of the session closed last on this context, when they are large enough (a
+    // recycled arena is cleared: what a session finds is what a fresh allocation holds)
+    hipError_t he = hipSuccess;
+    f->arena_bytes = lay.total;
+    f->act_bytes = (size_t)std::max(S, 1);
+    if (ctx->fit_arena && ctx->fit_arena_bytes >= lay.total) {
+        f->d_arena = ctx->fit_arena;
+        f->arena_bytes = ctx->fit_arena_bytes;
+        ctx->fit_arena = nullptr;
+        ctx->fit_arena_bytes = 0;
+        he = hipMemsetAsync(f->d_arena, 0, lay.total, ctx->stream);
+    } else {
+        he = hipMalloc(&f->d_arena, lay.total);
+    }
+    if (he == hipSuccess) {
+        if (ctx->fit_pin) { f->h_pin = (decltype(f->h_pin))ctx->fit_pin; ctx->fit_pin = nullptr; }
+        else he = hipHostMalloc((void**)&f->h_pin, 64, hipHostMallocDefault);
+    }
+    if (he == hipSuccess) {
+        if (ctx->fit_act && ctx->fit_act_bytes >= f->act_bytes) {
+            f->h_act = (uint8_t*)ctx->fit_act;
+            f->act_bytes = ctx->fit_act_bytes;
+            ctx->fit_act = nullptr;
+            ctx->fit_act_bytes = 0;
+        } else {
+            he = hipHostMalloc((void**)&f->h_act, f->act_bytes, hipHostMallocDefault);
+        }
+    }
     if (he != hipSuccess) {
         gh_set_error("gh_fit_create: %s", hipGetErrorString(he));
         gh_fit_destroy(f);

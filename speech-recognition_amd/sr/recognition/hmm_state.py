@@ -109,6 +109,20 @@ def euclidean(*args):
     return _hip.distance_matrix(_ctx(), a[None, :], b[None, :])[0, 0]
 
 
+def _allclose(a, b):
+    """np.allclose(a, b) (the comparison of hmm_state.py:161-170) without its general-purpose set-up: for finite arrays
+    |a - b| <= 1e-8 + 1e-5 |b| element by element IS numpy's test; anything else (nan, inf, shapes that do not
+    broadcast the plain way) goes to np.allclose itself."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape == b.shape and a.dtype == np.float64 and b.dtype == np.float64:
+        with np.errstate(invalid="ignore"):                         # (inf - inf: np.isclose is silent about it too)
+            if (np.abs(a - b) <= 1e-8 + 1e-5 * np.abs(b)).all():
+                return True
+        if np.isfinite(a).all() and np.isfinite(b).all():
+            return False
+    return bool(np.allclose(a, b))
+
+
 class HMMState:
     """Base class of all HMM states (hmm_state.py:61-78)."""
 
@@ -243,14 +257,32 @@ class GMM(HMMState):
     def update_models(self, mus, sigmas, weights):
         k = mus.shape[0]
         self.w[:k] = weights
+        sig = np.asarray(sigmas)
+        if sig.ndim == 2 and k:
+            # diagonal covariances (every caller of this package): what assigning `mean` / `cov` component after component
+            # does (hmm_state.py:29-30), with the inverses filled in one step (np.diag per component was 1.2 ms per outer
+            # iteration of continuous_train).  A zero variance raises at ITS component, the ones in front already updated,
+            # as in the reference
+            zero = np.flatnonzero((sig == 0).any(axis=1))
+            upto = int(zero[0]) if len(zero) else k
+            D = sig.shape[1]
+            inv = np.zeros((upto, D, D))
+            idx = np.arange(D)
+            inv[:, idx, idx] = 1.0 / sig[:upto]
+            for m in range(upto):
+                self.dists[m].__dict__.update(mean=mus[m, :], _cov=sigmas[m, :], inv_cov=inv[m])
+            if upto < k:
+                self.dists[upto].mean = mus[upto, :]
+                self.dists[upto].cov = sigmas[upto, :]            # raises numpy.linalg.LinAlgError
+            return
         for m in range(k):
             self.dists[m].mean = mus[m, :]
             self.dists[m].cov = sigmas[m, :]
 
     def __eq__(self, other):
-        if self.n_gaussians != other.n_gaussians or not np.allclose(self.w, other.w):
+        if self.n_gaussians != other.n_gaussians or not _allclose(self.w, other.w):
             return False
-        return all(np.allclose(a.mean, b.mean) and np.allclose(a.cov, b.cov)
+        return all(_allclose(a.mean, b.mean) and _allclose(a.cov, b.cov)
                    for a, b in zip(self.dists, other.dists))
 
     def __len__(self):

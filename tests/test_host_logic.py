@@ -195,6 +195,17 @@ def test_gmm_object_semantics_without_gpu(R):
     np.testing.assert_array_equal(g.dists[1].inv_cov, np.diag([0.5] * 3))
     with pytest.raises(np.linalg.LinAlgError):
         g.update_models(np.ones((1, 3)), np.zeros((1, 3)), np.array([1.0]))
+    # a zero variance in the SECOND component: the first is updated, the second keeps its inverse but has the new mean and
+    # the bad covariance -- the state the reference's component-after-component assignment leaves (hmm_state.py:29-30)
+    bad = np.array([[4.0, 4.0, 4.0], [1.0, 0.0, 1.0], [8.0, 8.0, 8.0]])
+    with pytest.raises(np.linalg.LinAlgError):
+        g.update_models(np.arange(9.0).reshape(3, 3), bad, np.array([0.2, 0.3, 0.5]))
+    np.testing.assert_array_equal(g.dists[0].inv_cov, np.diag([0.25] * 3))
+    np.testing.assert_array_equal(g.dists[1].mean, [3.0, 4.0, 5.0])
+    np.testing.assert_array_equal(g.dists[1].cov, bad[1])
+    np.testing.assert_array_equal(g.dists[1].inv_cov, np.diag([0.5] * 3))
+    np.testing.assert_array_equal(g.dists[2].mean, np.arange(3.0))          # never reached
+    assert all(sorted(d.__dict__) == ["_cov", "inv_cov", "mean"] for d in g.dists)
     import copy
     h = copy.deepcopy(g)
     assert h.id == g.id and hash(h) == hash(g)
@@ -331,6 +342,80 @@ def test_segment_order_regroups_like_segment_data():
     big = rng.normal(size=(40000, 39))
     idx = rng.permutation(40000)
     np.testing.assert_array_equal(km.gather_rows(big, idx), big[idx])      # (the threaded copy)
+
+
+def test_segment_order_by_brute_force():
+    """segment_order builds the order from the R x n runs: against a per-frame count of the segments that started, for
+    ragged words, one-segment models, segments that start at the template's end (empty) and several equal starts."""
+    import importlib
+    km = importlib.import_module("sr.recognition.kmeans")
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        W, n = int(rng.integers(1, 5)), int(rng.integers(1, 7))
+        n_temps = rng.integers(1, 5, size=W)
+        lengths = rng.integers(1, 12, size=int(n_temps.sum()))
+        starts = np.zeros((len(lengths), n), dtype=np.int64)
+        for r, L in enumerate(lengths):
+            starts[r, 1:] = np.sort(rng.integers(0, L + 1, size=n - 1))
+        order, counts = km.segment_order(lengths, n_temps, starts, n)
+        groups = [[] for _ in range(W * n)]
+        f = r = 0
+        for w in range(W):
+            for _ in range(n_temps[w]):
+                for t in range(lengths[r]):
+                    groups[w * n + sum(1 for s in range(1, n) if starts[r, s] <= t)].append(f)
+                    f += 1
+                r += 1
+        assert order.tolist() == [x for g in groups for x in g]
+        assert counts.reshape(-1).tolist() == [len(g) for g in groups]
+        ids, seg_lens = km._uniform_segments(lengths, n)           # kmeans.py:122-127: T // n frames each, the rest to the last
+        want = np.concatenate([np.minimum(np.arange(L) // max(L // n, 1), n - 1) if L // n else np.full(L, n - 1) for L in lengths])
+        np.testing.assert_array_equal(ids, want)
+        assert ids.dtype == np.int32 and seg_lens.tolist() == [[L // n] * n for L in lengths]
+
+
+def test_host_workspace_is_kept_and_never_shared():
+    import importlib
+    km = importlib.import_module("sr.recognition.kmeans")
+    a, rel_a = km.host_workspace((100, 39))
+    b, rel_b = km.host_workspace((10, 3))                          # while the first one is out: an ordinary array
+    assert a.shape == (100, 39) and a.dtype == np.float64 and not np.shares_memory(a, b)
+    rel_b()
+    rel_a()
+    c, rel_c = km.host_workspace((50, 39))
+    assert np.shares_memory(a, c)                                  # the kept buffer again
+    rel_c()
+    d, rel_d = km.host_workspace((400, 39))                        # grows
+    assert d.shape == (400, 39)
+    rel_d()
+    import os
+    os.environ["GMMHMM_HOST_WORKSPACE_MB"] = "0"
+    try:
+        e, rel_e = km.host_workspace((400, 39))
+        assert not np.shares_memory(d, e)
+        rel_e()
+    finally:
+        del os.environ["GMMHMM_HOST_WORKSPACE_MB"]
+
+
+def test_fast_allclose_is_numpys(R):
+    """GMM.__eq__ (hmm_state.py:161-170) compares with np.allclose; `_allclose` is its test for finite arrays and calls it
+    for everything else."""
+    from sr.recognition.hmm_state import _allclose
+    rng = np.random.default_rng(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # (inf - inf must stay silent, as in np.isclose)
+        for _ in range(4000):
+            n = int(rng.integers(1, 6))
+            a = rng.normal(size=n) * 10.0 ** rng.integers(-9, 3)
+            b = a + rng.normal(size=n) * 10.0 ** rng.integers(-12, -3) if rng.random() < 0.7 else rng.normal(size=n)
+            if rng.random() < 0.25:
+                i = rng.integers(0, n)
+                a[i] = rng.choice([np.inf, -np.inf, np.nan])
+                if rng.random() < 0.5:
+                    b[i] = a[i]
+            assert _allclose(a, b) == bool(np.allclose(a, b))
+    assert _allclose([1.0, 2.0], np.array([1.0, 2.0 + 1e-9])) and not _allclose(np.ones(3), np.ones(1) * 5) and _allclose(np.ones(3), 1.0)
 
 
 def test_id_hand_over_serves_eight_ranks_and_ignores_strangers():
