@@ -1268,6 +1268,9 @@ def main():
         # (also under a launcher: RCCL reads these when the communicator comes up, not when the process starts)
         os.environ.update(NCCL_HOSTID="gmmhmm-bench-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_P2P_DISABLE="1",
                           NCCL_SHM_DISABLE="1")
+        # the refit's TAIL launches keep workgroups waiting for the rest of their grid: that needs the card to this process
+        # alone (the occupancy check cannot see the other ranks' kernels), so the rehearsal on a shared card does without
+        os.environ.setdefault("GMMHMM_REFIT_TAIL", "0")
     all_cores = None
     if world == 1 and not args.no_cpu_baseline and not args.no_all_cores:
         try:      # (before the GPU is touched and before this process pins itself: see cpu_all_cores)
