@@ -717,6 +717,96 @@ __global__ __launch_bounds__(64) void fit_segsum_kernel(const double* __restrict
     out[(int64_t)s * (D + 1) + d] = acc;
 }
 
+// The same sums with the rows FETCHED by eight waves and ADDED by one.  The sum of a state is one dependent chain per
+// dimension (numpy's order), a few cycles per row once the row is there -- the kernel above waits for 32 rows, adds them, and
+// only then asks for the next 32: ~1 us per 32 rows, 0.87 ms for the 28 000-frame states of continuous_train, with 50 waves on
+// the whole chip.  Here a workgroup of 8 waves takes a state: in phase q wave w owns the rows [(8 q + w) 16, + 16) (lane =
+// dimension, BUFFER loads: a row behind the state's end reads as 0 and is never added), keeps FOUR phases in flight in
+// registers (4 x 8 x 16 rows = 160 KB per state instead of 10), and passes a phase's rows through one of two LDS buffers to
+// wave 0, which adds the 128 rows of phase q in order while the others already write phase q + 1 into the other buffer.
+// One barrier per phase: a buffer is rewritten two phases later, behind the barrier wave 0 only reaches after its adds.
+constexpr int SS_WAVES = 8, SS_ROWS = 16, SS_PHASE = SS_WAVES * SS_ROWS;
+__global__ __launch_bounds__(SS_WAVES * 64) void fit_segsum_wide_kernel(const double* __restrict__ X, int D, const int64_t* __restrict__ seg_off,
+                                                                        double* __restrict__ out /*[S, D+1]: sums | count*/) {
+    extern __shared__ double ss_rows[];                        // [2][SS_PHASE][64]
+    const int s = blockIdx.x, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t f0 = seg_off[s], n = seg_off[s + 1] - f0;
+    if (threadIdx.x == 0) out[(int64_t)s * (D + 1) + D] = (double)n;
+    // (the descriptor in scalar registers for certain: a descriptor the compiler takes for per-lane data puts a
+    //  readfirstlane loop around every load)
+    const uint64_t xa = (uint64_t)(X + f0 * D);
+    const uint64_t xu = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xa);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, __builtin_amdgcn_readfirstlane((int)(n * D * 8)), 0x00020000);
+    const unsigned row_b = (unsigned)D * 8u;
+    const int64_t n_phase = (n + SS_PHASE - 1) / SS_PHASE;
+    // (the whole offset is the per-lane one: lanes behind the last dimension and phases behind the state's end point out of
+    //  the descriptor's range and read 0)
+    auto issue = [&](double (&x)[SS_ROWS], int64_t q) {
+        const bool in = lane < D && q < n_phase;
+        const unsigned v0 = in ? (unsigned)((q * SS_WAVES + w) * SS_ROWS) * row_b + (unsigned)lane * 8u : 0x7ffffff0u;
+        const unsigned step = in ? row_b : 0u;
+#pragma unroll
+        for (int j = 0; j < SS_ROWS; ++j)
+            x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, v0 + (unsigned)j * step, 0, 0));
+    };
+    double acc = 0.0;
+    // LDS image of a phase: [pair of rows][lane][2] -- a lane's values of two consecutive rows side by side, written and read
+    // as 16 bytes (half the LDS instructions of the 8-byte form; the adds of wave 0 run 8 reads behind their data).
+    // Measured: 0.87 -> 0.37 ms for continuous_train's states, ~24 cycles per row against the 8.3 of the dependent
+    // v_add_f64 itself (tools/add_f64_latency.hip) -- what remains is the CU's load path, one 312-byte row per load
+    using pair_t = double __attribute__((ext_vector_type(2)));
+    pair_t* image = reinterpret_cast<pair_t*>(ss_rows);
+    // wave 0 adds the rows of phase q from LDS buffer q & 1; a full phase with the LDS reads one batch ahead of the adds
+    auto add_phase = [&](int64_t q) {
+        const int64_t left = n - q * SS_PHASE;
+        const pair_t* src = image + (size_t)(q & 1) * (SS_PHASE / 2) * 64 + lane;
+        if (left >= SS_PHASE) {
+            pair_t x0[8], x1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x0[j] = src[j * 64];
+#pragma unroll
+            for (int r = 0; r < SS_PHASE / 2; r += 16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x1[j] = src[(r + 8 + j) * 64];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc += x0[j].x; acc += x0[j].y; }
+                if (r + 16 < SS_PHASE / 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x0[j] = src[(r + 16 + j) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc += x1[j].x; acc += x1[j].y; }
+            }
+        } else {
+            for (int r = 0; r < (int)(left >> 1); ++r) { const pair_t v = src[r * 64]; acc += v.x; acc += v.y; }
+            if (left > 0 && (left & 1)) acc += src[(left >> 1) * 64].x;      // (a phase behind the state's end: left <= 0)
+        }
+    };
+    // NO condition around a phase or a load (a `break` or an `if` around either costs an s_waitcnt vmcnt(0), i.e. the
+    // read-ahead): the phases come in fours, one behind the state's end holds zeros and adds nothing
+    double a[SS_ROWS], b[SS_ROWS], c[SS_ROWS], d[SS_ROWS];
+    pair_t* mine = image + (size_t)w * (SS_ROWS / 2) * 64 + lane;
+    auto phase = [&](double (&x)[SS_ROWS], int64_t q) {
+        pair_t* dst = mine + (size_t)(q & 1) * (SS_PHASE / 2) * 64;
+#pragma unroll
+        for (int j = 0; j < SS_ROWS; j += 2) { pair_t v; v.x = x[j]; v.y = x[j + 1]; dst[(j >> 1) * 64] = v; }
+        issue(x, q + 4);
+        __syncthreads();
+        if (w == 0) add_phase(q);
+    };
+    issue(a, 0);
+    issue(b, 1);
+    issue(c, 2);
+    issue(d, 3);
+    for (int64_t p = 0; p < n_phase; p += 4) {
+        phase(a, p);
+        phase(b, p + 1);
+        phase(c, p + 2);
+        phase(d, p + 3);
+    }
+    if (w == 0 && lane < D) out[(int64_t)s * (D + 1) + lane] = acc;
+}
+
 // partition variances from (sum x | n) and sum (x - mean)^2: ddof = 1 (np.cov's default); n <= 1 -> NaN like numpy's
 // 0 * (1 / 0).  one_pass: from global sums over all ranks, cluster 0 only, copied to every cluster (the sharded rule).
 __global__ void fit_partvar_kernel(int S, int k, int D, int sstride, const double* __restrict__ sums /*[S][sstride]: [k][D+1]*/,
@@ -1092,8 +1182,13 @@ extern "C" int gh_fit_segment_means(gh_ctx* ctx, gh_fit* f, double* out /*[S, D+
     GH_REQUIRE(ctx && f && out && f->ctx == ctx, "gh_fit_segment_means: NULL argument / foreign context");
     GH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(fit_segsum_kernel, dim3((unsigned)f->S, (unsigned)((f->D + 63) / 64)), dim3(64), 0, st, (const double*)f->b->feats,
-                       f->D, f->d_segoff, f->d_sums);
+    static const bool narrow = [] { const char* e = getenv("GMMHMM_SEGSUM"); return e && !strcmp(e, "narrow"); }();
+    if (f->D <= 64 && !narrow)      // (a state stays below 2 GiB: gh_fit_create)
+        hipLaunchKernelGGL(fit_segsum_wide_kernel, dim3((unsigned)f->S), dim3(SS_WAVES * 64), (size_t)2 * SS_PHASE * 64 * 8, st,
+                           (const double*)f->b->feats, f->D, f->d_segoff, f->d_sums);
+    else
+        hipLaunchKernelGGL(fit_segsum_kernel, dim3((unsigned)f->S, (unsigned)((f->D + 63) / 64)), dim3(64), 0, st, (const double*)f->b->feats,
+                           f->D, f->d_segoff, f->d_sums);
     GH_HIP(hipGetLastError());
     GH_HIP(hipMemcpyAsync(out, f->d_sums, (size_t)f->S * (f->D + 1) * 8, hipMemcpyDeviceToHost, st));
     GH_HIP(hipStreamSynchronize(st));

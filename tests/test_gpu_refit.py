@@ -219,3 +219,32 @@ def test_more_than_eight_components_keep_the_tile_kernels():
     assert ("mean" in new) == ("mean" in old)
     if "mean" in new:
         np.testing.assert_array_equal(new["mean"], old["mean"])       # (the same kernels ran: the same bits)
+
+
+@pytest.mark.parametrize("D", [2, 13, 39, 63, 64])
+def test_segment_means_are_numpys_row_after_row_sums(D):
+    """gh_fit_segment_means (fit_segsum_wide_kernel: eight waves fetch, one adds): np.mean(segment, axis=0) bit for bit for
+    states of 0, 1 and a few frames, lengths around the 32 rows of a wave's share and the 256 rows of a phase, an odd
+    number of phases, and one long state; a NaN / inf frame lands where numpy puts it."""
+    from sr.recognition import _hip
+    ctx = _hip.default_context()
+    rng = np.random.default_rng(100 + D)
+    lens = [0, 1, 5, 31, 32, 33, 255, 256, 257, 511, 512, 513, 767, 768, 1025, 0, 20011]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    X = rng.normal(size=(int(off[-1]), D)) * 10.0 ** rng.integers(-3, 4, size=D)
+    X[off[9] + 7, 0] = np.nan
+    X[off[10] + 300, D - 1] = np.inf
+    b = _hip.Batch(ctx, feats=X, offsets=[0, len(X)])
+    fit = _hip.FitSession(ctx, b, off, 2)
+    try:
+        sums, counts = fit.segment_means()
+    finally:
+        fit.close()
+        b.close()
+    np.testing.assert_array_equal(counts, lens)
+    for s, n in enumerate(lens):
+        want = np.add.reduce(X[off[s]:off[s + 1]], axis=0) if n else np.zeros(D)
+        np.testing.assert_array_equal(sums[s], want, err_msg="state %d (%d frames)" % (s, n))
+        if n:
+            with np.errstate(invalid="ignore"):
+                np.testing.assert_array_equal(sums[s] / counts[s], np.mean(X[off[s]:off[s + 1]], axis=0))

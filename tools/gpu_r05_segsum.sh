@@ -1,0 +1,12 @@
+#!/bin/bash
+mkdir -p gpurun_out/r05c
+timeout -k 10 600 python -m pytest tests/test_gpu_refit.py tests/test_gpu_lockstep.py -x -q -m gpu -k "segment_means or session or device" > gpurun_out/r05c/segsum_tests.log 2>&1 || { tail -30 gpurun_out/r05c/segsum_tests.log; exit 1; }
+tail -2 gpurun_out/r05c/segsum_tests.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05c/prof_ctrain -o ctrain -- python3 $GRAFT_REPO_ROOT/tools/time_ctrain.py 2000 7 6 > $GRAFT_REPO_ROOT/gpurun_out/r05c/ctrain_prof.log 2>&1 || exit 1
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/r05c/prof_ctrain -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/r05c/ctrain_kernel_stats.csv
+rm -rf gpurun_out/r05c/prof_ctrain
+grep -i "segsum\|rowsum" gpurun_out/r05c/ctrain_kernel_stats.csv | cut -c1-160
+grep "steady\|per outer" gpurun_out/r05c/ctrain_prof.log
