@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-5 evidence in ONE gpurun call: bench (plain + under rocprofv3), kernel stats of the streaming refit kernels, of
-# continuous_train (+ steady-state time, host profile) and of train_words.  Outputs under gpurun_out/$TAG/ (TAG defaults to r05a).
+# continuous_train (+ steady-state time, host profile), of train_words (+ its stage times) and the decode over 12- / 16-state
+# word models.  Outputs under gpurun_out/$TAG/ (TAG defaults to r05a).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${TAG:-r05a}
@@ -15,6 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ctrain -o ct -- 
 CTRAIN_PROFILE=0 python3 tools/time_ctrain.py 2000 7 8 > $O/ctrain.log 2>&1; echo "ctrain exit $?"
 python3 tools/time_ctrain.py 2000 7 8 > $O/ctrain_host_profile.log 2>&1; echo "ctrain host profile exit $?"
 REPS=4 python3 tools/time_train_words.py > $O/train_words.log 2>&1; echo "train_words exit $?"
+REPS=5 python3 tools/prof_train_words.py > $O/train_words_stages.txt 2>&1; echo "train_words stages exit $?"
+python3 tools/time_layers_wide.py 5000 16 10 7 > $O/layers_wide.txt 2>&1 && python3 tools/time_layers_wide.py 5000 12 10 7 >> $O/layers_wide.txt 2>&1; echo "wide word models exit $?"
 for d in headline refit_k4 refit_k8 ctrain; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 rm -rf $O/prof_*
 ls $O
