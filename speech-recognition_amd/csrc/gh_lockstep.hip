@@ -721,33 +721,48 @@ __global__ __launch_bounds__(64) void fit_segsum_kernel(const double* __restrict
 // dimension (numpy's order), a few cycles per row once the row is there -- the kernel above waits for 32 rows, adds them, and
 // only then asks for the next 32: ~1 us per 32 rows, 0.87 ms for the 28 000-frame states of continuous_train, with 50 waves on
 // the whole chip.  Here a workgroup of 8 waves takes a state: in phase q wave w owns the rows [(8 q + w) 16, + 16) (lane =
-// dimension, BUFFER loads: a row behind the state's end reads as 0 and is never added), keeps FOUR phases in flight in
-// registers (4 x 8 x 16 rows = 160 KB per state instead of 10), and passes a phase's rows through one of two LDS buffers to
+// dimension, BUFFER loads: a row behind the state's end reads as 0 and is never added), keeps THREE phases in flight in
+// registers (3 x 8 x 16 rows = 120 KB per state instead of 10), and passes a phase's rows through one of two LDS buffers to
 // wave 0, which adds the 128 rows of phase q in order while the others already write phase q + 1 into the other buffer.
 // One barrier per phase: a buffer is rewritten two phases later, behind the barrier wave 0 only reaches after its adds.
 constexpr int SS_WAVES = 8, SS_ROWS = 16, SS_PHASE = SS_WAVES * SS_ROWS;
-__global__ __launch_bounds__(SS_WAVES * 64) void fit_segsum_wide_kernel(const double* __restrict__ X, int D, const int64_t* __restrict__ seg_off,
-                                                                        double* __restrict__ out /*[S, D+1]: sums | count*/) {
-    extern __shared__ double ss_rows[];                        // [2][SS_PHASE][64]
-    const int s = blockIdx.x, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t f0 = seg_off[s], n = seg_off[s + 1] - f0;
-    if (threadIdx.x == 0) out[(int64_t)s * (D + 1) + D] = (double)n;
+constexpr int SS_LIST_PAD = 2048;      // list entries a LIST chain may read behind its own (the id loads run six phases ahead)
+// The chain itself, for all threads of the workgroup; the sum is wave 0's (lane = dimension).  xs: the state's first frame,
+// state_bytes: its size (the descriptor's range).  LIST: row i of the chain is frame li[i] of the state (the frames of one
+// cluster, kmeans_rowsum_kernel's lists; li readable SS_LIST_PAD entries behind the chain's n), else frame i.
+template <bool LIST>
+__device__ __forceinline__ double wide_row_sum(const double* __restrict__ xs, int D, int64_t state_bytes, const int32_t* __restrict__ li,
+                                               int64_t n, double* __restrict__ ss_rows /*[2][SS_PHASE][64]*/) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (the descriptor in scalar registers for certain: a descriptor the compiler takes for per-lane data puts a
     //  readfirstlane loop around every load)
-    const uint64_t xa = (uint64_t)(X + f0 * D);
-    const uint64_t xu = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)xa);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, __builtin_amdgcn_readfirstlane((int)(n * D * 8)), 0x00020000);
+    auto uniform_ptr = [](const void* p) {
+        const uint64_t a = (uint64_t)p;
+        return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(xs), 0, __builtin_amdgcn_readfirstlane((int)state_bytes), 0x00020000);
     const unsigned row_b = (unsigned)D * 8u;
     const int64_t n_phase = (n + SS_PHASE - 1) / SS_PHASE;
-    // (the whole offset is the per-lane one: lanes behind the last dimension and phases behind the state's end point out of
-    //  the descriptor's range and read 0)
-    auto issue = [&](double (&x)[SS_ROWS], int64_t q) {
-        const bool in = lane < D && q < n_phase;
-        const unsigned v0 = in ? (unsigned)((q * SS_WAVES + w) * SS_ROWS) * row_b + (unsigned)lane * 8u : 0x7ffffff0u;
-        const unsigned step = in ? row_b : 0u;
+    // LIST: the 16 frame numbers of a wave's share of a phase sit in lanes 0 .. 15 of one register per set, fetched SIX phases
+    // ahead -- right behind the rows of three phases ahead in the (in-order) memory queue, so that waiting for them never
+    // waits for younger rows -- and handed to the row loads as scalar offsets by v_readlane
+    auto load_ids = [&](int& idv, int64_t q) { idv = li[(q * SS_WAVES + w) * SS_ROWS + (lane & 15)]; };
+    // (the per-lane offset does the masking: lanes behind the last dimension -- and, without a list, phases behind the chain's
+    //  end -- point out of the descriptor's range and read 0; with a list a row behind the end is some frame or 0, never added)
+    auto issue = [&](double (&x)[SS_ROWS], int64_t q, int idv) {
+        if (LIST) {
+            const unsigned v0 = lane < D ? (unsigned)lane * 8u : 0x7ffffff0u;
 #pragma unroll
-        for (int j = 0; j < SS_ROWS; ++j)
-            x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, v0 + (unsigned)j * step, 0, 0));
+            for (int j = 0; j < SS_ROWS; ++j)
+                x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, v0, (unsigned)__builtin_amdgcn_readlane(idv, j) * row_b, 0));
+        } else {
+            const bool in = lane < D && q < n_phase;
+            const unsigned v0 = in ? (unsigned)((q * SS_WAVES + w) * SS_ROWS) * row_b + (unsigned)lane * 8u : 0x7ffffff0u;
+            const unsigned step = in ? row_b : 0u;
+#pragma unroll
+            for (int j = 0; j < SS_ROWS; ++j)
+                x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, v0 + (unsigned)j * step, 0, 0));
+        }
     };
     double acc = 0.0;
     // LDS image of a phase: [pair of rows][lane][2] -- a lane's values of two consecutive rows side by side, written and read
@@ -779,32 +794,73 @@ __global__ __launch_bounds__(SS_WAVES * 64) void fit_segsum_wide_kernel(const do
             }
         } else {
             for (int r = 0; r < (int)(left >> 1); ++r) { const pair_t v = src[r * 64]; acc += v.x; acc += v.y; }
-            if (left > 0 && (left & 1)) acc += src[(left >> 1) * 64].x;      // (a phase behind the state's end: left <= 0)
+            if (left > 0 && (left & 1)) acc += src[(left >> 1) * 64].x;      // (a phase behind the chain's end: left <= 0)
         }
     };
     // NO condition around a phase or a load (a `break` or an `if` around either costs an s_waitcnt vmcnt(0), i.e. the
-    // read-ahead): the phases come in fours, one behind the state's end holds zeros and adds nothing
-    double a[SS_ROWS], b[SS_ROWS], c[SS_ROWS], d[SS_ROWS];
+    // read-ahead): the phases come in threes, one behind the chain's end adds nothing.  THREE sets of 16 rows in flight per
+    // wave, not four: vmcnt counts to 63, and with 64 loads outstanding the compiler's bookkeeping gives up -- it then drains
+    // the queue to 14 at the head of every round
+    double a[SS_ROWS], b[SS_ROWS], c[SS_ROWS];
     pair_t* mine = image + (size_t)w * (SS_ROWS / 2) * 64 + lane;
-    auto phase = [&](double (&x)[SS_ROWS], int64_t q) {
+    int ia = 0, ib = 0, ic = 0;
+    auto phase = [&](double (&x)[SS_ROWS], int& idv, int64_t q) {
         pair_t* dst = mine + (size_t)(q & 1) * (SS_PHASE / 2) * 64;
 #pragma unroll
         for (int j = 0; j < SS_ROWS; j += 2) { pair_t v; v.x = x[j]; v.y = x[j + 1]; dst[(j >> 1) * 64] = v; }
-        issue(x, q + 4);
+        issue(x, q + 3, idv);
+        if (LIST) load_ids(idv, q + 6);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (w == 0) add_phase(q);
     };
-    issue(a, 0);
-    issue(b, 1);
-    issue(c, 2);
-    issue(d, 3);
-    for (int64_t p = 0; p < n_phase; p += 4) {
-        phase(a, p);
-        phase(b, p + 1);
-        phase(c, p + 2);
-        phase(d, p + 3);
+    // (the sets' loads in program order, set after set: interleaved by the scheduler, the queue at the loop's head differs from
+    //  the one at its back edge and the wait counts fall back to draining it)
+    if (LIST) { load_ids(ia, 0); load_ids(ib, 1); load_ids(ic, 2); }
+    __builtin_amdgcn_sched_barrier(0);
+    issue(a, 0, ia);
+    if (LIST) load_ids(ia, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(b, 1, ib);
+    if (LIST) load_ids(ib, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(c, 2, ic);
+    if (LIST) load_ids(ic, 5);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t p = 0; p < n_phase; p += 3) {
+        phase(a, ia, p);
+        phase(b, ib, p + 1);
+        phase(c, ic, p + 2);
     }
-    if (w == 0 && lane < D) out[(int64_t)s * (D + 1) + lane] = acc;
+    return acc;
+}
+
+__global__ __launch_bounds__(SS_WAVES * 64) void fit_segsum_wide_kernel(const double* __restrict__ X, int D, const int64_t* __restrict__ seg_off,
+                                                                        double* __restrict__ out /*[S, D+1]: sums | count*/) {
+    extern __shared__ double ss_rows[];                        // [2][SS_PHASE][64]
+    const int s = blockIdx.x;
+    const int64_t f0 = seg_off[s], n = seg_off[s + 1] - f0;
+    if (threadIdx.x == 0) out[(int64_t)s * (D + 1) + D] = (double)n;
+    const double acc = wide_row_sum<false>(X + f0 * D, D, n * D * 8, nullptr, n, ss_rows);
+    if (threadIdx.x < D) out[(int64_t)s * (D + 1) + threadIdx.x] = acc;       // (threads 0 .. D-1: wave 0, D <= 64)
+}
+
+// kmeans_rowsum_kernel<0> over whole lists (chunk 0) in the same form: grid (S, k), the sum of every cluster's frames in
+// frame order.  `lists` readable SS_LIST_PAD entries behind its last one (gh_fit_create pads it).
+__global__ __launch_bounds__(SS_WAVES * 64) void kmeans_rowsum_wide_kernel(const double* __restrict__ X, int D, int k, const int64_t* __restrict__ seg_off,
+                                                                           const uint8_t* __restrict__ active, const int32_t* __restrict__ lists,
+                                                                           const int32_t* __restrict__ counts, const int32_t* __restrict__ cbase,
+                                                                           double* __restrict__ sums, int sstride) {
+    extern __shared__ double ss_rows[];
+    const int s = blockIdx.x, c = blockIdx.y;
+    if (active && !active[s]) return;
+    const int64_t f0 = seg_off[s];
+    const int n = counts[s * k + c];
+    double* out = sums + (int64_t)s * sstride + (int64_t)c * (D + 1);
+    if (threadIdx.x == 0) out[D] = (double)n;
+    if (n <= 0) return;                                        // (as the one-wave kernel: the sums of an empty cluster stay)
+    const double acc = wide_row_sum<true>(X + f0 * D, D, (seg_off[s + 1] - f0) * (int64_t)D * 8, lists + f0 + cbase[s * k + c], n, ss_rows);
+    if (threadIdx.x < D) out[threadIdx.x] = acc;
 }
 
 // partition variances from (sum x | n) and sum (x - mean)^2: ddof = 1 (np.cov's default); n <= 1 -> NaN like numpy's
@@ -1070,7 +1126,7 @@ extern "C" int gh_fit_create(gh_ctx* ctx, const gh_batch* b, int S, const int64_
     lay.add((void**)&f->d_tilecnt, nt * kmax * 4, nullptr);
     lay.add((void**)&f->d_counts, (size_t)S * kmax * 4, nullptr);
     lay.add((void**)&f->d_cbase, (size_t)S * kmax * 4, nullptr);
-    lay.add((void**)&f->d_lists, N1 * 4, nullptr);
+    lay.add((void**)&f->d_lists, (N1 + SS_LIST_PAD) * 4, nullptr);      // (kmeans_rowsum_wide_kernel reads ids ahead of a list's end)
     lay.add((void**)&f->d_changed, (size_t)S * 4, nullptr);
     lay.add((void**)&f->d_iters, (size_t)S * 4, nullptr);
     lay.add((void**)&f->d_cent, skd * 8, nullptr);
@@ -1463,8 +1519,13 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
     if (!exact_order && !comm) {
         // the centroids the reference returns: the mean of every cluster's frames summed IN FRAME ORDER (one sequential
         // pass per k-means call instead of one per iteration)
-        hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists, f->d_counts,
-                           f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0, 0, 0);
+        static const bool narrow = [] { const char* e = getenv("GMMHMM_SEGSUM"); return e && !strcmp(e, "narrow"); }();
+        if (D <= 64 && !narrow)
+            hipLaunchKernelGGL(kmeans_rowsum_wide_kernel, dim3((unsigned)S, (unsigned)k), dim3(SS_WAVES * 64), (size_t)2 * SS_PHASE * 64 * 8, st, X, D, k,
+                               f->d_segoff, (const uint8_t*)nullptr, f->d_lists, f->d_counts, f->d_cbase, f->d_sums, sstride);
+        else
+            hipLaunchKernelGGL(kmeans_rowsum_kernel<0>, skz, dim3(64), 0, st, X, D, k, f->d_segoff, (const uint8_t*)nullptr, f->d_lists, f->d_counts,
+                               f->d_cbase, f->d_sums, sstride, (const double*)nullptr, 0, 0, 0);
         hipLaunchKernelGGL(fit_final_centroids_kernel, dim3((unsigned)((S * k * D + 255) / 256)), dim3(256), 0, st, S, k, D, sstride,
                            (const double*)f->d_sums, f->d_cent);
         GH_HIP(hipGetLastError());

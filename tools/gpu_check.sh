@@ -1,0 +1,13 @@
+#!/bin/bash
+# refit / lock-step tests, then the kernel times of continuous_train (scratch check between evidence runs)
+mkdir -p gpurun_out/r05c
+timeout -k 10 900 python -m pytest tests/test_gpu_refit.py tests/test_gpu_lockstep.py tests/test_gpu_train_words.py tests/test_gpu_e2e.py -x -q -m gpu > gpurun_out/r05c/check_tests.log 2>&1 || { tail -30 gpurun_out/r05c/check_tests.log; exit 1; }
+tail -2 gpurun_out/r05c/check_tests.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05c/prof_ctrain -o ctrain -- python3 $GRAFT_REPO_ROOT/tools/time_ctrain.py 2000 7 6 > $GRAFT_REPO_ROOT/gpurun_out/r05c/ctrain_prof.log 2>&1 || exit 1
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/r05c/prof_ctrain -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/r05c/ctrain_kernel_stats.csv
+rm -rf gpurun_out/r05c/prof_ctrain
+grep -i "segsum\|rowsum" gpurun_out/r05c/ctrain_kernel_stats.csv | cut -c1-60,150-260
+grep "steady\|per outer" gpurun_out/r05c/ctrain_prof.log
