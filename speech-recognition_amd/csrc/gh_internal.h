@@ -181,7 +181,7 @@ struct gh_lattice_host {
 #define GH_LAYERS_MAXW 16
 #define GH_LAYERS_MAXN 16          // states per word the word templates hold (Viterbi, all three forms: 2..8, 12, 16: gh_seq_n_ok)
 #define GH_LAYERFORM_MAXN 8        // ... that the sequence-form forward-backward (and the EM session on it) is built for
-#define GH_LAYERS_MAXK 8
+#define GH_LAYERS_MAXK 16         // layers of the layer form: up to 8 with any word model above, 9 .. 16 with up to 8 states per word
 // states per word the word-template Viterbi kernels are instantiated for (gh_seq.hip, gh_viterbi_layers.hip): every count up to 8, and the 12 and 16
 // of wide word models (BASELINE configs[3]: 16 states per word), whose N costs still live in one lane's registers
 static inline bool gh_seq_n_ok(int N) { return (N >= 2 && N <= 8) || N == 12 || N == 16; }

@@ -376,7 +376,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
                 if (W == 0) { ok = false; break; }
             }
             if (ok && W == 1) N = P;
-            ok = ok && gh_seq_n_ok(N) && W <= GH_LAYERS_MAXW && W * N == P;
+            ok = ok && gh_seq_n_ok(N) && W <= GH_LAYERS_MAXW && W * N == P && (K <= 8 || N <= 8);   // (four register sets: N <= 8)
         }
         bool skip = false;
         for (int pos = 0; ok && pos < P; ++pos) {

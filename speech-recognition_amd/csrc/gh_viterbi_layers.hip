@@ -8,7 +8,7 @@
 //
 // gfx950 mapping -- ONE WAVE PER UTTERANCE, no LDS, no barrier:
 //   * lane = (layer mod 4, word): the four 16-lane DPP rows of the wave are four consecutive layers, a lane owns one
-//     word of its layer and keeps the word's N state costs in REGISTERS (two register sets: layers 0-3 and 4-7).
+//     word of its layer and keeps the word's N state costs in REGISTERS (two register sets: layers 0-3 and 4-7; four for 9-16 layers).
 //     The left neighbour of a state is therefore another register of the same lane -- no cross-lane traffic
 //     inside a word at all;
 //   * the non-emitting row after a layer is the minimum over the words' last states: four row_ror DPP steps leave the
@@ -75,25 +75,26 @@ __device__ __forceinline__ void push_bit(uint64_t& word, unsigned long long mask
     word = ((uint64_t)hi << 32) | lo;
 }
 
-// decision bits of one column and lane in the layer form: two register sets of N + 1 (+ N - 2 with skip arcs); they
-// fit a 32-bit word up to 8 states per word (and 12 without skip arcs), a 64-bit word up to 16
-template <int N, bool SKIP> struct LayerBits {
+// decision bits of one column and lane in the layer form: H register sets (2: up to 8 layers, 4: up to 16) of N + 1 (+ N - 2
+// with skip arcs); two sets fit a 32-bit word up to 8 states per word (and 12 without skip arcs), a 64-bit word up to 16;
+// four sets fit 64 bits up to 8 states per word
+template <int N, bool SKIP, int H = 2> struct LayerBits {
     static constexpr int HB = N + 1 + (SKIP ? N - 2 : 0);
-    static constexpr int BITS = 2 * HB;
+    static constexpr int BITS = H * HB;
     static constexpr bool WIDE = BITS > 32;
     static constexpr int CPW = (WIDE ? 64 : 32) / BITS;
+    static_assert(BITS <= 64, "the decision bits of a column must fit one word");
 };
 template <bool WIDE> struct DecisionWord { using type = uint32_t; };
 template <> struct DecisionWord<true> { using type = uint64_t; };
 
-template <typename ET, int N, bool SKIP, bool WANT_BP>
+template <typename ET, int N, bool SKIP, bool WANT_BP, int H = 2>     // H register sets: layers 0-3, 4-7 (, 8-11, 12-15)
 __global__ __launch_bounds__(64) void viterbi_layers_kernel(gh_layers_args a) {
-    constexpr int H = 2;                                      // register sets: layers 0-3 and 4-7
-    constexpr int HB = LayerBits<N, SKIP>::HB;                // decision bits per column and register set
-    constexpr int BITS = LayerBits<N, SKIP>::BITS;
-    constexpr int CPW = LayerBits<N, SKIP>::CPW;              // columns per decision word
+    constexpr int HB = LayerBits<N, SKIP, H>::HB;             // decision bits per column and register set
+    constexpr int BITS = LayerBits<N, SKIP, H>::BITS;
+    constexpr int CPW = LayerBits<N, SKIP, H>::CPW;           // columns per decision word
     constexpr int PF = N > 8 ? 2 : 4;                         // columns of emissions in flight
-    using WT = typename DecisionWord<LayerBits<N, SKIP>::WIDE>::type;
+    using WT = typename DecisionWord<LayerBits<N, SKIP, H>::WIDE>::type;
     static_assert(CPW >= 1, "decision bits of a column must fit one word");
     const int lane = threadIdx.x, kk = lane >> 4, w = lane & 15;
     const gh_layerform* __restrict__ lf = a.lf;
@@ -400,11 +401,11 @@ __global__ __launch_bounds__(64) void viterbi_loop_kernel(gh_layers_args a, int6
 // (gh_viterbi_labels) -- cells are visited end -> start, a run of labelled rows reports the label of its first row
 // in start -> end order, i.e. of the last one visited before an unlabelled row; labels are collected from the back of
 // the utterance's slot and moved to its front at the end.
-template <int N, bool SKIP, bool LOOP, int MODE>
+template <int N, bool SKIP, bool LOOP, int MODE, int H = 2>
 __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a, int64_t slot_end) {
-    constexpr int HB = LOOP ? LoopBits<N, SKIP>::HB : LayerBits<N, SKIP>::HB;
-    constexpr int BITS = LOOP ? HB : 2 * HB;
-    constexpr bool WIDE = !LOOP && LayerBits<N, SKIP>::WIDE;  // 64-bit decision words (viterbi_layers_kernel)
+    constexpr int HB = LOOP ? LoopBits<N, SKIP>::HB : LayerBits<N, SKIP, H>::HB;
+    constexpr int BITS = LOOP ? HB : H * HB;
+    constexpr bool WIDE = !LOOP && LayerBits<N, SKIP, H>::WIDE;  // 64-bit decision words (viterbi_layers_kernel)
     using WT = typename DecisionWord<WIDE>::type;
     constexpr int CPW = (WIDE ? 64 : 32) / BITS;
     constexpr int LPW = LOOP ? 16 : 64;                       // decision words per word index
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
                 key = want;
                 pw = (wi > 0) ? bpu[want - LPW] : WT(0);
             }
-            const uint32_t hb = (uint32_t)((cw >> (shift + (LOOP ? 0 : (1 - (bk >> 2)) * HB))) & (WT)((1ull << HB) - 1ull));
+            const uint32_t hb = (uint32_t)((cw >> (shift + (LOOP ? 0 : (H - 1 - (bk >> 2)) * HB))) & (WT)((1ull << HB) - 1ull));
             const int arcs = s_arcs[bw * GH_LAYERS_MAXN + bs];
             if (bs >= 1) {
                 int before = 0;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
         } else if (kind == 1) {
             if (!LOOP && kn == 0) { flag |= 2; break; }                       // the start row has no origin
             const int kp = LOOP ? 0 : kn - 1;
-            const int eq_shift = shift + (LOOP ? 2 : (1 - (kp >> 2)) * HB + 1);
+            const int eq_shift = shift + (LOOP ? 2 : (H - 1 - (kp >> 2)) * HB + 1);
             int found = -1;
             if constexpr (WIDE) {
                 const ulonglong2* rowp = reinterpret_cast<const ulonglong2*>(bpu + (int64_t)wi * LPW + (kp & 3) * 16);
@@ -559,9 +560,9 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
         const int cpw = 32 / hb;
         return (size_t)((T + cpw - 1) / cpw) * 16 * 2;
     }
-    const int hb = f.N + 1 + (f.skip ? f.N - 2 : 0);
-    const int wbits = 2 * hb > 32 ? 64 : 32;                  // (LayerBits)
-    const int cpw = wbits / (2 * hb);
+    const int hb = f.N + 1 + (f.skip ? f.N - 2 : 0), sets = f.K > 8 ? 4 : 2;
+    const int wbits = sets * hb > 32 ? 64 : 32;               // (LayerBits)
+    const int cpw = wbits / (sets * hb);
     return (size_t)((T + cpw - 1) / cpw) * 64 * (wbits / 16);
 }
 
@@ -599,8 +600,16 @@ int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_laye
         return GH_OK;
     }
     const dim3 grid((unsigned)n_utts);
+    // (more than 8 layers: four register sets, built for up to 8 states per word -- gh_layerform_ok)
 #define GH_LY(ET, NN, SK)                                                                                      \
     do {                                                                                                       \
+        if constexpr (NN <= 8) {                                                                               \
+            if (f.K > 8) {                                                                                     \
+                if (want_path) hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, true, 4>), grid, blk, 0, ctx->stream, b); \
+                else hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, false, 4>), grid, blk, 0, ctx->stream, b);          \
+                break;                                                                                         \
+            }                                                                                                  \
+        }                                                                                                      \
         if (want_path) hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, true>), grid, blk, 0, ctx->stream, b); \
         else hipLaunchKernelGGL((viterbi_layers_kernel<ET, NN, SK, false>), grid, blk, 0, ctx->stream, b);          \
     } while (0)
@@ -624,6 +633,13 @@ int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_l
             if (labels) hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, true, 1>), grid, blk, 0, ctx->stream, b, slot_end);  \
             else hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, true, 0>), grid, blk, 0, ctx->stream, b, slot_end);         \
         } else {                                                                                                        \
+            if constexpr (NN <= 8) {                                                                                    \
+                if (f.K > 8) {                                                                                          \
+                    if (labels) hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 1, 4>), grid, blk, 0, ctx->stream, b, slot_end); \
+                    else hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 0, 4>), grid, blk, 0, ctx->stream, b, slot_end);        \
+                    break;                                                                                              \
+                }                                                                                                       \
+            }                                                                                                           \
             if (labels) hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 1>), grid, blk, 0, ctx->stream, b, slot_end); \
             else hipLaunchKernelGGL((lattice_backtrace_kernel<NN, SK, false, 0>), grid, blk, 0, ctx->stream, b, slot_end);        \
         }                                                                                                               \

@@ -71,7 +71,10 @@ def test_layers_kernel_reference_goldens(hip, ctx, dtype):
                                         # wide word models: 12 states without skip arcs still pack two register sets into
                                         # a 32-bit decision word; the others take 64-bit words
                                         (4, 12, 3, False), (3, 12, 8, True), (5, 16, 2, False), (2, 16, 8, True),
-                                        (6, 16, 5, False)])
+                                        (6, 16, 5, False),
+                                        # more than 8 layers (ten-digit strings): four register sets, up to 8 states per word
+                                        (10, 5, 10, False), (4, 3, 16, True), (3, 8, 12, True), (2, 2, 9, False),
+                                        (5, 8, 16, False)])
 def test_layers_kernel_equals_lean_kernel(hip, ctx, W, n, K, skip):
     """Random word models (per-word transition costs, optional skip arcs), utterances from far too short to long:
     end costs BITWISE equal, same chosen end, same paths -- including the unreachable cases, where every candidate is
