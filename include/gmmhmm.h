@@ -480,7 +480,7 @@ int gh_gmm_update(gh_ctx* ctx, gh_gmm* g, const double* mean /*[S,M,D]*/, const 
  * the transition costs and the convergence test live on the device.  gh_em_iteration enqueues
  *     likelihoods -> forward-backward -> statistics -> [all-reduce over `comm`] -> M-step -> model re-pack
  * on the context's stream without a host synchronisation in between:
- *   - word models: W words x n states (n <= 8, arcs from s, s-1, s-2 only), mixtures [W*n, M, D], M <= 8, D <= 47,
+ *   - word models: W words x n states (n <= 16, arcs from s, s-1, s-2 only), mixtures [W*n, M, D], M <= 64, D <= 40,
  *     fp64 batch; anything else: GH_ERR_UNSUPPORTED (callers keep the call-by-call path)
  *   - utt_word[u]: the word utterance u is an example of
  *   - var_floor: lower bound of re-estimated variances; occ_floor: occupancies <= it are dropped from the statistics;

@@ -19,7 +19,7 @@
 //
 // No hipStreamSynchronize inside; the caller may fetch history[it] (one 32-byte D2H) per iteration or after many.
 // Scope: one-word transcripts (isolated-word EM, BASELINE configs[2]; the configs[3] shape -- 16 states x 32 mixtures --
-// too) on an fp64 batch, word models of n <= 16 states with arcs from s, s-1, s-2 only, M <= 64 mixtures, D <= 47 --
+// too) on an fp64 batch, word models of n <= 16 states with arcs from s, s-1, s-2 only, M <= 64 mixtures, D <= 40 --
 // what fb_chain_kernel / bw_fused_kernel cover; anything else returns GH_ERR_UNSUPPORTED and the caller keeps the
 // call-by-call path.
 //
@@ -268,8 +268,9 @@ extern "C" int gh_em_create(gh_ctx* ctx, gh_batch* b, int W, int n, int M, const
     const int D = b->D, S = W * n;
     const int64_t U = b->U;
     // ---- what the device-resident iteration covers ----
-    if (b->dtype != GH_F64 || n > GH_FBCHAIN_MAX || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
-        gh_set_error("gh_em_create: shape outside the device-resident path (fp64 batch, n <= 16, M <= 64, D <= 47)");
+    // (D <= 40: the fused statistics kernel is built for the operand depths of up to 40 features -- gh_bwf_plan_build)
+    if (b->dtype != GH_F64 || n > GH_FBCHAIN_MAX || M > 64 || D > 40 || U > 0x7fffffff) {
+        gh_set_error("gh_em_create: shape outside the device-resident path (fp64 batch, n <= 16, M <= 64, D <= 40)");
         return GH_ERR_UNSUPPORTED;
     }
     std::vector<gh_fbchain> chains(W);
@@ -436,8 +437,8 @@ extern "C" int gh_em_create_transcripts(gh_ctx* ctx, gh_batch* b, int W, int n, 
     *out = nullptr;
     const int D = b->D, S = W * n;
     const int64_t U = b->U;
-    if (b->dtype != GH_F64 || n < 2 || n > GH_LAYERFORM_MAXN || M > 64 || (D + 1 + 15) / 16 > 3 || U > 0x7fffffff) {
-        gh_set_error("gh_em_create_transcripts: shape outside the device-resident path (fp64 batch, 2 <= n <= %d, M <= 64, D <= 47)",
+    if (b->dtype != GH_F64 || n < 2 || n > GH_LAYERFORM_MAXN || M > 64 || D > 40 || U > 0x7fffffff) {
+        gh_set_error("gh_em_create_transcripts: shape outside the device-resident path (fp64 batch, 2 <= n <= %d, M <= 64, D <= 40)",
                      GH_LAYERFORM_MAXN);
         return GH_ERR_UNSUPPORTED;
     }
