@@ -64,5 +64,22 @@ def build_lib(force=False, verbose=True):
     return LIB
 
 
+def build_hostcopy(force=False, verbose=True):
+    """The CPython helper for the host-side copies (csrc/hostcopy.c -> sr/recognition/_hostcopy.<abi>.so), with the system
+    compiler; in-tree like the library, so that it travels with the snapshot."""
+    import sysconfig
+    src = os.path.join(CSRC, "hostcopy.c")
+    out = os.path.join(HERE, "sr", "recognition", "_hostcopy" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if force or _stale(out, [src]):
+        cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", out, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building _hostcopy failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv))
+    print(build_hostcopy(force="--force" in sys.argv))

@@ -81,10 +81,7 @@ def train_words(templates_by_word, n_segments, n_gaussians=4, use_gmm=True, use_
     D = np.asarray(templates_by_word[0][0]).shape[1]
     X, release = _km.host_workspace((int(lengths.sum()), D))
     try:
-        try:
-            np.concatenate([t for ts in templates_by_word for t in ts], out=X)      # [T, D] arrays: no per-template call
-        except (ValueError, TypeError):
-            np.concatenate([np.asarray(t).reshape(-1, D) for ts in templates_by_word for t in ts], out=X)
+        _km.concat_rows([t for ts in templates_by_word for t in ts], X)
     except BaseException:
         release()
         raise

@@ -398,6 +398,44 @@ def test_host_workspace_is_kept_and_never_shared():
         del os.environ["GMMHMM_HOST_WORKSPACE_MB"]
 
 
+def test_threaded_concat_rows_is_np_concatenate():
+    """kmeans.concat_rows: C-contiguous float64 pieces through csrc/hostcopy.c (threads, GIL released), everything else through
+    numpy -- same bytes either way; sizes that do not add up are an error, not a partial copy."""
+    import importlib
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gmmhmm_build_for_test", os.path.join(here, "speech-recognition_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build_hostcopy(verbose=False)
+    km = importlib.import_module("sr.recognition.kmeans")
+    from sr.recognition import _hostcopy
+    rng = np.random.default_rng(5)
+    parts = [rng.normal(size=(int(n), 39)) for n in rng.integers(0, 150, size=700)]
+    ref = np.concatenate(parts)
+    for threads in (1, 3, 8, 64):
+        out = np.full(ref.shape, np.nan)
+        _hostcopy.concat_rows(parts, out, threads)
+        np.testing.assert_array_equal(out, ref)
+    big = [rng.normal(size=(20000, 39)) for _ in range(3)] + [np.zeros((0, 39))]          # above the one-thread size
+    out = np.empty((60000, 39))
+    assert km.concat_rows(big, out) is out
+    np.testing.assert_array_equal(out, np.concatenate(big))
+    out = np.empty((4, 2))
+    km.concat_rows([np.ones((2, 2), dtype=np.float32), [[2.0, 3.0]], rng.normal(size=(3, 4))[:1, ::2] * 0], out)   # numpy's route
+    assert out.tolist() == [[1, 1], [1, 1], [2, 3], [0, 0]]
+    with pytest.raises(TypeError):
+        _hostcopy.concat_rows([np.ones((2, 2), dtype=np.float32)], np.empty((2, 2)))
+    with pytest.raises(TypeError):
+        _hostcopy.concat_rows([np.ones((4, 4))[:, :2]], np.empty((4, 2)))
+    with pytest.raises(ValueError):
+        _hostcopy.concat_rows(parts, np.empty((len(ref) + 1, 39)))
+    with pytest.raises(ValueError):
+        _hostcopy.concat_rows(parts, np.empty((len(ref) - 1, 39)))
+    _hostcopy.concat_rows([], np.empty((0, 39)))
+
+
 def test_fast_allclose_is_numpys(R):
     """GMM.__eq__ (hmm_state.py:161-170) compares with np.allclose; `_allclose` is its test for finite arrays and calls it
     for everything else."""
