@@ -6,8 +6,9 @@
  *       np.concatenate(arrays, out=out) does -- by `threads` threads with the GIL released.  62 MB in 2 000 pieces
  *       (train_words on ten words x 200 templates): 5.7 ms with numpy on one core; sublists handed to Python threads are
  *       SLOWER (a GIL hand-over per piece, profiles/r05c_host_copy_probe.txt).
- *       Raises TypeError for anything that is not a C-contiguous float64 buffer (the caller then takes numpy's route, with
- *       its casts) and ValueError when the sizes do not add up.
+ *       Raises TypeError for anything that is not a C-contiguous float64 buffer -- of `out`'s row width, when `out` is a
+ *       matrix -- (the caller then takes numpy's route, with its casts and its errors) and ValueError when the sizes do not
+ *       add up.
  *
  * Plain buffer protocol: no numpy headers.  Built by speech-recognition_amd/build.py with the system compiler.
  */
@@ -73,6 +74,11 @@ static PyObject* concat_rows(PyObject* self, PyObject* args, PyObject* kwargs) {
             }
             got = i + 1;
             if (!is_float64(&views[i])) { PyErr_Format(PyExc_TypeError, "concat_rows: item %zd is not float64", i); goto done; }
+            /* a matrix as `out`: every piece a matrix of the same width (sizes that merely ADD UP would pass the byte count) */
+            if (out.ndim == 2 && out.shape && (views[i].ndim != 2 || !views[i].shape || views[i].shape[1] != out.shape[1])) {
+                PyErr_Format(PyExc_TypeError, "concat_rows: item %zd is not a [rows, %zd] array", i, out.shape[1]);
+                goto done;
+            }
             if ((size_t)views[i].len > (size_t)out.len - at) { PyErr_SetString(PyExc_ValueError, "concat_rows: the pieces are larger than `out`"); goto done; }
             pieces[i].src = (const char*)views[i].buf;
             pieces[i].dst = (char*)out.buf + at;

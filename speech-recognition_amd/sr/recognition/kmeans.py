@@ -199,27 +199,7 @@ def host_workspace(shape, dtype=np.float64):
     return buf[:nbytes].view(dtype).reshape(shape), release
 
 
-def concat_rows(arrays, out):
-    """np.concatenate(arrays, out=out) for the caller's templates: C-contiguous float64 arrays go through the threaded copy of
-    `_hostcopy` (csrc/hostcopy.c: GMMHMM_HOST_THREADS threads, the GIL released; 62 MB in 2 000 pieces: 5.7 -> ~1.5 ms), anything
-    else -- other dtypes, strided views, lists -- through numpy with its casts."""
-    import os
-    try:
-        from . import _hostcopy
-    except ImportError:
-        _hostcopy = None
-    if _hostcopy is not None:
-        try:
-            _hostcopy.concat_rows(arrays, out, min(int(os.environ.get("GMMHMM_HOST_THREADS", "8")), os.cpu_count() or 1))
-            return out
-        except TypeError:
-            pass
-    D = out.shape[1]
-    try:
-        np.concatenate(arrays, out=out)                            # [T, D] arrays: no per-template call
-    except (ValueError, TypeError):
-        np.concatenate([np.asarray(t).reshape(-1, D) for t in arrays], out=out)
-    return out
+concat_rows = _hip.concat_rows
 
 
 def gather_rows(X, order):

@@ -429,6 +429,8 @@ def test_threaded_concat_rows_is_np_concatenate():
         _hostcopy.concat_rows([np.ones((2, 2), dtype=np.float32)], np.empty((2, 2)))
     with pytest.raises(TypeError):
         _hostcopy.concat_rows([np.ones((4, 4))[:, :2]], np.empty((4, 2)))
+    with pytest.raises(TypeError):                                  # widths that only ADD UP to the right size
+        _hostcopy.concat_rows([np.ones((2, 3)), np.ones((3, 2)), np.ones((3, 4))], np.empty((8, 3)))
     with pytest.raises(ValueError):
         _hostcopy.concat_rows(parts, np.empty((len(ref) + 1, 39)))
     with pytest.raises(ValueError):
