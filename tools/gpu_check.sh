@@ -1,26 +1,13 @@
 #!/bin/bash
-# scratch check between evidence runs: train_words tests, stage times, the threaded copy against numpy on this box
+# scratch check: EM tests, then fb_chain2's utterances per wave swept on the C2 EM iteration (kernel times under rocprofv3)
 mkdir -p gpurun_out/r05e
-timeout -k 10 600 python -m pytest tests/test_gpu_train_words.py tests/test_gpu_api.py -x -q -m gpu > gpurun_out/r05e/tw_tests.log 2>&1 || { tail -20 gpurun_out/r05e/tw_tests.log; exit 1; }
-tail -2 gpurun_out/r05e/tw_tests.log
-REPS=5 timeout -k 10 300 python3 tools/prof_train_words.py > gpurun_out/r05e/train_words_stages.txt 2>&1 || { tail gpurun_out/r05e/train_words_stages.txt; exit 1; }
-grep "train_words \[ms\]\|^call \|without" gpurun_out/r05e/train_words_stages.txt
-timeout -k 10 120 python3 - <<'PY'
-import sys, time
-sys.path.insert(0, "speech-recognition_amd")
-import numpy as np
-from sr.recognition import _hostcopy
-rng = np.random.default_rng(0)
-lens = rng.integers(50, 150, size=2000)
-parts = [rng.normal(size=(int(n), 39)) for n in lens]
-out = np.empty((int(lens.sum()), 39))
-for thr in (1, 2, 4, 8, 16):
-    ts = []
-    for _ in range(7):
-        t0 = time.perf_counter(); _hostcopy.concat_rows(parts, out, thr); ts.append((time.perf_counter() - t0) * 1e3)
-    print("concat_rows, %d threads: %.2f ms" % (thr, min(ts)))
-ts = []
-for _ in range(7):
-    t0 = time.perf_counter(); np.concatenate(parts, out=out); ts.append((time.perf_counter() - t0) * 1e3)
-print("np.concatenate(out=): %.2f ms" % min(ts))
-PY
+timeout -k 10 900 python -m pytest tests/test_gpu_em_session.py tests/test_gpu_fused.py tests/test_gpu_kernels.py -x -q -m gpu > gpurun_out/r05e/em_tests.log 2>&1 || { tail -20 gpurun_out/r05e/em_tests.log; exit 1; }
+tail -2 gpurun_out/r05e/em_tests.log
+cd /tmp && export TMPDIR=/tmp
+for upw in 4 3 2 1; do
+  export GMMHMM_FBCHAIN_UPW=$upw
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw -o em -- python3 $GRAFT_REPO_ROOT/tools/time_em.py 12500 > $GRAFT_REPO_ROOT/gpurun_out/r05e/em_upw$upw.log 2>&1 || exit 1
+  f=$(find $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw -name "*kernel_stats.csv" | head -1)
+  echo "upw $upw: $(grep -i 'fb_chain2_kernel' $f | awk -F'",' '{print $2}' | cut -d, -f1-3)  |  $(grep -i 'ms_per_iteration\|ms per iteration' $GRAFT_REPO_ROOT/gpurun_out/r05e/em_upw$upw.log | tail -1 | cut -c1-200)"
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw
+done
