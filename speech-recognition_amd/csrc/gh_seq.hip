@@ -189,12 +189,20 @@ __global__ __launch_bounds__(64) void seq_backtrace_kernel(gh_layers_args a, int
     int j = T - 1;
     int64_t key = -1;
     uint32_t cw = 0;
-    const uint8_t* arcp = a.seqwords[g->word[bk]].arcs;
+    // the arcs of the current word's states in registers (16 bytes, fetched when the layer changes): a load per CELL, in front
+    // of the decision it validates, was a round trip in the chain of every column
+    // (a second decision word fetched ahead -- 16 words below, the same layer CPW columns earlier -- made the kernel SLOWER,
+    //  634 -> 769 us on continuous_train's 2 000 utterances: the lanes' words lie on 64 different lines, twice the loads)
+    uint4 aw = *reinterpret_cast<const uint4*>(a.seqwords[g->word[bk]].arcs);
+    auto arcs_of = [&](int st) -> int {
+        const uint32_t w4 = st < 8 ? (st < 4 ? aw.x : aw.y) : (st < 12 ? aw.z : aw.w);
+        return (int)((w4 >> ((st & 3) * 8)) & 0xffu);
+    };
     while (j != 0) {
         const int64_t want = (int64_t)(j / CPW) * 16 + bk;
         if (want != key) { cw = bpu[want]; key = want; }
         const uint32_t hb = (cw >> ((CPW - 1 - j % CPW) * HB)) & ((1u << HB) - 1u);
-        const int arcs = arcp[bs];
+        const int arcs = arcs_of(bs);
         if (len + 2 > cap) { flag |= 4; break; }
         if (bs >= 1) {
             int before = 0;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64) void seq_backtrace_kernel(gh_layers_args a, int
             if (bk == 0) { flag |= 2; break; }                // ... the start row in a column > 0: no origin
             --bk;                                             // ... whose only origin is the last state of the layer before
             bs = N - 1;
-            arcp = a.seqwords[g->word[bk]].arcs;
+            aw = *reinterpret_cast<const uint4*>(a.seqwords[g->word[bk]].arcs);
             path[len++] = make_int2(bk * (N + 1) + 1 + bs, j);
         }
     }

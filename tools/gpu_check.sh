@@ -1,13 +1,13 @@
 #!/bin/bash
-# scratch check: EM tests, then fb_chain2's utterances per wave swept on the C2 EM iteration (kernel times under rocprofv3)
+# scratch check: sequence-form / alignment tests, then the kernel times of continuous_train
 mkdir -p gpurun_out/r05e
-timeout -k 10 900 python -m pytest tests/test_gpu_em_session.py tests/test_gpu_fused.py tests/test_gpu_kernels.py -x -q -m gpu > gpurun_out/r05e/em_tests.log 2>&1 || { tail -20 gpurun_out/r05e/em_tests.log; exit 1; }
-tail -2 gpurun_out/r05e/em_tests.log
+timeout -k 10 900 python -m pytest tests/test_gpu_seq.py tests/test_gpu_e2e.py tests/test_gpu_api.py tests/test_gpu_train_words.py tests/test_gpu_configs.py -x -q -m gpu > gpurun_out/r05e/seq_tests.log 2>&1 || { tail -30 gpurun_out/r05e/seq_tests.log; exit 1; }
+tail -2 gpurun_out/r05e/seq_tests.log
 cd /tmp && export TMPDIR=/tmp
-for upw in 4 3 2 1; do
-  export GMMHMM_FBCHAIN_UPW=$upw
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw -o em -- python3 $GRAFT_REPO_ROOT/tools/time_em.py 12500 > $GRAFT_REPO_ROOT/gpurun_out/r05e/em_upw$upw.log 2>&1 || exit 1
-  f=$(find $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw -name "*kernel_stats.csv" | head -1)
-  echo "upw $upw: $(grep -i 'fb_chain2_kernel' $f | awk -F'",' '{print $2}' | cut -d, -f1-3)  |  $(grep -i 'ms_per_iteration\|ms per iteration' $GRAFT_REPO_ROOT/gpurun_out/r05e/em_upw$upw.log | tail -1 | cut -c1-200)"
-  rm -rf $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_em_$upw
-done
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05e/prof_ctrain -o ctrain -- python3 $GRAFT_REPO_ROOT/tools/time_ctrain.py 2000 7 6 > $GRAFT_REPO_ROOT/gpurun_out/r05e/ctrain_prof.log 2>&1 || exit 1
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/r05e/prof_ctrain -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/r05e/ctrain_kernel_stats.csv
+rm -rf gpurun_out/r05e/prof_ctrain
+grep -i "backtrace\|cut_segments" gpurun_out/r05e/ctrain_kernel_stats.csv | awk -F'",' '{print substr($1,1,60), $2}'
+grep "steady\|per outer" gpurun_out/r05e/ctrain_prof.log
