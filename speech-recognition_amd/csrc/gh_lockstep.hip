@@ -880,6 +880,33 @@ __global__ void fit_partvar_kernel(int S, int k, int D, int sstride, const doubl
     cov[i] = v;
 }
 
+// The partition variances of SMALL states once more, in two passes.  The streaming pass forms them from one-pass sums
+// (count | sum y | sum y^2 around the state's shift point): accurate to ~1e-13 for groups of tens of frames, but a group of
+// TWO frames that happen to lie close together in some dimension has a variance of 1e-7 .. 1e-9 of the spread, and the
+// difference of squares keeps only 7-9 digits of it (1.4e-9 .. 5e-9 relative, tools/stress_refit.py).  States of up to
+// `max_frames` frames -- the only ones with such groups -- get np.cov's two passes in frame order (what the tile path's
+// kmeans_rowsum<0> / <1> + fit_partvar compute): grid (S, k), lane = dimension, D <= 64.
+__global__ __launch_bounds__(64) void fit_partvar_small_kernel(const double* __restrict__ X, int D, int k, const int64_t* __restrict__ seg_off,
+                                                               const int32_t* __restrict__ ids, int max_frames, double* __restrict__ cov /*[S,k,D]*/) {
+    const int s = blockIdx.x, c = blockIdx.y, d = threadIdx.x;
+    const int64_t f0 = seg_off[s];
+    const int64_t n = seg_off[s + 1] - f0;
+    if (n > max_frames || d >= D) return;
+    double sum = 0.0;
+    int cnt = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[f0 + i] == c) { sum += X[(f0 + i) * D + d]; ++cnt; }
+    double v = NAN;                                             // n <= 1: numpy's 0 * (1 / 0)
+    if (cnt > 1) {
+        const double ctr = sum / (double)cnt;
+        double q = 0.0;
+        for (int64_t i = 0; i < n; ++i)
+            if (ids[f0 + i] == c) { const double t = X[(f0 + i) * D + d] - ctr; q += t * t; }
+        v = q * (1.0 / (cnt - 1.0));
+    }
+    cov[((int64_t)s * k + c) * D + d] = v;
+}
+
 __global__ void fit_logdet_kernel(int S, int k, int D, const double* __restrict__ cov, double* __restrict__ logdet) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
@@ -1012,6 +1039,7 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
         const double dl = mu - m0;
         const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
         diff += !same(mu, m0) + !same(sg, var[at]);
+        if (sg == 0) atomicOr(counter + 1, 16);              // update_models raises before the convergence test (hmm_state.py:149)
         mean[at] = mu;
         var[at] = sg;
         mine += !fit_close(mu, old_mu[at]) + !fit_close(sg, old_sigma[at]);
@@ -1368,6 +1396,11 @@ extern "C" int gh_fit_kmeans(gh_ctx* ctx, gh_fit* f, gh_comm* comm, int k, const
             if (!rc && comm) rc = gh_comm_allreduce_enqueue(comm, f->d_stats, (int64_t)S * (k * (1 + 2 * D) + 1));
             if (!rc) rc = rf_launch_partvar(ctx, S, k, D, f->d_stats, comm ? 1 : 0, f->d_cov);
             if (rc) return rc;
+            if (!comm && D <= 64) {     // (sharded: the variances come from sums over all ranks -- one pass by construction)
+                hipLaunchKernelGGL(fit_partvar_small_kernel, dim3((unsigned)S, (unsigned)k), dim3(64), 0, st, X, D, k, f->d_segoff, (const int32_t*)f->d_ids,
+                                   64, f->d_cov);
+                GH_HIP(hipGetLastError());
+            }
         } else {
         GH_HIP(hipMemsetAsync(f->d_counts, 0, (size_t)S * k * 4, st));
         GH_HIP(hipMemsetAsync(f->d_cbase, 0, (size_t)S * k * 4, st));

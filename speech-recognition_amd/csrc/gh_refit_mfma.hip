@@ -240,11 +240,16 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
     auto same = [](double x, double y) { return x == y || (x != x && y != y); };
     double mu_l[2], sg_l[2], w_l = 0.0;            // this thread's entries (k D <= 512 = 2 per thread of a 256-thread block)
     int n_l = 0;
+    unsigned onept = 0xffu;                        // bit c: every entry of component c this thread holds says "one point"
     for (int i = tid; i < k * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
         const int64_t at = ((int64_t)s * k + c) * D + d;
         const double m0 = a.mean[at], dm = m0 - sh[d];
         const double s0 = st[c * Wd], T1 = st[c * Wd + 1 + d], T2 = st[c * Wd + 1 + D + d];
+        // all of the component's weight on ONE point (a frame, or identical ones): sum r y^2 . sum r = (sum r y)^2 up to the
+        // rounding of the three sums -- and only then in every dimension at once (several points: the two sides differ by
+        // s0^2 times the weighted variance, ~1 against 1e-15)
+        if (!(s0 > 0 && fabs(T1 * T1 - T2 * s0) <= 3.6e-15 * fabs(T2 * s0))) onept &= ~(1u << c);
         const double S1 = T1 - dm * s0;                                 // sum r (x - m0)
         const double S2 = T2 - dm * (2.0 * T1 - dm * s0);               // sum r (x - m0)^2
         const double occ = (s0 == 0) ? 1e-5 : s0;
@@ -252,6 +257,9 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
         const double dl = mu - m0;
         const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
         diff += !same(mu, m0) + !same(sg, a.var[at]);
+        // update_models installs the covariance BEFORE the convergence test (hmm_state.py:149): a zero variance raises
+        // LinAlgError there, whether or not the state would go on (the pack of the next pass only sees the states that do)
+        if (sg == 0) atomicOr(a.c.counter + 1, 16);
         rf_publish(a.mean + at, mu);
         rf_publish(a.var + at, sg);
         if (n_l < 2) { mu_l[n_l] = mu; sg_l[n_l] = sg; }
@@ -267,6 +275,13 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
     }
     if (mine) atomicAdd(&lds_i[0], mine);
     if (diff) atomicAdd(&lds_i[1], diff);
+    // A component that sits on one point: the reference's M-step (hmm_state.py:134-148) gets mu = that frame and a variance of
+    // EXACTLY 0 -- update_models raises LinAlgError -- or, when mu comes out one ulp beside the frame or denormal-small weights
+    // are left on other frames, a variance of 1e-32 .. 1e-74 of the spread, and NaN parameters one iteration later.  The centred
+    // sums here leave rounding noise (+-1e-16 of the spread, either sign) in both cases, which `sg == 0` cannot see and which
+    // would train on silently: both raise.
+    for (int c = 0; c < k; ++c)
+        if (__syncthreads_and((int)((onept >> c) & 1u)) && tid == 0) atomicOr(a.c.counter + 1, 16);
     __syncthreads();
     const int bad = lds_i[0], moved = lds_i[1];
     if (bad == 0) {                                  // np.allclose on all three: converged, the old values stay
