@@ -248,3 +248,83 @@ def test_segment_means_are_numpys_row_after_row_sums(D):
         if n:
             with np.errstate(invalid="ignore"):
                 np.testing.assert_array_equal(sums[s] / counts[s], np.mean(X[off[s]:off[s + 1]], axis=0))
+
+
+@pytest.mark.parametrize("max_iteration", [1, 6])
+def test_component_on_one_frame_raises_like_the_reference(max_iteration):
+    """A component whose weight ends up on ONE frame: the reference's M-step gives mu = that frame and a variance of exactly 0,
+    and `update_models` -> the covariance setter raises LinAlgError (hmm_state.py:24-30, 134-149) -- in the iteration it happens,
+    also when that is the state's last one.  The device forms sum centred moments, which leave rounding noise there: the
+    streaming update recognises the one-point component (sum r y^2 . sum r = (sum r y)^2 in every dimension)."""
+    rng = np.random.default_rng(8)
+    D, k = 5, 2
+    body = rng.normal(size=(60, D))
+    far = np.full((1, D), 60.0) + rng.normal(size=(1, D))       # one frame ~60 standard deviations out
+    seg = np.concatenate([body[:30], far, body[30:]])
+    other = rng.normal(size=(200, D)) * 2.0 + 3.0                # a healthy state beside it
+    segs = [seg, other]
+    n = np.array([len(x) for x in segs], dtype=np.float64)
+    mean0 = np.stack([np.stack([body.mean(axis=0), far[0] - 0.5]), np.stack([other.mean(axis=0) - 1.0, other.mean(axis=0) + 1.0])])
+    var0 = np.ones((2, k, D))
+    w0 = np.full((2, k), 0.5)
+    with pytest.raises(np.linalg.LinAlgError):                   # the oracle = the reference's arithmetic
+        m, v, w = mean0[0].copy(), var0[0].copy(), w0[0].copy()
+        O.gmm_em(seg, m, v, w, k, max_iteration=max_iteration, old=(np.zeros((k, D)), np.ones((k, D)), np.zeros(k)))
+    for tiles in (False, True):
+        b, fit, off = _session(segs, k, tiles=tiles)
+        try:
+            mean, var, w = mean0.copy(), var0.copy(), w0.copy()
+            with pytest.raises(np.linalg.LinAlgError):
+                fit.em(k, mean, var, w, np.zeros_like(mean), np.ones_like(mean), np.zeros_like(w), n, max_iteration=max_iteration)
+        finally:
+            fit.close()
+            b.close()
+
+
+def test_zero_variance_in_a_states_last_iteration_raises():
+    """A feature that is 0 in every frame: the M-step's variance is exactly 0 in the FIRST update, and with max_iteration = 1
+    that is also the last one -- the reference raises there (update_models runs before the convergence test)."""
+    rng = np.random.default_rng(9)
+    D, k = 4, 2
+    seg = rng.normal(size=(80, D))
+    seg[:, 2] = 0.0
+    n = np.array([80.0])
+    mean0 = np.stack([np.stack([seg.mean(axis=0) - 0.5, seg.mean(axis=0) + 0.5])])
+    mean0[0, :, 2] = 0.0
+    var0, w0 = np.ones((1, k, D)), np.full((1, k), 0.5)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.gmm_em(seg, mean0[0].copy(), var0[0].copy(), w0[0].copy(), k, max_iteration=1, old=(np.zeros((k, D)), np.ones((k, D)), np.zeros(k)))
+    for tiles in (False, True):
+        b, fit, off = _session([seg], k, tiles=tiles)
+        try:
+            mean, var, w = mean0.copy(), var0.copy(), w0.copy()
+            with pytest.raises(np.linalg.LinAlgError):
+                fit.em(k, mean, var, w, np.zeros_like(mean), np.ones_like(mean), np.zeros_like(w), n, max_iteration=1)
+        finally:
+            fit.close()
+            b.close()
+
+
+def test_partition_variances_of_tiny_groups_are_np_covs():
+    """Random partitions of SMALL states: a group of two frames that lie close together has a variance of 1e-8 of the spread; the
+    one-pass sums of the streaming pass keep 7-9 digits of it, so states of up to 64 frames take two passes (np.cov's numbers)."""
+    rng = np.random.default_rng(10)
+    D, k = 6, 3
+    small = rng.normal(size=(7, D)) * 2.0 + 5.0
+    small[4] = small[1] + rng.normal(size=D) * 1e-4             # frames 1 and 4: close together
+    big = rng.normal(size=(500, D)) + 1.0
+    part = np.concatenate([[0, 1, 2, 0, 1, 2, 0], rng.integers(0, k, size=500)]).astype(np.uint8)
+    c0 = np.stack([np.stack([x.mean(axis=0) + 0.1 * j for j in range(k)]) for x in (small, big)])
+    covs = []
+    for tiles in (False, True):
+        b, fit, off = _session([small, big], k, tiles=tiles)
+        try:
+            covs.append(fit.kmeans(k, c0, part, max_iteration=3)[1])
+        finally:
+            fit.close()
+            b.close()
+    want = np.array([np.cov(small[part[:7] == c].T).diagonal() for c in range(k)])
+    np.testing.assert_allclose(covs[0][0], want, rtol=1e-14)
+    np.testing.assert_allclose(covs[0][0], covs[1][0], rtol=5e-16)     # the tile path's two passes (an fma more or less)
+    np.testing.assert_allclose(covs[0][1], covs[1][1], rtol=1e-12)
+    assert covs[0][0][1].max() < 1e-7                            # (the group of the two close frames)
