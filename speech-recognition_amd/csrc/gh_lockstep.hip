@@ -1027,11 +1027,15 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
     const int Wd = 1 + 2 * D;
     const double* st = stats + (int64_t)s * plen;
     int mine = 0, diff = 0;
+    unsigned onept = 0xffffffffu;                  // bit c: every entry of component c this thread holds says "one point"
     // `same`: identical to the previous iteration's value, NaN counting as equal to NaN
     auto same = [](double a, double b) { return a == b || (a != a && b != b); };
     for (int i = tid; i < k * D; i += blockDim.x) {
         const int c = i / D, d = i - c * D;
         const double s0 = st[c * Wd], S1 = st[c * Wd + 1 + d], S2 = st[c * Wd + 1 + D + d];
+        // (a component with all its weight on ONE point -- see em_update_state, gh_refit_mfma.hip: the reference's variance is
+        //  exactly 0 there and update_models raises; the centred sums leave rounding noise)
+        if (!(s0 > 0 && fabs(S1 * S1 - S2 * s0) <= 3.6e-15 * fabs(S2 * s0))) onept &= ~(1u << c);
         const int64_t at = ((int64_t)s * k + c) * D + d;
         const double m0 = mean[at];
         const double occ = (s0 == 0) ? 1e-5 : s0;
@@ -1052,6 +1056,8 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
     }
     if (mine) atomicAdd(&bad, mine);
     if (diff) atomicAdd(&moved, diff);
+    for (int c = 0; c < k; ++c)
+        if (__syncthreads_and((int)((onept >> c) & 1u)) && tid == 0) atomicOr(counter + 1, 16);
     __syncthreads();
     if (bad == 0) {
         if (tid == 0) { active[s] = 0; conv_at[s] = it; }

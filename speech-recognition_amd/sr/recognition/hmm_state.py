@@ -224,6 +224,15 @@ class GMM(HMMState):
         # sum r (x - mu)^2 / N around the NEW mean (:141-143), from the centred sums
         delta = mu - means
         sigma = (stats[:, 1 + dim:] - delta * (2.0 * stats[:, 1:1 + dim] - delta * stats[:, 0][:, None])) / occ[:, None]
+        # A component with all its weight on ONE frame: the reference's two-pass variance is exactly 0 there and the covariance
+        # setter raises (hmm_state.py:24-30); the centred sums leave rounding noise (+-1e-16 of the spread).  One point <=>
+        # sum r y^2 . sum r = (sum r y)^2 in every dimension (to the rounding of the sums): such a row gets its exact 0, and
+        # update_models raises at that component with the ones in front installed, as in the reference.
+        with np.errstate(all="ignore"):
+            s0, S1, S2 = stats[:, 0][:, None], stats[:, 1:1 + dim], stats[:, 1 + dim:]
+            one_point = (stats[:, 0] > 0) & np.all(np.abs(S1 * S1 - S2 * s0) <= 3.6e-15 * np.abs(S2 * s0), axis=1)
+        if one_point.any():
+            sigma = np.where(one_point[:, None], 0.0, sigma)
         self.update_models(mu, sigma, weights)
         if np.allclose(mu, self.mu_old[:k, :]) and np.allclose(sigma, self.sigma_old[:k, :]) \
                 and np.allclose(weights, self.w_old[:k]):

@@ -281,6 +281,25 @@ def test_component_on_one_frame_raises_like_the_reference(max_iteration):
             b.close()
 
 
+def test_gmm_em_object_raises_for_a_component_on_one_frame():
+    """The same collapse through the object API (`GMM.em`: E-step statistics from the device, M-step on the host): the
+    covariance setter raises at the collapsed component, the component in front of it already updated."""
+    import sr.recognition as R
+    rng = np.random.default_rng(8)
+    D, k = 5, 2
+    body = rng.normal(size=(60, D))
+    far = np.full((1, D), 60.0) + rng.normal(size=(1, D))
+    seg = np.concatenate([body[:30], far, body[30:]])
+    g = R.GMM(body.mean(axis=0), np.ones(D), k)
+    g.update_models(np.stack([body.mean(axis=0), far[0] - 0.5]), np.ones((k, D)), np.full(k, 0.5))
+    before = np.array(g.dists[0].mean)
+    from test_gpu_api import quiet
+    with quiet(), pytest.raises(np.linalg.LinAlgError):
+        g.em(seg, k, max_iteration=4)
+    assert not np.array_equal(np.asarray(g.dists[0].mean), before)          # component 0 was installed first
+    np.testing.assert_array_equal(np.asarray(g.dists[1].cov), np.zeros(D))    # the value the setter refused to invert
+
+
 def test_zero_variance_in_a_states_last_iteration_raises():
     """A feature that is 0 in every frame: the M-step's variance is exactly 0 in the FIRST update, and with max_iteration = 1
     that is also the last one -- the reference raises there (update_models runs before the convergence test)."""
