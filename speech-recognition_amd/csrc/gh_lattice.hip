@@ -377,6 +377,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
             }
             if (ok && W == 1) N = P;
             ok = ok && gh_seq_n_ok(N) && W <= GH_LAYERS_MAXW && W * N == P && (K <= 8 || N <= 8);   // (four register sets: N <= 8)
+            ok = ok && (W <= GH_LAYERS_ROWW || (K <= 8 && N <= 8));                                   // (more than 16 words: the wide kernel)
         }
         bool skip = false;
         for (int pos = 0; ok && pos < P; ++pos) {
@@ -421,7 +422,7 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int r = 0; r < R; ++r) if (h_state[r] < 0) { ++n_nes; if (r > 0) Lr = r; }
         bool ok = R >= 4 && h_state[0] < 0 && n_nes == 2 && Lr > 1 && Lr < R - 1;
         const int W = ok ? R - 1 - Lr : 0;
-        ok = ok && W >= 1 && W <= GH_LAYERS_MAXW && (Lr - 1) % W == 0;
+        ok = ok && W >= 1 && W <= GH_LAYERS_ROWW && (Lr - 1) % W == 0;
         const int N = ok ? (Lr - 1) / W + 1 : 0;
         ok = ok && gh_seq_n_ok(N);
         ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);

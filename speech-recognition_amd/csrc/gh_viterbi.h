@@ -130,6 +130,11 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T);
 int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                              bool f64, bool want_path);
 int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);
+// more than GH_LAYERS_ROWW words per layer (gh_viterbi_layers_wide.hip: lane = word); the two launchers above hand over to these
+size_t gh_layers_wide_bp_entries(int64_t T);
+int gh_launch_viterbi_layers_wide(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
+                                  bool f64, bool want_path);
+int gh_launch_lattice_backtrace_wide(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);
 // sequence form (forced-alignment lattices, gh_seq.hip): forward sweep, four utterances per wave, and its back-trace
 size_t gh_seq_bp_entries(int N, int skip, int64_t T);
 int gh_launch_viterbi_seq(gh_ctx* ctx, const gh_layers_args& a, int N, int skip, int64_t u_begin, int64_t n_utts, bool f64,

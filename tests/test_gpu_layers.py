@@ -74,7 +74,10 @@ def test_layers_kernel_reference_goldens(hip, ctx, dtype):
                                         (6, 16, 5, False),
                                         # more than 8 layers (ten-digit strings): four register sets, up to 8 states per word
                                         (10, 5, 10, False), (4, 3, 16, True), (3, 8, 12, True), (2, 2, 9, False),
-                                        (5, 8, 16, False)])
+                                        (5, 8, 16, False),
+                                        # more than 16 words per layer (up to 64): the wide kernel, lane = word, the layers one
+                                        # after the other in the lane's registers
+                                        (17, 5, 7, False), (33, 3, 8, True), (64, 5, 3, False), (40, 8, 3, True), (20, 2, 1, False)])
 def test_layers_kernel_equals_lean_kernel(hip, ctx, W, n, K, skip):
     """Random word models (per-word transition costs, optional skip arcs), utterances from far too short to long:
     end costs BITWISE equal, same chosen end, same paths -- including the unreachable cases, where every candidate is

@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """Randomised sweep of the word-template Viterbi kernels -- layer form (K-layer lattice), loop form (word-loop grammar), sequence
 form (forced alignment, a graph per transcript) -- against the row-per-lane lean kernel, which implements the same
-decode_hmm_states semantics (decode.py:80-146) by another route: random word counts (1 .. 16), states per word (2 .. 8, 12,
+decode_hmm_states semantics (decode.py:80-146) by another route: random word counts (1 .. 16, and 17 .. 64 for the wide layer kernel), states per word (2 .. 8, 12,
 16), layers (1 .. 16), skip arcs, penalties, fp64 / fp32, utterances from too short to long.  End costs BITWISE, the chosen
 end, paths and labels equal.
 
@@ -86,6 +86,9 @@ for trial in range(trials):
     n = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 12, 16]))
     W = int(rng.integers(1, 17))
     K = int(rng.integers(1, 17 if n <= 8 else 9))
+    wide = n <= 8 and rng.random() < 0.3          # more than 16 words per layer: the wide layer kernel (K <= 8, N <= 8)
+    if wide:
+        W, K = int(rng.integers(17, 65)), int(rng.integers(1, 9))
     skip = bool(rng.random() < 0.4) and n >= 3
     M, D = int(rng.choice([1, 2, 3])), int(rng.choice([2, 6, 13]))
     dtype = np.float64 if rng.random() < 0.7 else np.float32
@@ -124,13 +127,14 @@ for trial in range(trials):
             problems.append("K = %d lattice not taken as layer form (%s)" % (K, sorted(lat.forms())))
         problems += compare("layers", lat, b, n, graph["row_state"])
         lat.close()
-        # loop form
-        graph = packed_loop_lattice(wt, n, float(rng.choice([0.0, 0.7, 2.5])))[0]
-        lat = _hip.Lattices(ctx, [graph])
-        if "loop" not in lat.forms():
-            problems.append("loop grammar not taken as loop form (%s)" % sorted(lat.forms()))
-        problems += compare("loop", lat, b, n, graph["row_state"])
-        lat.close()
+        # loop form (up to 16 words: four utterances per wave)
+        if W <= 16:
+            graph = packed_loop_lattice(wt, n, float(rng.choice([0.0, 0.7, 2.5])))[0]
+            lat = _hip.Lattices(ctx, [graph])
+            if "loop" not in lat.forms():
+                problems.append("loop grammar not taken as loop form (%s)" % sorted(lat.forms()))
+            problems += compare("loop", lat, b, n, graph["row_state"])
+            lat.close()
         # sequence form: every utterance against its own transcript
         keys, graphs, utt_graph = {}, [], np.empty(U, dtype=np.int32)
         for u, l in enumerate(labels):
