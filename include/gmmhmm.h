@@ -246,7 +246,10 @@ int gh_lattices_set_beam(gh_lattices* l, int beam);
  * gh_forward_backward are chosen by form; anything else runs on the row-per-lane kernels).  Bit 0: one left-to-right
  * chain (hmm.py:126-135); bit 1: K layers of the same W words (build_state_sequences, continuous_speech.py:13-53);
  * bit 2: word-loop grammar; bit 3: one word per layer, a graph per transcript (continuous_speech.py:80); bit 4:
- * one-word chains for forward-backward.  < 0: NULL argument. */
+ * one-word chains for forward-backward.  < 0: NULL argument.
+ * What the forms take: words of 2 .. 8, 12 or 16 states with arcs from s, s-1, s-2; bit 1: up to 16 words per layer
+ * and 8 layers (16 layers for words of <= 8 states), or 17 .. 64 words per layer with <= 8 layers of <= 8 states;
+ * bit 2: up to 16 words; bit 3: transcripts of up to 16 words. */
 int gh_lattices_forms(const gh_lattices* l);
 
 /* --------------------------------------------------- A6: decode_hmm_states
