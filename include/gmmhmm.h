@@ -249,7 +249,7 @@ int gh_lattices_set_beam(gh_lattices* l, int beam);
  * one-word chains for forward-backward.  < 0: NULL argument.
  * What the forms take: words of 2 .. 8, 12 or 16 states with arcs from s, s-1, s-2; bit 1: up to 16 words per layer
  * and 8 layers (16 layers for words of <= 8 states), or 17 .. 64 words per layer with <= 8 layers of <= 8 states;
- * bit 2: up to 16 words; bit 3: transcripts of up to 16 words. */
+ * bit 2: up to 16 words, or 17 .. 64 words of <= 8 states; bit 3: transcripts of up to 16 words. */
 int gh_lattices_forms(const gh_lattices* l);
 
 /* --------------------------------------------------- A6: decode_hmm_states

@@ -179,7 +179,7 @@ struct gh_lattice_host {
 // and states in every layer.  gh_viterbi runs such graphs with one WAVE per utterance: lane = (layer mod 4, word),
 // the N states of a word in registers (gh_viterbi_layers.hip).
 #define GH_LAYERS_MAXW 64          // words per layer of the layer form: up to GH_LAYERS_ROWW on the narrow kernel (lane = (layer, word)),
-#define GH_LAYERS_ROWW 16          //   up to 64 on the wide one (lane = word; K <= 8, N <= 8: gh_viterbi_layers_wide.hip); loop form: ROWW
+#define GH_LAYERS_ROWW 16          //   up to 64 on the wide one (lane = word; K <= 8, N <= 8: gh_viterbi_layers_wide.hip); loop form alike
 #define GH_LAYERS_MAXN 16          // states per word the word templates hold (Viterbi, all three forms: 2..8, 12, 16: gh_seq_n_ok)
 #define GH_LAYERFORM_MAXN 8        // ... that the sequence-form forward-backward (and the EM session on it) is built for
 #define GH_LAYERS_MAXK 16         // layers of the layer form: up to 8 with any word model above, 9 .. 16 with up to 8 states per word

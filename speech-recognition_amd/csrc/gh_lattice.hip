@@ -422,9 +422,9 @@ extern "C" int gh_lattices_create(gh_ctx* ctx, int L, const int64_t* row_off, co
         for (int r = 0; r < R; ++r) if (h_state[r] < 0) { ++n_nes; if (r > 0) Lr = r; }
         bool ok = R >= 4 && h_state[0] < 0 && n_nes == 2 && Lr > 1 && Lr < R - 1;
         const int W = ok ? R - 1 - Lr : 0;
-        ok = ok && W >= 1 && W <= GH_LAYERS_ROWW && (Lr - 1) % W == 0;
+        ok = ok && W >= 1 && W <= GH_LAYERS_MAXW && (Lr - 1) % W == 0;
         const int N = ok ? (Lr - 1) / W + 1 : 0;
-        ok = ok && gh_seq_n_ok(N);
+        ok = ok && gh_seq_n_ok(N) && (W <= GH_LAYERS_ROWW || N <= 8);          // (more than 16 words: the wide kernel, N <= 8)
         ok = ok && lt->lat[0].n_start == 1 && (h_start[0] & 1);
         auto row_of = [&](int w, int sx) { return sx == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (sx - 1); };
         std::vector<int> wof(R, -1), sof(R, -1);

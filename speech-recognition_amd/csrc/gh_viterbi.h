@@ -132,6 +132,7 @@ int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_laye
 int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);
 // more than GH_LAYERS_ROWW words per layer (gh_viterbi_layers_wide.hip: lane = word); the two launchers above hand over to these
 size_t gh_layers_wide_bp_entries(int64_t T);
+size_t gh_loop_wide_bp_entries(int64_t T);
 int gh_launch_viterbi_layers_wide(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                                   bool f64, bool want_path);
 int gh_launch_lattice_backtrace_wide(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts);

@@ -555,12 +555,12 @@ __global__ __launch_bounds__(64) void lattice_backtrace_kernel(gh_layers_args a,
 
 // back-pointer scratch of one utterance of T frames, in uint16 units (the lattice kernels' common unit)
 size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
+    if (f.W > GH_LAYERS_ROWW) return f.loop ? gh_loop_wide_bp_entries(T) : gh_layers_wide_bp_entries(T);
     if (f.loop) {
         const int hb = f.N + 2 + (f.skip ? f.N - 2 : 0);
         const int cpw = 32 / hb;
         return (size_t)((T + cpw - 1) / cpw) * 16 * 2;
     }
-    if (f.W > GH_LAYERS_ROWW) return gh_layers_wide_bp_entries(T);
     const int hb = f.N + 1 + (f.skip ? f.N - 2 : 0), sets = f.K > 8 ? 4 : 2;
     const int wbits = sets * hb > 32 ? 64 : 32;               // (LayerBits)
     const int cpw = wbits / (sets * hb);
@@ -584,7 +584,7 @@ size_t gh_layers_bp_entries(const gh_layerform& f, int64_t T) {
 int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                              bool f64, bool want_path) {
     if (n_utts <= 0) return GH_OK;
-    if (!f.loop && f.W > GH_LAYERS_ROWW) return gh_launch_viterbi_layers_wide(ctx, a, f, u_begin, n_utts, f64, want_path);
+    if (f.W > GH_LAYERS_ROWW) return gh_launch_viterbi_layers_wide(ctx, a, f, u_begin, n_utts, f64, want_path);
     gh_layers_args b = a;
     b.slot0 = u_begin;
     const dim3 blk(64);
@@ -624,7 +624,7 @@ int gh_launch_viterbi_layers(gh_ctx* ctx, const gh_layers_args& a, const gh_laye
 // the path (a.path) or the label sequences (a.labels) of the utterances [u_begin, u_begin + n_utts) from the decision words
 int gh_launch_lattice_backtrace(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts) {
     if (n_utts <= 0 || !(a.path || a.labels)) return GH_OK;
-    if (!f.loop && f.W > GH_LAYERS_ROWW) return gh_launch_lattice_backtrace_wide(ctx, a, f, u_begin, n_utts);
+    if (f.W > GH_LAYERS_ROWW) return gh_launch_lattice_backtrace_wide(ctx, a, f, u_begin, n_utts);
     gh_layers_args b = a;
     b.slot0 = u_begin;
     const dim3 grid((unsigned)((n_utts + 63) / 64)), blk(64);

@@ -305,10 +305,241 @@ __global__ __launch_bounds__(64) void lattice_backtrace_wide_kernel(gh_layers_ar
     out_n[u] = (int32_t)len;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE LOOP form: the word-loop grammar (gh_layerform.loop, see viterbi_loop_kernel) with 17 .. 64 words: ONE utterance per
+// wave (the narrow kernel holds four, a DPP row each), lane = word, the N states of the word in registers.  Per column: the
+// states from the previous column, the loop row = the minimum over ALL words' last states of this column, the first states
+// from (start row, loop row, self) in that candidate order.  N + 2 (+ N - 2 with skip arcs) decision bits per column and
+// lane: one 32-bit word, [column][lane].
+template <typename ET, int N, bool SKIP, bool WANT_BP>
+__global__ __launch_bounds__(64) void viterbi_loop_wide_kernel(gh_layers_args a) {
+    constexpr int PF = 4;
+    const int lane = threadIdx.x, w = lane;
+    const gh_layerform* __restrict__ lf = a.lf;
+    const int W = lf->W, Lr = lf->loop_row;
+    const int64_t slot = a.slot0 + blockIdx.x;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const int64_t f0 = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - f0);
+    const double INF = INFINITY;
+    const bool wact = w < W;
+    const int wc = wact ? w : 0;
+    double c0[N], c1[N], c2[N];
+    unsigned sto[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        c0[s] = wact ? lf->c0[wc][s] : INF;
+        c1[s] = wact ? lf->c1[wc][s] : INF;
+        c2[s] = (SKIP && wact) ? lf->c2[wc][s] : INF;
+        sto[s] = (unsigned)lf->state[wc][s] * (unsigned)sizeof(ET);
+    }
+    const double cin = wact ? lf->cin[wc] : INF, cin0 = wact ? lf->cin0[wc] : INF, cout = wact ? lf->cout[wc] : INF;
+    const char* nllb = static_cast<const char*>(a.nll) + (T > 0 ? f0 : 0) * a.S * (int64_t)sizeof(ET);
+    const int64_t rowb = (int64_t)a.S * (int64_t)sizeof(ET);
+    ET ring[PF][N];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+        for (int s = 0; s < N; ++s)
+            ring[k][s] = (k < T) ? *reinterpret_cast<const ET*>(nllb + k * rowb + sto[s]) : ET(0);
+    double prev[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) prev[s] = INF;
+    uint32_t* bp = WANT_BP ? reinterpret_cast<uint32_t*>(a.bp + a.bp_off[slot]) + lane : nullptr;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto push32 = [](uint32_t& word, unsigned long long mask) {
+        unsigned long long carry_out;
+        asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(word), "=s"(carry_out) : "v"(word), "s"(mask));
+    };
+    auto column = [&](int t, const ET (&ev)[N]) {
+        double e[N];
+#pragma unroll
+        for (int s = 0; s < N; ++s) e[s] = (double)ev[s];
+        uint32_t word = 0;
+        const double base0 = c0[0] + prev[0];
+#pragma unroll
+        for (int s = N - 1; s >= 1; --s) {
+            const double v0 = c0[s] + prev[s];
+            const double v1 = c1[s] + prev[s - 1];
+            double best;
+            if (SKIP && s >= 2) {
+                const double v2 = c2[s] + prev[s - 2];
+                const bool b_a = v1 < v2;
+                const double m = vmin(v1, v2);
+                const bool b_b = v0 < m;
+                best = vmin(v0, m);
+                if (WANT_BP) { push32(word, __ballot(b_a)); push32(word, __ballot(b_b)); }
+            } else {
+                const bool b = v0 < v1;
+                best = vmin(v0, v1);
+                if (WANT_BP) push32(word, __ballot(b));
+            }
+            prev[s] = vmin(best + e[s], INF);
+        }
+        // the loop row: minimum over the words' last states of THIS column
+        const double cand = prev[N - 1] + cout;
+        const double rm = wave_min(cand);
+        if (WANT_BP) push32(word, __ballot(cand == rm));
+        // state 0: start row (row 0), loop row, self -- ascending origin, strict '<'
+        const double cs = ((t == 0) ? 0.0 : INF) + cin0;
+        const double cl = rm + cin;
+        const bool b_l = cl < cs;
+        const double m2 = vmin(cl, cs);
+        const bool b_s = base0 < m2;
+        if (WANT_BP) { push32(word, __ballot(b_l)); push32(word, __ballot(b_s)); }
+        prev[0] = vmin(vmin(base0, m2) + e[0], INF);
+        if (WANT_BP) bp[(int64_t)t * 64] = word;
+    };
+    int t0 = 0;
+    for (; t0 + PF <= T; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            column(t, ring[k]);
+            const int tn = (t + PF < T) ? t + PF : T - 1;
+            const char* colp = nllb + (int64_t)tn * rowb;
+#pragma unroll
+            for (int s = 0; s < N; ++s) ring[k][s] = *reinterpret_cast<const ET*>(colp + sto[s]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PF - 1; ++k)
+        if (t0 + k < T) column(t0 + k, ring[k]);
+    // ---- end costs + end selection ('>=': the last of equal minima) ----
+    double best_v = INF;
+    int best_slot = -1;
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        if (wact) {
+            const int r = s == 0 ? Lr + 1 + w : 1 + w * (N - 1) + (s - 1);
+            const int es = a.end_slot[r];
+            if (es >= 0) {
+                const double v = T > 0 ? prev[s] : INF;
+                if (a.end_cost) a.end_cost[u * a.n_end + es] = v;
+                if (v < best_v || (v == best_v && es > best_slot)) { best_v = v; best_slot = es; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(best_v, o);
+        const int os = __shfl_xor(best_slot, o);
+        if (ov < best_v || (ov == best_v && os > best_slot)) { best_v = ov; best_slot = os; }
+    }
+    if (lane == 0 && a.best_end) a.best_end[u] = T > 0 ? best_slot : -1;
+}
+
+// its back-trace: one lane per utterance, the decision word of (column j, word bw) is bpu[j 64 + bw]
+template <int N, bool SKIP, int MODE>
+__global__ __launch_bounds__(64) void loop_backtrace_wide_kernel(gh_layers_args a, int64_t slot_end) {
+    constexpr int HB = N + 2 + (SKIP ? N - 2 : 0);
+    __shared__ uint8_t s_arcs[GH_LAYERS_MAXW * GH_LAYERS_MAXN];
+    const gh_layerform* __restrict__ lf = a.lf;
+    for (int i = threadIdx.x; i < GH_LAYERS_MAXW * GH_LAYERS_MAXN; i += 64) s_arcs[i] = (&lf->arcs[0][0])[i];
+    __syncthreads();
+    const int W = lf->W, Lr = lf->loop_row;
+    const int64_t slot = a.slot0 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= slot_end) return;
+    const int64_t u = a.perm ? a.perm[slot] : slot;
+    const int T = (int)(a.utt_off[u + 1] - a.utt_off[u]);
+    const int be = a.best_end[u];
+    int32_t* out_n = MODE == 0 ? a.path_len : a.n_labels;
+    if (T <= 1 || be < 0) { out_n[u] = 0; return; }
+    auto row_of = [&](int ww, int ss) { return ss == 0 ? Lr + 1 + ww : 1 + ww * (N - 1) + (ss - 1); };
+    int bw, bs;
+    {
+        const int r = a.end_rows[be];
+        if (r > Lr) { bw = r - Lr - 1; bs = 0; } else { bw = (r - 1) / (N - 1); bs = (r - 1) % (N - 1) + 1; }
+    }
+    const uint32_t* bpu = reinterpret_cast<const uint32_t*>(a.bp + a.bp_off[slot]);
+    int32_t* path = MODE == 0 ? a.path + 2 * a.path_off[u] : nullptr;
+    int32_t* labs = MODE == 1 ? a.labels + a.label_off[u] : nullptr;
+    const int64_t cap = MODE == 0 ? a.path_off[u + 1] - a.path_off[u] : a.label_off[u + 1] - a.label_off[u];
+    int64_t len = 0;
+    int prev_label = -1;
+    int j = T - 1, kind = 0;                                  // kind 0 emitting (bw, bs); 1 the loop row; 2 the start row
+    int flag = 0;
+    auto visit = [&](int row, int col) {
+        if (MODE == 0) {
+            if (len >= cap) { flag |= 4; return; }
+            reinterpret_cast<int2*>(path)[len] = make_int2(row, col);
+            ++len;
+        } else {
+            const int l = a.row_label[row];
+            if (prev_label >= 0 && l < 0) {
+                if (len >= cap) { flag |= 8; return; }
+                labs[cap - 1 - len] = prev_label;
+                ++len;
+            }
+            prev_label = l;
+        }
+    };
+    while (j != 0 && !flag) {
+        if (kind == 0) {
+            const uint32_t hb = bpu[(int64_t)j * 64 + bw] & (uint32_t)((1ull << HB) - 1ull);
+            const int arcs = s_arcs[bw * GH_LAYERS_MAXN + bs];
+            if (bs >= 1) {
+                int before = 0;
+                for (int s2 = N - 1; s2 > bs; --s2) before += (SKIP && s2 >= 2) ? 2 : 1;
+                int code;
+                if (SKIP && bs >= 2) {
+                    const int b_a = (hb >> (HB - 1 - before)) & 1, b_b = (hb >> (HB - 2 - before)) & 1;
+                    code = b_b ? 0 : (b_a ? 1 : 2);
+                } else {
+                    code = ((hb >> (HB - 1 - before)) & 1) ? 0 : 1;
+                }
+                if (!((arcs >> code) & 1)) code = (arcs & 4) ? 2 : (arcs & 2) ? 1 : (arcs & 1) ? 0 : -1;
+                if (code < 0) { flag |= 2; break; }
+                bs -= code;
+                --j;
+                visit(row_of(bw, bs), j);
+            } else {
+                // candidates in ascending origin order: start row (arcs bit4), loop row (bit3), self (bit0)
+                const int b_l = (hb >> 1) & 1, b_s = hb & 1;
+                int pick = b_s ? 0 : (b_l ? 3 : 4);
+                if (!((arcs >> pick) & 1)) pick = (arcs & 16) ? 4 : (arcs & 8) ? 3 : (arcs & 1) ? 0 : -1;
+                if (pick < 0) { flag |= 2; break; }
+                if (pick == 0) { --j; visit(row_of(bw, 0), j); }
+                else if (pick == 3) { kind = 1; visit(Lr, j); }
+                else { kind = 2; visit(0, j); }
+            }
+        } else if (kind == 1) {
+            const uint4* rowp = reinterpret_cast<const uint4*>(bpu + (int64_t)j * 64);
+            int found = -1;
+            for (int q4 = (W + 3) / 4 - 1; q4 >= 0; --q4) {                    // the words' decision words of this column
+                const uint4 v = rowp[q4];
+                if ((v.w >> 2) & 1u) found = 4 * q4 + 3;
+                if ((v.z >> 2) & 1u) found = 4 * q4 + 2;
+                if ((v.y >> 2) & 1u) found = 4 * q4 + 1;
+                if ((v.x >> 2) & 1u) found = 4 * q4;
+            }
+            if (found < 0 || found >= W) { flag |= 2; break; }                 // lowest word = lowest origin row (np.argmin)
+            bw = found;
+            bs = N - 1;
+            kind = 0;
+            visit(row_of(bw, bs), j);
+        } else {
+            flag |= 2;                                                          // the start row, reached in a column > 0
+            break;
+        }
+    }
+    if (flag) atomicOr(a.flag, flag);
+    if (MODE == 1) {
+        if (!flag && prev_label >= 0) {
+            if (len >= cap) atomicOr(a.flag, 8);
+            else { labs[cap - 1 - len] = prev_label; ++len; }
+        }
+        for (int64_t i = 0; i < len; ++i) labs[i] = labs[cap - len + i];
+    }
+    out_n[u] = (int32_t)len;
+}
+
 }  // namespace
 
 // decision words of one utterance of T frames in uint16 units: two 64-bit words per column and lane
 size_t gh_layers_wide_bp_entries(int64_t T) { return (size_t)T * WL_SETS * 64 * 4; }
+// ... wide loop form: one 32-bit word per column and lane
+size_t gh_loop_wide_bp_entries(int64_t T) { return (size_t)T * 64 * 2; }
 
 #define GH_LW_CASES(MACRO)                       \
     switch (f.N) {                               \
@@ -325,10 +556,26 @@ size_t gh_layers_wide_bp_entries(int64_t T) { return (size_t)T * WL_SETS * 64 * 
 int gh_launch_viterbi_layers_wide(gh_ctx* ctx, const gh_layers_args& a, const gh_layerform& f, int64_t u_begin, int64_t n_utts,
                                   bool f64, bool want_path) {
     if (n_utts <= 0) return GH_OK;
-    if (f.K > 4 * WL_SETS) { gh_set_error("gh_viterbi: wide layer form with %d layers", f.K); return GH_ERR_UNSUPPORTED; }
     gh_layers_args b = a;
     b.slot0 = u_begin;
     const dim3 grid((unsigned)n_utts), blk(64);
+    if (f.loop) {
+#define GH_LPW(NN, SK)                                                                                                      \
+    do {                                                                                                                    \
+        if (f64) {                                                                                                          \
+            if (want_path) hipLaunchKernelGGL((viterbi_loop_wide_kernel<double, NN, SK, true>), grid, blk, 0, ctx->stream, b);    \
+            else hipLaunchKernelGGL((viterbi_loop_wide_kernel<double, NN, SK, false>), grid, blk, 0, ctx->stream, b);             \
+        } else {                                                                                                            \
+            if (want_path) hipLaunchKernelGGL((viterbi_loop_wide_kernel<float, NN, SK, true>), grid, blk, 0, ctx->stream, b);     \
+            else hipLaunchKernelGGL((viterbi_loop_wide_kernel<float, NN, SK, false>), grid, blk, 0, ctx->stream, b);              \
+        }                                                                                                                   \
+    } while (0)
+        GH_LW_CASES(GH_LPW)
+#undef GH_LPW
+        GH_HIP(hipGetLastError());
+        return GH_OK;
+    }
+    if (f.K > 4 * WL_SETS) { gh_set_error("gh_viterbi: wide layer form with %d layers", f.K); return GH_ERR_UNSUPPORTED; }
 #define GH_LW(NN, SK)                                                                                                       \
     do {                                                                                                                    \
         if (f64) {                                                                                                          \
@@ -354,8 +601,13 @@ int gh_launch_lattice_backtrace_wide(gh_ctx* ctx, const gh_layers_args& a, const
     const bool labels = a.labels != nullptr;
 #define GH_BW(NN, SK)                                                                                                       \
     do {                                                                                                                    \
-        if (labels) hipLaunchKernelGGL((lattice_backtrace_wide_kernel<NN, SK, 1>), grid, blk, 0, ctx->stream, b, slot_end); \
-        else hipLaunchKernelGGL((lattice_backtrace_wide_kernel<NN, SK, 0>), grid, blk, 0, ctx->stream, b, slot_end);        \
+        if (f.loop) {                                                                                                       \
+            if (labels) hipLaunchKernelGGL((loop_backtrace_wide_kernel<NN, SK, 1>), grid, blk, 0, ctx->stream, b, slot_end); \
+            else hipLaunchKernelGGL((loop_backtrace_wide_kernel<NN, SK, 0>), grid, blk, 0, ctx->stream, b, slot_end);        \
+        } else {                                                                                                            \
+            if (labels) hipLaunchKernelGGL((lattice_backtrace_wide_kernel<NN, SK, 1>), grid, blk, 0, ctx->stream, b, slot_end); \
+            else hipLaunchKernelGGL((lattice_backtrace_wide_kernel<NN, SK, 0>), grid, blk, 0, ctx->stream, b, slot_end);        \
+        }                                                                                                                   \
     } while (0)
     GH_LW_CASES(GH_BW)
 #undef GH_BW

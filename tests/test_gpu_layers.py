@@ -223,7 +223,9 @@ def test_loop_kernel_reference_goldens(hip, ctx, dtype):
 
 @pytest.mark.parametrize("W,n,skip,penalty", [(10, 5, False, 0.0), (11, 5, False, 2.5), (1, 2, False, 0.0), (16, 3, True, 1.0),
                                               (5, 8, True, 0.0), (7, 4, False, 0.7), (3, 6, True, 3.0), (2, 7, False, 0.0),
-                                              (4, 12, False, 0.5), (3, 12, True, 1.0), (5, 16, False, 0.0), (2, 16, True, 2.0)])
+                                              (4, 12, False, 0.5), (3, 12, True, 1.0), (5, 16, False, 0.0), (2, 16, True, 2.0),
+                                              # more than 16 words: the wide loop kernel (one utterance per wave, lane = word)
+                                              (17, 5, False, 0.5), (40, 3, True, 1.0), (64, 5, False, 0.0), (33, 8, True, 2.0)])
 def test_loop_kernel_equals_lean_kernel(hip, ctx, W, n, skip, penalty):
     """Random word models through the loop grammar: ragged utterances (1 .. 6 words, a few too short for even one
     word, counts that are not a multiple of the four utterances a wave holds): end costs BITWISE, chosen ends, paths

@@ -127,8 +127,8 @@ for trial in range(trials):
             problems.append("K = %d lattice not taken as layer form (%s)" % (K, sorted(lat.forms())))
         problems += compare("layers", lat, b, n, graph["row_state"])
         lat.close()
-        # loop form (up to 16 words: four utterances per wave)
-        if W <= 16:
+        # loop form (up to 16 words: four utterances per wave; more: one per wave, up to 8 states per word)
+        if W <= 16 or n <= 8:
             graph = packed_loop_lattice(wt, n, float(rng.choice([0.0, 0.7, 2.5])))[0]
             lat = _hip.Lattices(ctx, [graph])
             if "loop" not in lat.forms():
