@@ -235,7 +235,37 @@ def case_skmeans_session():
     b.close()
 
 
-CASES = [(case_batches, 3), (case_frontend, 1), (case_loglik_viterbi, 4), (case_em_sessions, 3), (case_fit_session, 3), (case_skmeans_session, 2)]
+def case_decode_lattices():
+    """The continuous decoder's graphs: K-layer lattice and word-loop grammar over 1 .. 64 words of 2 .. 16 states -- the form
+    recognition of gh_lattices_create (narrow / four-set / wide layer form, loop and wide loop form, or none), the decision-word
+    planning and the launch arguments of gh_viterbi / gh_viterbi_labels."""
+    from sr.recognition.continuous_speech import packed_lattice, packed_loop_lattice
+    W = int(rng.choice([1, 3, 10, 16, 17, 40, 64]))
+    n = int(rng.choice([2, 5, 8, 12, 16]))
+    K = int(rng.integers(1, 17))
+    if K * (W * n + 1) > 6000:
+        K = max(1, 6000 // (W * n + 1))
+    M, D = int(rng.choice([1, 4])), int(rng.choice([6, 13]))
+    gmm = model(W * n, M, D)
+    U = int(rng.integers(1, 10))
+    xs = [rng.normal(size=(tt, D)) for tt in lengths(U, allow_short=False)]
+    b = _hip.Batch(ctx, xs, dtype=rng.choice([np.float64, np.float32]))
+    b.loglik(gmm, fetch=False)
+    trans = [ltr_trans(n, skip=bool(rng.random() < 0.3)) for _ in range(W)]
+    for graph in (packed_lattice(trans, n, [list(range(W))] * K)[0], packed_loop_lattice(trans, n, float(rng.choice([0.0, 1.5])))[0]):
+        lat = _hip.Lattices(ctx, [graph])
+        t(lat.forms)
+        t(lambda: lat.viterbi(b, want_path=bool(rng.random() < 0.7)))
+        row_word = np.where(graph["row_state"] >= 0, graph["row_state"] // n, -1).astype(np.int32)
+        t(lambda: lat.viterbi_labels(b, row_word))
+        t(lambda: lat.viterbi_labels(b, row_word, as_lists=False))
+        lat.close()
+    b.close()
+    gmm.close()
+
+
+CASES = [(case_batches, 3), (case_frontend, 1), (case_loglik_viterbi, 4), (case_em_sessions, 3), (case_fit_session, 3), (case_skmeans_session, 2),
+         (case_decode_lattices, 3)]
 pool = [f for f, wgt in CASES for _ in range(wgt)]
 # a small scratch budget part of the time: the chunk planners cut the launches
 for i in range(n_cases):
