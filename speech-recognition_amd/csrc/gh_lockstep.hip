@@ -1035,7 +1035,10 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
         const double s0 = st[c * Wd], S1 = st[c * Wd + 1 + d], S2 = st[c * Wd + 1 + D + d];
         // (a component with all its weight on ONE point -- see em_update_state, gh_refit_mfma.hip: the reference's variance is
         //  exactly 0 there and update_models raises; the centred sums leave rounding noise)
-        if (!(s0 > 0 && fabs(S1 * S1 - S2 * s0) <= 3.6e-15 * fabs(S2 * s0))) onept &= ~(1u << c);
+        {
+            const double mq = S1 / s0, qq = S2 / s0;       // (weighted mean and mean square: products of the sums underflow for s0 ~ 1e-200)
+            if (!(s0 >= 1e-290 && fabs(mq * mq - qq) <= 3.6e-15 * fabs(qq))) onept &= ~(1u << c);
+        }
         const int64_t at = ((int64_t)s * k + c) * D + d;
         const double m0 = mean[at];
         const double occ = (s0 == 0) ? 1e-5 : s0;
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(256) void fit_em_update_kernel(int k, int D, int pl
         const double dl = mu - m0;
         const double sg = (S2 - dl * (2.0 * S1 - dl * s0)) / occ;
         diff += !same(mu, m0) + !same(sg, var[at]);
-        if (sg == 0) atomicOr(counter + 1, 16);              // update_models raises before the convergence test (hmm_state.py:149)
+        if (sg <= 0) atomicOr(counter + 1, 16);              // update_models raises before the convergence test (hmm_state.py:149); < 0: below the sums' rounding noise
         mean[at] = mu;
         var[at] = sg;
         mine += !fit_close(mu, old_mu[at]) + !fit_close(sg, old_sigma[at]);

@@ -249,7 +249,12 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
         // all of the component's weight on ONE point (a frame, or identical ones): sum r y^2 . sum r = (sum r y)^2 up to the
         // rounding of the three sums -- and only then in every dimension at once (several points: the two sides differ by
         // s0^2 times the weighted variance, ~1 against 1e-15)
-        if (!(s0 > 0 && fabs(T1 * T1 - T2 * s0) <= 3.6e-15 * fabs(T2 * s0))) onept &= ~(1u << c);
+        // (as weighted mean and mean square, not as products of the sums: a component nobody is close to has s0 ~ 1e-200, and
+        //  T1 T1, T2 s0 would both underflow to 0 and "agree")
+        {
+            const double mq = T1 / s0, qq = T2 / s0;
+            if (!(s0 >= 1e-290 && fabs(mq * mq - qq) <= 3.6e-15 * fabs(qq))) onept &= ~(1u << c);
+        }
         const double S1 = T1 - dm * s0;                                 // sum r (x - m0)
         const double S2 = T2 - dm * (2.0 * T1 - dm * s0);               // sum r (x - m0)^2
         const double occ = (s0 == 0) ? 1e-5 : s0;
@@ -259,7 +264,10 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
         diff += !same(mu, m0) + !same(sg, a.var[at]);
         // update_models installs the covariance BEFORE the convergence test (hmm_state.py:149): a zero variance raises
         // LinAlgError there, whether or not the state would go on (the pack of the next pass only sees the states that do)
-        if (sg == 0) atomicOr(a.c.counter + 1, 16);
+        // (sg < 0: a variance below the rounding noise of the centred sums -- a component with ~1e-22 of the weight, whose true
+        //  variance of ~1e-19 the reference inverts for one more iteration before it collapses onto a frame and raises: numerically
+        //  singular here already, and log(sg) would turn the whole state into NaN)
+        if (sg <= 0) atomicOr(a.c.counter + 1, 16);
         rf_publish(a.mean + at, mu);
         rf_publish(a.var + at, sg);
         if (n_l < 2) { mu_l[n_l] = mu; sg_l[n_l] = sg; }

@@ -229,10 +229,14 @@ class GMM(HMMState):
         # sum r y^2 . sum r = (sum r y)^2 in every dimension (to the rounding of the sums): such a row gets its exact 0, and
         # update_models raises at that component with the ones in front installed, as in the reference.
         with np.errstate(all="ignore"):
-            s0, S1, S2 = stats[:, 0][:, None], stats[:, 1:1 + dim], stats[:, 1 + dim:]
-            one_point = (stats[:, 0] > 0) & np.all(np.abs(S1 * S1 - S2 * s0) <= 3.6e-15 * np.abs(S2 * s0), axis=1)
+            # (as weighted mean and mean square: for a component nobody is close to, s0 ~ 1e-200, products of the sums underflow)
+            s0 = stats[:, 0][:, None]
+            mq, qq = stats[:, 1:1 + dim] / s0, stats[:, 1 + dim:] / s0
+            one_point = (stats[:, 0] >= 1e-290) & np.all(np.abs(mq * mq - qq) <= 3.6e-15 * np.abs(qq), axis=1)
         if one_point.any():
             sigma = np.where(one_point[:, None], 0.0, sigma)
+        with np.errstate(invalid="ignore"):
+            sigma = np.where(sigma < 0, 0.0, sigma)          # below the rounding noise of the centred sums: numerically singular
         self.update_models(mu, sigma, weights)
         if np.allclose(mu, self.mu_old[:k, :]) and np.allclose(sigma, self.sigma_old[:k, :]) \
                 and np.allclose(weights, self.w_old[:k]):
