@@ -267,7 +267,9 @@ __device__ bool em_update_state(const rf_em_args& a, int s, int it, const double
         // (sg < 0: a variance below the rounding noise of the centred sums -- a component with ~1e-22 of the weight, whose true
         //  variance of ~1e-19 the reference inverts for one more iteration before it collapses onto a frame and raises: numerically
         //  singular here already, and log(sg) would turn the whole state into NaN)
-        if (sg <= 0) atomicOr(a.c.counter + 1, 16);
+        //  The same for a variance within the noise ABOVE zero: sg <= 128 eps E[(x - shift)^2] -- a feature that is constant over the
+        //  component's frames (the reference: exactly 0, LinAlgError) comes out as +-1e-16 y^2 here
+        if (sg <= 0 || sg <= 2.8e-14 * (T2 / occ)) atomicOr(a.c.counter + 1, 16);
         rf_publish(a.mean + at, mu);
         rf_publish(a.var + at, sg);
         if (n_l < 2) { mu_l[n_l] = mu; sg_l[n_l] = sg; }

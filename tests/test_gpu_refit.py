@@ -324,6 +324,33 @@ def test_zero_variance_in_a_states_last_iteration_raises():
             b.close()
 
 
+def test_constant_feature_is_singular_whatever_the_rounding():
+    """A feature with the same non-zero value in every frame, the start means beside it: the reference's variance in that
+    dimension is exactly 0 or, when sum(p x) / sum(p) lands an ulp beside x, ~1e-31 (LinAlgError now or NaN later); the sums
+    centred on the shift point give +-1e-16 y^2 -- within the noise, and the streaming update raises."""
+    rng = np.random.default_rng(11)
+    D, k = 4, 2
+    seg = rng.normal(size=(120, D))
+    seg[:, 1] = 3.7
+    mean0 = np.stack([np.stack([seg.mean(axis=0) - 0.5, seg.mean(axis=0) + 0.5])])
+    mean0[0, :, 1] = [3.4, 3.9]
+    var0, w0 = np.ones((1, k, D)), np.full((1, k), 0.5)
+    m, v, w = mean0[0].copy(), var0[0].copy(), w0[0].copy()
+    try:
+        O.gmm_em(seg, m, v, w, k, max_iteration=1, old=(np.zeros((k, D)), np.ones((k, D)), np.zeros(k)))
+        assert v[:, 1].max() < 1e-25                              # (not exactly 0 this time: an ulp beside the constant)
+    except np.linalg.LinAlgError:
+        pass
+    b, fit, off = _session([seg], k)
+    try:
+        mean, var, ww = mean0.copy(), var0.copy(), w0.copy()
+        with pytest.raises(np.linalg.LinAlgError):
+            fit.em(k, mean, var, ww, np.zeros_like(mean), np.ones_like(mean), np.zeros_like(ww), np.array([120.0]), max_iteration=3)
+    finally:
+        fit.close()
+        b.close()
+
+
 def test_partition_variances_of_tiny_groups_are_np_covs():
     """Random partitions of SMALL states: a group of two frames that lie close together has a variance of 1e-8 of the spread; the
     one-pass sums of the streaming pass keep 7-9 digits of it, so states of up to 64 frames take two passes (np.cov's numbers)."""
