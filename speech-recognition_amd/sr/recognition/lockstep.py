@@ -100,6 +100,7 @@ class PartitionStream:
         self.n_max = int(n_max)
         self.state0 = np.random.get_state()
         self.buf = np.empty(self.n_max, dtype=np.uint32)
+        self.low = np.empty(self.n_max, dtype=np.uint8)        # the low byte of every draw (k <= 256: all a partition needs)
         self.snaps = []
         self.error = None
         self.thread = threading.Thread(target=self._run, name="gmmhmm-partitions", daemon=True)
@@ -113,6 +114,7 @@ class PartitionStream:
                 self.snaps.append(rs.get_state())
                 b = min(self.n_max, a + self.CHUNK)
                 self.buf[a:b] = rs.randint(0, 1 << 32, b - a, dtype=np.uint32)
+                self.low[a:b] = self.buf[a:b]                     # (same_kind cast, modulo 256: on the worker, not in take())
         except BaseException as e:        # (re-raised by take)
             self.error = e
 
@@ -123,6 +125,7 @@ class PartitionStream:
             np.random.set_state(self.state0)
             raise self.error
         lengths = [int(n) for n in lengths]
+        assert n_splits <= 8, "PartitionStream: more than 256 groups"
         used = n_splits * sum(lengths)
         assert used <= self.n_max, "PartitionStream: the refit draws more values than were made"
         rs = np.random.RandomState()
@@ -140,7 +143,7 @@ class PartitionStream:
         for n in lengths:
             row = []
             for i in range(n_splits):
-                row.append((self.buf[at:at + n] & np.uint32(2 ** (i + 1) - 1)).astype(np.uint8))
+                row.append(self.low[at:at + n] & np.uint8(2 ** (i + 1) - 1))
                 at += n
             parts.append(row)
         return parts
