@@ -374,3 +374,50 @@ def test_partition_variances_of_tiny_groups_are_np_covs():
     np.testing.assert_allclose(covs[0][0], covs[1][0], rtol=5e-16)     # the tile path's two passes (an fma more or less)
     np.testing.assert_allclose(covs[0][1], covs[1][1], rtol=1e-12)
     assert covs[0][0][1].max() < 1e-7                            # (the group of the two close frames)
+
+
+def test_tail_launches_change_nothing(capfd):
+    """The multi-iteration (TAIL) launches -- up to 64 lock-step iterations inside one launch once the states still active fit
+    the chip -- against one launch per iteration (GMMHMM_REFIT_TAIL=0): assignments, iteration counts and centroids are the same
+    BITS, mixtures agree to 1e-12 with the same converged_at; and the session's own count says the tail launches really ran
+    (GMMHMM_REFIT_DEBUG)."""
+    import re
+    rng = np.random.default_rng(21)
+    D, k = 13, 4
+    # (clusters that overlap: k-means and EM take tens of iterations, the tail launches start behind the first poll at 8)
+    segs = _mixture_data(rng, (3000, 2500, 1300, 900, 4000, 400), D, k, spread=0.6)
+    N = sum(len(x) for x in segs)
+    part = rng.integers(0, k, size=N).astype(np.uint8)
+    c0 = np.stack([np.stack([x.mean(axis=0) * f for f in np.linspace(0.97, 1.03, k)]) for x in segs])
+    res, counts = [], []
+    for tail in ("1", "0"):
+        os.environ["GMMHMM_REFIT_TAIL"] = tail
+        os.environ["GMMHMM_REFIT_DEBUG"] = "1"
+        try:
+            b, fit, off = _session(segs, k)
+            cen, cov, cnt, its = fit.kmeans(k, c0, part, max_iteration=200)
+            ids = fit.clusters()
+            n = np.diff(off).astype(np.float64)
+            mean, var, w = cen.copy(), cov.copy(), cnt / n[:, None]
+            conv = fit.em(k, mean, var, w, np.zeros_like(mean), np.ones_like(mean), np.zeros_like(w), n, max_iteration=300)
+            capfd.readouterr()
+            fit.close()
+            b.close()
+            err = capfd.readouterr().err
+        finally:
+            os.environ.pop("GMMHMM_REFIT_TAIL", None)
+            os.environ.pop("GMMHMM_REFIT_DEBUG", None)
+        m = re.search(r"(\d+) tail launches \((\d+) iterations\), (\d+) refused, (\d+) ordinary launches", err)
+        assert m, err
+        counts.append(tuple(int(v) for v in m.groups()))
+        res.append(dict(cen=cen, cov=cov, cnt=cnt, its=its, ids=ids, mean=mean, var=var, w=w, conv=conv))
+    assert counts[0][0] > 0 and counts[0][1] > counts[0][0]         # several iterations per tail launch
+    assert counts[1][0] == 0 and counts[1][3] > counts[0][3]        # none when switched off: more ordinary launches instead
+    for name in ("cen", "cov", "cnt", "its", "ids"):                 # k-means: assignments are exact, sums in a fixed order
+        np.testing.assert_array_equal(res[0][name], res[1][name], err_msg=name)
+    # EM: the TAIL form is its own instantiation of the kernel template -- the same operations, but the compiler contracts
+    # multiply-adds on its own in each (1e-15 relative); the stop rule sees the same numbers to that accuracy
+    for name in ("mean", "var", "w"):
+        np.testing.assert_allclose(res[0][name], res[1][name], rtol=1e-12, atol=1e-14, err_msg=name)
+    np.testing.assert_array_equal(res[0]["conv"], res[1]["conv"])
+    assert res[0]["its"].max() > 8 and (res[0]["conv"] >= 0).any()
