@@ -18,6 +18,12 @@ python3 tools/time_ctrain.py 2000 7 8 > $O/ctrain_host_profile.log 2>&1; echo "c
 REPS=4 python3 tools/time_train_words.py > $O/train_words.log 2>&1; echo "train_words exit $?"
 REPS=5 python3 tools/prof_train_words.py > $O/train_words_stages.txt 2>&1; echo "train_words stages exit $?"
 python3 tools/time_layers_wide.py 5000 16 10 7 > $O/layers_wide.txt 2>&1 && python3 tools/time_layers_wide.py 5000 12 10 7 >> $O/layers_wide.txt 2>&1; echo "wide word models exit $?"
+# the randomised sweeps (each a few seconds): streaming vs tile refit kernels, word-template vs lean Viterbi kernels, train_words vs
+# the word-after-word loop, continuous_train's device path vs the compat_cov host path
+python3 tools/stress_refit.py 400 2 > $O/stress_refit.txt 2>&1; echo "stress_refit exit $?"
+python3 tools/stress_decode.py 400 2 > $O/stress_decode.txt 2>&1; echo "stress_decode exit $?"
+python3 tools/stress_train_words.py 300 2 > $O/stress_train_words.txt 2>&1; echo "stress_train_words exit $?"
+python3 tools/stress_ctrain.py 150 2 > $O/stress_ctrain.txt 2>&1; echo "stress_ctrain exit $?"
 for d in headline refit_k4 refit_k8 ctrain; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv; done
 rm -rf $O/prof_*
 ls $O
