@@ -1028,7 +1028,7 @@ def _c4_em_config(ctx, group, U):
     return out
 
 
-def _ctrain_config(ctx, U, K=7, iters=6):
+def _ctrain_config(ctx, U, K=7, iters=8):
     """The reference's ACTUAL training algorithm on configs[2]'s model: continuous_train (continuous_speech.py:56-179) --
     per outer iteration forced alignment of every utterance, frames regrouped per state, every state refit by
     binary-split k-means + EM, transition costs re-estimated, models pickled -- on `U` synthetic K-word utterances.
@@ -1064,11 +1064,14 @@ def _ctrain_config(ctx, U, K=7, iters=6):
         cs.continuous_train(data, models, labels, out, n_gaussians=M, n_segments=n, max_iteration=iters)
     per = np.diff(stamps.t + [time.perf_counter()])
     N = int(sum(len(x) for x in data))
-    steady = float(np.median(per[len(per) // 2:]))
+    # steady state: the second half WITHOUT the last iteration (its stamp runs until the call has returned: the wait for the
+    # pickle writer, the handles, the temporary directory).  The workload of every iteration is the same -- two runs give the
+    # same bits and the same launch counts -- so what the median leaves out are host hiccups
+    steady = float(np.median(per[len(per) // 2:-1])) if len(per) >= 4 else float(np.median(per[len(per) // 2:]))
     return {"workload": "configs[2] model, continuous_train on %d utterances of %d words (%d frames), %d mixtures" % (U, K, N, M),
             "outer_iterations": int(len(per)), "ms_per_outer_iteration": [round(1e3 * float(x), 1) for x in per],
             "ms_per_outer_iteration_steady": steady * 1e3, "frames_per_s": N / steady, "utterances_per_s": U / steady,
-            "note": "steady = median of the second half of the iterations (the first ones grow the scratch arenas); round 2: 750 ms"}
+            "note": "steady = median of the second half of the iterations without the last one, which carries the call's teardown (the first ones grow the scratch arenas); round 2: 750 ms"}
 
 
 def _train_words_config(ctx, W=10, templates=200, n=5, ng=4):
