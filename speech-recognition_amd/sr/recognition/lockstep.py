@@ -95,12 +95,20 @@ class PartitionStream:
     draw from np.random between construction and take()."""
 
     CHUNK = 1 << 16
+    _kept = None                # (buf, low) of the stream used last
 
     def __init__(self, n_max):
         self.n_max = int(n_max)
         self.state0 = np.random.get_state()
-        self.buf = np.empty(self.n_max, dtype=np.uint32)
-        self.low = np.empty(self.n_max, dtype=np.uint8)        # the low byte of every draw (k <= 256: all a partition needs)
+        # (the two buffers are kept between streams: continuous_train makes one per outer iteration, and 14 MB of fresh pages
+        #  touched by the worker while the main thread drives the device cost the 2nd and 3rd iteration of a run 25-35 ms each)
+        kept = PartitionStream._kept
+        PartitionStream._kept = None
+        if kept is not None and len(kept[0]) >= self.n_max:
+            self.buf, self.low = kept
+        else:
+            self.buf = np.empty(self.n_max, dtype=np.uint32)
+            self.low = np.empty(self.n_max, dtype=np.uint8)    # the low byte of every draw (k <= 256: all a partition needs)
         self.snaps = []
         self.error = None
         self.thread = threading.Thread(target=self._run, name="gmmhmm-partitions", daemon=True)
@@ -146,12 +154,14 @@ class PartitionStream:
                 row.append(self.low[at:at + n] & np.uint8(2 ** (i + 1) - 1))
                 at += n
             parts.append(row)
+        PartitionStream._kept = (self.buf, self.low)          # (the partitions above are arrays of their own)
         return parts
 
     def cancel(self):
         """Nothing was used: the global generator stays where it was."""
         self.thread.join()
         np.random.set_state(self.state0)
+        PartitionStream._kept = (self.buf, self.low)
 
 
 class LockstepFitter:
