@@ -378,9 +378,8 @@ def test_partition_variances_of_tiny_groups_are_np_covs():
 
 def test_tail_launches_change_nothing(capfd):
     """The multi-iteration (TAIL) launches -- up to 64 lock-step iterations inside one launch once the states still active fit
-    the chip -- against one launch per iteration (GMMHMM_REFIT_TAIL=0): assignments, iteration counts and centroids are the same
-    BITS, mixtures agree to 1e-12 with the same converged_at; and the session's own count says the tail launches really ran
-    (GMMHMM_REFIT_DEBUG)."""
+    the chip -- against one launch per iteration (GMMHMM_REFIT_TAIL=0): assignments, iteration counts, centroids, mixtures and
+    converged_at are the same BITS; and the session's own count says the tail launches really ran (GMMHMM_REFIT_DEBUG)."""
     import re
     rng = np.random.default_rng(21)
     D, k = 13, 4
@@ -413,11 +412,8 @@ def test_tail_launches_change_nothing(capfd):
         res.append(dict(cen=cen, cov=cov, cnt=cnt, its=its, ids=ids, mean=mean, var=var, w=w, conv=conv))
     assert counts[0][0] > 0 and counts[0][1] > counts[0][0]         # several iterations per tail launch
     assert counts[1][0] == 0 and counts[1][3] > counts[0][3]        # none when switched off: more ordinary launches instead
-    for name in ("cen", "cov", "cnt", "its", "ids"):                 # k-means: assignments are exact, sums in a fixed order
+    # the same BITS: the sums run in a fixed order in both forms, and gh_refit_mfma.hip is built with -ffp-contract=on, so that
+    # the two instantiations of a kernel contract the same multiply-adds (hipcc's default left the EM 1e-15 apart)
+    for name in res[0]:
         np.testing.assert_array_equal(res[0][name], res[1][name], err_msg=name)
-    # EM: the TAIL form is its own instantiation of the kernel template -- the same operations, but the compiler contracts
-    # multiply-adds on its own in each (1e-15 relative); the stop rule sees the same numbers to that accuracy
-    for name in ("mean", "var", "w"):
-        np.testing.assert_allclose(res[0][name], res[1][name], rtol=1e-12, atol=1e-14, err_msg=name)
-    np.testing.assert_array_equal(res[0]["conv"], res[1]["conv"])
     assert res[0]["its"].max() > 8 and (res[0]["conv"] >= 0).any()
